@@ -1,0 +1,139 @@
+"""ctypes bindings of the in-tree native libraries.
+
+libhelm_hip.so  (include/helm_hip.h)    HIP kernels + C ABI  -- the hot path
+libhelm_host.so (include/helm_client.h) CPU client + netlist front end
+
+There is no Python or CPU fallback for the hot path: a missing library raises
+ImportError here, and a missing GPU makes helm_hip_ctx_create() fail with
+HELM_ERR_NO_DEVICE, which surfaces as HelmError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+
+
+class HelmError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [(f, C.c_int32) for f in ("torus_bits", "n", "k", "N", "pbs_l", "pbs_logB", "ks_l", "ks_logB",
+                                         "pbs_order", "grouping_factor")]
+
+    def as_tuple7(self):
+        """(n, k, N, pbs_l, pbs_logB, ks_l, ks_logB)"""
+        return (self.n, self.k, self.N, self.pbs_l, self.pbs_logB, self.ks_l, self.ks_logB)
+
+    def __repr__(self):
+        return "Params(" + ", ".join(f"{f}={getattr(self, f)}" for f, _ in self._fields_) + ")"
+
+
+class Timing(C.Structure):
+    _fields_ = [("pbs_ms", C.c_double), ("ks_ms", C.c_double), ("linear_ms", C.c_double),
+                ("pbs_launches", C.c_int64), ("pbs_count", C.c_int64),
+                ("ks_launches", C.c_int64), ("ks_count", C.c_int64)]
+
+
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+u8p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+
+
+def _load(name):
+    path = os.path.join(_CSRC, name)
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `make -C {_CSRC}` "
+                          "(or __graft_entry__.build()); helm_amd has no fallback path")
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+hip = _load("libhelm_hip.so")
+host = _load("libhelm_host.so")
+
+# every symbol include/helm_hip.h declares: (restype, argtypes)
+HIP_API = {
+    "helm_hip_last_error": (C.c_char_p, []),
+    "helm_hip_device_count": (C.c_int, []),
+    "helm_hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(Params), C.POINTER(vp)]),
+    "helm_hip_ctx_destroy": (C.c_int, [vp]),
+    "helm_hip_set_stream": (C.c_int, [vp, vp]),
+    "helm_hip_sync": (C.c_int, [vp]),
+    "helm_hip_load_bootstrap_key": (C.c_int, [vp, u32p, C.c_size_t]),
+    "helm_hip_load_keyswitch_key": (C.c_int, [vp, u32p, C.c_size_t]),
+    "helm_hip_wires_alloc": (C.c_int, [vp, C.c_int64, C.POINTER(vp)]),
+    "helm_hip_wires_free": (C.c_int, [vp, vp]),
+    "helm_hip_wires_upload": (C.c_int, [vp, vp, i32p, u32p, C.c_int64]),
+    "helm_hip_wires_download": (C.c_int, [vp, vp, i32p, u32p, C.c_int64]),
+    "helm_hip_wires_set_trivial": (C.c_int, [vp, vp, i32p, u8p, C.c_int64]),
+    "helm_hip_wires_device_ptr": (C.c_int, [vp, vp, C.POINTER(vp), i64p]),
+    "helm_hip_eval_gate_level": (C.c_int, [vp, vp, i32p, i32p, i32p, i32p, i32p, C.c_int64]),
+    "helm_hip_program_create": (C.c_int, [vp, i32p, i32p, i32p, i32p, i32p, i64p, C.c_int64, C.POINTER(vp)]),
+    "helm_hip_program_destroy": (C.c_int, [vp, vp]),
+    "helm_hip_program_run": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64]),
+    "helm_hip_program_chunk_rows": (C.c_int64, [vp, C.c_int64, C.c_int]),
+    "helm_hip_program_run_level_shard": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
+    "helm_hip_program_scatter_level": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
+    "helm_hip_program_level_pbs": (C.c_int64, [vp, C.c_int64]),
+    "helm_hip_pbs_batch": (C.c_int, [vp, u32p, u32p, C.c_int64, i32p, u32p, C.c_int64]),
+    "helm_hip_keyswitch_batch": (C.c_int, [vp, u32p, u32p, C.c_int64]),
+    "helm_hip_ntt_roundtrip": (C.c_int, [vp, u32p, u32p, C.c_int64]),
+    "helm_hip_timing_enable": (C.c_int, [vp, C.c_int]),
+    "helm_hip_get_timing": (C.c_int, [vp, C.POINTER(Timing), C.c_int]),
+}
+
+CLIENT_API = {
+    "helm_client_named_params": (C.c_int, [C.c_char_p, C.POINTER(Params), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "helm_client_last_error": (C.c_char_p, []),
+    "helm_client_keygen": (C.c_int, [C.POINTER(Params), C.c_double, C.c_double, C.c_uint64, C.POINTER(vp)]),
+    "helm_client_key_free": (None, [vp]),
+    "helm_client_bsk_words": (C.c_size_t, [vp]),
+    "helm_client_ksk_words": (C.c_size_t, [vp]),
+    "helm_client_bsk": (u32p, [vp]),
+    "helm_client_ksk": (u32p, [vp]),
+    "helm_client_lwe_secret": (u32p, [vp]),
+    "helm_client_glwe_secret": (u32p, [vp]),
+    "helm_client_encrypt_bool": (C.c_int, [vp, u8p, C.c_int64, u32p]),
+    "helm_client_decrypt_bool": (C.c_int, [vp, u32p, C.c_int64, u8p]),
+    "helm_client_phase": (C.c_int, [vp, u32p, C.c_int64, C.c_int, u32p]),
+}
+
+for _lib, _api in ((hip, HIP_API), (host, CLIENT_API)):
+    for _name, (_res, _args) in _api.items():
+        _fn = getattr(_lib, _name)  # AttributeError here = header/library mismatch
+        _fn.restype = _res
+        _fn.argtypes = _args
+
+
+def hip_check(rc):
+    if rc != 0:
+        raise HelmError(f"helm_hip error {rc}: {hip.helm_hip_last_error().decode()}")
+
+
+def client_check(rc):
+    if rc != 0:
+        raise HelmError(f"helm_client error {rc}: {host.helm_client_last_error().decode()}")
+
+
+def as_u32p(a):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u32p)
+
+
+def as_i32p(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(i32p)
+
+
+def as_i64p(a):
+    assert a.dtype == np.int64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(i64p)
+
+
+def as_u8p(a):
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u8p)

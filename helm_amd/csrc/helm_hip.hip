@@ -1,0 +1,1287 @@
+// helm_hip.hip — gfx950 kernels + C ABI (include/helm_hip.h) of the gate-bootstrap
+// engine.  Replaces the tfhe::boolean::ServerKey calls HELM issues per gate
+// (reference src/gates.rs:254-275) with level-batched device kernels:
+//
+//   k_linear        NOT / BUF / DFF / constants (no bootstrap)    gates.rs:256,268,272-274
+//   k_pbs           gate linear step + modulus switch + blind rotate (CMUX chain over
+//                   the NTT-domain bootstrapping key) + sample extract, one workgroup
+//                   of (k+1) waves per bootstrap
+//   k_keyswitch     big-key LWE -> small-key LWE, MUX recombination fused in
+//   k_bsk_convert   standard-domain BSK -> NTT domain (once per key)
+//   k_scatter_rows  multi-GPU: all-gathered level outputs -> wire table
+//
+// There is no CPU fallback in this file.
+#include "../../include/helm_hip.h"
+#include "ntt_fp64.h"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace helm;
+
+// ------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess)                                                                      \
+            return fail(HELM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));          \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------
+#define PT_TRUE 0x20000000u  // +1/8, reference src/circuit.rs:29
+#define PT_FALSE 0xE0000000u // -1/8, reference src/circuit.rs:33
+
+struct PbsJob {
+    int32_t op;    // helm_gate_op, or -1: raw LWE taken from `raw_in`
+    int32_t which; // MUX: 0 -> AND(sel, in0) half, 1 -> AND(!sel, in1) half
+    int32_t in0, in1, in2;
+    int32_t tv;    // test-vector row
+};
+
+struct KsJob {
+    int32_t big0, big1; // rows of the big-LWE buffer to add (big1 = -1: single)
+    int32_t out;        // destination row (wire index, or staging row)
+    uint32_t add_body;  // constant added to the body before switching (MUX: +1/8)
+};
+
+struct LinJob {
+    int32_t op, in0, out;
+};
+
+// Gate linear step, tfhe boolean engine formulas (see oracle/tfhe_oracle.c header).
+__device__ __forceinline__ uint32_t gate_lincomb(int op, int which, uint32_t l, uint32_t r, uint32_t c, bool body)
+{
+    const uint32_t t = body ? PT_TRUE : 0u, f = body ? PT_FALSE : 0u;
+    switch (op) {
+    case HELM_GATE_AND: return l + r + f;
+    case HELM_GATE_OR: return l + r + t;
+    case HELM_GATE_NAND: return 0u - (l + r) + t;
+    case HELM_GATE_NOR: return 0u - (l + r) + f;
+    case HELM_GATE_XOR: return 2u * (l + r + t);
+    case HELM_GATE_XNOR: return 2u * (0u - (l + r + t));
+    case HELM_GATE_MUX: return which == 0 ? (c + l + f) : (0u - c + r + f);
+    default: return 0u;
+    }
+}
+
+__device__ __forceinline__ uint32_t modswitch(uint32_t x, int log2_2N)
+{
+    uint32_t r = (x >> (32 - log2_2N - 1)) + 1u;
+    return (r >> 1) & ((1u << log2_2N) - 1u);
+}
+
+// Signed gadget decomposition, closest representable + balanced digits; dig[0] is
+// the most significant level.  L and logB are compile-time / uniform.
+template <int L>
+__device__ __forceinline__ void decompose(uint32_t x, int logB, int (&dig)[L])
+{
+    const int rep = logB * L;
+    uint32_t state = (x + (1u << (31 - rep))) >> (32 - rep);
+    const uint32_t mask = (1u << logB) - 1u;
+#pragma unroll
+    for (int lev = L - 1; lev >= 0; lev--) {
+        uint32_t d = state & mask;
+        state >>= logB;
+        uint32_t carry = (((d - 1u) | state) & d) >> (logB - 1);
+        state += carry;
+        dig[lev] = (int)d - (int)(carry << logB);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_pbs: one workgroup = one bootstrap; wave p owns accumulator polynomial p.
+// Dynamic LDS (one array, see layout below).
+// ------------------------------------------------------------------------------------
+template <int LOGN, int K, int L>
+struct PbsLds {
+    using G = Geo<LOGN>;
+    static constexpr int K1 = K + 1;
+    static constexpr size_t X_OFF = 0;                                          // double [K1][L][XPAD]
+    static constexpr size_t R_OFF = X_OFF + sizeof(double) * K1 * L * G::XPAD;  // double [K1][K][N]
+    static constexpr size_t ACC_OFF = R_OFF + sizeof(double) * K1 * K * G::N;   // u32 [K1][N]
+    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint32_t) * K1 * G::N;    // u32 [n+1] (n <= MAX_SMALL_N)
+    static constexpr int MAX_SMALL_N = 1024;
+    static constexpr size_t BYTES = MS_OFF + sizeof(uint32_t) * (MAX_SMALL_N + 1);
+};
+
+template <int LOGN, int K, int L>
+__global__ __launch_bounds__(64 * (K + 1)) void k_pbs(const PbsJob *__restrict__ jobs,
+                                                      const uint32_t *__restrict__ wires,  // rows of n+1
+                                                      const uint32_t *__restrict__ raw_in, // rows of n+1 (op == -1)
+                                                      const uint32_t *__restrict__ tvs,    // rows of N
+                                                      const double *__restrict__ bsk,      // NTT domain
+                                                      const double *__restrict__ tw_fwd,
+                                                      const double *__restrict__ tw_inv,
+                                                      uint32_t *__restrict__ out_big, // rows of K*N+1
+                                                      int n, int logB)
+{
+    using G = Geo<LOGN>;
+    using S = PbsLds<LOGN, K, L>;
+    constexpr int N = G::N, E = G::E, K1 = K + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *X = reinterpret_cast<double *>(smem + S::X_OFF);
+    double *R = reinterpret_cast<double *>(smem + S::R_OFF);
+    uint32_t *ACC = reinterpret_cast<uint32_t *>(smem + S::ACC_OFF);
+    uint32_t *MS = reinterpret_cast<uint32_t *>(smem + S::MS_OFF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int p = __builtin_amdgcn_readfirstlane(tid >> 6); // this wave's polynomial
+    const PbsJob job = jobs[blockIdx.x];
+    const size_t row = (size_t)n + 1;
+
+    // ---- gate linear step + modulus switch (whole workgroup) ------------------------
+    {
+        const uint32_t *a0 = nullptr, *a1 = nullptr, *a2 = nullptr;
+        if (job.op < 0) a0 = raw_in + row * (size_t)job.in0;
+        else {
+            if (job.in0 >= 0) a0 = wires + row * (size_t)job.in0;
+            if (job.in1 >= 0) a1 = wires + row * (size_t)job.in1;
+            if (job.in2 >= 0) a2 = wires + row * (size_t)job.in2;
+        }
+        for (int i = tid; i <= n; i += 64 * K1) {
+            uint32_t v;
+            if (job.op < 0) v = a0[i];
+            else v = gate_lincomb(job.op, job.which, a0 ? a0[i] : 0u, a1 ? a1[i] : 0u, a2 ? a2[i] : 0u, i == n);
+            MS[i] = modswitch(v, LOGN + 1);
+        }
+    }
+    __syncthreads();
+
+    // ---- accumulator init: (0,...,0, X^{-b~} * tv) ------------------------------------
+    uint32_t *acc_p = ACC + p * N;
+    uint32_t accr[E];
+    {
+        const int bt = (int)MS[n];
+        const uint32_t *tv = tvs + (size_t)job.tv * N;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int j = G::jA(lane, e);
+            uint32_t v = 0;
+            if (p == K) {
+                const int idx = (j + bt) & (2 * N - 1);
+                v = tv[idx & (N - 1)];
+                if (idx >= N) v = 0u - v;
+            }
+            accr[e] = v;
+            acc_p[j] = v;
+        }
+    }
+    wave_sync();
+
+    double *xb = X + (size_t)p * L * G::XPAD; // this wave's L exchange buffers
+    const size_t bsk_step = (size_t)K1 * K1 * L * N; // doubles per LWE coefficient
+    const size_t bsk_lev = (size_t)N;                // doubles per polynomial
+
+    // ---- blind rotation: acc += BSK_i (x) (X^{a_i} acc - acc) -------------------------
+    for (int i = 0; i < n; i++) {
+        const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
+        if (a == 0) continue; // uniform over the workgroup
+
+        // (X^a acc_p - acc_p), decomposed into L digit polynomials
+        double x[L][E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int j = G::jA(lane, e);
+            const int src = (j - a) & (2 * N - 1);
+            uint32_t v = acc_p[src & (N - 1)];
+            if (src >= N) v = 0u - v;
+            int dig[L];
+            decompose<L>(v - accr[e], logB, dig);
+#pragma unroll
+            for (int lev = 0; lev < L; lev++) x[lev][e] = (double)dig[lev];
+        }
+#pragma unroll
+        for (int lev = 0; lev < L; lev++) ntt_forward<LOGN>(x[lev], xb + lev * G::XPAD, tw_fwd, lane);
+
+        // pointwise: partial[c] = sum_lev x[lev] * BSK_i[p][c][lev]
+        const double2 *bp = reinterpret_cast<const double2 *>(bsk + (size_t)i * bsk_step + (size_t)p * K1 * L * bsk_lev);
+        double mine[E];
+#pragma unroll
+        for (int c = 0; c < K1; c++) {
+            double part[E];
+#pragma unroll
+            for (int e2 = 0; e2 < E / 2; e2++) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int lev = 0; lev < L; lev++) {
+                    const double2 w = bp[((size_t)(c * L + lev) * (E / 2) + e2) * 64 + lane];
+                    s0 += mulmod(x[lev][2 * e2], w.x);
+                    s1 += mulmod(x[lev][2 * e2 + 1], w.y);
+                }
+                part[2 * e2] = reduce(s0);
+                part[2 * e2 + 1] = reduce(s1);
+            }
+            if (c == p) {
+#pragma unroll
+                for (int e = 0; e < E; e++) mine[e] = part[e];
+            } else {
+                // R[src = p][slot][N]: slot indexes the destination among the K others
+                double *dst = R + ((size_t)p * K + (c < p ? c : c - 1)) * N;
+#pragma unroll
+                for (int e = 0; e < E; e++) dst[e * 64 + lane] = part[e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < K1; q++) {
+            if (q == p) continue;
+            const double *src = R + ((size_t)q * K + (p < q ? p : p - 1)) * N;
+#pragma unroll
+            for (int e = 0; e < E; e++) mine[e] += src[e * 64 + lane];
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) mine[e] = reduce(mine[e]);
+        __syncthreads(); // R may be overwritten by the next step
+
+        ntt_inverse<LOGN>(mine, xb, tw_inv, lane);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            accr[e] += to_torus32(mine[e]);
+            acc_p[G::jA(lane, e)] = accr[e];
+        }
+        wave_sync();
+    }
+
+    // ---- sample extract (coefficient 0): wave p writes its own polynomial -------------
+    uint32_t *ob = out_big + (size_t)blockIdx.x * ((size_t)K * N + 1);
+    if (p < K) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int j = G::jA(lane, e); // accr[e] = A_p[j]
+            // out[p*N + t] = (t == 0) ? A[0] : -A[N - t]
+            if (j == 0) ob[p * N] = accr[e];
+            else ob[p * N + (N - j)] = 0u - accr[e];
+        }
+    } else if (lane == 0) {
+        ob[K * N] = accr[0]; // body = B[0]
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_keyswitch: grid (n_jobs, column chunks); 256 threads; one column per thread.
+// out[c] = (c == n ? body : 0) - sum_t sum_j digit(t,j) * KSK[t][j][c]
+// ------------------------------------------------------------------------------------
+template <int KSL>
+__global__ __launch_bounds__(256) void k_keyswitch(const KsJob *__restrict__ jobs, const uint32_t *__restrict__ big,
+                                                   const uint32_t *__restrict__ ksk, uint32_t *__restrict__ out,
+                                                   int n, int kN, int logB)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    int8_t *DIG = reinterpret_cast<int8_t *>(smem); // [kN][KSL]
+    const KsJob job = jobs[blockIdx.x];
+    const size_t brow = (size_t)kN + 1;
+    const uint32_t *b0 = big + brow * (size_t)job.big0;
+    const uint32_t *b1 = job.big1 >= 0 ? big + brow * (size_t)job.big1 : nullptr;
+    for (int t = threadIdx.x; t < kN; t += 256) {
+        uint32_t v = b0[t] + (b1 ? b1[t] : 0u);
+        int dig[KSL];
+        decompose<KSL>(v, logB, dig);
+#pragma unroll
+        for (int j = 0; j < KSL; j++) DIG[t * KSL + j] = (int8_t)dig[j];
+    }
+    __syncthreads();
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c > n) return;
+    const size_t krow = (size_t)n + 1;
+    uint32_t acc = 0;
+    const uint32_t *kp = ksk + c;
+#pragma unroll 4
+    for (int t = 0; t < kN; t++) {
+#pragma unroll
+        for (int j = 0; j < KSL; j++) {
+            const int d = DIG[t * KSL + j];
+            acc += (uint32_t)d * kp[((size_t)t * KSL + j) * krow];
+        }
+    }
+    uint32_t body = 0;
+    if (c == n) body = b0[kN] + (b1 ? b1[kN] : 0u) + job.add_body;
+    out[krow * (size_t)job.out + c] = body - acc;
+}
+
+// ------------------------------------------------------------------------------------
+// k_linear: NOT / BUF / DFF / constants.  One workgroup per gate.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_linear(const LinJob *__restrict__ jobs, const uint32_t *__restrict__ wires,
+                                                uint32_t *__restrict__ out, int n)
+{
+    const LinJob job = jobs[blockIdx.x];
+    const size_t row = (size_t)n + 1;
+    const uint32_t *src = job.in0 >= 0 ? wires + row * (size_t)job.in0 : nullptr;
+    uint32_t *dst = out + row * (size_t)job.out;
+    for (int i = threadIdx.x; i <= n; i += 256) {
+        uint32_t v;
+        switch (job.op) {
+        case HELM_GATE_NOT: v = 0u - src[i]; break;
+        case HELM_GATE_BUF:
+        case HELM_GATE_DFF: v = src[i]; break;
+        case HELM_GATE_CONST_ONE: v = (i == n) ? PT_TRUE : 0u; break;
+        case HELM_GATE_CONST_ZERO: v = (i == n) ? PT_FALSE : 0u; break;
+        default: v = 0u; break;
+        }
+        dst[i] = v;
+    }
+}
+
+// rows gathered[r] -> wires[dst_row[r]] (dst_row < 0: padding, skipped)
+__global__ __launch_bounds__(256) void k_scatter_rows(const uint32_t *__restrict__ gathered,
+                                                      const int32_t *__restrict__ dst_row,
+                                                      uint32_t *__restrict__ wires, int n)
+{
+    const int d = dst_row[blockIdx.x];
+    if (d < 0) return;
+    const size_t row = (size_t)n + 1;
+    for (int i = threadIdx.x; i <= n; i += 256) wires[row * (size_t)d + i] = gathered[row * (size_t)blockIdx.x + i];
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(const uint32_t *__restrict__ wires,
+                                                     const int32_t *__restrict__ src_row,
+                                                     uint32_t *__restrict__ packed, int n)
+{
+    const int s = src_row[blockIdx.x];
+    const size_t row = (size_t)n + 1;
+    for (int i = threadIdx.x; i <= n; i += 256)
+        packed[row * (size_t)blockIdx.x + i] = s < 0 ? 0u : wires[row * (size_t)s + i];
+}
+
+__global__ __launch_bounds__(256) void k_set_trivial(const int32_t *__restrict__ idx, const uint8_t *__restrict__ val,
+                                                     uint32_t *__restrict__ wires, int n)
+{
+    const size_t row = (size_t)n + 1;
+    uint32_t *dst = wires + row * (size_t)idx[blockIdx.x];
+    const uint32_t body = val[blockIdx.x] ? PT_TRUE : PT_FALSE;
+    for (int i = threadIdx.x; i <= n; i += 256) dst[i] = (i == n) ? body : 0u;
+}
+
+// ------------------------------------------------------------------------------------
+// k_bsk_convert: one wave per BSK polynomial.  Standard-domain u32 coefficients (taken
+// as signed) -> forward NTT -> * N^{-1} -> centred doubles in the lane-order k_pbs reads:
+//   dst[i][r][c][lev][e/2][lane][e&1]      (src is [i][lev][r][c][N])
+// ------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(64) void k_bsk_convert(const uint32_t *__restrict__ src, double *__restrict__ dst,
+                                                    const double *__restrict__ tw_fwd, double n_inv, int K1, int L)
+{
+    using G = Geo<LOGN>;
+    constexpr int N = G::N, E = G::E;
+    __shared__ double xbuf[G::XPAD];
+    const int lane = threadIdx.x;
+    const size_t poly = blockIdx.x; // index in src order
+    const int c = poly % K1;
+    const int r = (poly / K1) % K1;
+    const int lev = (poly / ((size_t)K1 * K1)) % L;
+    const size_t i = poly / ((size_t)K1 * K1 * L);
+    double x[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) x[e] = (double)(int32_t)src[poly * N + G::jA(lane, e)];
+    // |x| <= 2^31: far below p/2, so the digit-sized input bound of ntt_forward holds
+    ntt_forward<LOGN>(x, xbuf, tw_fwd, lane);
+    const size_t dpoly = ((i * K1 + r) * K1 + c) * L + lev;
+    double *d = dst + dpoly * N;
+#pragma unroll
+    for (int e = 0; e < E; e++) d[((e >> 1) * 64 + lane) * 2 + (e & 1)] = reduce(mulmod(x[e], n_inv));
+}
+
+// NTT self-test: forward, scale, inverse; must reproduce the input exactly.
+template <int LOGN>
+__global__ __launch_bounds__(64) void k_ntt_roundtrip(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                                                      const double *__restrict__ tw_fwd,
+                                                      const double *__restrict__ tw_inv, double n_inv)
+{
+    using G = Geo<LOGN>;
+    constexpr int N = G::N, E = G::E;
+    __shared__ double xbuf[G::XPAD];
+    const int lane = threadIdx.x;
+    double x[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) x[e] = (double)(int32_t)src[(size_t)blockIdx.x * N + G::jA(lane, e)];
+    ntt_forward<LOGN>(x, xbuf, tw_fwd, lane);
+#pragma unroll
+    for (int e = 0; e < E; e++) x[e] = reduce(mulmod(x[e], n_inv));
+    ntt_inverse<LOGN>(x, xbuf, tw_inv, lane);
+#pragma unroll
+    for (int e = 0; e < E; e++) dst[(size_t)blockIdx.x * N + G::jA(lane, e)] = to_torus32(x[e]);
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+namespace {
+
+typedef unsigned __int128 u128;
+uint64_t mulmod_u64(uint64_t a, uint64_t b) { return (uint64_t)((u128)a * b % NTT_P_U64); }
+uint64_t powmod_u64(uint64_t a, uint64_t e)
+{
+    uint64_t r = 1;
+    while (e) {
+        if (e & 1) r = mulmod_u64(r, a);
+        a = mulmod_u64(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+double centred(uint64_t v)
+{
+    return v > NTT_P_U64 / 2 ? (double)((int64_t)v - (int64_t)NTT_P_U64) : (double)(int64_t)v;
+}
+int bitrev(int x, int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; i++) {
+        r = (r << 1) | (x & 1);
+        x >>= 1;
+    }
+    return r;
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(n, (size_t)64);
+        if (hipMalloc(&p, want * sizeof(T)) != hipSuccess) return -1;
+        cap = want;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct LevelPlan {
+    std::vector<PbsJob> pbs;
+    std::vector<KsJob> ks;
+    std::vector<LinJob> lin;
+};
+
+} // namespace
+
+struct helm_hip_wires {
+    helm_hip_ctx *owner;
+    uint32_t *d;
+    int64_t n_wires;
+};
+
+struct helm_hip_ctx {
+    int device = 0;
+    helm_hip_params P{};
+    int logN = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    double *tw_fwd = nullptr, *tw_inv = nullptr;
+    double n_inv = 0;
+    double *bsk = nullptr;
+    uint32_t *ksk = nullptr;
+    uint32_t *tv_bool = nullptr; // one row: all +1/8
+    bool have_bsk = false, have_ksk = false;
+    // per-call scratch
+    DevBuf<PbsJob> d_pbs;
+    DevBuf<KsJob> d_ks;
+    DevBuf<LinJob> d_lin;
+    DevBuf<uint32_t> d_big;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pbs, ev_ks, ev_lin;
+    helm_hip_timing tacc{};
+};
+
+struct helm_hip_program {
+    helm_hip_ctx *owner;
+    int64_t n_levels;
+    std::vector<int64_t> off;
+    std::vector<int32_t> op, in0, in1, in2, out;
+    // device copies of the full job lists, with per-level offsets
+    PbsJob *d_pbs = nullptr;
+    KsJob *d_ks = nullptr;
+    LinJob *d_lin = nullptr;
+    std::vector<int64_t> pbs_off, ks_off, lin_off;
+    std::vector<LevelPlan> plans; // host copies (used for sharding)
+    // shard scratch
+    DevBuf<PbsJob> s_pbs;
+    DevBuf<KsJob> s_ks;
+    DevBuf<LinJob> s_lin;
+    DevBuf<int32_t> s_rows;
+};
+
+static bool needs_pbs(int op)
+{
+    switch (op) {
+    case HELM_GATE_AND: case HELM_GATE_NAND: case HELM_GATE_OR: case HELM_GATE_NOR:
+    case HELM_GATE_XOR: case HELM_GATE_XNOR: case HELM_GATE_MUX: return true;
+    default: return false;
+    }
+}
+static bool is_linear(int op)
+{
+    switch (op) {
+    case HELM_GATE_NOT: case HELM_GATE_BUF: case HELM_GATE_DFF:
+    case HELM_GATE_CONST_ONE: case HELM_GATE_CONST_ZERO: return true;
+    default: return false;
+    }
+}
+
+// Build the job lists of one level.  `out_row(g)` maps gate g to its destination row.
+template <typename F>
+static int plan_level(const int32_t *op, const int32_t *in0, const int32_t *in1, const int32_t *in2, int64_t count,
+                      F out_row, LevelPlan &pl)
+{
+    pl.pbs.clear();
+    pl.ks.clear();
+    pl.lin.clear();
+    for (int64_t g = 0; g < count; g++) {
+        const int o = op[g];
+        if (needs_pbs(o)) {
+            if (in0[g] < 0 || in1[g] < 0 || (o == HELM_GATE_MUX && in2[g] < 0))
+                return fail(HELM_ERR_INVALID, "gate " + std::to_string(g) + ": missing operand");
+            KsJob k;
+            k.big0 = (int32_t)pl.pbs.size();
+            k.big1 = -1;
+            k.out = out_row(g);
+            k.add_body = 0;
+            pl.pbs.push_back(PbsJob{o, 0, in0[g], in1[g], in2[g], 0});
+            if (o == HELM_GATE_MUX) {
+                k.big1 = (int32_t)pl.pbs.size();
+                k.add_body = PT_TRUE;
+                pl.pbs.push_back(PbsJob{o, 1, in0[g], in1[g], in2[g], 0});
+            }
+            pl.ks.push_back(k);
+        } else if (is_linear(o)) {
+            if ((o == HELM_GATE_NOT || o == HELM_GATE_BUF || o == HELM_GATE_DFF) && in0[g] < 0)
+                return fail(HELM_ERR_INVALID, "gate " + std::to_string(g) + ": missing operand");
+            pl.lin.push_back(LinJob{o, in0[g], out_row(g)});
+        } else {
+            // gates.rs:257-264: LUT / arithmetic gates panic in boolean mode
+            return fail(HELM_ERR_INVALID, "gate " + std::to_string(g) + ": op " + std::to_string(o) +
+                                              " can't be mixed with Boolean gates");
+        }
+    }
+    return 0;
+}
+
+template <int LOGN, int K, int L>
+static hipError_t launch_pbs_t(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
+                               const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
+{
+    using S = PbsLds<LOGN, K, L>;
+    static bool attr_done[64] = {false};
+    auto kern = k_pbs<LOGN, K, L>;
+    if (!attr_done[ctx->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES);
+        if (e != hipSuccess) return e;
+        attr_done[ctx->device & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * (K + 1)), S::BYTES, ctx->stream, jobs, wires, raw, tvs,
+                       ctx->bsk, ctx->tw_fwd, ctx->tw_inv, out_big, ctx->P.n, ctx->P.pbs_logB);
+    return hipGetLastError();
+}
+
+static bool pbs_supported(const helm_hip_params &P)
+{
+    if (P.N == 512 && P.k == 2 && P.pbs_l == 3) return true;
+    if (P.N == 512 && P.k == 1 && P.pbs_l == 3) return true;
+    if (P.N == 512 && P.k == 1 && P.pbs_l == 2) return true;
+    if (P.N == 1024 && P.k == 1 && P.pbs_l == 3) return true;
+    if (P.N == 1024 && P.k == 1 && P.pbs_l == 2) return true;
+    return false;
+}
+
+static hipError_t launch_pbs(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
+                             const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
+{
+    const helm_hip_params &P = ctx->P;
+    if (P.N == 512 && P.k == 2 && P.pbs_l == 3) return launch_pbs_t<9, 2, 3>(ctx, jobs, count, wires, raw, tvs, out_big);
+    if (P.N == 512 && P.k == 1 && P.pbs_l == 3) return launch_pbs_t<9, 1, 3>(ctx, jobs, count, wires, raw, tvs, out_big);
+    if (P.N == 512 && P.k == 1 && P.pbs_l == 2) return launch_pbs_t<9, 1, 2>(ctx, jobs, count, wires, raw, tvs, out_big);
+    if (P.N == 1024 && P.k == 1 && P.pbs_l == 3) return launch_pbs_t<10, 1, 3>(ctx, jobs, count, wires, raw, tvs, out_big);
+    if (P.N == 1024 && P.k == 1 && P.pbs_l == 2) return launch_pbs_t<10, 1, 2>(ctx, jobs, count, wires, raw, tvs, out_big);
+    return hipErrorInvalidValue;
+}
+
+static hipError_t launch_ks(helm_hip_ctx *ctx, const KsJob *jobs, int64_t count, const uint32_t *big, uint32_t *out)
+{
+    const helm_hip_params &P = ctx->P;
+    const int kN = P.k * P.N;
+    dim3 grid((unsigned)count, (unsigned)((P.n + 1 + 255) / 256));
+    const size_t lds = (size_t)kN * P.ks_l;
+#define KS_CASE(LV)                                                                                       \
+    case LV:                                                                                              \
+        hipLaunchKernelGGL(k_keyswitch<LV>, grid, dim3(256), lds, ctx->stream, jobs, big, ctx->ksk, out, P.n, kN, \
+                           P.ks_logB);                                                                    \
+        break;
+    switch (P.ks_l) {
+        KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) KS_CASE(5) KS_CASE(6) KS_CASE(8)
+    default: return hipErrorInvalidValue;
+    }
+#undef KS_CASE
+    return hipGetLastError();
+}
+
+struct TimedScope {
+    helm_hip_ctx *ctx;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> *list;
+    hipEvent_t a = nullptr, b = nullptr;
+    TimedScope(helm_hip_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> *l) : ctx(c), list(l)
+    {
+        if (ctx->timing) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, ctx->stream);
+        }
+    }
+    ~TimedScope()
+    {
+        if (ctx->timing) {
+            (void)hipEventRecord(b, ctx->stream);
+            list->push_back({a, b});
+        }
+    }
+};
+
+// Run one planned level whose job arrays are already on the device.
+static int run_level_device(helm_hip_ctx *ctx, const PbsJob *d_pbs, int64_t n_pbs, const KsJob *d_ks, int64_t n_ks,
+                            const LinJob *d_lin, int64_t n_lin, const uint32_t *wires_in, uint32_t *dst)
+{
+    const helm_hip_params &P = ctx->P;
+    if (n_pbs > 0) {
+        if (!ctx->have_bsk || !ctx->have_ksk) return fail(HELM_ERR_STATE, "bootstrapping / keyswitching key not loaded");
+        if (ctx->d_big.ensure((size_t)n_pbs * ((size_t)P.k * P.N + 1))) return fail(HELM_ERR_OOM, "big-LWE scratch");
+        {
+            TimedScope t(ctx, &ctx->ev_pbs);
+            HIP_TRY(launch_pbs(ctx, d_pbs, n_pbs, wires_in, nullptr, ctx->tv_bool, ctx->d_big.p));
+        }
+        ctx->tacc.pbs_launches++;
+        ctx->tacc.pbs_count += n_pbs;
+        {
+            TimedScope t(ctx, &ctx->ev_ks);
+            HIP_TRY(launch_ks(ctx, d_ks, n_ks, ctx->d_big.p, dst));
+        }
+        ctx->tacc.ks_launches++;
+        ctx->tacc.ks_count += n_ks;
+    }
+    if (n_lin > 0) {
+        TimedScope t(ctx, &ctx->ev_lin);
+        hipLaunchKernelGGL(k_linear, dim3((unsigned)n_lin), dim3(256), 0, ctx->stream, d_lin, wires_in, dst, P.n);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------
+extern "C" {
+
+const char *helm_hip_last_error(void) { return g_err.c_str(); }
+
+int helm_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_ctx **out)
+{
+    if (!params || !out) return fail(HELM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const helm_hip_params &P = *params;
+    if (P.torus_bits != 32) return fail(HELM_ERR_INVALID, "only torus_bits = 32 is implemented");
+    if (P.pbs_order != 0) return fail(HELM_ERR_INVALID, "only pbs_order = 0 (bootstrap then keyswitch)");
+    if (P.grouping_factor != 1) return fail(HELM_ERR_INVALID, "multi-bit PBS (grouping_factor > 1) not implemented");
+    if (!pbs_supported(P))
+        return fail(HELM_ERR_INVALID, "unsupported (N,k,pbs_l): built variants are (512,2,3) (512,1,3) (512,1,2) "
+                                      "(1024,1,3) (1024,1,2)");
+    if (P.n < 1 || P.n > 1024) return fail(HELM_ERR_INVALID, "n must be in [1,1024]");
+    if (P.pbs_logB < 1 || P.pbs_logB * P.pbs_l > 32) return fail(HELM_ERR_INVALID, "bad PBS decomposition");
+    if (P.ks_logB < 1 || P.ks_logB > 7 || P.ks_logB * P.ks_l > 32 ||
+        !(P.ks_l >= 1 && (P.ks_l <= 6 || P.ks_l == 8)))
+        return fail(HELM_ERR_INVALID, "bad keyswitch decomposition (ks_logB <= 7, ks_l in {1..6,8})");
+    // exactness: |sum| <= (k+1) * l * N * (B/2) * 2^31 must stay below p/2
+    {
+        const double bound = (double)(P.k + 1) * P.pbs_l * P.N * (double)(1u << (P.pbs_logB - 1)) * 2147483648.0;
+        if (bound * 1.0001 >= NTT_P / 2) return fail(HELM_ERR_INVALID, "parameter set exceeds the single-prime NTT capacity");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(HELM_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail(HELM_ERR_NO_DEVICE, "device_id out of range");
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(HELM_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+
+    helm_hip_ctx *ctx = new (std::nothrow) helm_hip_ctx();
+    if (!ctx) return fail(HELM_ERR_OOM, "ctx");
+    ctx->device = device_id;
+    ctx->P = P;
+    while ((1 << ctx->logN) < P.N) ctx->logN++;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+
+    // twiddle tables: bit-reversed powers of psi (primitive 2N-th root) and of psi^-1
+    const int N = P.N, logN = ctx->logN;
+    const uint64_t psi = powmod_u64(NTT_GEN, (NTT_P_U64 - 1) / (2 * (uint64_t)N));
+    const uint64_t psi_inv = powmod_u64(psi, NTT_P_U64 - 2);
+    std::vector<double> tf(N), ti(N);
+    uint64_t a = 1, b = 1;
+    for (int i = 0; i < N; i++) {
+        tf[bitrev(i, logN)] = centred(a);
+        ti[bitrev(i, logN)] = centred(b);
+        a = mulmod_u64(a, psi);
+        b = mulmod_u64(b, psi_inv);
+    }
+    ctx->n_inv = centred(powmod_u64((uint64_t)N, NTT_P_U64 - 2));
+    HIP_TRY(hipMalloc(&ctx->tw_fwd, sizeof(double) * N));
+    HIP_TRY(hipMalloc(&ctx->tw_inv, sizeof(double) * N));
+    HIP_TRY(hipMemcpy(ctx->tw_fwd, tf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->tw_inv, ti.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    std::vector<uint32_t> tv(N, PT_TRUE);
+    HIP_TRY(hipMalloc(&ctx->tv_bool, sizeof(uint32_t) * N));
+    HIP_TRY(hipMemcpy(ctx->tv_bool, tv.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+    *out = ctx;
+    return 0;
+}
+
+int helm_hip_ctx_destroy(helm_hip_ctx *ctx)
+{
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto *l : {&ctx->ev_pbs, &ctx->ev_ks, &ctx->ev_lin})
+        for (auto &p : *l) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    (void)hipFree(ctx->tw_fwd);
+    (void)hipFree(ctx->tw_inv);
+    (void)hipFree(ctx->bsk);
+    (void)hipFree(ctx->ksk);
+    (void)hipFree(ctx->tv_bool);
+    ctx->d_pbs.release();
+    ctx->d_ks.release();
+    ctx->d_lin.release();
+    ctx->d_big.release();
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return 0;
+}
+
+int helm_hip_set_stream(helm_hip_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return 0;
+}
+
+int helm_hip_sync(helm_hip_ctx *ctx)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int helm_hip_load_bootstrap_key(helm_hip_ctx *ctx, const uint32_t *bsk_std, size_t n_words)
+{
+    if (!ctx || !bsk_std) return fail(HELM_ERR_INVALID, "null argument");
+    const helm_hip_params &P = ctx->P;
+    const size_t K1 = P.k + 1;
+    const size_t polys = (size_t)P.n * P.pbs_l * K1 * K1;
+    if (n_words != polys * P.N)
+        return fail(HELM_ERR_INVALID, "bootstrapping key: expected " + std::to_string(polys * P.N) + " words, got " +
+                                          std::to_string(n_words));
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint32_t *d_std = nullptr;
+    HIP_TRY(hipMalloc(&d_std, n_words * sizeof(uint32_t)));
+    if (!ctx->bsk) HIP_TRY(hipMalloc(&ctx->bsk, n_words * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(d_std, bsk_std, n_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (P.N == 512)
+        hipLaunchKernelGGL(k_bsk_convert<9>, dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk,
+                           ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
+    else
+        hipLaunchKernelGGL(k_bsk_convert<10>, dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk,
+                           ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_std));
+    ctx->have_bsk = true;
+    return 0;
+}
+
+int helm_hip_load_keyswitch_key(helm_hip_ctx *ctx, const uint32_t *ksk, size_t n_words)
+{
+    if (!ctx || !ksk) return fail(HELM_ERR_INVALID, "null argument");
+    const helm_hip_params &P = ctx->P;
+    const size_t want = (size_t)P.k * P.N * P.ks_l * ((size_t)P.n + 1);
+    if (n_words != want)
+        return fail(HELM_ERR_INVALID, "keyswitching key: expected " + std::to_string(want) + " words, got " +
+                                          std::to_string(n_words));
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->ksk) HIP_TRY(hipMalloc(&ctx->ksk, want * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(ctx->ksk, ksk, want * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->have_ksk = true;
+    return 0;
+}
+
+int helm_hip_wires_alloc(helm_hip_ctx *ctx, int64_t n_wires, helm_hip_wires **out)
+{
+    if (!ctx || !out || n_wires <= 0) return fail(HELM_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    helm_hip_wires *w = new (std::nothrow) helm_hip_wires();
+    if (!w) return fail(HELM_ERR_OOM, "wires");
+    w->owner = ctx;
+    w->n_wires = n_wires;
+    const size_t bytes = (size_t)n_wires * ((size_t)ctx->P.n + 1) * sizeof(uint32_t);
+    if (hipMalloc(&w->d, bytes) != hipSuccess) {
+        delete w;
+        return fail(HELM_ERR_OOM, "wire table of " + std::to_string(bytes) + " bytes");
+    }
+    HIP_TRY(hipMemsetAsync(w->d, 0, bytes, ctx->stream));
+    *out = w;
+    return 0;
+}
+
+int helm_hip_wires_free(helm_hip_ctx *ctx, helm_hip_wires *w)
+{
+    if (!w) return 0;
+    if (!ctx || w->owner != ctx) return fail(HELM_ERR_STATE, "wire table belongs to another context");
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(w->d);
+    delete w;
+    return 0;
+}
+
+static int check_idx(const helm_hip_wires *w, const int32_t *idx, int64_t count, bool allow_neg)
+{
+    for (int64_t i = 0; i < count; i++)
+        if (idx[i] >= w->n_wires || (idx[i] < 0 && !(allow_neg && idx[i] == -1)))
+            return fail(HELM_ERR_INVALID, "wire index " + std::to_string(idx[i]) + " out of range at position " +
+                                              std::to_string(i));
+    return 0;
+}
+
+int helm_hip_wires_upload(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t *idx, const uint32_t *lwe_host,
+                          int64_t count)
+{
+    if (!ctx || !w || !idx || !lwe_host || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
+    if (w->owner != ctx) return fail(HELM_ERR_STATE, "wire table belongs to another context");
+    if (count == 0) return 0;
+    if (int rc = check_idx(w, idx, count, false)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t row = (size_t)ctx->P.n + 1;
+    uint32_t *d_rows = nullptr;
+    int32_t *d_idx = nullptr;
+    HIP_TRY(hipMalloc(&d_rows, (size_t)count * row * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_idx, (size_t)count * sizeof(int32_t)));
+    HIP_TRY(hipMemcpyAsync(d_rows, lwe_host, (size_t)count * row * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_idx, idx, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_rows, d_idx, w->d, ctx->P.n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_rows));
+    HIP_TRY(hipFree(d_idx));
+    return 0;
+}
+
+int helm_hip_wires_download(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t *idx, uint32_t *lwe_host, int64_t count)
+{
+    if (!ctx || !w || !idx || !lwe_host || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
+    if (w->owner != ctx) return fail(HELM_ERR_STATE, "wire table belongs to another context");
+    if (count == 0) return 0;
+    if (int rc = check_idx(w, idx, count, false)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t row = (size_t)ctx->P.n + 1;
+    uint32_t *d_rows = nullptr;
+    int32_t *d_idx = nullptr;
+    HIP_TRY(hipMalloc(&d_rows, (size_t)count * row * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_idx, (size_t)count * sizeof(int32_t)));
+    HIP_TRY(hipMemcpyAsync(d_idx, idx, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)count), dim3(256), 0, ctx->stream, w->d, d_idx, d_rows, ctx->P.n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(lwe_host, d_rows, (size_t)count * row * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_rows));
+    HIP_TRY(hipFree(d_idx));
+    return 0;
+}
+
+int helm_hip_wires_set_trivial(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t *idx, const uint8_t *value,
+                               int64_t count)
+{
+    if (!ctx || !w || !idx || !value || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
+    if (w->owner != ctx) return fail(HELM_ERR_STATE, "wire table belongs to another context");
+    if (count == 0) return 0;
+    if (int rc = check_idx(w, idx, count, false)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int32_t *d_idx = nullptr;
+    uint8_t *d_val = nullptr;
+    HIP_TRY(hipMalloc(&d_idx, (size_t)count * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&d_val, (size_t)count));
+    HIP_TRY(hipMemcpyAsync(d_idx, idx, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_val, value, (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_set_trivial, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_idx, d_val, w->d, ctx->P.n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_idx));
+    HIP_TRY(hipFree(d_val));
+    return 0;
+}
+
+int helm_hip_wires_device_ptr(helm_hip_ctx *ctx, helm_hip_wires *w, void **dev_ptr, int64_t *n_wires)
+{
+    if (!ctx || !w || !dev_ptr) return fail(HELM_ERR_INVALID, "bad argument");
+    if (w->owner != ctx) return fail(HELM_ERR_STATE, "wire table belongs to another context");
+    *dev_ptr = w->d;
+    if (n_wires) *n_wires = w->n_wires;
+    return 0;
+}
+
+int helm_hip_eval_gate_level(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t *opcode, const int32_t *in0,
+                             const int32_t *in1, const int32_t *in2, const int32_t *out, int64_t count)
+{
+    if (!ctx || !w || !opcode || !in0 || !in1 || !in2 || !out || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
+    if (w->owner != ctx) return fail(HELM_ERR_STATE, "wire table belongs to another context");
+    if (count == 0) return 0;
+    if (int rc = check_idx(w, in0, count, true)) return rc;
+    if (int rc = check_idx(w, in1, count, true)) return rc;
+    if (int rc = check_idx(w, in2, count, true)) return rc;
+    if (int rc = check_idx(w, out, count, false)) return rc;
+    LevelPlan pl;
+    if (int rc = plan_level(opcode, in0, in1, in2, count, [&](int64_t g) { return out[g]; }, pl)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->d_pbs.ensure(pl.pbs.size()) || ctx->d_ks.ensure(pl.ks.size()) || ctx->d_lin.ensure(pl.lin.size()))
+        return fail(HELM_ERR_OOM, "job buffers");
+    // the previous level may still be reading the job buffers: same stream => ordered
+    if (!pl.pbs.empty())
+        HIP_TRY(hipMemcpyAsync(ctx->d_pbs.p, pl.pbs.data(), pl.pbs.size() * sizeof(PbsJob), hipMemcpyHostToDevice, ctx->stream));
+    if (!pl.ks.empty())
+        HIP_TRY(hipMemcpyAsync(ctx->d_ks.p, pl.ks.data(), pl.ks.size() * sizeof(KsJob), hipMemcpyHostToDevice, ctx->stream));
+    if (!pl.lin.empty())
+        HIP_TRY(hipMemcpyAsync(ctx->d_lin.p, pl.lin.data(), pl.lin.size() * sizeof(LinJob), hipMemcpyHostToDevice, ctx->stream));
+    // pageable-memory async copies return after staging, so `pl` may go out of scope
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return run_level_device(ctx, ctx->d_pbs.p, (int64_t)pl.pbs.size(), ctx->d_ks.p, (int64_t)pl.ks.size(), ctx->d_lin.p,
+                            (int64_t)pl.lin.size(), w->d, w->d);
+}
+
+int helm_hip_program_create(helm_hip_ctx *ctx, const int32_t *opcode, const int32_t *in0, const int32_t *in1,
+                            const int32_t *in2, const int32_t *out, const int64_t *level_offsets, int64_t n_levels,
+                            helm_hip_program **prog)
+{
+    if (!ctx || !opcode || !in0 || !in1 || !in2 || !out || !level_offsets || !prog || n_levels < 0)
+        return fail(HELM_ERR_INVALID, "bad argument");
+    *prog = nullptr;
+    for (int64_t l = 0; l < n_levels; l++)
+        if (level_offsets[l + 1] < level_offsets[l]) return fail(HELM_ERR_INVALID, "level_offsets must be non-decreasing");
+    if (n_levels > 0 && level_offsets[0] != 0) return fail(HELM_ERR_INVALID, "level_offsets[0] must be 0");
+    helm_hip_program *pr = new (std::nothrow) helm_hip_program();
+    if (!pr) return fail(HELM_ERR_OOM, "program");
+    pr->owner = ctx;
+    pr->n_levels = n_levels;
+    pr->off.assign(level_offsets, level_offsets + n_levels + 1);
+    const int64_t total = n_levels ? level_offsets[n_levels] : 0;
+    pr->op.assign(opcode, opcode + total);
+    pr->in0.assign(in0, in0 + total);
+    pr->in1.assign(in1, in1 + total);
+    pr->in2.assign(in2, in2 + total);
+    pr->out.assign(out, out + total);
+    pr->plans.resize(n_levels);
+    std::vector<PbsJob> all_pbs;
+    std::vector<KsJob> all_ks;
+    std::vector<LinJob> all_lin;
+    pr->pbs_off.push_back(0);
+    pr->ks_off.push_back(0);
+    pr->lin_off.push_back(0);
+    for (int64_t l = 0; l < n_levels; l++) {
+        const int64_t b = pr->off[l], cnt = pr->off[l + 1] - b;
+        const int32_t *o = pr->out.data() + b;
+        int rc = plan_level(pr->op.data() + b, pr->in0.data() + b, pr->in1.data() + b, pr->in2.data() + b, cnt,
+                            [&](int64_t g) { return o[g]; }, pr->plans[l]);
+        if (rc) {
+            delete pr;
+            return rc;
+        }
+        all_pbs.insert(all_pbs.end(), pr->plans[l].pbs.begin(), pr->plans[l].pbs.end());
+        all_ks.insert(all_ks.end(), pr->plans[l].ks.begin(), pr->plans[l].ks.end());
+        all_lin.insert(all_lin.end(), pr->plans[l].lin.begin(), pr->plans[l].lin.end());
+        pr->pbs_off.push_back((int64_t)all_pbs.size());
+        pr->ks_off.push_back((int64_t)all_ks.size());
+        pr->lin_off.push_back((int64_t)all_lin.size());
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!all_pbs.empty()) {
+        HIP_TRY(hipMalloc(&pr->d_pbs, all_pbs.size() * sizeof(PbsJob)));
+        HIP_TRY(hipMemcpy(pr->d_pbs, all_pbs.data(), all_pbs.size() * sizeof(PbsJob), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&pr->d_ks, all_ks.size() * sizeof(KsJob)));
+        HIP_TRY(hipMemcpy(pr->d_ks, all_ks.data(), all_ks.size() * sizeof(KsJob), hipMemcpyHostToDevice));
+    }
+    if (!all_lin.empty()) {
+        HIP_TRY(hipMalloc(&pr->d_lin, all_lin.size() * sizeof(LinJob)));
+        HIP_TRY(hipMemcpy(pr->d_lin, all_lin.data(), all_lin.size() * sizeof(LinJob), hipMemcpyHostToDevice));
+    }
+    *prog = pr;
+    return 0;
+}
+
+int helm_hip_program_destroy(helm_hip_ctx *ctx, helm_hip_program *prog)
+{
+    if (!prog) return 0;
+    if (!ctx || prog->owner != ctx) return fail(HELM_ERR_STATE, "program belongs to another context");
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(prog->d_pbs);
+    (void)hipFree(prog->d_ks);
+    (void)hipFree(prog->d_lin);
+    prog->s_pbs.release();
+    prog->s_ks.release();
+    prog->s_lin.release();
+    prog->s_rows.release();
+    delete prog;
+    return 0;
+}
+
+static int check_program(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w)
+{
+    if (!ctx || !prog || !w) return fail(HELM_ERR_INVALID, "null argument");
+    if (prog->owner != ctx || w->owner != ctx) return fail(HELM_ERR_STATE, "handle belongs to another context");
+    for (size_t i = 0; i < prog->out.size(); i++) {
+        const int32_t v[4] = {prog->in0[i], prog->in1[i], prog->in2[i], prog->out[i]};
+        for (int q = 0; q < 4; q++)
+            if (v[q] >= w->n_wires || v[q] < -1 || (q == 3 && v[q] < 0))
+                return fail(HELM_ERR_INVALID, "program references wire " + std::to_string(v[q]) + " outside the table");
+    }
+    return 0;
+}
+
+int helm_hip_program_run(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, int64_t level_begin,
+                         int64_t level_end)
+{
+    if (int rc = check_program(ctx, prog, w)) return rc;
+    if (level_begin < 0 || level_end > prog->n_levels || level_begin > level_end)
+        return fail(HELM_ERR_INVALID, "level range out of bounds");
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int64_t l = level_begin; l < level_end; l++) {
+        int rc = run_level_device(ctx, prog->d_pbs + prog->pbs_off[l], prog->pbs_off[l + 1] - prog->pbs_off[l],
+                                  prog->d_ks + prog->ks_off[l], prog->ks_off[l + 1] - prog->ks_off[l],
+                                  prog->d_lin + prog->lin_off[l], prog->lin_off[l + 1] - prog->lin_off[l], w->d, w->d);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int64_t helm_hip_program_chunk_rows(helm_hip_program *prog, int64_t level, int world)
+{
+    if (!prog || level < 0 || level >= prog->n_levels || world <= 0) return -1;
+    const int64_t cnt = prog->off[level + 1] - prog->off[level];
+    return (cnt + world - 1) / world;
+}
+
+int64_t helm_hip_program_level_pbs(helm_hip_program *prog, int64_t level)
+{
+    if (!prog || level < 0 || level >= prog->n_levels) return -1;
+    return prog->pbs_off[level + 1] - prog->pbs_off[level];
+}
+
+int helm_hip_program_run_level_shard(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, int64_t level,
+                                     int rank, int world, void *staging_dev)
+{
+    if (int rc = check_program(ctx, prog, w)) return rc;
+    if (level < 0 || level >= prog->n_levels || world <= 0 || rank < 0 || rank >= world || !staging_dev)
+        return fail(HELM_ERR_INVALID, "bad shard arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t b = prog->off[level], cnt = prog->off[level + 1] - b;
+    const int64_t chunk = (cnt + world - 1) / world;
+    const int64_t g0 = std::min(cnt, chunk * rank), g1 = std::min(cnt, g0 + chunk);
+    const size_t row = (size_t)ctx->P.n + 1;
+    // padding rows of the staging chunk must be defined (they travel through the all-gather)
+    if (g1 - g0 < chunk)
+        HIP_TRY(hipMemsetAsync(static_cast<uint32_t *>(staging_dev) + row * (size_t)(g1 - g0), 0,
+                               row * (size_t)(chunk - (g1 - g0)) * sizeof(uint32_t), ctx->stream));
+    if (g1 == g0) return 0;
+    LevelPlan pl;
+    if (int rc = plan_level(prog->op.data() + b + g0, prog->in0.data() + b + g0, prog->in1.data() + b + g0,
+                            prog->in2.data() + b + g0, g1 - g0, [&](int64_t g) { return (int32_t)g; }, pl))
+        return rc;
+    if (prog->s_pbs.ensure(pl.pbs.size()) || prog->s_ks.ensure(pl.ks.size()) || prog->s_lin.ensure(pl.lin.size()))
+        return fail(HELM_ERR_OOM, "shard job buffers");
+    if (!pl.pbs.empty())
+        HIP_TRY(hipMemcpyAsync(prog->s_pbs.p, pl.pbs.data(), pl.pbs.size() * sizeof(PbsJob), hipMemcpyHostToDevice, ctx->stream));
+    if (!pl.ks.empty())
+        HIP_TRY(hipMemcpyAsync(prog->s_ks.p, pl.ks.data(), pl.ks.size() * sizeof(KsJob), hipMemcpyHostToDevice, ctx->stream));
+    if (!pl.lin.empty())
+        HIP_TRY(hipMemcpyAsync(prog->s_lin.p, pl.lin.data(), pl.lin.size() * sizeof(LinJob), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return run_level_device(ctx, prog->s_pbs.p, (int64_t)pl.pbs.size(), prog->s_ks.p, (int64_t)pl.ks.size(),
+                            prog->s_lin.p, (int64_t)pl.lin.size(), w->d, static_cast<uint32_t *>(staging_dev));
+}
+
+int helm_hip_program_scatter_level(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, int64_t level,
+                                   int world, const void *gathered_dev)
+{
+    if (int rc = check_program(ctx, prog, w)) return rc;
+    if (level < 0 || level >= prog->n_levels || world <= 0 || !gathered_dev)
+        return fail(HELM_ERR_INVALID, "bad scatter arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t b = prog->off[level], cnt = prog->off[level + 1] - b;
+    if (cnt == 0) return 0;
+    const int64_t chunk = (cnt + world - 1) / world;
+    std::vector<int32_t> rows((size_t)(chunk * world), -1);
+    for (int64_t g = 0; g < cnt; g++) rows[(size_t)g] = prog->out[(size_t)(b + g)]; // chunks are contiguous: row g = gate g
+    if (prog->s_rows.ensure(rows.size())) return fail(HELM_ERR_OOM, "scatter rows");
+    HIP_TRY(hipMemcpyAsync(prog->s_rows.p, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)rows.size()), dim3(256), 0, ctx->stream,
+                       static_cast<const uint32_t *>(gathered_dev), prog->s_rows.p, w->d, ctx->P.n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int helm_hip_pbs_batch(helm_hip_ctx *ctx, const uint32_t *lwe_in, const uint32_t *test_vectors, int64_t n_tv,
+                       const int32_t *tv_index, uint32_t *out_big, int64_t count)
+{
+    if (!ctx || !lwe_in || !test_vectors || !tv_index || !out_big || count < 0 || n_tv <= 0)
+        return fail(HELM_ERR_INVALID, "bad argument");
+    if (!ctx->have_bsk) return fail(HELM_ERR_STATE, "bootstrapping key not loaded");
+    if (count == 0) return 0;
+    const helm_hip_params &P = ctx->P;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t row = (size_t)P.n + 1, brow = (size_t)P.k * P.N + 1;
+    std::vector<PbsJob> jobs((size_t)count);
+    for (int64_t g = 0; g < count; g++) {
+        if (tv_index[g] < 0 || tv_index[g] >= n_tv) return fail(HELM_ERR_INVALID, "tv_index out of range");
+        jobs[(size_t)g] = PbsJob{-1, 0, (int32_t)g, -1, -1, tv_index[g]};
+    }
+    uint32_t *d_in = nullptr, *d_tv = nullptr, *d_out = nullptr;
+    PbsJob *d_jobs = nullptr;
+    HIP_TRY(hipMalloc(&d_in, (size_t)count * row * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_tv, (size_t)n_tv * P.N * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_out, (size_t)count * brow * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_jobs, (size_t)count * sizeof(PbsJob)));
+    HIP_TRY(hipMemcpyAsync(d_in, lwe_in, (size_t)count * row * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_tv, test_vectors, (size_t)n_tv * P.N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), (size_t)count * sizeof(PbsJob), hipMemcpyHostToDevice, ctx->stream));
+    {
+        TimedScope t(ctx, &ctx->ev_pbs);
+        HIP_TRY(launch_pbs(ctx, d_jobs, count, nullptr, d_in, d_tv, d_out));
+    }
+    ctx->tacc.pbs_launches++;
+    ctx->tacc.pbs_count += count;
+    HIP_TRY(hipMemcpyAsync(out_big, d_out, (size_t)count * brow * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_in));
+    HIP_TRY(hipFree(d_tv));
+    HIP_TRY(hipFree(d_out));
+    HIP_TRY(hipFree(d_jobs));
+    return 0;
+}
+
+int helm_hip_keyswitch_batch(helm_hip_ctx *ctx, const uint32_t *in_big, uint32_t *out, int64_t count)
+{
+    if (!ctx || !in_big || !out || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
+    if (!ctx->have_ksk) return fail(HELM_ERR_STATE, "keyswitching key not loaded");
+    if (count == 0) return 0;
+    const helm_hip_params &P = ctx->P;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t row = (size_t)P.n + 1, brow = (size_t)P.k * P.N + 1;
+    std::vector<KsJob> jobs((size_t)count);
+    for (int64_t g = 0; g < count; g++) jobs[(size_t)g] = KsJob{(int32_t)g, -1, (int32_t)g, 0u};
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    KsJob *d_jobs = nullptr;
+    HIP_TRY(hipMalloc(&d_in, (size_t)count * brow * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_out, (size_t)count * row * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_jobs, (size_t)count * sizeof(KsJob)));
+    HIP_TRY(hipMemcpyAsync(d_in, in_big, (size_t)count * brow * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), (size_t)count * sizeof(KsJob), hipMemcpyHostToDevice, ctx->stream));
+    {
+        TimedScope t(ctx, &ctx->ev_ks);
+        HIP_TRY(launch_ks(ctx, d_jobs, count, d_in, d_out));
+    }
+    ctx->tacc.ks_launches++;
+    ctx->tacc.ks_count += count;
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)count * row * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_in));
+    HIP_TRY(hipFree(d_out));
+    HIP_TRY(hipFree(d_jobs));
+    return 0;
+}
+
+int helm_hip_ntt_roundtrip(helm_hip_ctx *ctx, const uint32_t *poly_in, uint32_t *poly_out, int64_t count)
+{
+    if (!ctx || !poly_in || !poly_out || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
+    if (count == 0) return 0;
+    const int N = ctx->P.N;
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, (size_t)count * N * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_out, (size_t)count * N * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(d_in, poly_in, (size_t)count * N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (N == 512)
+        hipLaunchKernelGGL(k_ntt_roundtrip<9>, dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in, d_out, ctx->tw_fwd,
+                           ctx->tw_inv, ctx->n_inv);
+    else
+        hipLaunchKernelGGL(k_ntt_roundtrip<10>, dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in, d_out,
+                           ctx->tw_fwd, ctx->tw_inv, ctx->n_inv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(poly_out, d_out, (size_t)count * N * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_in));
+    HIP_TRY(hipFree(d_out));
+    return 0;
+}
+
+int helm_hip_timing_enable(helm_hip_ctx *ctx, int enable)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");
+    ctx->timing = enable != 0;
+    return 0;
+}
+
+int helm_hip_get_timing(helm_hip_ctx *ctx, helm_hip_timing *out, int reset)
+{
+    if (!ctx || !out) return fail(HELM_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    auto drain = [](std::vector<std::pair<hipEvent_t, hipEvent_t>> &l, double &acc) {
+        for (auto &p : l) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) acc += ms;
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        l.clear();
+    };
+    drain(ctx->ev_pbs, ctx->tacc.pbs_ms);
+    drain(ctx->ev_ks, ctx->tacc.ks_ms);
+    drain(ctx->ev_lin, ctx->tacc.linear_ms);
+    *out = ctx->tacc;
+    if (reset) ctx->tacc = helm_hip_timing{};
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,197 @@
+// ntt_fp64.h — exact negacyclic NTT over a 51-bit prime field, computed with the
+// fp64 FMA pipe of CDNA4.
+//
+// Why fp64: measured on MI355X (profiles/r01_ubench_modmul.txt) a complete modular
+// butterfly costs ~34 SIMD-cycles per wave with fp64 FMA error-free products, ~137
+// with a 64-bit Goldilocks multiply and ~64 with two 31-bit Shoup primes: 32x32->64
+// integer multiplies are quarter-rate on gfx950 while v_fma_f64 is half-rate.
+//
+// Every value is an INTEGER held exactly in a double (|v| < 2^53).  Products are
+// formed error-free (h = a*w rounded, l = fma(a,w,-h) its exact error) and reduced
+// with a rounded quotient, so results are exact residues: the transform is an exact
+// NTT, and the polynomial products it yields are bit-identical to schoolbook
+// arithmetic mod 2^32 as long as the true integer result fits in (-p/2, p/2).
+//
+// One wave transforms one polynomial: lane holds E = N/64 coefficients, the log2(N)
+// radix-2 stages are fused into three in-register blocks separated by two
+// wave-private LDS transposes (no workgroup barrier inside a transform).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace helm {
+
+// p = 0x6060002B00001 = 1695446975119361 = 2^20 * 5 * 323380847 + 1, generator 3.
+// p/2 = 0.7529 * 2^50 exceeds the largest exact coefficient any supported
+// parameter set can produce ((k+1) * l * N * B/2 * 2^31 <= 0.75 * 2^50, checked at
+// context creation) while leaving 2^53 / p = 5.31 of headroom for lazy additions.
+constexpr double NTT_P = 1695446975119361.0;
+constexpr double NTT_PINV = 1.0 / NTT_P;
+constexpr uint64_t NTT_P_U64 = 1695446975119361ull;
+constexpr uint64_t NTT_GEN = 3;
+
+// a*w mod p for integers |a| < 2^53, |w| <= p/2.  Result r == a*w (mod p) exactly,
+// |r| <= (0.5 + 0.75 * |a| * 2^-52) * p  (<= 2p for any admissible a).
+__device__ __forceinline__ double mulmod(double a, double w)
+{
+    double h = a * w;
+    double l = __builtin_fma(a, w, -h);
+    double q = __builtin_rint(h * NTT_PINV);
+    double r = __builtin_fma(-q, NTT_P, h);
+    return r + l;
+}
+
+// a mod p, centred: |result| <= (0.5 + eps) * p.
+__device__ __forceinline__ double reduce(double a)
+{
+    double q = __builtin_rint(a * NTT_PINV);
+    return __builtin_fma(-q, NTT_P, a);
+}
+
+// Exact integer in a double (|v| < 2^51) -> v mod 2^32.
+__device__ __forceinline__ uint32_t to_torus32(double v)
+{
+    return (uint32_t)__double2loint(v + 6755399441055744.0 /* 1.5 * 2^52 */);
+}
+
+// Wave-private LDS hand-off: LDS operations of one wave execute in order, so no
+// s_barrier is needed; this only stops the compiler from reordering the accesses.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int LOGN>
+struct Geo {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int LOGE = LOGN - 6;
+    static constexpr int E = 1 << LOGE;           // coefficients per lane
+    static constexpr int BA = (LOGN == 9) ? 3 : 4; // stages in the first block
+    static constexpr int BC = 3;                   // stages in the last block
+    static constexpr int BB = LOGN - BA - BC;      // stages in the middle block
+    static constexpr int XPAD = N + 64;            // padded exchange buffer (doubles)
+    static_assert(LOGN == 9 || LOGN == 10 || LOGN == 11, "supported polynomial sizes");
+    static_assert(BA <= LOGE && BB <= LOGE && BC <= LOGE, "block does not fit in registers");
+
+    // Three register layouts: which coefficient index j lane holds in slot e.
+    __device__ static __forceinline__ int jA(int lane, int e) { return (e << 6) | lane; }
+    __device__ static __forceinline__ int jB(int lane, int e)
+    {
+        return ((lane >> BC) << (BC + LOGE)) | (e << BC) | (lane & ((1 << BC) - 1));
+    }
+    __device__ static __forceinline__ int jC(int lane, int e) { return (lane << LOGE) | e; }
+    // LDS paddings making both sides of each transpose bank-conflict free.
+    __device__ static __forceinline__ int pad1(int j) { return j + ((j >> (LOGN - 3)) << 3); }
+    __device__ static __forceinline__ int pad2(int j) { return j + (j >> LOGE); }
+};
+
+// Fused radix-2 stages acting on stride bits [SB_LO, SB_HI] of the coefficient
+// index, all of which are register-slot bits (slot bit = stride bit - SHIFT).
+// `jbase` is the lane's coefficient index with all slot bits zero.
+// Twiddle of the butterfly on stride bit sb for coefficient j:
+//   table[(N >> (sb+1)) + (j >> (sb+1))], table = bit-reversed powers of psi.
+template <int LOGN, int SHIFT, int SB_HI, int SB_LO>
+__device__ __forceinline__ void fwd_block(double (&x)[Geo<LOGN>::E], const double *__restrict__ tw, int jbase)
+{
+    constexpr int E = Geo<LOGN>::E, N = Geo<LOGN>::N;
+#pragma unroll
+    for (int sb = SB_HI; sb >= SB_LO; sb--) {
+        const int eb = sb - SHIFT;
+#pragma unroll
+        for (int hi = 0; hi < (E >> (eb + 1)); hi++) {
+            const int jh = jbase | (hi << (eb + 1 + SHIFT));
+            const double w = tw[(N >> (sb + 1)) + (jh >> (sb + 1))];
+#pragma unroll
+            for (int lo = 0; lo < (1 << eb); lo++) {
+                const int e0 = (hi << (eb + 1)) | lo, e1 = e0 | (1 << eb);
+                double U = x[e0], V = mulmod(x[e1], w);
+                x[e0] = U + V;
+                x[e1] = U - V;
+            }
+        }
+    }
+}
+
+template <int LOGN, int SHIFT, int SB_LO, int SB_HI>
+__device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const double *__restrict__ tw, int jbase)
+{
+    constexpr int E = Geo<LOGN>::E, N = Geo<LOGN>::N;
+#pragma unroll
+    for (int sb = SB_LO; sb <= SB_HI; sb++) {
+        const int eb = sb - SHIFT;
+        if (sb - SB_LO == 2 && SB_HI - SB_LO == 3) {
+            // 4-stage block: the pure-sum path has doubled twice; recentre.
+#pragma unroll
+            for (int e = 0; e < E; e++) x[e] = reduce(x[e]);
+        }
+#pragma unroll
+        for (int hi = 0; hi < (E >> (eb + 1)); hi++) {
+            const int jh = jbase | (hi << (eb + 1 + SHIFT));
+            const double w = tw[(N >> (sb + 1)) + (jh >> (sb + 1))];
+#pragma unroll
+            for (int lo = 0; lo < (1 << eb); lo++) {
+                const int e0 = (hi << (eb + 1)) | lo, e1 = e0 | (1 << eb);
+                double U = x[e0], V = x[e1];
+                x[e0] = U + V;
+                x[e1] = mulmod(U - V, w);
+            }
+        }
+    }
+}
+
+// Forward negacyclic NTT of one polynomial held by one wave.
+// in : x[e] = coefficient jA(lane,e), |x| <= 0.5p.
+// out: x[e] = transform word at position jC(lane,e) of the bit-reversed output,
+//      |x| <= ~3p (not recentred: the pointwise product absorbs it).
+// xbuf: wave-private LDS scratch of Geo::XPAD doubles.
+template <int LOGN>
+__device__ __forceinline__ void ntt_forward(double (&x)[Geo<LOGN>::E], double *xbuf, const double *__restrict__ tw,
+                                            int lane)
+{
+    using G = Geo<LOGN>;
+    fwd_block<LOGN, 6, LOGN - 1, LOGN - G::BA>(x, tw, G::jA(lane, 0));
+#pragma unroll
+    for (int e = 0; e < G::E; e++) xbuf[G::pad1(G::jA(lane, e))] = reduce(x[e]);
+    wave_sync();
+#pragma unroll
+    for (int e = 0; e < G::E; e++) x[e] = xbuf[G::pad1(G::jB(lane, e))];
+    wave_sync();
+    fwd_block<LOGN, G::BC, G::BC + G::BB - 1, G::BC>(x, tw, G::jB(lane, 0));
+#pragma unroll
+    for (int e = 0; e < G::E; e++) xbuf[G::pad2(G::jB(lane, e))] = reduce(x[e]);
+    wave_sync();
+#pragma unroll
+    for (int e = 0; e < G::E; e++) x[e] = xbuf[G::pad2(G::jC(lane, e))];
+    wave_sync();
+    fwd_block<LOGN, 0, G::BC - 1, 0>(x, tw, G::jC(lane, 0));
+}
+
+// Inverse (without the 1/N factor, which is folded into the bootstrapping key).
+// in : x[e] = transform word at jC(lane,e), |x| <= 0.5p.
+// out: x[e] = coefficient jA(lane,e), exactly centred (|x| <= p/2).
+template <int LOGN>
+__device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *xbuf, const double *__restrict__ twi,
+                                            int lane)
+{
+    using G = Geo<LOGN>;
+    inv_block<LOGN, 0, 0, G::BC - 1>(x, twi, G::jC(lane, 0));
+#pragma unroll
+    for (int e = 0; e < G::E; e++) xbuf[G::pad2(G::jC(lane, e))] = reduce(x[e]);
+    wave_sync();
+#pragma unroll
+    for (int e = 0; e < G::E; e++) x[e] = xbuf[G::pad2(G::jB(lane, e))];
+    wave_sync();
+    inv_block<LOGN, G::BC, G::BC, G::BC + G::BB - 1>(x, twi, G::jB(lane, 0));
+#pragma unroll
+    for (int e = 0; e < G::E; e++) xbuf[G::pad1(G::jB(lane, e))] = reduce(x[e]);
+    wave_sync();
+#pragma unroll
+    for (int e = 0; e < G::E; e++) x[e] = xbuf[G::pad1(G::jA(lane, e))];
+    wave_sync();
+    inv_block<LOGN, 6, LOGN - G::BA, LOGN - 1>(x, twi, G::jA(lane, 0));
+#pragma unroll
+    for (int e = 0; e < G::E; e++) x[e] = reduce(x[e]);
+}
+
+} // namespace helm

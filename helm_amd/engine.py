@@ -1,0 +1,248 @@
+"""Thin object layer over the C ABIs: ClientKey (CPU), ServerKey (GPU engine
+context with keys loaded), DeviceWires (HBM-resident wire table), Program
+(levelised netlist on the device).
+
+Mirrors the roles of tfhe::boolean::{ClientKey, ServerKey} as HELM uses them
+(reference src/bin/helm.rs:241, src/circuit.rs:69-73).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nv
+from ._native import Params, Timing, hip, host, hip_check, client_check
+
+
+def named_params(name):
+    """-> (Params, lwe_noise_std, glwe_noise_std)"""
+    p = Params()
+    a, b = C.c_double(), C.c_double()
+    client_check(host.helm_client_named_params(name.encode(), C.byref(p), C.byref(a), C.byref(b)))
+    return p, a.value, b.value
+
+
+class ClientKey:
+    """Secret keys + the exported server key material (CPU)."""
+
+    def __init__(self, params, lwe_std, glwe_std, seed=1):
+        self.params = params
+        h = nv.vp()
+        client_check(host.helm_client_keygen(C.byref(params), lwe_std, glwe_std, seed, C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def generate(cls, name="boolean_default", seed=1):
+        p, a, b = named_params(name)
+        return cls(p, a, b, seed)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            host.helm_client_key_free(self._h)
+            self._h = None
+
+    def _view(self, fn, count):
+        ptr = fn(self._h)
+        return np.ctypeslib.as_array(ptr, shape=(count,))
+
+    @property
+    def bsk(self):
+        return self._view(host.helm_client_bsk, host.helm_client_bsk_words(self._h))
+
+    @property
+    def ksk(self):
+        return self._view(host.helm_client_ksk, host.helm_client_ksk_words(self._h))
+
+    @property
+    def lwe_secret(self):
+        return self._view(host.helm_client_lwe_secret, self.params.n)
+
+    @property
+    def glwe_secret(self):
+        return self._view(host.helm_client_glwe_secret, self.params.k * self.params.N)
+
+    def encrypt(self, bits):
+        """bool or sequence of bools -> [count, n+1] uint32 (ClientKey::encrypt)."""
+        scalar = np.isscalar(bits) or isinstance(bits, (bool, np.bool_))
+        b = np.ascontiguousarray(np.atleast_1d(np.asarray(bits)).astype(np.uint8))
+        out = np.zeros((len(b), self.params.n + 1), dtype=np.uint32)
+        client_check(host.helm_client_encrypt_bool(self._h, nv.as_u8p(b), len(b), nv.as_u32p(out)))
+        return out[0] if scalar else out
+
+    def decrypt(self, lwe):
+        """[count, n+1] (or one row) -> bool array (ClientKey::decrypt)."""
+        a = np.ascontiguousarray(lwe, dtype=np.uint32)
+        one = a.ndim == 1
+        a2 = a.reshape(-1, self.params.n + 1)
+        out = np.zeros(len(a2), dtype=np.uint8)
+        client_check(host.helm_client_decrypt_bool(self._h, nv.as_u32p(a2), len(a2), nv.as_u8p(out)))
+        return bool(out[0]) if one else out.astype(bool)
+
+    def phase(self, lwe, big=False):
+        dim = self.params.k * self.params.N if big else self.params.n
+        a2 = np.ascontiguousarray(lwe, dtype=np.uint32).reshape(-1, dim + 1)
+        out = np.zeros(len(a2), dtype=np.uint32)
+        client_check(host.helm_client_phase(self._h, nv.as_u32p(a2), len(a2), int(big), nv.as_u32p(out)))
+        return out
+
+
+class ServerKey:
+    """GPU engine context with the bootstrapping and keyswitching keys resident
+    in HBM.  Construction fails (HelmError) when no gfx950 device is usable."""
+
+    def __init__(self, client_key=None, params=None, bsk=None, ksk=None, device=0):
+        self.params = client_key.params if client_key is not None else params
+        h = nv.vp()
+        hip_check(hip.helm_hip_ctx_create(device, C.byref(self.params), C.byref(h)))
+        self._h = h
+        self.device = device
+        if client_key is not None:
+            bsk, ksk = client_key.bsk, client_key.ksk
+        if bsk is not None:
+            bsk = np.ascontiguousarray(bsk, dtype=np.uint32).reshape(-1)
+            hip_check(hip.helm_hip_load_bootstrap_key(self._h, nv.as_u32p(bsk), bsk.size))
+        if ksk is not None:
+            ksk = np.ascontiguousarray(ksk, dtype=np.uint32).reshape(-1)
+            hip_check(hip.helm_hip_load_keyswitch_key(self._h, nv.as_u32p(ksk), ksk.size))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            hip.helm_hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_stream(self, stream_ptr):
+        hip_check(hip.helm_hip_set_stream(self._h, nv.vp(stream_ptr)))
+
+    def sync(self):
+        hip_check(hip.helm_hip_sync(self._h))
+
+    def wires(self, n_wires):
+        return DeviceWires(self, n_wires)
+
+    # primitive batch ops -------------------------------------------------
+    def pbs_batch(self, lwe_in, test_vectors, tv_index=None):
+        p = self.params
+        lwe_in = np.ascontiguousarray(lwe_in, dtype=np.uint32).reshape(-1, p.n + 1)
+        tvs = np.ascontiguousarray(test_vectors, dtype=np.uint32).reshape(-1, p.N)
+        if tv_index is None:
+            tv_index = np.zeros(len(lwe_in), dtype=np.int32)
+        tv_index = np.ascontiguousarray(tv_index, dtype=np.int32)
+        out = np.zeros((len(lwe_in), p.k * p.N + 1), dtype=np.uint32)
+        hip_check(hip.helm_hip_pbs_batch(self._h, nv.as_u32p(lwe_in), nv.as_u32p(tvs), len(tvs), nv.as_i32p(tv_index),
+                                         nv.as_u32p(out), len(lwe_in)))
+        return out
+
+    def keyswitch_batch(self, big):
+        p = self.params
+        big = np.ascontiguousarray(big, dtype=np.uint32).reshape(-1, p.k * p.N + 1)
+        out = np.zeros((len(big), p.n + 1), dtype=np.uint32)
+        hip_check(hip.helm_hip_keyswitch_batch(self._h, nv.as_u32p(big), nv.as_u32p(out), len(big)))
+        return out
+
+    def ntt_roundtrip(self, polys):
+        polys = np.ascontiguousarray(polys, dtype=np.uint32).reshape(-1, self.params.N)
+        out = np.zeros_like(polys)
+        hip_check(hip.helm_hip_ntt_roundtrip(self._h, nv.as_u32p(polys), nv.as_u32p(out), len(polys)))
+        return out
+
+    def timing_enable(self, on=True):
+        hip_check(hip.helm_hip_timing_enable(self._h, int(on)))
+
+    def timing(self, reset=False):
+        t = Timing()
+        hip_check(hip.helm_hip_get_timing(self._h, C.byref(t), int(reset)))
+        return t
+
+
+class DeviceWires:
+    """HBM-resident wire table: n_wires rows of n+1 words."""
+
+    def __init__(self, server_key, n_wires):
+        self.sk = server_key
+        self.n_wires = int(n_wires)
+        h = nv.vp()
+        hip_check(hip.helm_hip_wires_alloc(server_key._h, self.n_wires, C.byref(h)))
+        self._h = h
+
+    def free(self):
+        if getattr(self, "_h", None) and getattr(self.sk, "_h", None):
+            hip.helm_hip_wires_free(self.sk._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        self.free()
+
+    def upload(self, idx, lwe):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        lwe = np.ascontiguousarray(lwe, dtype=np.uint32).reshape(len(idx), self.sk.params.n + 1)
+        hip_check(hip.helm_hip_wires_upload(self.sk._h, self._h, nv.as_i32p(idx), nv.as_u32p(lwe), len(idx)))
+
+    def download(self, idx=None):
+        if idx is None:
+            idx = np.arange(self.n_wires)
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        out = np.zeros((len(idx), self.sk.params.n + 1), dtype=np.uint32)
+        hip_check(hip.helm_hip_wires_download(self.sk._h, self._h, nv.as_i32p(idx), nv.as_u32p(out), len(idx)))
+        return out
+
+    def set_trivial(self, idx, values):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(values), idx.shape).astype(np.uint8))
+        hip_check(hip.helm_hip_wires_set_trivial(self.sk._h, self._h, nv.as_i32p(idx), nv.as_u8p(v), len(idx)))
+
+    def device_ptr(self):
+        p = nv.vp()
+        n = C.c_int64()
+        hip_check(hip.helm_hip_wires_device_ptr(self.sk._h, self._h, C.byref(p), C.byref(n)))
+        return p.value
+
+    def eval_gate_level(self, opcode, in0, in1, in2, out):
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (opcode, in0, in1, in2, out)]
+        hip_check(hip.helm_hip_eval_gate_level(self.sk._h, self._h, *[nv.as_i32p(a) for a in arrs], len(arrs[0])))
+
+
+class Program:
+    """A levelised netlist uploaded once (level_map of reference circuit.rs:174-239)."""
+
+    def __init__(self, server_key, opcode, in0, in1, in2, out, level_offsets):
+        self.sk = server_key
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (opcode, in0, in1, in2, out)]
+        off = np.ascontiguousarray(level_offsets, dtype=np.int64)
+        self.n_levels = len(off) - 1
+        self.level_offsets = off
+        h = nv.vp()
+        hip_check(hip.helm_hip_program_create(server_key._h, *[nv.as_i32p(a) for a in arrs], nv.as_i64p(off),
+                                              self.n_levels, C.byref(h)))
+        self._h = h
+
+    def destroy(self):
+        if getattr(self, "_h", None) and getattr(self.sk, "_h", None):
+            hip.helm_hip_program_destroy(self.sk._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        self.destroy()
+
+    def run(self, wires, level_begin=0, level_end=None):
+        if level_end is None:
+            level_end = self.n_levels
+        hip_check(hip.helm_hip_program_run(self.sk._h, self._h, wires._h, level_begin, level_end))
+
+    def level_pbs(self, level):
+        return int(hip.helm_hip_program_level_pbs(self._h, level))
+
+    def total_pbs(self):
+        return sum(self.level_pbs(l) for l in range(self.n_levels))
+
+    def chunk_rows(self, level, world):
+        return int(hip.helm_hip_program_chunk_rows(self._h, level, world))
+
+    def run_level_shard(self, wires, level, rank, world, staging_ptr):
+        hip_check(hip.helm_hip_program_run_level_shard(self.sk._h, self._h, wires._h, level, rank, world,
+                                                       nv.vp(staging_ptr)))
+
+    def scatter_level(self, wires, level, world, gathered_ptr):
+        hip_check(hip.helm_hip_program_scatter_level(self.sk._h, self._h, wires._h, level, world,
+                                                     nv.vp(gathered_ptr)))

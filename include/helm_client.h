@@ -1,0 +1,63 @@
+/*
+ * helm_client.h — client-side key material, encryption and decryption (CPU).
+ *
+ * In the reference these are the `tfhe` client/server key objects:
+ *   tfhe::boolean::gen_keys()                      reference src/bin/helm.rs:241
+ *   ClientKey::encrypt / ClientKey::decrypt        reference src/circuit.rs:463-476, 558
+ *   concrete-core key generation (feature "gpu")   reference src/bin/helm.rs:154-186
+ * Key generation and (en/de)cryption are client operations and run on the CPU in
+ * the reference too; the server-side hot path is include/helm_hip.h.
+ *
+ * The "server key" is exported in the standard (coefficient) domain in the
+ * layouts include/helm_hip.h documents, ready for helm_hip_load_*_key().
+ * All randomness comes from one seeded xoshiro256** generator so that runs are
+ * reproducible (the reference seeds from the OS; tests/circuit_test.rs:119 uses
+ * a fixed seed for the same reason).
+ */
+#ifndef HELM_CLIENT_H
+#define HELM_CLIENT_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "helm_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct helm_client_key helm_client_key;
+
+/* Named parameter sets.  "boolean_default": tfhe 0.4.1 boolean::DEFAULT_PARAMETERS
+ * (what gen_keys() uses, helm.rs:241) as recalled in SURVEY.md App. B;
+ * "helm_cuda": the set hard-coded at helm.rs:141-146.  Returns 0 or HELM_ERR_INVALID. */
+int helm_client_named_params(const char *name, helm_hip_params *params, double *lwe_noise_std,
+                             double *glwe_noise_std);
+
+const char *helm_client_last_error(void);
+
+/* Generate the LWE secret key (n bits), the GLWE secret key (k*N bits), the
+ * bootstrapping key and the keyswitching key. Noise standard deviations are
+ * relative to the torus (as in tfhe's StandardDev). */
+int helm_client_keygen(const helm_hip_params *params, double lwe_noise_std, double glwe_noise_std,
+                       uint64_t seed, helm_client_key **out);
+void helm_client_key_free(helm_client_key *key);
+
+size_t helm_client_bsk_words(const helm_client_key *key);
+size_t helm_client_ksk_words(const helm_client_key *key);
+const uint32_t *helm_client_bsk(const helm_client_key *key); /* [n][pbs_l][k+1][k+1][N] */
+const uint32_t *helm_client_ksk(const helm_client_key *key); /* [k*N][ks_l][n+1]       */
+/* Secret key bits as 0/1 words (tests and the oracle's decrypt use them). */
+const uint32_t *helm_client_lwe_secret(const helm_client_key *key);  /* n   */
+const uint32_t *helm_client_glwe_secret(const helm_client_key *key); /* k*N */
+
+/* ClientKey::encrypt(bool): rows of n+1 words under the small key. */
+int helm_client_encrypt_bool(helm_client_key *key, const uint8_t *bits, int64_t count, uint32_t *lwe_out);
+/* ClientKey::decrypt: phase < 2^31 => true (reference src/circuit.rs:948). */
+int helm_client_decrypt_bool(const helm_client_key *key, const uint32_t *lwe, int64_t count, uint8_t *bits_out);
+/* Raw phases b - <a,s> (noise measurements). big != 0: ciphertexts under the k*N key. */
+int helm_client_phase(const helm_client_key *key, const uint32_t *lwe, int64_t count, int big, uint32_t *phase_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

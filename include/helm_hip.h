@@ -1,0 +1,198 @@
+/*
+ * helm_hip.h — C ABI of the MI355X-native gate-bootstrap engine.
+ *
+ * This header is the drop-in boundary for HELM's hot path.  In the reference the
+ * boundary is not an FFI but the set of `tfhe` calls issued per gate:
+ *
+ *   reference src/gates.rs:254-275     Gate::evaluate_encrypted ->
+ *        tfhe::boolean::ServerKey::{and,nand,or,nor,xor,xnor,mux,not,trivial_encrypt}
+ *   reference src/circuit.rs:524-543   GateCircuit::evaluate_encrypted: per level,
+ *        gates.par_iter_mut() -> one synchronous ServerKey call per gate
+ *   reference src/circuit.rs:799-872   (feature "gpu", precedent for a batched shape)
+ *        discard_{and,...}_lwe_ciphertext_vector(out, in1, in2, &bsk, &ksk, idx)
+ *
+ * The replacement is level-batched and device-resident: the wire table of
+ * circuit.rs:517-520 (HashMap<String, Arc<RwLock<Ciphertext>>>) lives in HBM and
+ * one call evaluates every gate of a netlist level.  INTEGRATION.md shows the
+ * Rust `extern "C"` block + `impl EvalCircuit` shim a HELM maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative helm_status on failure;
+ *     helm_hip_last_error() returns the message of the calling thread's last
+ *     failure.  Nothing throws or aborts across this ABI.
+ *   - the caller owns all host buffers; the library owns device memory behind the
+ *     opaque handles.  A context is bound to one device and one stream and is not
+ *     re-entrant (one context per host thread, or external locking).
+ *   - level / batch calls are stream-asynchronous; helm_hip_sync() waits.
+ *   - there is NO CPU fallback: without a usable gfx950 device
+ *     helm_hip_ctx_create() fails with HELM_ERR_NO_DEVICE.
+ *
+ * Data layouts (torus_bits = 32: all words are uint32_t, arithmetic mod 2^32)
+ *   LWE ciphertext      n mask words then 1 body word            (n+1 words)
+ *   wire table          n_wires rows of n+1 words                (row-major)
+ *   bootstrapping key   standard (coefficient) domain, as tfhe's
+ *                       LweBootstrapKey: [n][pbs_l][k+1][k+1][N]
+ *                       entry [i][j][r][c][*] = polynomial c of the GLWE row that
+ *                       multiplies digit j (weight 2^(32-pbs_logB*(j+1))) of input
+ *                       polynomial r in GGSW(s_i).
+ *   keyswitching key    [k*N][ks_l][n+1]; entry [t][j] = LWE_small(
+ *                       s_big[t] * 2^(32-ks_logB*(j+1)) )
+ *   "big" LWE           k*N mask words + body (sample-extracted GLWE)
+ *   boolean encoding    true = 1<<29 (+1/8), false = 7<<29 (-1/8)
+ *                       (reference src/circuit.rs:29,33); decrypt = phase < 2^31
+ *                       (src/circuit.rs:948)
+ */
+#ifndef HELM_HIP_H
+#define HELM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct helm_hip_ctx helm_hip_ctx;
+typedef struct helm_hip_wires helm_hip_wires;
+typedef struct helm_hip_program helm_hip_program;
+
+typedef enum {
+    HELM_OK = 0,
+    HELM_ERR_INVALID = -1,    /* bad argument / unsupported parameter set */
+    HELM_ERR_NO_DEVICE = -2,  /* no usable gfx950 device                   */
+    HELM_ERR_HIP = -3,        /* a HIP runtime call failed                 */
+    HELM_ERR_STATE = -4,      /* keys not loaded, handle from other ctx …  */
+    HELM_ERR_OOM = -5
+} helm_status;
+
+/* Runtime crypto parameters.  Replaces the hard-coded parameter choices of
+ * reference src/bin/helm.rs:141-146 (n=512,k=1,N=1024,l=3,logB=7,ks 8/2) and
+ * helm.rs:241 (tfhe::boolean::gen_keys() -> DEFAULT_PARAMETERS). */
+typedef struct {
+    int32_t torus_bits;      /* 32 (64 reserved for LUT / arithmetic mode)   */
+    int32_t n;               /* small LWE dimension                          */
+    int32_t k;               /* GLWE dimension                               */
+    int32_t N;               /* polynomial size: 512 or 1024                 */
+    int32_t pbs_l;           /* bootstrap decomposition level count          */
+    int32_t pbs_logB;        /* bootstrap decomposition base log             */
+    int32_t ks_l;            /* keyswitch decomposition level count          */
+    int32_t ks_logB;         /* keyswitch decomposition base log             */
+    int32_t pbs_order;       /* 0 = bootstrap then keyswitch (wires under the
+                                small key; tfhe boolean default)             */
+    int32_t grouping_factor; /* 1 (multi-bit PBS reserved)                   */
+} helm_hip_params;
+
+/* Gate op-codes = discriminants of `enum GateType`, reference src/gates.rs:23-45,
+ * in declaration order. */
+typedef enum {
+    HELM_GATE_AND = 0, HELM_GATE_DFF = 1, HELM_GATE_LUT = 2, HELM_GATE_MUX = 3,
+    HELM_GATE_NAND = 4, HELM_GATE_NOR = 5, HELM_GATE_NOT = 6, HELM_GATE_OR = 7,
+    HELM_GATE_XNOR = 8, HELM_GATE_XOR = 9, HELM_GATE_BUF = 10,
+    HELM_GATE_CONST_ONE = 11, HELM_GATE_CONST_ZERO = 12,
+    HELM_GATE_MULT = 13, HELM_GATE_ADD = 14, HELM_GATE_SUB = 15, HELM_GATE_DIV = 16,
+    HELM_GATE_SHL = 17, HELM_GATE_SHR = 18, HELM_GATE_COPY = 19
+} helm_gate_op;
+
+const char *helm_hip_last_error(void);
+/* Number of visible HIP devices (does not initialise a device context). */
+int helm_hip_device_count(void);
+
+/* -- context --------------------------------------------------------------- */
+/* Replaces ServerKey construction (reference src/bin/helm.rs:241, 187-192). */
+int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_ctx **out);
+int helm_hip_ctx_destroy(helm_hip_ctx *ctx);
+/* Run on an existing hipStream_t (e.g. torch's current stream); NULL = the
+ * context's own stream. */
+int helm_hip_set_stream(helm_hip_ctx *ctx, void *hip_stream);
+int helm_hip_sync(helm_hip_ctx *ctx);
+
+/* -- keys ------------------------------------------------------------------ */
+/* Replaces convert_lwe_bootstrap_key / convert_lwe_keyswitch_key (reference
+ * src/bin/helm.rs:187-192): standard-domain keys from the host are uploaded and
+ * the BSK is converted on the device to the engine's NTT domain. */
+int helm_hip_load_bootstrap_key(helm_hip_ctx *ctx, const uint32_t *bsk_std, size_t n_words);
+int helm_hip_load_keyswitch_key(helm_hip_ctx *ctx, const uint32_t *ksk, size_t n_words);
+
+/* -- device-resident wire table -------------------------------------------- */
+/* Replaces the HashMap<String, Arc<RwLock<Ciphertext>>> of circuit.rs:517-520. */
+int helm_hip_wires_alloc(helm_hip_ctx *ctx, int64_t n_wires, helm_hip_wires **out);
+int helm_hip_wires_free(helm_hip_ctx *ctx, helm_hip_wires *w);
+/* lwe_host: count rows of n+1 words; row r goes to / comes from wire idx[r]. */
+int helm_hip_wires_upload(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t *idx,
+                          const uint32_t *lwe_host, int64_t count);
+int helm_hip_wires_download(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t *idx,
+                            uint32_t *lwe_host, int64_t count);
+/* ServerKey::trivial_encrypt(value) (circuit.rs:455-458): zero mask, body = encoding. */
+int helm_hip_wires_set_trivial(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t *idx,
+                               const uint8_t *value, int64_t count);
+/* Raw device pointer of the table (for collectives driven by the host). */
+int helm_hip_wires_device_ptr(helm_hip_ctx *ctx, helm_hip_wires *w, void **dev_ptr, int64_t *n_wires);
+
+/* -- one netlist level ----------------------------------------------------- */
+/* Replaces the body of the level loop, reference src/circuit.rs:531-541:
+ * `count` independent gates; gate g reads wires in0[g], in1[g], in2[g] (-1 =
+ * unused) and writes wire out[g].  Operand meaning follows gates.rs:255-274:
+ * binary gates use (in0,in1); MUX is sel=in2 ? in0 : in1; NOT/BUF/DFF use in0.
+ * No gate of the level may read a wire written in the same level (guaranteed by
+ * Circuit::compute_levels, circuit.rs:174-239).  Index arrays are host memory. */
+int helm_hip_eval_gate_level(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t *opcode,
+                             const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                             const int32_t *out, int64_t count);
+
+/* -- whole levelised netlist ("program") ------------------------------------ */
+/* The level_map of circuit.rs:174-239 uploaded once: gates sorted by level,
+ * level_offsets[0..n_levels] delimiting them.  Avoids re-sending index arrays
+ * every level / every cycle. */
+int helm_hip_program_create(helm_hip_ctx *ctx, const int32_t *opcode, const int32_t *in0,
+                            const int32_t *in1, const int32_t *in2, const int32_t *out,
+                            const int64_t *level_offsets, int64_t n_levels,
+                            helm_hip_program **prog);
+int helm_hip_program_destroy(helm_hip_ctx *ctx, helm_hip_program *prog);
+/* Evaluate levels [level_begin, level_end) in order (GateCircuit::evaluate_encrypted,
+ * circuit.rs:506-549). */
+int helm_hip_program_run(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w,
+                         int64_t level_begin, int64_t level_end);
+/* Multi-GPU: this rank evaluates the contiguous slice `rank` of `world` of the
+ * level's gates and packs the slice's output ciphertexts into `staging`
+ * (device memory, chunk_rows(level, world) rows of n+1 words, zero padded).
+ * After an all-gather of the staging buffers (RCCL, driven by the caller),
+ * helm_hip_program_scatter_level() writes all `world` chunks into the wire
+ * table.  Keys and the wire table are replicated on every rank. */
+int64_t helm_hip_program_chunk_rows(helm_hip_program *prog, int64_t level, int world);
+int helm_hip_program_run_level_shard(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w,
+                                     int64_t level, int rank, int world, void *staging_dev);
+int helm_hip_program_scatter_level(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w,
+                                   int64_t level, int world, const void *gathered_dev);
+/* Number of programmable bootstraps a level costs (binary gate 1, MUX 2, others 0). */
+int64_t helm_hip_program_level_pbs(helm_hip_program *prog, int64_t level);
+
+/* -- primitive batch ops (tests, LUT / integer layers) ---------------------- */
+/* Host-buffer convenience forms; each is the batched equivalent of one tfhe
+ * primitive.  lwe_in: count x (n+1).  test_vectors: n_tv x N (body polynomial of
+ * the accumulator); tv_index[g] selects one per ciphertext.  out_big: count x (k*N+1). */
+int helm_hip_pbs_batch(helm_hip_ctx *ctx, const uint32_t *lwe_in, const uint32_t *test_vectors,
+                       int64_t n_tv, const int32_t *tv_index, uint32_t *out_big, int64_t count);
+/* in_big: count x (k*N+1) -> out: count x (n+1) */
+int helm_hip_keyswitch_batch(helm_hip_ctx *ctx, const uint32_t *in_big, uint32_t *out, int64_t count);
+/* Forward-transform one polynomial of N uint32 (as signed) and return the
+ * engine's NTT-domain words, then invert: out[t] == in[t] (round-trip self test
+ * of the fp64 NTT; used by tests). */
+int helm_hip_ntt_roundtrip(helm_hip_ctx *ctx, const uint32_t *poly_in, uint32_t *poly_out, int64_t count);
+
+/* -- timing ----------------------------------------------------------------- */
+typedef struct {
+    double pbs_ms;      /* accumulated device time in the blind-rotate kernel */
+    double ks_ms;       /* ... keyswitch kernel                               */
+    double linear_ms;   /* ... NOT/BUF/const kernel                           */
+    int64_t pbs_launches, pbs_count; /* launches, bootstraps                   */
+    int64_t ks_launches, ks_count;
+} helm_hip_timing;
+/* When enabled, HIP events on the context's stream bracket each kernel launch
+ * (adds a sync per get_timing call, not per launch). */
+int helm_hip_timing_enable(helm_hip_ctx *ctx, int enable);
+int helm_hip_get_timing(helm_hip_ctx *ctx, helm_hip_timing *out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HELM_HIP_H */

@@ -1,0 +1,139 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+ctypes bindings of oracle/liborc.so, the plain-C restatement of the TFHE
+gate-bootstrap that HELM reaches through `tfhe::boolean::ServerKey`
+(reference src/gates.rs:254-275).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this package; helm_amd/ never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+AND, DFF, LUT, MUX, NAND, NOR, NOT, OR, XNOR, XOR, BUF, CONST_ONE, CONST_ZERO = range(13)
+
+
+class Params(C.Structure):
+    _fields_ = [(f, C.c_int32) for f in ("n", "k", "N", "pbs_l", "pbs_logB", "ks_l", "ks_logB")]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liborc.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        u32p = C.POINTER(C.c_uint32)
+        i32p = C.POINTER(C.c_int32)
+        L.orc_bsk_ntt_new.restype = C.c_void_p
+        L.orc_bsk_ntt_new.argtypes = [C.POINTER(Params), u32p]
+        L.orc_bsk_ntt_free.argtypes = [C.c_void_p]
+        L.orc_gate.argtypes = [C.POINTER(Params), u32p, C.c_void_p, u32p, C.c_int, u32p, u32p, u32p, u32p]
+        L.orc_eval_level.argtypes = [C.POINTER(Params), u32p, C.c_void_p, u32p, u32p, i32p, i32p, i32p, i32p, i32p,
+                                     C.c_int, C.c_int]
+        L.orc_bootstrap_noks.argtypes = [C.POINTER(Params), u32p, C.c_void_p, u32p, u32p, u32p]
+        L.orc_keyswitch.argtypes = [C.POINTER(Params), u32p, u32p, u32p]
+        L.orc_gate_lincomb.argtypes = [C.c_int, C.c_int, C.c_int, u32p, u32p, u32p, u32p]
+        L.orc_extprod_add.argtypes = [C.POINTER(Params), u32p, C.c_void_p, C.c_int, u32p, u32p]
+        L.orc_phase.restype = C.c_uint32
+        L.orc_phase.argtypes = [C.c_int, u32p, u32p]
+        L.orc_modswitch.restype = C.c_uint32
+        L.orc_modswitch.argtypes = [C.c_uint32, C.c_int]
+        L.orc_decompose.argtypes = [C.c_uint32, C.c_int, C.c_int, i32p]
+        L.orc_max_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _u32(a):
+    if a is None:
+        return None
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _i32(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Oracle:
+    """Server-side evaluation with a given (bsk, ksk), both in the standard
+    domain layouts documented in include/helm_hip.h."""
+
+    def __init__(self, params, bsk_std, ksk, use_ntt=True):
+        self.p = Params(*[int(x) for x in params])
+        self.bsk = np.ascontiguousarray(bsk_std, dtype=np.uint32)
+        self.ksk = np.ascontiguousarray(ksk, dtype=np.uint32)
+        self._ntt = lib().orc_bsk_ntt_new(C.byref(self.p), _u32(self.bsk)) if use_ntt else None
+
+    def __del__(self):
+        if getattr(self, "_ntt", None):
+            lib().orc_bsk_ntt_free(self._ntt)
+            self._ntt = None
+
+    def gate(self, op, in0, in1=None, in2=None):
+        out = np.zeros(self.p.n + 1, dtype=np.uint32)
+        lib().orc_gate(C.byref(self.p), _u32(self.bsk), self._ntt, _u32(self.ksk), int(op), _u32(in0), _u32(in1),
+                       _u32(in2), _u32(out))
+        return out
+
+    def bootstrap_noks(self, lwe, tv):
+        out = np.zeros(self.p.k * self.p.N + 1, dtype=np.uint32)
+        lib().orc_bootstrap_noks(C.byref(self.p), _u32(self.bsk), self._ntt, _u32(lwe), _u32(tv), _u32(out))
+        return out
+
+    def keyswitch(self, big):
+        out = np.zeros(self.p.n + 1, dtype=np.uint32)
+        lib().orc_keyswitch(C.byref(self.p), _u32(self.ksk), _u32(big), _u32(out))
+        return out
+
+    def eval_level(self, wires, opcode, in0, in1, in2, outw, nthreads=0):
+        """In-place on `wires` ([n_wires, n+1] uint32)."""
+        assert wires.dtype == np.uint32 and wires.flags["C_CONTIGUOUS"]
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (opcode, in0, in1, in2, outw)]
+        lib().orc_eval_level(C.byref(self.p), _u32(self.bsk), self._ntt, _u32(self.ksk), _u32(wires),
+                             *[_i32(a) for a in arrs], len(arrs[0]), int(nthreads))
+
+    def extprod_add(self, i, diff, acc):
+        bsk_i = self.bsk.reshape(self.p.n, -1)[i]
+        lib().orc_extprod_add(C.byref(self.p), _u32(np.ascontiguousarray(bsk_i)), self._ntt, int(i), _u32(diff),
+                              _u32(acc))
+
+
+def lincomb(n, op, which, in0, in1, in2=None):
+    out = np.zeros(n + 1, dtype=np.uint32)
+    lib().orc_gate_lincomb(n, int(op), int(which), _u32(in0), _u32(in1), _u32(in2), _u32(out))
+    return out
+
+
+def phase(sk_bits, ct):
+    sk = np.ascontiguousarray(sk_bits, dtype=np.uint32)
+    return int(lib().orc_phase(len(sk), _u32(sk), _u32(ct)))
+
+
+def decrypt_bool(sk_bits, ct):
+    return phase(sk_bits, ct) < (1 << 31)
+
+
+def modswitch(x, log2_2N):
+    return int(lib().orc_modswitch(int(x), int(log2_2N)))
+
+
+def decompose(x, logB, l):
+    d = np.zeros(l, dtype=np.int32)
+    lib().orc_decompose(int(x), int(logB), int(l), _i32(d))
+    return d
+
+
+def max_threads():
+    return int(lib().orc_max_threads())

@@ -1,0 +1,148 @@
+"""GPU parity: the HIP path (through the C ABI) must be BIT-EXACT with the CPU
+oracle on the same keys and inputs, and decrypt to the plaintext truth tables the
+reference's own tests pin (reference tests/gates_test.rs:82-107)."""
+import numpy as np
+import pytest
+
+import helm_amd
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+GATES2 = {
+    oracle.AND: lambda a, b: a & b,
+    oracle.OR: lambda a, b: a | b,
+    oracle.NAND: lambda a, b: 1 - (a & b),
+    oracle.NOR: lambda a, b: 1 - (a | b),
+    oracle.XOR: lambda a, b: a ^ b,
+    oracle.XNOR: lambda a, b: 1 - (a ^ b),
+}
+
+
+@pytest.fixture(scope="module", params=["toy", "toy_k2", "toy_1024"])
+def small(request):
+    ck = helm_amd.ClientKey.generate(request.param, seed=11)
+    sk = helm_amd.ServerKey(ck)
+    orc = oracle.Oracle(ck.params.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True)
+    yield ck, sk, orc
+    sk.close()
+
+
+def test_ntt_roundtrip(small):
+    ck, sk, _ = small
+    rng = np.random.default_rng(1)
+    polys = rng.integers(0, 2**32, size=(64, ck.params.N), dtype=np.uint32)
+    polys[0] = 0
+    polys[1] = 0x80000000
+    polys[2] = 0x7FFFFFFF
+    out = sk.ntt_roundtrip(polys)
+    assert np.array_equal(out, polys)
+
+
+def test_pbs_batch_bit_exact(small):
+    ck, sk, orc = small
+    p = ck.params
+    rng = np.random.default_rng(2)
+    lwe = rng.integers(0, 2**32, size=(6, p.n + 1), dtype=np.uint32)
+    lwe[0] = ck.encrypt(True)
+    lwe[1] = ck.encrypt(False)
+    lwe[2, :] = 0          # all a_i = 0: every CMUX skipped
+    tvs = rng.integers(0, 2**32, size=(2, p.N), dtype=np.uint32)
+    tvs[0] = 1 << 29
+    idx = np.array([0, 0, 1, 1, 0, 1], dtype=np.int32)
+    got = sk.pbs_batch(lwe, tvs, idx)
+    for g in range(len(lwe)):
+        exp = orc.bootstrap_noks(lwe[g], tvs[idx[g]])
+        assert np.array_equal(got[g], exp), f"ciphertext {g} differs"
+    ph = ck.phase(got[:2], big=True).astype(np.int64)
+    assert abs(ph[0] - (1 << 29)) < (1 << 24) and abs(ph[1] - (7 << 29)) < (1 << 24)
+
+
+def test_keyswitch_batch_bit_exact(small):
+    ck, sk, orc = small
+    p = ck.params
+    rng = np.random.default_rng(3)
+    big = rng.integers(0, 2**32, size=(5, p.k * p.N + 1), dtype=np.uint32)
+    big[0] = 0
+    big[1] = 0xFFFFFFFF
+    got = sk.keyswitch_batch(big)
+    for g in range(len(big)):
+        assert np.array_equal(got[g], orc.keyswitch(big[g]))
+
+
+def test_gate_level_bit_exact_and_truth_tables(small):
+    ck, sk, orc = small
+    p = ck.params
+    # wires 0,1 = enc(false), enc(true); 2 = trivial true; outputs from 3
+    ct = ck.encrypt([False, True])
+    ops, i0, i1, i2, exp_bits = [], [], [], [], []
+    for op, f in GATES2.items():
+        for a in (0, 1):
+            for b in (0, 1):
+                ops.append(op); i0.append(a); i1.append(b); i2.append(-1); exp_bits.append(f(a, b))
+    for s in (0, 1):
+        for a in (0, 1):
+            for b in (0, 1):
+                ops.append(oracle.MUX); i0.append(a); i1.append(b); i2.append(s); exp_bits.append(a if s else b)
+    for a in (0, 1):
+        ops.append(oracle.NOT); i0.append(a); i1.append(-1); i2.append(-1); exp_bits.append(1 - a)
+        ops.append(oracle.BUF); i0.append(a); i1.append(-1); i2.append(-1); exp_bits.append(a)
+        ops.append(oracle.DFF); i0.append(a); i1.append(-1); i2.append(-1); exp_bits.append(a)
+    ops += [oracle.CONST_ONE, oracle.CONST_ZERO]; i0 += [-1, -1]; i1 += [-1, -1]; i2 += [-1, -1]; exp_bits += [1, 0]
+    # AND with a trivial operand
+    ops.append(oracle.AND); i0.append(1); i1.append(2); i2.append(-1); exp_bits.append(1)
+    n_g = len(ops)
+    outs = np.arange(3, 3 + n_g, dtype=np.int32)
+    n_w = 3 + n_g
+    w = sk.wires(n_w)
+    w.upload([0, 1], ct)
+    w.set_trivial([2], [1])
+    w.eval_gate_level(ops, i0, i1, i2, outs)
+    got = w.download()
+    ref = np.zeros((n_w, p.n + 1), dtype=np.uint32)
+    ref[0:2] = ct
+    ref[2, p.n] = 1 << 29
+    orc.eval_level(ref, ops, i0, i1, i2, outs)
+    assert np.array_equal(got[:3], ref[:3])
+    for g in range(n_g):
+        assert np.array_equal(got[3 + g], ref[3 + g]), f"gate {g} (op {ops[g]}) differs from the oracle"
+    dec = ck.decrypt(got[3:])
+    assert list(dec.astype(int)) == exp_bits
+
+
+@pytest.mark.parametrize("name", ["boolean_default", "helm_cuda"])
+def test_full_parameter_sets(name):
+    """Full-size parameter sets: tfhe boolean DEFAULT (helm.rs:241) and the set
+    hard-coded at helm.rs:141-146.  A few gates bit-exact vs the oracle, plus
+    decrypted truth tables for all of them."""
+    ck = helm_amd.ClientKey.generate(name, seed=5)
+    p = ck.params
+    sk = helm_amd.ServerKey(ck)
+    orc = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True)
+    ct = ck.encrypt([False, True])
+    ops, i0, i1, i2, exp_bits = [], [], [], [], []
+    for op, f in GATES2.items():
+        for a in (0, 1):
+            for b in (0, 1):
+                ops.append(op); i0.append(a); i1.append(b); i2.append(-1); exp_bits.append(f(a, b))
+    for s in (0, 1):
+        for a in (0, 1):
+            for b in (0, 1):
+                ops.append(oracle.MUX); i0.append(a); i1.append(b); i2.append(s); exp_bits.append(a if s else b)
+    n_g = len(ops)
+    outs = np.arange(2, 2 + n_g, dtype=np.int32)
+    w = sk.wires(2 + n_g)
+    w.upload([0, 1], ct)
+    w.eval_gate_level(ops, i0, i1, i2, outs)
+    got = w.download()
+    dec = ck.decrypt(got[2:])
+    assert list(dec.astype(int)) == exp_bits
+    # bit-exact on a subset (the CPU oracle takes ~0.1-0.3 s per bootstrap)
+    sub = [0, 5, 10, 15, 20, 23, 24, 31]
+    ref = np.zeros_like(got)
+    ref[0:2] = ct
+    orc.eval_level(ref, [ops[g] for g in sub], [i0[g] for g in sub], [i1[g] for g in sub], [i2[g] for g in sub],
+                   [outs[g] for g in sub])
+    for g in sub:
+        assert np.array_equal(got[2 + g], ref[2 + g]), f"gate {g} differs from the oracle"
+    sk.close()
