@@ -20,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace helm;
@@ -105,21 +106,29 @@ __device__ __forceinline__ void decompose(uint32_t x, int logB, int (&dig)[L])
 
 // ------------------------------------------------------------------------------------
 // k_pbs: one workgroup = one bootstrap; wave p owns accumulator polynomial p.
-// Dynamic LDS (one array, see layout below).
+//
+// Per CMUX step, wave p: rotates/subtracts its polynomial (LDS), decomposes it into L
+// digit polynomials, transforms them (L interleaved NTTs, wave-private LDS transposes),
+// multiplies by its (k+1)*L key polynomials (prefetched one step ahead into registers),
+// hands the K partial sums that belong to other waves over through LDS (the only two
+// workgroup barriers of the step), inverse-transforms its own sum and accumulates.
+// TWREG: keep this lane's twiddles in registers (N = 512) or read them from an LDS copy
+// of the tables (N = 1024, where registers are needed for the key prefetch).
 // ------------------------------------------------------------------------------------
-template <int LOGN, int K, int L>
+template <int LOGN, int K, int L, bool TWREG>
 struct PbsLds {
     using G = Geo<LOGN>;
     static constexpr int K1 = K + 1;
+    static constexpr int MAX_SMALL_N = 1024;
     static constexpr size_t X_OFF = 0;                                          // double [K1][L][XPAD]
     static constexpr size_t R_OFF = X_OFF + sizeof(double) * K1 * L * G::XPAD;  // double [K1][K][N]
-    static constexpr size_t ACC_OFF = R_OFF + sizeof(double) * K1 * K * G::N;   // u32 [K1][N]
-    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint32_t) * K1 * G::N;    // u32 [n+1] (n <= MAX_SMALL_N)
-    static constexpr int MAX_SMALL_N = 1024;
+    static constexpr size_t TW_OFF = R_OFF + sizeof(double) * K1 * K * G::N;    // double [2][N] (if !TWREG)
+    static constexpr size_t ACC_OFF = TW_OFF + (TWREG ? 0 : sizeof(double) * 2 * G::N); // u32 [K1][N]
+    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint32_t) * K1 * G::N;    // u32 [n+1]
     static constexpr size_t BYTES = MS_OFF + sizeof(uint32_t) * (MAX_SMALL_N + 1);
 };
 
-template <int LOGN, int K, int L>
+template <int LOGN, int K, int L, bool TWREG>
 __global__ __launch_bounds__(64 * (K + 1)) void k_pbs(const PbsJob *__restrict__ jobs,
                                                       const uint32_t *__restrict__ wires,  // rows of n+1
                                                       const uint32_t *__restrict__ raw_in, // rows of n+1 (op == -1)
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(64 * (K + 1)) void k_pbs(const PbsJob *__restrict__
                                                       int n, int logB)
 {
     using G = Geo<LOGN>;
-    using S = PbsLds<LOGN, K, L>;
+    using S = PbsLds<LOGN, K, L, TWREG>;
     constexpr int N = G::N, E = G::E, K1 = K + 1;
     extern __shared__ __align__(16) unsigned char smem[];
     double *X = reinterpret_cast<double *>(smem + S::X_OFF);
@@ -160,6 +169,21 @@ __global__ __launch_bounds__(64 * (K + 1)) void k_pbs(const PbsJob *__restrict__
             MS[i] = modswitch(v, LOGN + 1);
         }
     }
+    // ---- twiddles: registers, or an LDS copy of both tables --------------------------
+    using TwF = typename std::conditional<TWREG, TwReg<G::NTW>, TwMem>::type;
+    TwF twf, twi;
+    if constexpr (TWREG) {
+        tw_fill_forward<LOGN>(twf, tw_fwd, lane);
+        tw_fill_inverse<LOGN>(twi, tw_inv, lane);
+    } else {
+        double *TW = reinterpret_cast<double *>(smem + S::TW_OFF);
+        for (int i = tid; i < N; i += 64 * K1) {
+            TW[i] = tw_fwd[i];
+            TW[N + i] = tw_inv[i];
+        }
+        twf.t = TW;
+        twi.t = TW + N;
+    }
     __syncthreads();
 
     // ---- accumulator init: (0,...,0, X^{-b~} * tv) ------------------------------------
@@ -181,35 +205,52 @@ __global__ __launch_bounds__(64 * (K + 1)) void k_pbs(const PbsJob *__restrict__
             acc_p[j] = v;
         }
     }
-    wave_sync();
+    lds_wave_sync();
 
     double *xb = X + (size_t)p * L * G::XPAD; // this wave's L exchange buffers
-    const size_t bsk_step = (size_t)K1 * K1 * L * N; // doubles per LWE coefficient
-    const size_t bsk_lev = (size_t)N;                // doubles per polynomial
+    // key words of step i for this wave: [c][lev][e/2][lane] as double2
+    const size_t bsk_step = (size_t)K1 * K1 * L * (N / 2); // double2 per LWE coefficient
+    const double2 *bsk_p = reinterpret_cast<const double2 *>(bsk) + (size_t)p * K1 * L * (N / 2) + lane;
+    double2 bw[K1][L][E / 2];
+    auto prefetch = [&](int i) {
+        const double2 *bp = bsk_p + (size_t)i * bsk_step;
+#pragma unroll
+        for (int c = 0; c < K1; c++)
+#pragma unroll
+            for (int lev = 0; lev < L; lev++)
+#pragma unroll
+                for (int e2 = 0; e2 < E / 2; e2++) bw[c][lev][e2] = bp[((c * L + lev) * (E / 2) + e2) * 64];
+    };
+    auto next_nonzero = [&](int i) {
+        while (i < n && __builtin_amdgcn_readfirstlane((int)MS[i]) == 0) i++;
+        return i;
+    };
 
     // ---- blind rotation: acc += BSK_i (x) (X^{a_i} acc - acc) -------------------------
-    for (int i = 0; i < n; i++) {
+    int i = next_nonzero(0);
+    if (i < n) prefetch(i);
+    while (i < n) {
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
-        if (a == 0) continue; // uniform over the workgroup
 
         // (X^a acc_p - acc_p), decomposed into L digit polynomials
         double x[L][E];
+        {
+            uint32_t rot[E];
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const int j = G::jA(lane, e);
-            const int src = (j - a) & (2 * N - 1);
-            uint32_t v = acc_p[src & (N - 1)];
-            if (src >= N) v = 0u - v;
-            int dig[L];
-            decompose<L>(v - accr[e], logB, dig);
+            for (int e = 0; e < E; e++) rot[e] = acc_p[(G::jA(lane, e) - a) & (N - 1)];
 #pragma unroll
-            for (int lev = 0; lev < L; lev++) x[lev][e] = (double)dig[lev];
+            for (int e = 0; e < E; e++) {
+                const int src = (G::jA(lane, e) - a) & (2 * N - 1);
+                const uint32_t v = src >= N ? 0u - rot[e] : rot[e];
+                int dig[L];
+                decompose<L>(v - accr[e], logB, dig);
+#pragma unroll
+                for (int lev = 0; lev < L; lev++) x[lev][e] = (double)dig[lev];
+            }
         }
-#pragma unroll
-        for (int lev = 0; lev < L; lev++) ntt_forward<LOGN>(x[lev], xb + lev * G::XPAD, tw_fwd, lane);
+        ntt_forward<LOGN, L>(x, xb, twf, lane);
 
         // pointwise: partial[c] = sum_lev x[lev] * BSK_i[p][c][lev]
-        const double2 *bp = reinterpret_cast<const double2 *>(bsk + (size_t)i * bsk_step + (size_t)p * K1 * L * bsk_lev);
         double mine[E];
 #pragma unroll
         for (int c = 0; c < K1; c++) {
@@ -219,9 +260,8 @@ __global__ __launch_bounds__(64 * (K + 1)) void k_pbs(const PbsJob *__restrict__
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                 for (int lev = 0; lev < L; lev++) {
-                    const double2 w = bp[((size_t)(c * L + lev) * (E / 2) + e2) * 64 + lane];
-                    s0 += mulmod(x[lev][2 * e2], w.x);
-                    s1 += mulmod(x[lev][2 * e2 + 1], w.y);
+                    s0 += mulmod(x[lev][2 * e2], bw[c][lev][e2].x);
+                    s1 += mulmod(x[lev][2 * e2 + 1], bw[c][lev][e2].y);
                 }
                 part[2 * e2] = reduce(s0);
                 part[2 * e2 + 1] = reduce(s1);
@@ -236,7 +276,12 @@ __global__ __launch_bounds__(64 * (K + 1)) void k_pbs(const PbsJob *__restrict__
                 for (int e = 0; e < E; e++) dst[e * 64 + lane] = part[e];
             }
         }
-        __syncthreads();
+        // key words of the next step: in flight during the exchange, the inverse
+        // transform and the next step's forward transforms
+        const int inext = next_nonzero(i + 1);
+        if (inext < n) prefetch(inext);
+
+        lds_block_sync();
 #pragma unroll
         for (int q = 0; q < K1; q++) {
             if (q == p) continue;
@@ -246,15 +291,16 @@ __global__ __launch_bounds__(64 * (K + 1)) void k_pbs(const PbsJob *__restrict__
         }
 #pragma unroll
         for (int e = 0; e < E; e++) mine[e] = reduce(mine[e]);
-        __syncthreads(); // R may be overwritten by the next step
+        lds_block_sync(); // R may be overwritten by the next step
 
-        ntt_inverse<LOGN>(mine, xb, tw_inv, lane);
+        ntt_inverse<LOGN>(mine, xb, twi, lane);
 #pragma unroll
         for (int e = 0; e < E; e++) {
             accr[e] += to_torus32(mine[e]);
             acc_p[G::jA(lane, e)] = accr[e];
         }
-        wave_sync();
+        lds_wave_sync();
+        i = inext;
     }
 
     // ---- sample extract (coefficient 0): wave p writes its own polynomial -------------
@@ -385,15 +431,15 @@ __global__ __launch_bounds__(64) void k_bsk_convert(const uint32_t *__restrict__
     const int r = (poly / K1) % K1;
     const int lev = (poly / ((size_t)K1 * K1)) % L;
     const size_t i = poly / ((size_t)K1 * K1 * L);
-    double x[E];
+    double x[1][E];
 #pragma unroll
-    for (int e = 0; e < E; e++) x[e] = (double)(int32_t)src[poly * N + G::jA(lane, e)];
+    for (int e = 0; e < E; e++) x[0][e] = (double)(int32_t)src[poly * N + G::jA(lane, e)];
     // |x| <= 2^31: far below p/2, so the digit-sized input bound of ntt_forward holds
-    ntt_forward<LOGN>(x, xbuf, tw_fwd, lane);
+    ntt_forward<LOGN, 1>(x, xbuf, TwMem{tw_fwd}, lane);
     const size_t dpoly = ((i * K1 + r) * K1 + c) * L + lev;
     double *d = dst + dpoly * N;
 #pragma unroll
-    for (int e = 0; e < E; e++) d[((e >> 1) * 64 + lane) * 2 + (e & 1)] = reduce(mulmod(x[e], n_inv));
+    for (int e = 0; e < E; e++) d[((e >> 1) * 64 + lane) * 2 + (e & 1)] = reduce(mulmod(x[0][e], n_inv));
 }
 
 // NTT self-test: forward, scale, inverse; must reproduce the input exactly.
@@ -406,15 +452,15 @@ __global__ __launch_bounds__(64) void k_ntt_roundtrip(const uint32_t *__restrict
     constexpr int N = G::N, E = G::E;
     __shared__ double xbuf[G::XPAD];
     const int lane = threadIdx.x;
-    double x[E];
+    double x[1][E];
 #pragma unroll
-    for (int e = 0; e < E; e++) x[e] = (double)(int32_t)src[(size_t)blockIdx.x * N + G::jA(lane, e)];
-    ntt_forward<LOGN>(x, xbuf, tw_fwd, lane);
+    for (int e = 0; e < E; e++) x[0][e] = (double)(int32_t)src[(size_t)blockIdx.x * N + G::jA(lane, e)];
+    ntt_forward<LOGN, 1>(x, xbuf, TwMem{tw_fwd}, lane);
 #pragma unroll
-    for (int e = 0; e < E; e++) x[e] = reduce(mulmod(x[e], n_inv));
-    ntt_inverse<LOGN>(x, xbuf, tw_inv, lane);
+    for (int e = 0; e < E; e++) x[0][e] = reduce(mulmod(x[0][e], n_inv));
+    ntt_inverse<LOGN>(x[0], xbuf, TwMem{tw_inv}, lane);
 #pragma unroll
-    for (int e = 0; e < E; e++) dst[(size_t)blockIdx.x * N + G::jA(lane, e)] = to_torus32(x[e]);
+    for (int e = 0; e < E; e++) dst[(size_t)blockIdx.x * N + G::jA(lane, e)] = to_torus32(x[0][e]);
 }
 
 // ------------------------------------------------------------------------------------
@@ -579,13 +625,13 @@ static int plan_level(const int32_t *op, const int32_t *in0, const int32_t *in1,
     return 0;
 }
 
-template <int LOGN, int K, int L>
+template <int LOGN, int K, int L, bool TWREG = (LOGN == 9)>
 static hipError_t launch_pbs_t(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
                                const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
 {
-    using S = PbsLds<LOGN, K, L>;
+    using S = PbsLds<LOGN, K, L, TWREG>;
     static bool attr_done[64] = {false};
-    auto kern = k_pbs<LOGN, K, L>;
+    auto kern = k_pbs<LOGN, K, L, TWREG>;
     if (!attr_done[ctx->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES);

@@ -14,7 +14,9 @@
 //
 // One wave transforms one polynomial: lane holds E = N/64 coefficients, the log2(N)
 // radix-2 stages are fused into three in-register blocks separated by two
-// wave-private LDS transposes (no workgroup barrier inside a transform).
+// wave-private LDS transposes (no workgroup barrier inside a transform).  Several
+// polynomials of one wave are transformed together so that their LDS round trips
+// and fp64 dependency chains overlap.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -55,11 +57,28 @@ __device__ __forceinline__ uint32_t to_torus32(double v)
 }
 
 // Wave-private LDS hand-off: LDS operations of one wave execute in order, so no
-// s_barrier is needed; this only stops the compiler from reordering the accesses.
-__device__ __forceinline__ void wave_sync()
+// s_barrier is needed; the LDS-only fence just stops the compiler from reordering
+// the accesses (global loads in flight are NOT affected, unlike __syncthreads()).
+__device__ __forceinline__ void lds_wave_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
+}
+
+// Workgroup barrier ordering LDS only: global prefetches stay in flight across it.
+__device__ __forceinline__ void lds_block_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// twiddles one lane needs for a block: sum over its stages of E >> (eb+1)
+constexpr int ntw_count(int E, int shift, int sb_lo, int sb_hi)
+{
+    int c = 0;
+    for (int sb = sb_lo; sb <= sb_hi; sb++) c += E >> (sb - shift + 1);
+    return c;
 }
 
 template <int LOGN>
@@ -74,6 +93,11 @@ struct Geo {
     static_assert(LOGN == 9 || LOGN == 10 || LOGN == 11, "supported polynomial sizes");
     static_assert(BA <= LOGE && BB <= LOGE && BC <= LOGE, "block does not fit in registers");
 
+    static constexpr int TWA = ntw_count(E, 6, LOGN - BA, LOGN - 1);
+    static constexpr int TWB = ntw_count(E, BC, BC, BC + BB - 1);
+    static constexpr int TWC = ntw_count(E, 0, 0, BC - 1);
+    static constexpr int NTW = TWA + TWB + TWC; // per direction
+
     // Three register layouts: which coefficient index j lane holds in slot e.
     __device__ static __forceinline__ int jA(int lane, int e) { return (e << 6) | lane; }
     __device__ static __forceinline__ int jB(int lane, int e)
@@ -86,37 +110,88 @@ struct Geo {
     __device__ static __forceinline__ int pad2(int j) { return j + (j >> LOGE); }
 };
 
-// Fused radix-2 stages acting on stride bits [SB_LO, SB_HI] of the coefficient
-// index, all of which are register-slot bits (slot bit = stride bit - SHIFT).
-// `jbase` is the lane's coefficient index with all slot bits zero.
-// Twiddle of the butterfly on stride bit sb for coefficient j:
-//   table[(N >> (sb+1)) + (j >> (sb+1))], table = bit-reversed powers of psi.
-template <int LOGN, int SHIFT, int SB_HI, int SB_LO>
-__device__ __forceinline__ void fwd_block(double (&x)[Geo<LOGN>::E], const double *__restrict__ tw, int jbase)
+// Twiddle sources.  Twiddle of the butterfly on stride bit sb for coefficient j is
+// table[(N >> (sb+1)) + (j >> (sb+1))] (table = bit-reversed powers of psi).
+// TwMem fetches it (LDS or global table); TwReg holds one lane's twiddles of one
+// direction in registers, filled once per kernel in the order the blocks consume them.
+struct TwMem {
+    const double *t;
+    __device__ __forceinline__ double get(int idx, int /*slot*/) const { return t[idx]; }
+};
+template <int NT>
+struct TwReg {
+    double v[NT];
+    __device__ __forceinline__ double get(int /*idx*/, int slot) const { return v[slot]; }
+};
+
+// Enumerate (in consumption order) the table indices of a block's twiddles.
+template <int LOGN, int SHIFT, int SB_FIRST, int SB_LAST, int SLOT0, int NT>
+__device__ __forceinline__ void tw_fill_block(TwReg<NT> &r, const double *__restrict__ table, int jbase)
 {
     constexpr int E = Geo<LOGN>::E, N = Geo<LOGN>::N;
+    constexpr int DIR = SB_FIRST <= SB_LAST ? 1 : -1;
+    int slot = SLOT0;
+#pragma unroll
+    for (int sb = SB_FIRST; sb != SB_LAST + DIR; sb += DIR) {
+        const int eb = sb - SHIFT;
+#pragma unroll
+        for (int hi = 0; hi < (E >> (eb + 1)); hi++) {
+            const int jh = jbase | (hi << (eb + 1 + SHIFT));
+            r.v[slot++] = table[(N >> (sb + 1)) + (jh >> (sb + 1))];
+        }
+    }
+}
+template <int LOGN>
+__device__ __forceinline__ void tw_fill_forward(TwReg<Geo<LOGN>::NTW> &r, const double *__restrict__ table, int lane)
+{
+    using G = Geo<LOGN>;
+    tw_fill_block<LOGN, 6, LOGN - 1, LOGN - G::BA, 0>(r, table, G::jA(lane, 0));
+    tw_fill_block<LOGN, G::BC, G::BC + G::BB - 1, G::BC, G::TWA>(r, table, G::jB(lane, 0));
+    tw_fill_block<LOGN, 0, G::BC - 1, 0, G::TWA + G::TWB>(r, table, G::jC(lane, 0));
+}
+template <int LOGN>
+__device__ __forceinline__ void tw_fill_inverse(TwReg<Geo<LOGN>::NTW> &r, const double *__restrict__ table, int lane)
+{
+    using G = Geo<LOGN>;
+    tw_fill_block<LOGN, 0, 0, G::BC - 1, 0>(r, table, G::jC(lane, 0));
+    tw_fill_block<LOGN, G::BC, G::BC, G::BC + G::BB - 1, G::TWC>(r, table, G::jB(lane, 0));
+    tw_fill_block<LOGN, 6, LOGN - G::BA, LOGN - 1, G::TWC + G::TWB>(r, table, G::jA(lane, 0));
+}
+
+// Fused radix-2 Cooley-Tukey stages on stride bits SB_HI..SB_LO (descending), all of
+// which are register-slot bits (slot bit = stride bit - SHIFT), for M polynomials.
+template <int LOGN, int M, int SHIFT, int SB_HI, int SB_LO, int SLOT0, typename TW>
+__device__ __forceinline__ void fwd_block(double (&x)[M][Geo<LOGN>::E], const TW &tw, int jbase)
+{
+    constexpr int E = Geo<LOGN>::E, N = Geo<LOGN>::N;
+    int slot = SLOT0;
 #pragma unroll
     for (int sb = SB_HI; sb >= SB_LO; sb--) {
         const int eb = sb - SHIFT;
 #pragma unroll
         for (int hi = 0; hi < (E >> (eb + 1)); hi++) {
             const int jh = jbase | (hi << (eb + 1 + SHIFT));
-            const double w = tw[(N >> (sb + 1)) + (jh >> (sb + 1))];
+            const double w = tw.get((N >> (sb + 1)) + (jh >> (sb + 1)), slot++);
 #pragma unroll
             for (int lo = 0; lo < (1 << eb); lo++) {
                 const int e0 = (hi << (eb + 1)) | lo, e1 = e0 | (1 << eb);
-                double U = x[e0], V = mulmod(x[e1], w);
-                x[e0] = U + V;
-                x[e1] = U - V;
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    double U = x[m][e0], V = mulmod(x[m][e1], w);
+                    x[m][e0] = U + V;
+                    x[m][e1] = U - V;
+                }
             }
         }
     }
 }
 
-template <int LOGN, int SHIFT, int SB_LO, int SB_HI>
-__device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const double *__restrict__ tw, int jbase)
+// Gentleman-Sande stages on stride bits SB_LO..SB_HI (ascending).
+template <int LOGN, int SHIFT, int SB_LO, int SB_HI, int SLOT0, typename TW>
+__device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const TW &tw, int jbase)
 {
     constexpr int E = Geo<LOGN>::E, N = Geo<LOGN>::N;
+    int slot = SLOT0;
 #pragma unroll
     for (int sb = SB_LO; sb <= SB_HI; sb++) {
         const int eb = sb - SHIFT;
@@ -128,7 +203,7 @@ __device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const doubl
 #pragma unroll
         for (int hi = 0; hi < (E >> (eb + 1)); hi++) {
             const int jh = jbase | (hi << (eb + 1 + SHIFT));
-            const double w = tw[(N >> (sb + 1)) + (jh >> (sb + 1))];
+            const double w = tw.get((N >> (sb + 1)) + (jh >> (sb + 1)), slot++);
 #pragma unroll
             for (int lo = 0; lo < (1 << eb); lo++) {
                 const int e0 = (hi << (eb + 1)) | lo, e1 = e0 | (1 << eb);
@@ -140,56 +215,62 @@ __device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const doubl
     }
 }
 
-// Forward negacyclic NTT of one polynomial held by one wave.
-// in : x[e] = coefficient jA(lane,e), |x| <= 0.5p.
-// out: x[e] = transform word at position jC(lane,e) of the bit-reversed output,
+// Forward negacyclic NTT of M polynomials held by one wave.
+// in : x[m][e] = coefficient jA(lane,e), |x| <= 0.5p.
+// out: x[m][e] = transform word at position jC(lane,e) of the bit-reversed output,
 //      |x| <= ~3p (not recentred: the pointwise product absorbs it).
-// xbuf: wave-private LDS scratch of Geo::XPAD doubles.
-template <int LOGN>
-__device__ __forceinline__ void ntt_forward(double (&x)[Geo<LOGN>::E], double *xbuf, const double *__restrict__ tw,
-                                            int lane)
+// xbuf: wave-private LDS scratch of M * Geo::XPAD doubles.
+template <int LOGN, int M, typename TW>
+__device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double *xbuf, const TW &tw, int lane)
 {
     using G = Geo<LOGN>;
-    fwd_block<LOGN, 6, LOGN - 1, LOGN - G::BA>(x, tw, G::jA(lane, 0));
+    fwd_block<LOGN, M, 6, LOGN - 1, LOGN - G::BA, 0>(x, tw, G::jA(lane, 0));
 #pragma unroll
-    for (int e = 0; e < G::E; e++) xbuf[G::pad1(G::jA(lane, e))] = reduce(x[e]);
-    wave_sync();
+    for (int m = 0; m < M; m++)
 #pragma unroll
-    for (int e = 0; e < G::E; e++) x[e] = xbuf[G::pad1(G::jB(lane, e))];
-    wave_sync();
-    fwd_block<LOGN, G::BC, G::BC + G::BB - 1, G::BC>(x, tw, G::jB(lane, 0));
+        for (int e = 0; e < G::E; e++) xbuf[m * G::XPAD + G::pad1(G::jA(lane, e))] = reduce(x[m][e]);
+    lds_wave_sync();
 #pragma unroll
-    for (int e = 0; e < G::E; e++) xbuf[G::pad2(G::jB(lane, e))] = reduce(x[e]);
-    wave_sync();
+    for (int m = 0; m < M; m++)
 #pragma unroll
-    for (int e = 0; e < G::E; e++) x[e] = xbuf[G::pad2(G::jC(lane, e))];
-    wave_sync();
-    fwd_block<LOGN, 0, G::BC - 1, 0>(x, tw, G::jC(lane, 0));
+        for (int e = 0; e < G::E; e++) x[m][e] = xbuf[m * G::XPAD + G::pad1(G::jB(lane, e))];
+    lds_wave_sync();
+    fwd_block<LOGN, M, G::BC, G::BC + G::BB - 1, G::BC, G::TWA>(x, tw, G::jB(lane, 0));
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+        for (int e = 0; e < G::E; e++) xbuf[m * G::XPAD + G::pad2(G::jB(lane, e))] = reduce(x[m][e]);
+    lds_wave_sync();
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+        for (int e = 0; e < G::E; e++) x[m][e] = xbuf[m * G::XPAD + G::pad2(G::jC(lane, e))];
+    lds_wave_sync();
+    fwd_block<LOGN, M, 0, G::BC - 1, 0, G::TWA + G::TWB>(x, tw, G::jC(lane, 0));
 }
 
 // Inverse (without the 1/N factor, which is folded into the bootstrapping key).
 // in : x[e] = transform word at jC(lane,e), |x| <= 0.5p.
 // out: x[e] = coefficient jA(lane,e), exactly centred (|x| <= p/2).
-template <int LOGN>
-__device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *xbuf, const double *__restrict__ twi,
-                                            int lane)
+template <int LOGN, typename TW>
+__device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *xbuf, const TW &tw, int lane)
 {
     using G = Geo<LOGN>;
-    inv_block<LOGN, 0, 0, G::BC - 1>(x, twi, G::jC(lane, 0));
+    inv_block<LOGN, 0, 0, G::BC - 1, 0>(x, tw, G::jC(lane, 0));
 #pragma unroll
     for (int e = 0; e < G::E; e++) xbuf[G::pad2(G::jC(lane, e))] = reduce(x[e]);
-    wave_sync();
+    lds_wave_sync();
 #pragma unroll
     for (int e = 0; e < G::E; e++) x[e] = xbuf[G::pad2(G::jB(lane, e))];
-    wave_sync();
-    inv_block<LOGN, G::BC, G::BC, G::BC + G::BB - 1>(x, twi, G::jB(lane, 0));
+    lds_wave_sync();
+    inv_block<LOGN, G::BC, G::BC, G::BC + G::BB - 1, G::TWC>(x, tw, G::jB(lane, 0));
 #pragma unroll
     for (int e = 0; e < G::E; e++) xbuf[G::pad1(G::jB(lane, e))] = reduce(x[e]);
-    wave_sync();
+    lds_wave_sync();
 #pragma unroll
     for (int e = 0; e < G::E; e++) x[e] = xbuf[G::pad1(G::jA(lane, e))];
-    wave_sync();
-    inv_block<LOGN, 6, LOGN - G::BA, LOGN - 1>(x, twi, G::jA(lane, 0));
+    lds_wave_sync();
+    inv_block<LOGN, 6, LOGN - G::BA, LOGN - 1, G::TWC + G::TWB>(x, tw, G::jA(lane, 0));
 #pragma unroll
     for (int e = 0; e < G::E; e++) x[e] = reduce(x[e]);
 }
