@@ -7,3 +7,12 @@ in-tree native libraries; see include/helm_hip.h for the drop-in C ABI.
 from . import _native  # noqa: F401  (fails loudly if the native libraries are missing)
 from .engine import ClientKey, ServerKey, DeviceWires, Program, named_params  # noqa: F401
 from ._native import HelmError, Params  # noqa: F401
+from . import verilog_parser, circuit, gates, netlists  # noqa: F401,E402
+from .circuit import Circuit, GateCircuit, EvalCircuit, EncWireMap  # noqa: F401,E402
+from .gates import PtxtType, GateType, Gate  # noqa: F401,E402
+
+
+def gen_keys(name="boolean_default", seed=1, device=0):
+    """tfhe::boolean::gen_keys() (reference src/bin/helm.rs:241) -> (client_key, server_key)."""
+    ck = ClientKey.generate(name, seed)
+    return ck, ServerKey(ck, device=device)

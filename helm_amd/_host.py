@@ -1,0 +1,76 @@
+"""ctypes bindings of include/helm_host.h (libhelm_host.so)."""
+import ctypes as C
+
+from ._native import host, vp, u32p, HelmError, Params  # noqa: F401
+
+cp = C.c_char_p
+cpp = C.POINTER(C.c_void_p)  # char** returned as raw pointer so we can free it
+
+HOST_API = {
+    "helm_host_last_error": (cp, []),
+    "helm_host_free": (None, [vp]),
+    "helm_host_read_verilog_file": (C.c_int, [cp, C.c_int, C.POINTER(vp)]),
+    "helm_host_read_verilog_text": (C.c_int, [cp, C.c_int, C.POINTER(vp)]),
+    "helm_host_netlist_free": (None, [vp]),
+    "helm_host_netlist_list": (vp, [vp, C.c_int]),
+    "helm_host_netlist_flags": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "helm_host_read_input_wires": (C.c_int, [cp, cp, C.POINTER(vp)]),
+    "helm_host_write_output_wires": (C.c_int, [cp, cp]),
+    "helm_host_parse_input_wire": (C.c_int, [cp, cp, C.POINTER(vp)]),
+    "helm_host_hex_to_bitstring": (C.c_int, [cp, C.POINTER(vp)]),
+    "helm_host_circuit_new": (C.c_int, [vp, cp, cp, cp, C.POINTER(vp)]),
+    "helm_host_circuit_free": (None, [vp]),
+    "helm_host_circuit_sort_circuit": (C.c_int, [vp]),
+    "helm_host_circuit_compute_levels": (C.c_int, [vp]),
+    "helm_host_circuit_get_ordered_gates": (vp, [vp]),
+    "helm_host_circuit_level_map": (vp, [vp]),
+    "helm_host_circuit_initialize_wire_map": (C.c_int, [vp, cp, cp, cp, C.POINTER(vp)]),
+    "helm_host_circuit_evaluate": (C.c_int, [vp, cp, C.POINTER(vp)]),
+    "helm_host_enc_map_new": (C.c_int, [vp, C.POINTER(vp)]),
+    "helm_host_enc_map_free": (None, [vp]),
+    "helm_host_enc_map_insert": (C.c_int, [vp, cp, u32p]),
+    "helm_host_enc_map_get": (C.c_int, [vp, cp, u32p]),
+    "helm_host_enc_map_contains_key": (C.c_int, [vp, cp]),
+    "helm_host_enc_map_keys": (vp, [vp]),
+    "helm_host_gate_circuit_new": (C.c_int, [vp, vp, vp, C.POINTER(vp)]),
+    "helm_host_gate_circuit_free": (None, [vp]),
+    "helm_host_gate_circuit_encrypt_inputs": (C.c_int, [vp, cp, cp, C.POINTER(vp)]),
+    "helm_host_gate_circuit_evaluate_encrypted": (C.c_int, [vp, vp, C.c_int64, cp, C.POINTER(vp)]),
+    "helm_host_gate_circuit_init_ready": (C.c_int, [vp, C.POINTER(vp)]),
+    "helm_host_gate_circuit_evaluate_ready": (C.c_int, [vp, vp, vp]),
+    "helm_host_gate_circuit_decrypt_outputs": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
+    "helm_host_gate_circuit_log": (vp, [vp]),
+    "helm_host_gate_circuit_pbs_per_cycle": (C.c_int64, [vp]),
+}
+for _name, (_res, _args) in HOST_API.items():
+    _fn = getattr(host, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class Panic(HelmError):
+    """The reference would have panicked here; the message is the panic message."""
+
+
+def check(rc):
+    if rc != 0:
+        raise Panic(host.helm_host_last_error().decode())
+
+
+def take(ptr):
+    """malloc'd char* -> str (and free it)."""
+    if not ptr:
+        return ""
+    s = C.string_at(ptr).decode()
+    host.helm_host_free(ptr)
+    return s
+
+
+def out_text(fn, *args):
+    p = vp()
+    check(fn(*args, C.byref(p)))
+    return take(p.value)
+
+
+def nl(names):
+    return "\n".join(names).encode()

@@ -61,6 +61,7 @@ HIP_API = {
     "helm_hip_device_count": (C.c_int, []),
     "helm_hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(Params), C.POINTER(vp)]),
     "helm_hip_ctx_destroy": (C.c_int, [vp]),
+    "helm_hip_get_params": (C.c_int, [vp, C.POINTER(Params)]),
     "helm_hip_set_stream": (C.c_int, [vp, vp]),
     "helm_hip_sync": (C.c_int, [vp]),
     "helm_hip_load_bootstrap_key": (C.c_int, [vp, u32p, C.c_size_t]),
@@ -91,6 +92,7 @@ CLIENT_API = {
     "helm_client_last_error": (C.c_char_p, []),
     "helm_client_keygen": (C.c_int, [C.POINTER(Params), C.c_double, C.c_double, C.c_uint64, C.POINTER(vp)]),
     "helm_client_key_free": (None, [vp]),
+    "helm_client_params": (C.c_int, [vp, C.POINTER(Params)]),
     "helm_client_bsk_words": (C.c_size_t, [vp]),
     "helm_client_ksk_words": (C.c_size_t, [vp]),
     "helm_client_bsk": (u32p, [vp]),

@@ -1,0 +1,148 @@
+"""Circuit, EvalCircuit, GateCircuit — mirror of reference src/circuit.rs over the C++
+host library (helm_amd/csrc/host).  The level loop, the device program and all
+ciphertext handling live in C++; this file only marshals names and values."""
+import ctypes as C
+
+import numpy as np
+
+from . import _host as H
+from . import _native as nv
+from .gates import parse_gate_lines, text_to_map, map_to_text
+
+
+class Circuit:
+    """reference src/circuit.rs:60-67, 104-381"""
+
+    def __init__(self, gates, input_wires, output_wires, dff_outputs):
+        h = H.vp()
+        H.check(H.host.helm_host_circuit_new(gates._h, H.nl(input_wires), H.nl(output_wires), H.nl(dff_outputs),
+                                             C.byref(h)))
+        self._h = h
+        self.input_wires, self.output_wires, self.dff_outputs = list(input_wires), list(output_wires), list(dff_outputs)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            H.host.helm_host_circuit_free(self._h)
+            self._h = None
+
+    def sort_circuit(self):
+        H.check(H.host.helm_host_circuit_sort_circuit(self._h))
+
+    def compute_levels(self):
+        H.check(H.host.helm_host_circuit_compute_levels(self._h))
+
+    def get_ordered_gates(self):
+        return parse_gate_lines(H.take(H.host.helm_host_circuit_get_ordered_gates(self._h)), with_level=True)
+
+    def level_map(self):
+        m = {}
+        for g in parse_gate_lines(H.take(H.host.helm_host_circuit_level_map(self._h)), with_level=True):
+            m.setdefault(g.level, []).append(g)
+        return m
+
+    def initialize_wire_map(self, wire_set, user_inputs, ptxt_type):
+        return text_to_map(H.out_text(H.host.helm_host_circuit_initialize_wire_map, self._h, H.nl(sorted(wire_set)),
+                                      map_to_text(user_inputs).encode(), ptxt_type.encode()))
+
+    def evaluate(self, wire_map):
+        return text_to_map(H.out_text(H.host.helm_host_circuit_evaluate, self._h, map_to_text(wire_map).encode()))
+
+
+class EncWireMap:
+    """HashMap<String, Ciphertext> whose values live in an HBM wire table."""
+
+    def __init__(self, server_key=None, _handle=None, _n=None):
+        if _handle is None:
+            h = H.vp()
+            H.check(H.host.helm_host_enc_map_new(server_key._h, C.byref(h)))
+            _handle, _n = h, server_key.params.n
+        self._h, self._n = _handle, _n
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            H.host.helm_host_enc_map_free(self._h)
+            self._h = None
+
+    def insert(self, wire, ct):
+        ct = np.ascontiguousarray(ct, dtype=np.uint32)
+        assert ct.shape == (self._n + 1,)
+        H.check(H.host.helm_host_enc_map_insert(self._h, wire.encode(), nv.as_u32p(ct)))
+
+    __setitem__ = insert
+
+    def __getitem__(self, wire):
+        out = np.zeros(self._n + 1, dtype=np.uint32)
+        H.check(H.host.helm_host_enc_map_get(self._h, wire.encode(), nv.as_u32p(out)))
+        return out
+
+    def contains_key(self, wire):
+        return bool(H.host.helm_host_enc_map_contains_key(self._h, wire.encode()))
+
+    __contains__ = contains_key
+
+    def keys(self):
+        return [k for k in H.take(H.host.helm_host_enc_map_keys(self._h)).splitlines() if k]
+
+    def __len__(self):
+        return len(self.keys())
+
+
+class EvalCircuit:
+    """trait EvalCircuit<C>, reference src/circuit.rs:35-58 (static-call style of the tests:
+    EvalCircuit.evaluate_encrypted(circuit, map, cycle, datatype))."""
+
+    @staticmethod
+    def encrypt_inputs(c, wire_set, input_wire_map): return c.encrypt_inputs(wire_set, input_wire_map)
+    @staticmethod
+    def evaluate_encrypted(c, enc_wire_map, current_cycle, ptxt_type): return c.evaluate_encrypted(enc_wire_map, current_cycle, ptxt_type)
+    @staticmethod
+    def init_ready(c): return c.init_ready()
+    @staticmethod
+    def evaluate_ready(c, enc_wire_map, valid_outputs): return c.evaluate_ready(enc_wire_map, valid_outputs)
+    @staticmethod
+    def decrypt_outputs(c, enc_wire_map, verbose): return c.decrypt_outputs(enc_wire_map, verbose)
+
+
+class GateCircuit(EvalCircuit):
+    """reference src/circuit.rs:69-73, 449-577"""
+
+    def __init__(self, client_key, server_key, circuit):
+        h = H.vp()
+        H.check(H.host.helm_host_gate_circuit_new(client_key._h, server_key._h, circuit._h, C.byref(h)))
+        self._h = h
+        self._ck, self._sk, self.circuit = client_key, server_key, circuit  # keep alive
+        self._n = server_key.params.n
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            H.host.helm_host_gate_circuit_free(self._h)
+            self._h = None
+
+    def _map(self, fn, *args):
+        h = H.vp()
+        H.check(fn(self._h, *args, C.byref(h)))
+        return EncWireMap(_handle=h, _n=self._n)
+
+    def encrypt_inputs(self, wire_set, input_wire_map):
+        return self._map(H.host.helm_host_gate_circuit_encrypt_inputs, H.nl(sorted(wire_set)),
+                         map_to_text(input_wire_map).encode())
+
+    def evaluate_encrypted(self, enc_wire_map, current_cycle, ptxt_type="bool"):
+        return self._map(H.host.helm_host_gate_circuit_evaluate_encrypted, enc_wire_map._h, int(current_cycle),
+                         ptxt_type.encode())
+
+    def init_ready(self):
+        return self._map(H.host.helm_host_gate_circuit_init_ready)
+
+    def evaluate_ready(self, enc_wire_map, valid_outputs):
+        H.check(H.host.helm_host_gate_circuit_evaluate_ready(self._h, enc_wire_map._h, valid_outputs._h))
+
+    def decrypt_outputs(self, enc_wire_map, verbose=False):
+        return text_to_map(H.out_text(H.host.helm_host_gate_circuit_decrypt_outputs, self._h, enc_wire_map._h,
+                                      int(verbose)))
+
+    def log(self):
+        return H.take(H.host.helm_host_gate_circuit_log(self._h))
+
+    def pbs_per_cycle(self):
+        return int(H.host.helm_host_gate_circuit_pbs_per_cycle(self._h))

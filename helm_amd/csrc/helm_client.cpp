@@ -188,6 +188,12 @@ int helm_client_keygen(const helm_hip_params *params, double lwe_std, double glw
 
 void helm_client_key_free(helm_client_key *key) { delete key; }
 
+int helm_client_params(const helm_client_key *key, helm_hip_params *out)
+{
+    if (!key || !out) return fail(HELM_ERR_INVALID, "null argument");
+    *out = key->P;
+    return 0;
+}
 size_t helm_client_bsk_words(const helm_client_key *key) { return key ? key->bsk.size() : 0; }
 size_t helm_client_ksk_words(const helm_client_key *key) { return key ? key->ksk.size() : 0; }
 const uint32_t *helm_client_bsk(const helm_client_key *key) { return key ? key->bsk.data() : nullptr; }

@@ -835,6 +835,13 @@ int helm_hip_ctx_destroy(helm_hip_ctx *ctx)
     return 0;
 }
 
+int helm_hip_get_params(const helm_hip_ctx *ctx, helm_hip_params *out)
+{
+    if (!ctx || !out) return fail(HELM_ERR_INVALID, "null argument");
+    *out = ctx->P;
+    return 0;
+}
+
 int helm_hip_set_stream(helm_hip_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");

@@ -1,0 +1,216 @@
+// helm_host.hpp — host side of the gates-mode path, C++ mirror of the reference's
+// Rust interface (the Rust toolchain is absent from this image):
+//
+//   helm::GateType, helm::Gate            reference src/gates.rs:23-60, 104-280
+//   helm::verilog_parser::*               reference src/verilog_parser.rs
+//   helm::Circuit                         reference src/circuit.rs:60-67, 104-381
+//   helm::EvalCircuit / helm::GateCircuit reference src/circuit.rs:35-58, 449-577
+//   helm::PtxtType, parse_input_wire,
+//   get_input_wire_map, hex_to_bitstring  reference src/lib.rs:20-29, 90-194
+//
+// Same names, argument meaning and error behaviour; where the reference panics this
+// code throws helm::Panic carrying the same message.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <optional>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/helm_client.h"
+#include "../../../include/helm_hip.h"
+
+namespace helm {
+
+struct Panic : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// reference src/lib.rs:20-29
+struct PtxtType {
+    enum Kind { None = 0, Bool, U8, U16, U32, U64, U128 } kind = None;
+    unsigned __int128 value = 0;
+    static PtxtType none() { return {}; }
+    static PtxtType boolean(bool b) { return {Bool, (unsigned __int128)(b ? 1 : 0)}; }
+    bool as_bool() const { return value != 0; }
+    bool operator==(const PtxtType &o) const { return kind == o.kind && value == o.value; }
+    bool operator!=(const PtxtType &o) const { return !(*this == o); }
+    std::string to_string() const; // Rust Display of the inner value ("true"/"false"/integer)
+};
+
+// reference src/gates.rs:23-45 (declaration order = helm_gate_op)
+enum class GateType : int {
+    And = 0, Dff, Lut, Mux, Nand, Nor, Not, Or, Xnor, Xor, Buf, ConstOne, ConstZero,
+    Mult, Add, Sub, Div, Shl, Shr, Copy
+};
+const char *gate_type_name(GateType t);
+
+// reference src/gates.rs:47-60, 104-149
+class Gate {
+  public:
+    Gate(std::string gate_name, GateType gate_type, std::vector<std::string> input_wires,
+         std::optional<std::vector<uint64_t>> lut_const, std::string output_wire, size_t level)
+        : gate_name_(std::move(gate_name)), gate_type_(gate_type), input_wires_(std::move(input_wires)),
+          lut_const_(std::move(lut_const)), output_wire_(std::move(output_wire)), level_(level)
+    {
+    }
+    const std::vector<std::string> &get_input_wires() const { return input_wires_; }
+    const std::string &get_output_wire() const { return output_wire_; }
+    GateType get_gate_type() const { return gate_type_; }
+    const std::string &get_gate_name() const { return gate_name_; }
+    const std::optional<std::vector<uint64_t>> &get_lut_const() const { return lut_const_; }
+    void set_level(size_t level) { level_ = level; }
+    size_t get_level() const { return level_; }
+    // reference src/gates.rs:151-239
+    PtxtType evaluate(const std::vector<PtxtType> &input_values);
+    // identity / ordering by gate name, reference src/gates.rs:62-87
+    bool operator==(const Gate &o) const { return gate_name_ == o.gate_name_; }
+    bool operator<(const Gate &o) const { return gate_name_ < o.gate_name_; }
+    std::string debug() const; // reference src/gates.rs:89-102
+
+  private:
+    std::string gate_name_;
+    GateType gate_type_;
+    std::vector<std::string> input_wires_;
+    std::optional<std::vector<uint64_t>> lut_const_;
+    std::string output_wire_;
+    size_t level_;
+    size_t cycle_ = 0;
+    PtxtType output_;
+};
+
+// HashSet<Gate> keyed by gate name (a second gate with the same name is dropped,
+// like HashSet::insert).
+using GateSet = std::map<std::string, Gate>;
+
+namespace verilog_parser {
+struct Netlist {
+    GateSet gates;
+    std::set<std::string> wire_set; // gate-output wires
+    std::vector<std::string> inputs, outputs, dff_outputs;
+    bool has_luts = false, has_arith = false;
+};
+Gate parse_gate(const std::vector<std::string> &tokens);                 // verilog_parser.rs:31-120
+std::optional<std::pair<size_t, size_t>> parse_range(const std::string &s); // :122-136
+Netlist read_verilog_file(const std::string &file_name, bool is_arith); // :138-276
+Netlist read_verilog_text(const std::string &text, bool is_arith);      // same, from memory
+std::map<std::string, PtxtType> read_input_wires(const std::string &file_name, const std::string &ptxt_type); // :278-317
+void write_output_wires(const std::optional<std::string> &file_name,
+                        const std::map<std::string, PtxtType> &input_map); // :319-349
+} // namespace verilog_parser
+
+PtxtType parse_input_wire(const std::string &wire, const std::string &ptxt_type); // lib.rs:90-106
+std::string hex_to_bitstring(const std::string &hex);                             // lib.rs:181-194
+std::map<std::string, PtxtType> get_input_wire_map(const std::optional<std::string> &inputs_filename,
+                                                   const std::vector<std::vector<std::string>> &wire_inputs,
+                                                   const std::string &arithmetic_type); // lib.rs:113-179
+
+// reference src/circuit.rs:60-67, 104-381
+class Circuit {
+  public:
+    Circuit(GateSet gates, std::vector<std::string> input_wires, std::vector<std::string> output_wires,
+            std::vector<std::string> dff_outputs)
+        : gates_(std::move(gates)), input_wires_(std::move(input_wires)), output_wires_(std::move(output_wires)),
+          dff_outputs_(std::move(dff_outputs))
+    {
+    }
+    void sort_circuit();   // circuit.rs:122-171
+    void compute_levels(); // circuit.rs:174-239
+    std::map<std::string, PtxtType> initialize_wire_map(const std::set<std::string> &wire_set,
+                                                        const std::map<std::string, PtxtType> &user_inputs,
+                                                        const std::string &ptxt_type) const; // :245-333
+    std::string print_level_map() const;                                                       // :335-342
+    const std::vector<Gate> &get_ordered_gates() const { return ordered_gates_; }
+    std::map<std::string, PtxtType> evaluate(const std::map<std::string, PtxtType> &wire_map); // :348-381
+
+    const std::map<size_t, std::vector<Gate>> &level_map() const { return level_map_; }
+    const std::vector<std::string> &input_wires() const { return input_wires_; }
+    const std::vector<std::string> &output_wires() const { return output_wires_; }
+    const std::vector<std::string> &dff_outputs() const { return dff_outputs_; }
+    bool gates_empty() const { return gates_.empty(); }
+
+  private:
+    GateSet gates_;
+    std::vector<std::string> input_wires_, output_wires_, dff_outputs_;
+    std::vector<Gate> ordered_gates_;
+    std::map<size_t, std::vector<Gate>> level_map_;
+};
+
+// Device-resident replacement of HashMap<String, Ciphertext> (circuit.rs:517-520):
+// wire name -> row of an HBM wire table owned by the engine context.
+class EncWireMap {
+  public:
+    EncWireMap(helm_hip_ctx *ctx, int n) : ctx_(ctx), n_(n) {}
+    ~EncWireMap();
+    EncWireMap(const EncWireMap &) = delete;
+    EncWireMap &operator=(const EncWireMap &) = delete;
+    bool contains_key(const std::string &k) const { return index_.count(k) != 0; }
+    size_t len() const { return index_.size(); }
+    std::vector<std::string> keys() const;
+    int row(const std::string &k) const; // throws Panic if absent
+    std::vector<uint32_t> get(const std::string &k) const;        // download one ciphertext
+    void insert(const std::string &k, const uint32_t *lwe);       // upload (adds the key if new)
+    std::unique_ptr<EncWireMap> clone() const;                    // fresh owned map, device copy
+    helm_hip_wires *table() const { return wires_; }
+    helm_hip_ctx *ctx() const { return ctx_; }
+    // build with a fixed key set (rows in iteration order of `names`)
+    void reserve_keys(const std::vector<std::string> &names);
+
+  private:
+    void grow(int64_t rows);
+    helm_hip_ctx *ctx_;
+    int n_;
+    helm_hip_wires *wires_ = nullptr;
+    int64_t cap_ = 0;
+    std::unordered_map<std::string, int> index_;
+};
+
+// reference src/circuit.rs:35-58
+template <typename MapT> class EvalCircuit {
+  public:
+    virtual ~EvalCircuit() = default;
+    virtual std::unique_ptr<MapT> encrypt_inputs(const std::set<std::string> &wire_set,
+                                                 const std::map<std::string, PtxtType> &input_wire_map) = 0;
+    virtual std::unique_ptr<MapT> evaluate_encrypted(const MapT &enc_wire_map, size_t current_cycle,
+                                                     const std::string &ptxt_type) = 0;
+    virtual std::unique_ptr<MapT> init_ready() = 0;
+    virtual void evaluate_ready(const MapT &enc_wire_map, MapT &valid_outputs) = 0;
+    virtual std::map<std::string, PtxtType> decrypt_outputs(const MapT &enc_wire_map, bool verbose) = 0;
+};
+
+// reference src/circuit.rs:69-73, 383-391, 449-577.  client_key: the CPU client;
+// server_key: an engine context with both keys loaded.
+class GateCircuit : public EvalCircuit<EncWireMap> {
+  public:
+    GateCircuit(helm_client_key *client_key, helm_hip_ctx *server_key, Circuit circuit);
+    ~GateCircuit() override;
+    std::unique_ptr<EncWireMap> encrypt_inputs(const std::set<std::string> &wire_set,
+                                               const std::map<std::string, PtxtType> &input_wire_map) override;
+    std::unique_ptr<EncWireMap> evaluate_encrypted(const EncWireMap &enc_wire_map, size_t current_cycle,
+                                                   const std::string &ptxt_type) override;
+    std::unique_ptr<EncWireMap> init_ready() override;
+    void evaluate_ready(const EncWireMap &enc_wire_map, EncWireMap &valid_outputs) override;
+    std::map<std::string, PtxtType> decrypt_outputs(const EncWireMap &enc_wire_map, bool verbose) override;
+
+    const Circuit &circuit() const { return circuit_; }
+    int64_t pbs_per_cycle() const { return pbs_count_; }
+    std::string log() { std::string s; s.swap(log_); return s; } // progress lines (circuit.rs:542)
+
+  private:
+    helm_client_key *client_key_;
+    helm_hip_ctx *server_key_;
+    Circuit circuit_;
+    int n_;
+    // program cache: rebuilt when the wire-name -> row mapping changes
+    helm_hip_program *prog_ = nullptr;
+    std::vector<std::string> prog_keys_;
+    std::vector<int> prog_rows_;
+    int64_t pbs_count_ = 0;
+    std::string log_;
+};
+
+} // namespace helm

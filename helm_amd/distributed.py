@@ -1,0 +1,99 @@
+"""Multi-GPU evaluation of a levelised netlist: one process per GPU, keys and the wire
+table replicated, each level's gates split into `world` contiguous chunks and only the
+chunk outputs (small LWE ciphertexts, (n+1) words per gate) all-gathered over RCCL.
+
+The reference has no multi-GPU code; the level is its unit of
+parallelism (src/circuit.rs:531) and is what is sharded here.
+
+The per-level exchange is latency-bound (a 512-gate level of the boolean set moves
+1.5 MB in total), so levels that one GPU can absorb in a single wave of workgroups
+(<= `replicate_below` bootstraps: one per CU) are computed redundantly on every rank
+instead of being sharded: that costs nothing in time and removes the collective.
+"""
+import numpy as np
+
+
+class GpuLevelExecutor:
+    """Level executor over the C ABI (helm_hip_program_*): the product path."""
+
+    def __init__(self, program, wires):
+        import torch
+        self.torch = torch
+        self.program, self.wires = program, wires
+        self.n_levels = program.n_levels
+        self.row_words = program.sk.params.n + 1
+        self.device = torch.device("cuda", program.sk.device)
+
+    def level_count(self, level):
+        off = self.program.level_offsets
+        return int(off[level + 1] - off[level])
+
+    def level_pbs(self, level):
+        return self.program.level_pbs(level)
+
+    def new_buffer(self, rows):
+        return self.torch.empty((rows, self.row_words), dtype=self.torch.int32, device=self.device)
+
+    def run_level(self, level):
+        self.program.run(self.wires, level, level + 1)
+
+    def run_level_shard(self, level, rank, world, staging):
+        self.program.run_level_shard(self.wires, level, rank, world, staging.data_ptr())
+
+    def scatter_level(self, level, world, gathered):
+        self.program.scatter_level(self.wires, level, world, gathered.data_ptr())
+
+
+class ShardedRunner:
+    """Drives one evaluation pass over all levels on `world` ranks.
+
+    `dist` is torch.distributed (backend "nccl" = RCCL on GPUs; "gloo" in the CPU
+    tests); with world == 1 nothing is imported and nothing is exchanged."""
+
+    def __init__(self, executor, rank=0, world=1, dist=None, replicate_below=256):
+        self.ex, self.rank, self.world, self.dist = executor, rank, world, dist
+        self.replicate_below = replicate_below
+        self.sharded_levels = []
+        self._staging, self._gathered = {}, {}
+        if world > 1:
+            for l in range(executor.n_levels):
+                if executor.level_pbs(l) > replicate_below:
+                    self.sharded_levels.append(l)
+            rows = max([-(-executor.level_count(l) // world) for l in self.sharded_levels], default=0)
+            if rows:
+                self._stage = executor.new_buffer(rows)
+                self._gather = executor.new_buffer(rows * world)
+        self._sharded = set(self.sharded_levels)
+
+    def run(self):
+        ex = self.ex
+        for l in range(ex.n_levels):
+            if l not in self._sharded:
+                ex.run_level(l)
+                continue
+            rows = -(-ex.level_count(l) // self.world)
+            stage = self._stage[:rows]
+            gathered = self._gather[:rows * self.world]
+            ex.run_level_shard(l, self.rank, self.world, stage)
+            self.dist.all_gather_into_tensor(gathered, stage)
+            ex.scatter_level(l, self.world, gathered)
+
+    def exchanged_bytes_per_pass(self):
+        ex = self.ex
+        return sum(-(-ex.level_count(l) // self.world) * self.world * ex.row_words * 4 for l in self.sharded_levels)
+
+
+def level_arrays(circuit, index):
+    """level_map of a Circuit -> (opcode, in0, in1, in2, out, level_offsets) over wire rows
+    given by `index` (name -> row)."""
+    ops, i0, i1, i2, out, off = [], [], [], [], [], [0]
+    lm = circuit.level_map()
+    for lvl in sorted(lm):
+        for gate in lm[lvl]:
+            ins = [index[w] for w in gate.input_wires] + [-1, -1, -1]
+            ops.append(int(gate.gate_type))
+            i0.append(ins[0]); i1.append(ins[1]); i2.append(ins[2])
+            out.append(index[gate.output_wire])
+        off.append(len(ops))
+    return (np.array(ops, np.int32), np.array(i0, np.int32), np.array(i1, np.int32), np.array(i2, np.int32),
+            np.array(out, np.int32), np.array(off, np.int64))

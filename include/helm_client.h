@@ -42,6 +42,8 @@ int helm_client_keygen(const helm_hip_params *params, double lwe_noise_std, doub
                        uint64_t seed, helm_client_key **out);
 void helm_client_key_free(helm_client_key *key);
 
+/* The parameter set the key was generated for. */
+int helm_client_params(const helm_client_key *key, helm_hip_params *out);
 size_t helm_client_bsk_words(const helm_client_key *key);
 size_t helm_client_ksk_words(const helm_client_key *key);
 const uint32_t *helm_client_bsk(const helm_client_key *key); /* [n][pbs_l][k+1][k+1][N] */

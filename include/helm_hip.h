@@ -101,7 +101,9 @@ int helm_hip_device_count(void);
 /* Replaces ServerKey construction (reference src/bin/helm.rs:241, 187-192). */
 int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_ctx **out);
 int helm_hip_ctx_destroy(helm_hip_ctx *ctx);
-/* Run on an existing hipStream_t (e.g. torch's current stream); NULL = the
+/* The parameter set the context was created with. */
+int helm_hip_get_params(const helm_hip_ctx *ctx, helm_hip_params *out);
+/* Run on an existing hipStream_t (e.g. the host framework's current stream); NULL = the
  * context's own stream. */
 int helm_hip_set_stream(helm_hip_ctx *ctx, void *hip_stream);
 int helm_hip_sync(helm_hip_ctx *ctx);

@@ -1,0 +1,90 @@
+/*
+ * helm_host.h — flat C view of the C++ host front end (helm_amd/csrc/host/helm_host.hpp)
+ * for language bindings (the Python test harness binds it with ctypes).
+ *
+ * Every call mirrors one item of the reference's Rust API; names follow it:
+ *   verilog_parser::{read_verilog_file, read_input_wires, write_output_wires}
+ *                                          reference src/verilog_parser.rs:138-349
+ *   parse_input_wire / hex_to_bitstring    reference src/lib.rs:90-106, 181-194
+ *   Circuit::{new, sort_circuit, compute_levels, evaluate, ...}
+ *                                          reference src/circuit.rs:104-381
+ *   GateCircuit + trait EvalCircuit        reference src/circuit.rs:35-58, 449-577
+ *
+ * Conventions: 0 = ok, -1 = the reference would have panicked (message from
+ * helm_host_last_error()).  Returned `char*` texts are malloc'd; free them with
+ * helm_host_free().  Lists are newline-separated; wire maps are lines of
+ * "name<TAB>Kind<TAB>value" with Kind in None/Bool/U8/U16/U32/U64/U128.
+ */
+#ifndef HELM_HOST_H
+#define HELM_HOST_H
+#include <stdint.h>
+#include "helm_client.h"
+#include "helm_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct helm_netlist helm_netlist;          /* parsed netlist: (gates, wire_set, inputs, outputs, dff_outputs, has_luts, has_arith) */
+typedef struct helm_circuit helm_circuit;          /* Circuit */
+typedef struct helm_gate_circuit helm_gate_circuit; /* GateCircuit */
+typedef struct helm_enc_map helm_enc_map;          /* HashMap<String, Ciphertext> on the device */
+
+const char *helm_host_last_error(void);
+void helm_host_free(char *text);
+
+/* verilog_parser */
+int helm_host_read_verilog_file(const char *file_name, int is_arith, helm_netlist **out);
+int helm_host_read_verilog_text(const char *text, int is_arith, helm_netlist **out);
+void helm_host_netlist_free(helm_netlist *nl);
+/* which: 0 gates (one line per gate: name<TAB>Type<TAB>output<TAB>lut_const_or_-<TAB>in0,in1,...),
+ *        1 wire_set, 2 inputs, 3 outputs, 4 dff_outputs */
+char *helm_host_netlist_list(const helm_netlist *nl, int which);
+int helm_host_netlist_flags(const helm_netlist *nl, int *has_luts, int *has_arith);
+int helm_host_read_input_wires(const char *file_name, const char *ptxt_type, char **out_map);
+int helm_host_write_output_wires(const char *file_name, const char *wire_map);
+int helm_host_parse_input_wire(const char *wire, const char *ptxt_type, char **out_value);
+int helm_host_hex_to_bitstring(const char *hex, char **out_bits);
+
+/* Circuit */
+int helm_host_circuit_new(const helm_netlist *gates_from, const char *input_wires, const char *output_wires,
+                          const char *dff_outputs, helm_circuit **out);
+void helm_host_circuit_free(helm_circuit *c);
+int helm_host_circuit_sort_circuit(helm_circuit *c);
+int helm_host_circuit_compute_levels(helm_circuit *c);
+/* gates (same line format as netlist_list 0, plus <TAB>level) in ordered_gates order */
+char *helm_host_circuit_get_ordered_gates(const helm_circuit *c);
+/* level_map: same gate lines, ascending level */
+char *helm_host_circuit_level_map(const helm_circuit *c);
+int helm_host_circuit_initialize_wire_map(const helm_circuit *c, const char *wire_set, const char *user_inputs,
+                                          const char *ptxt_type, char **out_map);
+int helm_host_circuit_evaluate(helm_circuit *c, const char *wire_map, char **out_map);
+
+/* encrypted wire maps */
+int helm_host_enc_map_new(helm_hip_ctx *server_key, helm_enc_map **out);
+void helm_host_enc_map_free(helm_enc_map *m);
+int helm_host_enc_map_insert(helm_enc_map *m, const char *wire, const uint32_t *lwe);
+int helm_host_enc_map_get(const helm_enc_map *m, const char *wire, uint32_t *lwe_out);
+int helm_host_enc_map_contains_key(const helm_enc_map *m, const char *wire);
+char *helm_host_enc_map_keys(const helm_enc_map *m);
+
+/* GateCircuit::new(client_key, server_key, circuit) — the circuit is copied */
+int helm_host_gate_circuit_new(helm_client_key *client_key, helm_hip_ctx *server_key, const helm_circuit *circuit,
+                               helm_gate_circuit **out);
+void helm_host_gate_circuit_free(helm_gate_circuit *gc);
+int helm_host_gate_circuit_encrypt_inputs(helm_gate_circuit *gc, const char *wire_set, const char *input_wire_map,
+                                          helm_enc_map **out);
+int helm_host_gate_circuit_evaluate_encrypted(helm_gate_circuit *gc, const helm_enc_map *enc_wire_map,
+                                              int64_t current_cycle, const char *ptxt_type, helm_enc_map **out);
+int helm_host_gate_circuit_init_ready(helm_gate_circuit *gc, helm_enc_map **out);
+int helm_host_gate_circuit_evaluate_ready(helm_gate_circuit *gc, const helm_enc_map *enc_wire_map,
+                                          helm_enc_map *valid_outputs);
+int helm_host_gate_circuit_decrypt_outputs(helm_gate_circuit *gc, const helm_enc_map *enc_wire_map, int verbose,
+                                           char **out_map);
+/* progress / output lines the reference prints (circuit.rs:542, 562-573); drains the buffer */
+char *helm_host_gate_circuit_log(helm_gate_circuit *gc);
+int64_t helm_host_gate_circuit_pbs_per_cycle(const helm_gate_circuit *gc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,100 @@
+"""The C-ABI libraries load and export every symbol include/*.h declares; on a GPU-less
+box the engine refuses to create a context (no CPU fallback) and argument validation
+works without touching a device.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helm_amd
+from helm_amd import _native as nv
+from helm_amd import _host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(" + prefix + r"\w+)\s*\(", text)))
+
+
+@pytest.mark.parametrize("header,prefix,lib,table", [
+    ("helm_hip.h", "helm_hip_", nv.hip, nv.HIP_API),
+    ("helm_client.h", "helm_client_", nv.host, nv.CLIENT_API),
+    ("helm_host.h", "helm_host_", nv.host, _host.HOST_API),
+])
+def test_every_declared_symbol_is_exported_and_bound(header, prefix, lib, table):
+    names = _declared(header, prefix)
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/{header} but not exported"
+        assert n in table, f"{n} declared in include/{header} but not bound in the Python layer"
+    for n in table:
+        assert n in names, f"{n} bound but not declared in include/{header}"
+
+
+def test_no_torch_types_in_the_abi():
+    for h in ("helm_hip.h", "helm_client.h", "helm_host.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        assert "torch" not in text.lower() and "at::" not in text and "#include <hip" not in text
+
+
+def test_product_package_never_touches_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "helm_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "liborc" not in src, f
+                assert "tfhe_oracle" not in src.replace("oracle/tfhe_oracle.c header", ""), f
+
+
+def test_parameter_validation_needs_no_device():
+    p, _, _ = helm_amd.named_params("boolean_default")
+    h = nv.vp()
+    bad = helm_amd.Params.from_buffer_copy(p)
+    bad.torus_bits = 64
+    assert nv.hip.helm_hip_ctx_create(0, C.byref(bad), C.byref(h)) == -1
+    assert b"torus_bits" in nv.hip.helm_hip_last_error()
+    bad = helm_amd.Params.from_buffer_copy(p)
+    bad.N = 2048
+    assert nv.hip.helm_hip_ctx_create(0, C.byref(bad), C.byref(h)) == -1
+    bad = helm_amd.Params.from_buffer_copy(p)
+    bad.pbs_logB = 8  # (k+1) l N B/2 2^31 would exceed the NTT prime's exact range
+    assert nv.hip.helm_hip_ctx_create(0, C.byref(bad), C.byref(h)) == -1
+    assert b"capacity" in nv.hip.helm_hip_last_error()
+    assert nv.hip.helm_hip_ctx_create(0, None, C.byref(h)) == -1
+
+
+def test_no_cpu_fallback(have_gpu):
+    if have_gpu:
+        pytest.skip("GPU present: covered by the gpu tests")
+    ck = helm_amd.ClientKey.generate("toy", seed=1)
+    with pytest.raises(helm_amd.HelmError, match="no HIP device|no CPU fallback|-2"):
+        helm_amd.ServerKey(ck)
+
+
+def test_client_roundtrip_and_noise():
+    for name in ("toy", "boolean_default"):
+        ck = helm_amd.ClientKey.generate(name, seed=9)
+        bits = np.random.default_rng(0).integers(0, 2, size=64).astype(bool)
+        ct = ck.encrypt(bits)
+        assert ct.shape == (64, ck.params.n + 1)
+        assert np.array_equal(ck.decrypt(ct), bits)
+        ph = ck.phase(ct).astype(np.int64)
+        want = np.where(bits, 1 << 29, 7 << 29)
+        err = (ph - want + 2**31) % 2**32 - 2**31
+        _, lwe_std, _ = helm_amd.named_params(name)
+        assert np.abs(err).max() < 8 * lwe_std * 2**32 + 2
+        assert ck.bsk.size == ck.params.n * ck.params.pbs_l * (ck.params.k + 1) ** 2 * ck.params.N
+        assert ck.ksk.size == ck.params.k * ck.params.N * ck.params.ks_l * (ck.params.n + 1)
+
+
+def test_named_params_match_the_reference():
+    p, lwe, glwe = helm_amd.named_params("helm_cuda")  # reference src/bin/helm.rs:141-146
+    assert (p.n, p.k, p.N, p.pbs_l, p.pbs_logB, p.ks_l, p.ks_logB) == (512, 1, 1024, 3, 7, 8, 2)
+    assert lwe == glwe == 0.00000002980232238769531
+    with pytest.raises(helm_amd.HelmError):
+        helm_amd.named_params("nope")
