@@ -177,9 +177,34 @@ static void extprod_add_schoolbook(const orc_params *P, const u32 *bsk_i,
 /* Route 2: Goldilocks NTT.                                                    */
 /* ------------------------------------------------------------------------- */
 #define GL_P 0xFFFFFFFF00000001ull
-static inline u64 gl_add(u64 a, u64 b) { u64 r = a + b; if (r < a || r >= GL_P) r -= GL_P; return r; }
-static inline u64 gl_sub(u64 a, u64 b) { return a >= b ? a - b : a + (GL_P - b); }
-static inline u64 gl_mul(u64 a, u64 b) { return (u64)(((u128)a * b) % GL_P); }
+/* branch-free (data-dependent branches mispredict on random residues) */
+static inline u64 gl_add(u64 a, u64 b)
+{
+    u64 r = a + b;
+    r += (0 - (u64)(r < a)) & 0xFFFFFFFFull;  /* wrapped past 2^64: 2^64 = 2^32 - 1 */
+    r -= (0 - (u64)(r >= GL_P)) & GL_P;
+    return r;
+}
+static inline u64 gl_sub(u64 a, u64 b)
+{
+    u64 r = a - b;
+    r -= (0 - (u64)(a < b)) & 0xFFFFFFFFull;  /* borrowed: subtract 2^32 - 1, i.e. add p */
+    return r;
+}
+/* 128-bit product reduced with 2^64 = 2^32 - 1 and 2^96 = -1 (mod p); result canonical. */
+static inline u64 gl_mul(u64 a, u64 b)
+{
+    u128 t = (u128)a * b;
+    u64 lo = (u64)t, hi = (u64)(t >> 64);
+    u64 hh = hi >> 32, hl = hi & 0xFFFFFFFFull;
+    u64 r = lo - hh;
+    r -= (0 - (u64)(lo < hh)) & 0xFFFFFFFFull;
+    u64 m = hl * 0xFFFFFFFFull;
+    u64 s = r + m;
+    s += (0 - (u64)(s < m)) & 0xFFFFFFFFull;
+    s -= (0 - (u64)(s >= GL_P)) & GL_P;
+    return s;
+}
 static u64 gl_pow(u64 a, u64 e) { u64 r = 1; while (e) { if (e & 1) r = gl_mul(r, a); a = gl_mul(a, a); e >>= 1; } return r; }
 static inline u64 gl_from_i64(int64_t v) { return v >= 0 ? (u64)v : GL_P - (u64)(-v); }
 
@@ -227,7 +252,7 @@ static void gl_ntt_fwd(const gl_tables *T, u64 *a)
         }
     }
 }
-/* inverse, bit-reversed in -> natural out, includes 1/N */
+/* inverse, bit-reversed in -> natural out; the 1/N factor is folded into the key */
 static void gl_ntt_inv(const gl_tables *T, u64 *a)
 {
     int N = T->N, t = 1;
@@ -243,7 +268,6 @@ static void gl_ntt_inv(const gl_tables *T, u64 *a)
         }
         t <<= 1;
     }
-    for (int j = 0; j < N; j++) a[j] = gl_mul(a[j], T->n_inv);
 }
 
 /* Bootstrapping key in the oracle's NTT domain. */
@@ -265,6 +289,7 @@ orc_bsk_ntt *orc_bsk_ntt_new(const orc_params *P, const u32 *bsk_std)
         const u32 *src = bsk_std + (size_t)q * P->N;
         for (int t = 0; t < P->N; t++) dst[t] = gl_from_i64((int64_t)(int32_t)src[t]);
         gl_ntt_fwd(B->T, dst);
+        for (int t = 0; t < P->N; t++) dst[t] = gl_mul(dst[t], B->T->n_inv);
     }
     return B;
 }
