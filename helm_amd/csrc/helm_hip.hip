@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -120,16 +121,16 @@ struct PbsLds {
     using G = Geo<LOGN>;
     static constexpr int K1 = K + 1;
     static constexpr int MAX_SMALL_N = 1024;
+    static_assert(L - 1 >= K, "partial sums are handed over through exchange slots 1..K");
     static constexpr size_t X_OFF = 0;                                          // double [K1][L][XPAD]
-    static constexpr size_t R_OFF = X_OFF + sizeof(double) * K1 * L * G::XPAD;  // double [K1][K][N]
-    static constexpr size_t TW_OFF = R_OFF + sizeof(double) * K1 * K * G::N;    // double [2][N] (if !TWREG)
+    static constexpr size_t TW_OFF = X_OFF + sizeof(double) * K1 * L * G::XPAD; // double [2][N] (if !TWREG)
     static constexpr size_t ACC_OFF = TW_OFF + (TWREG ? 0 : sizeof(double) * 2 * G::N); // u32 [K1][N]
     static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint32_t) * K1 * G::N;    // u32 [n+1]
     static constexpr size_t BYTES = MS_OFF + sizeof(uint32_t) * (MAX_SMALL_N + 1);
 };
 
 template <int LOGN, int K, int L, bool TWREG>
-__global__ __launch_bounds__(64 * (K + 1)) void k_pbs(const PbsJob *__restrict__ jobs,
+__global__ __launch_bounds__(64 * (K + 1), (TWREG || LOGN != 9) ? 1 : 2) void k_pbs(const PbsJob *__restrict__ jobs,
                                                       const uint32_t *__restrict__ wires,  // rows of n+1
                                                       const uint32_t *__restrict__ raw_in, // rows of n+1 (op == -1)
                                                       const uint32_t *__restrict__ tvs,    // rows of N
@@ -144,7 +145,6 @@ __global__ __launch_bounds__(64 * (K + 1)) void k_pbs(const PbsJob *__restrict__
     constexpr int N = G::N, E = G::E, K1 = K + 1;
     extern __shared__ __align__(16) unsigned char smem[];
     double *X = reinterpret_cast<double *>(smem + S::X_OFF);
-    double *R = reinterpret_cast<double *>(smem + S::R_OFF);
     uint32_t *ACC = reinterpret_cast<uint32_t *>(smem + S::ACC_OFF);
     uint32_t *MS = reinterpret_cast<uint32_t *>(smem + S::MS_OFF);
 
@@ -270,8 +270,9 @@ __global__ __launch_bounds__(64 * (K + 1)) void k_pbs(const PbsJob *__restrict__
 #pragma unroll
                 for (int e = 0; e < E; e++) mine[e] = part[e];
             } else {
-                // R[src = p][slot][N]: slot indexes the destination among the K others
-                double *dst = R + ((size_t)p * K + (c < p ? c : c - 1)) * N;
+                // handed over through this wave's exchange slots 1..K (free until the next
+                // step's forward transforms): slot indexes the destination among the K others
+                double *dst = xb + (size_t)(1 + (c < p ? c : c - 1)) * G::XPAD;
 #pragma unroll
                 for (int e = 0; e < E; e++) dst[e * 64 + lane] = part[e];
             }
@@ -285,13 +286,13 @@ __global__ __launch_bounds__(64 * (K + 1)) void k_pbs(const PbsJob *__restrict__
 #pragma unroll
         for (int q = 0; q < K1; q++) {
             if (q == p) continue;
-            const double *src = R + ((size_t)q * K + (p < q ? p : p - 1)) * N;
+            const double *src = X + ((size_t)q * L + 1 + (p < q ? p : p - 1)) * G::XPAD;
 #pragma unroll
             for (int e = 0; e < E; e++) mine[e] += src[e * 64 + lane];
         }
 #pragma unroll
         for (int e = 0; e < E; e++) mine[e] = reduce(mine[e]);
-        lds_block_sync(); // R may be overwritten by the next step
+        lds_block_sync(); // the slots may be overwritten by the next step's forward transforms
 
         ntt_inverse<LOGN>(mine, xb, twi, lane);
 #pragma unroll
@@ -541,6 +542,8 @@ struct helm_hip_ctx {
     uint32_t *ksk = nullptr;
     uint32_t *tv_bool = nullptr; // one row: all +1/8
     bool have_bsk = false, have_ksk = false;
+    int n_cus = 256;
+    int pbs_variant = 0; // 0 = by launch size, 1 = latency build, 2 = throughput build (HELM_HIP_PBS_VARIANT)
     // per-call scratch
     DevBuf<PbsJob> d_pbs;
     DevBuf<KsJob> d_ks;
@@ -625,8 +628,8 @@ static int plan_level(const int32_t *op, const int32_t *in0, const int32_t *in1,
     return 0;
 }
 
-template <int LOGN, int K, int L, bool TWREG = (LOGN == 9)>
-static hipError_t launch_pbs_t(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
+template <int LOGN, int K, int L, bool TWREG>
+static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
                                const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
 {
     using S = PbsLds<LOGN, K, L, TWREG>;
@@ -651,6 +654,27 @@ static bool pbs_supported(const helm_hip_params &P)
     if (P.N == 1024 && P.k == 1 && P.pbs_l == 3) return true;
     if (P.N == 1024 && P.k == 1 && P.pbs_l == 2) return true;
     return false;
+}
+
+// Two builds of the kernel: "latency" (twiddles in registers, one workgroup per CU) for
+// launches that do not fill the chip, "throughput" (twiddles from LDS, <= 256 registers,
+// two workgroups per CU) for wide levels.  N = 1024 only has the LDS-twiddle build.
+template <int LOGN, int K, int L>
+static hipError_t launch_pbs_t(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
+                               const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
+{
+    if constexpr (LOGN == 9) {
+        // Measured on MI355X (profiles/r01): one workgroup per CU takes t1 per wave of
+        // workgroups with the latency build; the throughput build takes 1.15 t1 alone on a
+        // CU and 1.74 t1 when two share it.  Pick the build with the smaller estimate.
+        const int64_t C = ctx->n_cus;
+        const double lat = (double)((count + C - 1) / C);
+        const int64_t rem = count % (2 * C);
+        const double thr = (double)(count / (2 * C)) * 1.74 + (rem == 0 ? 0.0 : rem <= C ? 1.15 : 1.74);
+        const bool latency = ctx->pbs_variant == 1 || (ctx->pbs_variant == 0 && lat <= thr);
+        if (latency) return launch_pbs_v<LOGN, K, L, true>(ctx, jobs, count, wires, raw, tvs, out_big);
+    }
+    return launch_pbs_v<LOGN, K, L, false>(ctx, jobs, count, wires, raw, tvs, out_big);
 }
 
 static hipError_t launch_pbs(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
@@ -783,6 +807,8 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
     if (!ctx) return fail(HELM_ERR_OOM, "ctx");
     ctx->device = device_id;
     ctx->P = P;
+    ctx->n_cus = prop.multiProcessorCount;
+    if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) ctx->pbs_variant = atoi(v);
     while ((1 << ctx->logN) < P.N) ctx->logN++;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
