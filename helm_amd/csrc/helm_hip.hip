@@ -109,44 +109,55 @@ __device__ __forceinline__ void decompose(uint32_t x, int logB, int (&dig)[L])
 // k_pbs: one workgroup = one bootstrap; wave p owns accumulator polynomial p.
 //
 // Per CMUX step, wave p: rotates/subtracts its polynomial (LDS), decomposes it into L
-// digit polynomials, transforms them (L interleaved NTTs, wave-private LDS transposes),
-// multiplies by its (k+1)*L key polynomials (prefetched one step ahead into registers),
-// hands the K partial sums that belong to other waves over through LDS (the only two
-// workgroup barriers of the step), inverse-transforms its own sum and accumulates.
-// TWREG: keep this lane's twiddles in registers (N = 512) or read them from an LDS copy
-// of the tables (N = 1024, where registers are needed for the key prefetch).
+// digit polynomials, transforms them (M at a time, wave-private LDS transposes),
+// multiplies by its (k+1)*L key polynomials, hands the K partial sums that belong to
+// other waves over through LDS (the only two workgroup barriers of the step),
+// inverse-transforms its own sum and accumulates.
+//
+// Builds (struct PbsCfg); latency / balanced are picked per launch from the launch size:
+//   latency    M = L, key words prefetched one step ahead into registers, twiddles in
+//              registers; ~330 registers -> one workgroup per CU.  Narrow levels.
+//   balanced   as above, twiddles from an LDS copy; 256 registers -> two workgroups/CU.
+//   occupancy  M = 1, no prefetch, twiddles from the (L1-resident) global table;
+//              <= 168 registers and ~37 KB LDS -> four workgroups per CU (three waves per
+//              SIMD): the other waves hide every latency.  Wide levels.
 // ------------------------------------------------------------------------------------
-template <int LOGN, int K, int L, bool TWREG>
-struct PbsLds {
+enum { TW_REG = 0, TW_LDS = 1, TW_GLOBAL = 2 };
+
+template <int LOGN_, int K_, int L_, int M_, int TW_, bool PREFETCH_, int MINW_>
+struct PbsCfg {
+    static constexpr int LOGN = LOGN_, K = K_, L = L_, M = M_, TW = TW_, MINW = MINW_;
+    static constexpr bool PREFETCH = PREFETCH_;
     using G = Geo<LOGN>;
     static constexpr int K1 = K + 1;
+    static constexpr int SLOTS = M > K ? M : K; // exchange slots per wave (also carry the hand-over)
     static constexpr int MAX_SMALL_N = 1024;
-    static_assert(L - 1 >= K, "partial sums are handed over through exchange slots 1..K");
-    static constexpr size_t X_OFF = 0;                                          // double [K1][L][XPAD]
-    static constexpr size_t TW_OFF = X_OFF + sizeof(double) * K1 * L * G::XPAD; // double [2][N] (if !TWREG)
-    static constexpr size_t ACC_OFF = TW_OFF + (TWREG ? 0 : sizeof(double) * 2 * G::N); // u32 [K1][N]
-    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint32_t) * K1 * G::N;    // u32 [n+1]
+    static_assert(L % M == 0, "levels are transformed M at a time");
+    static constexpr size_t X_OFF = 0;                                               // double [K1][SLOTS][XPAD]
+    static constexpr size_t TW_OFF = X_OFF + sizeof(double) * K1 * SLOTS * G::XPAD;  // double [2][N] (TW_LDS)
+    static constexpr size_t ACC_OFF = TW_OFF + (TW == TW_LDS ? sizeof(double) * 2 * G::N : 0); // u32 [K1][N]
+    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint32_t) * K1 * G::N;         // u32 [n+1]
     static constexpr size_t BYTES = MS_OFF + sizeof(uint32_t) * (MAX_SMALL_N + 1);
 };
 
-template <int LOGN, int K, int L, bool TWREG>
-__global__ __launch_bounds__(64 * (K + 1), (TWREG || LOGN != 9) ? 1 : 2) void k_pbs(const PbsJob *__restrict__ jobs,
-                                                      const uint32_t *__restrict__ wires,  // rows of n+1
-                                                      const uint32_t *__restrict__ raw_in, // rows of n+1 (op == -1)
-                                                      const uint32_t *__restrict__ tvs,    // rows of N
-                                                      const double *__restrict__ bsk,      // NTT domain
-                                                      const double *__restrict__ tw_fwd,
-                                                      const double *__restrict__ tw_inv,
-                                                      uint32_t *__restrict__ out_big, // rows of K*N+1
-                                                      int n, int logB)
+template <typename C>
+__global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *__restrict__ jobs,
+                                                                  const uint32_t *__restrict__ wires,  // rows of n+1
+                                                                  const uint32_t *__restrict__ raw_in, // rows of n+1
+                                                                  const uint32_t *__restrict__ tvs,    // rows of N
+                                                                  const double *__restrict__ bsk,      // NTT domain
+                                                                  const double *__restrict__ tw_fwd,
+                                                                  const double *__restrict__ tw_inv,
+                                                                  uint32_t *__restrict__ out_big, // rows of K*N+1
+                                                                  int n, int logB)
 {
+    constexpr int LOGN = C::LOGN, K = C::K, L = C::L, M = C::M;
     using G = Geo<LOGN>;
-    using S = PbsLds<LOGN, K, L, TWREG>;
     constexpr int N = G::N, E = G::E, K1 = K + 1;
     extern __shared__ __align__(16) unsigned char smem[];
-    double *X = reinterpret_cast<double *>(smem + S::X_OFF);
-    uint32_t *ACC = reinterpret_cast<uint32_t *>(smem + S::ACC_OFF);
-    uint32_t *MS = reinterpret_cast<uint32_t *>(smem + S::MS_OFF);
+    double *X = reinterpret_cast<double *>(smem + C::X_OFF);
+    uint32_t *ACC = reinterpret_cast<uint32_t *>(smem + C::ACC_OFF);
+    uint32_t *MS = reinterpret_cast<uint32_t *>(smem + C::MS_OFF);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int p = __builtin_amdgcn_readfirstlane(tid >> 6); // this wave's polynomial
@@ -169,20 +180,23 @@ __global__ __launch_bounds__(64 * (K + 1), (TWREG || LOGN != 9) ? 1 : 2) void k_
             MS[i] = modswitch(v, LOGN + 1);
         }
     }
-    // ---- twiddles: registers, or an LDS copy of both tables --------------------------
-    using TwF = typename std::conditional<TWREG, TwReg<G::NTW>, TwMem>::type;
+    // ---- twiddles: registers, an LDS copy of both tables, or the global tables ---------
+    using TwF = typename std::conditional<C::TW == TW_REG, TwReg<G::NTW>, TwMem>::type;
     TwF twf, twi;
-    if constexpr (TWREG) {
+    if constexpr (C::TW == TW_REG) {
         tw_fill_forward<LOGN>(twf, tw_fwd, lane);
         tw_fill_inverse<LOGN>(twi, tw_inv, lane);
-    } else {
-        double *TW = reinterpret_cast<double *>(smem + S::TW_OFF);
+    } else if constexpr (C::TW == TW_LDS) {
+        double *TW = reinterpret_cast<double *>(smem + C::TW_OFF);
         for (int i = tid; i < N; i += 64 * K1) {
             TW[i] = tw_fwd[i];
             TW[N + i] = tw_inv[i];
         }
         twf.t = TW;
         twi.t = TW + N;
+    } else {
+        twf.t = tw_fwd;
+        twi.t = tw_inv;
     }
     __syncthreads();
 
@@ -207,19 +221,21 @@ __global__ __launch_bounds__(64 * (K + 1), (TWREG || LOGN != 9) ? 1 : 2) void k_
     }
     lds_wave_sync();
 
-    double *xb = X + (size_t)p * L * G::XPAD; // this wave's L exchange buffers
+    double *xb = X + (size_t)p * C::SLOTS * G::XPAD; // this wave's exchange slots
     // key words of step i for this wave: [c][lev][e/2][lane] as double2
     const size_t bsk_step = (size_t)K1 * K1 * L * (N / 2); // double2 per LWE coefficient
     const double2 *bsk_p = reinterpret_cast<const double2 *>(bsk) + (size_t)p * K1 * L * (N / 2) + lane;
-    double2 bw[K1][L][E / 2];
+    double2 bw[C::PREFETCH ? K1 : 1][C::PREFETCH ? L : 1][C::PREFETCH ? E / 2 : 1];
     auto prefetch = [&](int i) {
-        const double2 *bp = bsk_p + (size_t)i * bsk_step;
+        if constexpr (C::PREFETCH) {
+            const double2 *bp = bsk_p + (size_t)i * bsk_step;
 #pragma unroll
-        for (int c = 0; c < K1; c++)
+            for (int c = 0; c < K1; c++)
 #pragma unroll
-            for (int lev = 0; lev < L; lev++)
+                for (int lev = 0; lev < L; lev++)
 #pragma unroll
-                for (int e2 = 0; e2 < E / 2; e2++) bw[c][lev][e2] = bp[((c * L + lev) * (E / 2) + e2) * 64];
+                    for (int e2 = 0; e2 < E / 2; e2++) bw[c][lev][e2] = bp[((c * L + lev) * (E / 2) + e2) * 64];
+        }
     };
     auto next_nonzero = [&](int i) {
         while (i < n && __builtin_amdgcn_readfirstlane((int)MS[i]) == 0) i++;
@@ -231,50 +247,111 @@ __global__ __launch_bounds__(64 * (K + 1), (TWREG || LOGN != 9) ? 1 : 2) void k_
     if (i < n) prefetch(i);
     while (i < n) {
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
-
-        // (X^a acc_p - acc_p), decomposed into L digit polynomials
-        double x[L][E];
-        {
-            uint32_t rot[E];
-#pragma unroll
-            for (int e = 0; e < E; e++) rot[e] = acc_p[(G::jA(lane, e) - a) & (N - 1)];
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                const int src = (G::jA(lane, e) - a) & (2 * N - 1);
-                const uint32_t v = src >= N ? 0u - rot[e] : rot[e];
-                int dig[L];
-                decompose<L>(v - accr[e], logB, dig);
-#pragma unroll
-                for (int lev = 0; lev < L; lev++) x[lev][e] = (double)dig[lev];
-            }
+        const double2 *bp_i = bsk_p + (size_t)i * bsk_step;
+        if constexpr (C::TW == TW_GLOBAL) {
+            // keep the (L1-resident) twiddle loads inside the step: hoisted out of the loop
+            // they would pin ~90 registers and defeat the occupancy this build exists for
+            asm volatile("" : "+s"(twf.t), "+s"(twi.t));
         }
-        ntt_forward<LOGN, L>(x, xb, twf, lane);
 
-        // pointwise: partial[c] = sum_lev x[lev] * BSK_i[p][c][lev]
         double mine[E];
+        if constexpr (M == L) {
+            // ---- all L levels transformed together (latency / balanced builds) ----------
+            double x[L][E];
+            {
+                uint32_t rot[E];
 #pragma unroll
-        for (int c = 0; c < K1; c++) {
-            double part[E];
+                for (int e = 0; e < E; e++) rot[e] = acc_p[(G::jA(lane, e) - a) & (N - 1)];
 #pragma unroll
-            for (int e2 = 0; e2 < E / 2; e2++) {
-                double s0 = 0.0, s1 = 0.0;
+                for (int e = 0; e < E; e++) {
+                    const int src = (G::jA(lane, e) - a) & (2 * N - 1);
+                    const uint32_t v = src >= N ? 0u - rot[e] : rot[e];
+                    int dig[L];
+                    decompose<L>(v - accr[e], logB, dig);
 #pragma unroll
-                for (int lev = 0; lev < L; lev++) {
-                    s0 += mulmod(x[lev][2 * e2], bw[c][lev][e2].x);
-                    s1 += mulmod(x[lev][2 * e2 + 1], bw[c][lev][e2].y);
+                    for (int lev = 0; lev < L; lev++) x[lev][e] = (double)dig[lev];
                 }
-                part[2 * e2] = reduce(s0);
-                part[2 * e2 + 1] = reduce(s1);
             }
-            if (c == p) {
+            ntt_forward<LOGN, L>(x, xb, twf, lane);
+            // part[c] = sum_lev x[lev] * BSK_i[p][c][lev]; the partial sums of the other
+            // polynomials are handed over through this wave's exchange slots 0..K-1 (idle
+            // until the inverse transform, which starts after the second barrier)
 #pragma unroll
-                for (int e = 0; e < E; e++) mine[e] = part[e];
-            } else {
-                // handed over through this wave's exchange slots 1..K (free until the next
-                // step's forward transforms): slot indexes the destination among the K others
-                double *dst = xb + (size_t)(1 + (c < p ? c : c - 1)) * G::XPAD;
+            for (int c = 0; c < K1; c++) {
+                double part[E];
 #pragma unroll
-                for (int e = 0; e < E; e++) dst[e * 64 + lane] = part[e];
+                for (int e2 = 0; e2 < E / 2; e2++) {
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int lev = 0; lev < L; lev++) {
+                        double2 w;
+                        if constexpr (C::PREFETCH) w = bw[c][lev][e2];
+                        else w = bp_i[((c * L + lev) * (E / 2) + e2) * 64];
+                        s0 += mulmod(x[lev][2 * e2], w.x);
+                        s1 += mulmod(x[lev][2 * e2 + 1], w.y);
+                    }
+                    part[2 * e2] = reduce(s0);
+                    part[2 * e2 + 1] = reduce(s1);
+                }
+                if (c == p) {
+#pragma unroll
+                    for (int e = 0; e < E; e++) mine[e] = part[e];
+                } else {
+                    double *dst = xb + (size_t)(c < p ? c : c - 1) * G::XPAD;
+#pragma unroll
+                    for (int e = 0; e < E; e++) dst[e * 64 + lane] = part[e];
+                }
+            }
+        } else {
+            // ---- one level at a time, least significant first (occupancy build): the
+            //      decomposition state is carried in registers, digits are produced in the
+            //      order the signed decomposition generates them ---------------------------
+            static_assert(M == 1, "level-at-a-time path");
+            uint32_t state[E];
+            {
+                const int rep = logB * L;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int src = (G::jA(lane, e) - a) & (2 * N - 1);
+                    uint32_t v = acc_p[src & (N - 1)];
+                    if (src >= N) v = 0u - v;
+                    state[e] = ((v - accr[e]) + (1u << (31 - rep))) >> (32 - rep);
+                }
+            }
+            double part[K1][E];
+            const uint32_t mask = (1u << logB) - 1u;
+#pragma unroll
+            for (int lev = L - 1; lev >= 0; lev--) {
+                double x[1][E];
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    uint32_t d = state[e] & mask;
+                    uint32_t st = state[e] >> logB;
+                    const uint32_t carry = (((d - 1u) | st) & d) >> (logB - 1);
+                    state[e] = st + carry;
+                    x[0][e] = (double)((int)d - (int)(carry << logB));
+                }
+                ntt_forward<LOGN, 1>(x, xb, twf, lane);
+#pragma unroll
+                for (int c = 0; c < K1; c++)
+#pragma unroll
+                    for (int e2 = 0; e2 < E / 2; e2++) {
+                        const double2 w = bp_i[((c * L + lev) * (E / 2) + e2) * 64];
+                        const double t0 = mulmod(x[0][2 * e2], w.x), t1 = mulmod(x[0][2 * e2 + 1], w.y);
+                        part[c][2 * e2] = lev == L - 1 ? t0 : part[c][2 * e2] + t0;
+                        part[c][2 * e2 + 1] = lev == L - 1 ? t1 : part[c][2 * e2 + 1] + t1;
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < K1; c++) {
+                if (c == p) {
+#pragma unroll
+                    for (int e = 0; e < E; e++) mine[e] = reduce(part[c][e]);
+                } else {
+                    double *dst = xb + (size_t)(c < p ? c : c - 1) * G::XPAD;
+#pragma unroll
+                    for (int e = 0; e < E; e++) dst[e * 64 + lane] = reduce(part[c][e]);
+                }
             }
         }
         // key words of the next step: in flight during the exchange, the inverse
@@ -286,13 +363,13 @@ __global__ __launch_bounds__(64 * (K + 1), (TWREG || LOGN != 9) ? 1 : 2) void k_
 #pragma unroll
         for (int q = 0; q < K1; q++) {
             if (q == p) continue;
-            const double *src = X + ((size_t)q * L + 1 + (p < q ? p : p - 1)) * G::XPAD;
+            const double *src = X + ((size_t)q * C::SLOTS + (p < q ? p : p - 1)) * G::XPAD;
 #pragma unroll
             for (int e = 0; e < E; e++) mine[e] += src[e * 64 + lane];
         }
 #pragma unroll
         for (int e = 0; e < E; e++) mine[e] = reduce(mine[e]);
-        lds_block_sync(); // the slots may be overwritten by the next step's forward transforms
+        lds_block_sync(); // every hand-over slot has been read: the slots are free again
 
         ntt_inverse<LOGN>(mine, xb, twi, lane);
 #pragma unroll
@@ -543,7 +620,7 @@ struct helm_hip_ctx {
     uint32_t *tv_bool = nullptr; // one row: all +1/8
     bool have_bsk = false, have_ksk = false;
     int n_cus = 256;
-    int pbs_variant = 0; // 0 = by launch size, 1 = latency build, 2 = throughput build (HELM_HIP_PBS_VARIANT)
+    int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 occupancy (HELM_HIP_PBS_VARIANT)
     // per-call scratch
     DevBuf<PbsJob> d_pbs;
     DevBuf<KsJob> d_ks;
@@ -628,22 +705,54 @@ static int plan_level(const int32_t *op, const int32_t *in0, const int32_t *in1,
     return 0;
 }
 
-template <int LOGN, int K, int L, bool TWREG>
+template <typename C>
 static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
                                const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
 {
-    using S = PbsLds<LOGN, K, L, TWREG>;
     static bool attr_done[64] = {false};
-    auto kern = k_pbs<LOGN, K, L, TWREG>;
+    auto kern = k_pbs<C>;
     if (!attr_done[ctx->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
         if (e != hipSuccess) return e;
         attr_done[ctx->device & 63] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * (K + 1)), S::BYTES, ctx->stream, jobs, wires, raw, tvs,
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * (C::K + 1)), C::BYTES, ctx->stream, jobs, wires, raw, tvs,
                        ctx->bsk, ctx->tw_fwd, ctx->tw_inv, out_big, ctx->P.n, ctx->P.pbs_logB);
     return hipGetLastError();
+}
+
+// Build choice.  Measured on MI355X (profiles/r01/microbench_nand_*): per wave of
+// workgroups the latency build takes t1 with one workgroup per CU; the balanced build
+// takes 1.15 t1 alone on a CU and 1.74 t1 when two share it.  The build with the smaller
+// estimate for this launch is used.  (A third, high-occupancy build - one level at a
+// time, no prefetch, 168 registers, four workgroups per CU - measured 1.7x SLOWER than
+// the latency build at every size: without the register prefetch each wave serialises
+// ~66 L2 round trips per step and three waves per SIMD do not hide them.  It is kept
+// reachable with HELM_HIP_PBS_VARIANT=3 for profiling only.)
+template <int LOGN, int K, int L>
+static hipError_t launch_pbs_t(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
+                               const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
+{
+    if constexpr (LOGN == 9) {
+        using Lat = PbsCfg<LOGN, K, L, L, TW_REG, true, 1>;
+        using Bal = PbsCfg<LOGN, K, L, L, TW_LDS, true, 2>;
+        using Occ = PbsCfg<LOGN, K, L, 1, TW_GLOBAL, false, 3>;
+        int v = ctx->pbs_variant;
+        if (v == 0) {
+            const int64_t Cu = ctx->n_cus;
+            const double lat = (double)((count + Cu - 1) / Cu);
+            const int64_t rem = count % (2 * Cu);
+            const double bal = (double)(count / (2 * Cu)) * 1.74 + (rem == 0 ? 0.0 : rem <= Cu ? 1.15 : 1.74);
+            v = lat <= bal ? 1 : 2;
+        }
+        if (v == 1) return launch_pbs_v<Lat>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if (v == 2) return launch_pbs_v<Bal>(ctx, jobs, count, wires, raw, tvs, out_big);
+        return launch_pbs_v<Occ>(ctx, jobs, count, wires, raw, tvs, out_big);
+    } else {
+        using Big = PbsCfg<LOGN, K, L, L, TW_LDS, true, 1>;
+        return launch_pbs_v<Big>(ctx, jobs, count, wires, raw, tvs, out_big);
+    }
 }
 
 static bool pbs_supported(const helm_hip_params &P)
@@ -654,27 +763,6 @@ static bool pbs_supported(const helm_hip_params &P)
     if (P.N == 1024 && P.k == 1 && P.pbs_l == 3) return true;
     if (P.N == 1024 && P.k == 1 && P.pbs_l == 2) return true;
     return false;
-}
-
-// Two builds of the kernel: "latency" (twiddles in registers, one workgroup per CU) for
-// launches that do not fill the chip, "throughput" (twiddles from LDS, <= 256 registers,
-// two workgroups per CU) for wide levels.  N = 1024 only has the LDS-twiddle build.
-template <int LOGN, int K, int L>
-static hipError_t launch_pbs_t(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
-                               const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
-{
-    if constexpr (LOGN == 9) {
-        // Measured on MI355X (profiles/r01): one workgroup per CU takes t1 per wave of
-        // workgroups with the latency build; the throughput build takes 1.15 t1 alone on a
-        // CU and 1.74 t1 when two share it.  Pick the build with the smaller estimate.
-        const int64_t C = ctx->n_cus;
-        const double lat = (double)((count + C - 1) / C);
-        const int64_t rem = count % (2 * C);
-        const double thr = (double)(count / (2 * C)) * 1.74 + (rem == 0 ? 0.0 : rem <= C ? 1.15 : 1.74);
-        const bool latency = ctx->pbs_variant == 1 || (ctx->pbs_variant == 0 && lat <= thr);
-        if (latency) return launch_pbs_v<LOGN, K, L, true>(ctx, jobs, count, wires, raw, tvs, out_big);
-    }
-    return launch_pbs_v<LOGN, K, L, false>(ctx, jobs, count, wires, raw, tvs, out_big);
 }
 
 static hipError_t launch_pbs(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
