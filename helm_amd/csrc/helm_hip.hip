@@ -397,44 +397,71 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
 }
 
 // ------------------------------------------------------------------------------------
-// k_keyswitch: grid (n_jobs, column chunks); 256 threads; one column per thread.
-// out[c] = (c == n ? body : 0) - sum_t sum_j digit(t,j) * KSK[t][j][c]
+// k_keyswitch: grid (ceil(jobs / 4), column chunks); 256 threads; one output column per
+// thread, FOUR gates per workgroup so that every key word fetched (from L2 / Infinity
+// Cache: the key is 12 MB and shared by all gates) feeds four multiply-adds.
+//   out[c] = (c == n ? body : 0) - sum_t sum_j digit(t,j) * KSK[t][j][c]
+// The digits of the four gates are decomposed once into LDS, packed as 4 x int8 per word
+// (one broadcast ds_read_b32 per key word).  MUX recombination (sum of two bootstrap
+// outputs + 1/8) is folded into the input read.
 // ------------------------------------------------------------------------------------
 template <int KSL>
 __global__ __launch_bounds__(256) void k_keyswitch(const KsJob *__restrict__ jobs, const uint32_t *__restrict__ big,
                                                    const uint32_t *__restrict__ ksk, uint32_t *__restrict__ out,
-                                                   int n, int kN, int logB)
+                                                   int n, int kN, int logB, int count)
 {
+    constexpr int G = 4;
     extern __shared__ __align__(16) unsigned char smem[];
-    int8_t *DIG = reinterpret_cast<int8_t *>(smem); // [kN][KSL]
-    const KsJob job = jobs[blockIdx.x];
-    const size_t brow = (size_t)kN + 1;
-    const uint32_t *b0 = big + brow * (size_t)job.big0;
-    const uint32_t *b1 = job.big1 >= 0 ? big + brow * (size_t)job.big1 : nullptr;
-    for (int t = threadIdx.x; t < kN; t += 256) {
-        uint32_t v = b0[t] + (b1 ? b1[t] : 0u);
-        int dig[KSL];
-        decompose<KSL>(v, logB, dig);
+    uint32_t *DIG = reinterpret_cast<uint32_t *>(smem); // [kN * KSL] words, byte g = digit of gate g
+    const int g0 = blockIdx.x * G;
+    const int ng = min(G, count - g0);
+    KsJob job[G];
 #pragma unroll
-        for (int j = 0; j < KSL; j++) DIG[t * KSL + j] = (int8_t)dig[j];
+    for (int g = 0; g < G; g++) job[g] = jobs[g0 + (g < ng ? g : 0)];
+    const size_t brow = (size_t)kN + 1;
+    for (int t = threadIdx.x; t < kN; t += 256) {
+        uint32_t packed[KSL];
+#pragma unroll
+        for (int j = 0; j < KSL; j++) packed[j] = 0;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (g < ng) {
+                uint32_t v = big[brow * (size_t)job[g].big0 + t];
+                if (job[g].big1 >= 0) v += big[brow * (size_t)job[g].big1 + t];
+                int dig[KSL];
+                decompose<KSL>(v, logB, dig);
+#pragma unroll
+                for (int j = 0; j < KSL; j++) packed[j] |= ((uint32_t)dig[j] & 0xFFu) << (8 * g);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KSL; j++) DIG[t * KSL + j] = packed[j];
     }
     __syncthreads();
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c > n) return;
     const size_t krow = (size_t)n + 1;
-    uint32_t acc = 0;
+    uint32_t acc[G] = {0, 0, 0, 0};
     const uint32_t *kp = ksk + c;
-#pragma unroll 4
-    for (int t = 0; t < kN; t++) {
+    const int rows = kN * KSL;
+#pragma unroll 8
+    for (int r = 0; r < rows; r++) {
+        const uint32_t w = kp[(size_t)r * krow];
+        const uint32_t pk = DIG[r];
 #pragma unroll
-        for (int j = 0; j < KSL; j++) {
-            const int d = DIG[t * KSL + j];
-            acc += (uint32_t)d * kp[((size_t)t * KSL + j) * krow];
+        for (int g = 0; g < G; g++) acc[g] += (uint32_t)__builtin_amdgcn_sbfe(pk, 8 * g, 8) * w;
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        if (g < ng) {
+            uint32_t body = 0;
+            if (c == n) {
+                body = big[brow * (size_t)job[g].big0 + kN] + job[g].add_body;
+                if (job[g].big1 >= 0) body += big[brow * (size_t)job[g].big1 + kN];
+            }
+            out[krow * (size_t)job[g].out + c] = body - acc[g];
         }
     }
-    uint32_t body = 0;
-    if (c == n) body = b0[kN] + (b1 ? b1[kN] : 0u) + job.add_body;
-    out[krow * (size_t)job.out + c] = body - acc;
 }
 
 // ------------------------------------------------------------------------------------
@@ -781,12 +808,12 @@ static hipError_t launch_ks(helm_hip_ctx *ctx, const KsJob *jobs, int64_t count,
 {
     const helm_hip_params &P = ctx->P;
     const int kN = P.k * P.N;
-    dim3 grid((unsigned)count, (unsigned)((P.n + 1 + 255) / 256));
-    const size_t lds = (size_t)kN * P.ks_l;
+    dim3 grid((unsigned)((count + 3) / 4), (unsigned)((P.n + 1 + 255) / 256));
+    const size_t lds = (size_t)kN * P.ks_l * sizeof(uint32_t);
 #define KS_CASE(LV)                                                                                       \
     case LV:                                                                                              \
         hipLaunchKernelGGL(k_keyswitch<LV>, grid, dim3(256), lds, ctx->stream, jobs, big, ctx->ksk, out, P.n, kN, \
-                           P.ks_logB);                                                                    \
+                           P.ks_logB, (int)count);                                                        \
         break;
     switch (P.ks_l) {
         KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) KS_CASE(5) KS_CASE(6) KS_CASE(8)
