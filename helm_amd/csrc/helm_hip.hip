@@ -124,8 +124,9 @@ __device__ __forceinline__ void decompose(uint32_t x, int logB, int (&dig)[L])
 // ------------------------------------------------------------------------------------
 enum { TW_REG = 0, TW_LDS = 1, TW_GLOBAL = 2 };
 
-template <int LOGN_, int K_, int L_, int M_, int TW_, bool PREFETCH_, int MINW_>
+template <typename F_, int LOGN_, int K_, int L_, int M_, int TW_, bool PREFETCH_, int MINW_>
 struct PbsCfg {
+    using F = F_;
     static constexpr int LOGN = LOGN_, K = K_, L = L_, M = M_, TW = TW_, MINW = MINW_;
     static constexpr bool PREFETCH = PREFETCH_;
     using G = Geo<LOGN>;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
                                                                   int n, int logB)
 {
     constexpr int LOGN = C::LOGN, K = C::K, L = C::L, M = C::M;
+    using F = typename C::F;
     using G = Geo<LOGN>;
     constexpr int N = G::N, E = G::E, K1 = K + 1;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
                     for (int lev = 0; lev < L; lev++) x[lev][e] = (double)dig[lev];
                 }
             }
-            ntt_forward<LOGN, L>(x, xb, twf, lane);
+            ntt_forward<F, LOGN, L>(x, xb, twf, lane);
             // part[c] = sum_lev x[lev] * BSK_i[p][c][lev]; the partial sums of the other
             // polynomials are handed over through this wave's exchange slots 0..K-1 (idle
             // until the inverse transform, which starts after the second barrier)
@@ -287,11 +289,11 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
                         double2 w;
                         if constexpr (C::PREFETCH) w = bw[c][lev][e2];
                         else w = bp_i[((c * L + lev) * (E / 2) + e2) * 64];
-                        s0 += mulmod(x[lev][2 * e2], w.x);
-                        s1 += mulmod(x[lev][2 * e2 + 1], w.y);
+                        s0 += mulmod<F>(x[lev][2 * e2], w.x);
+                        s1 += mulmod<F>(x[lev][2 * e2 + 1], w.y);
                     }
-                    part[2 * e2] = reduce(s0);
-                    part[2 * e2 + 1] = reduce(s1);
+                    part[2 * e2] = reduce_unless_lazy<F>(s0);
+                    part[2 * e2 + 1] = reduce_unless_lazy<F>(s1);
                 }
                 if (c == p) {
 #pragma unroll
@@ -331,13 +333,13 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
                     state[e] = st + carry;
                     x[0][e] = (double)((int)d - (int)(carry << logB));
                 }
-                ntt_forward<LOGN, 1>(x, xb, twf, lane);
+                ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
 #pragma unroll
                 for (int c = 0; c < K1; c++)
 #pragma unroll
                     for (int e2 = 0; e2 < E / 2; e2++) {
                         const double2 w = bp_i[((c * L + lev) * (E / 2) + e2) * 64];
-                        const double t0 = mulmod(x[0][2 * e2], w.x), t1 = mulmod(x[0][2 * e2 + 1], w.y);
+                        const double t0 = mulmod<F>(x[0][2 * e2], w.x), t1 = mulmod<F>(x[0][2 * e2 + 1], w.y);
                         part[c][2 * e2] = lev == L - 1 ? t0 : part[c][2 * e2] + t0;
                         part[c][2 * e2 + 1] = lev == L - 1 ? t1 : part[c][2 * e2 + 1] + t1;
                     }
@@ -346,11 +348,11 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
             for (int c = 0; c < K1; c++) {
                 if (c == p) {
 #pragma unroll
-                    for (int e = 0; e < E; e++) mine[e] = reduce(part[c][e]);
+                    for (int e = 0; e < E; e++) mine[e] = reduce_unless_lazy<F>(part[c][e]);
                 } else {
                     double *dst = xb + (size_t)(c < p ? c : c - 1) * G::XPAD;
 #pragma unroll
-                    for (int e = 0; e < E; e++) dst[e * 64 + lane] = reduce(part[c][e]);
+                    for (int e = 0; e < E; e++) dst[e * 64 + lane] = reduce_unless_lazy<F>(part[c][e]);
                 }
             }
         }
@@ -368,10 +370,10 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
             for (int e = 0; e < E; e++) mine[e] += src[e * 64 + lane];
         }
 #pragma unroll
-        for (int e = 0; e < E; e++) mine[e] = reduce(mine[e]);
+        for (int e = 0; e < E; e++) mine[e] = reduce<F>(mine[e]);
         lds_block_sync(); // every hand-over slot has been read: the slots are free again
 
-        ntt_inverse<LOGN>(mine, xb, twi, lane);
+        ntt_inverse<F, LOGN>(mine, xb, twi, lane);
 #pragma unroll
         for (int e = 0; e < E; e++) {
             accr[e] += to_torus32(mine[e]);
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(256) void k_set_trivial(const int32_t *__restrict__
 // as signed) -> forward NTT -> * N^{-1} -> centred doubles in the lane-order k_pbs reads:
 //   dst[i][r][c][lev][e/2][lane][e&1]      (src is [i][lev][r][c][N])
 // ------------------------------------------------------------------------------------
-template <int LOGN>
+template <typename F, int LOGN>
 __global__ __launch_bounds__(64) void k_bsk_convert(const uint32_t *__restrict__ src, double *__restrict__ dst,
                                                     const double *__restrict__ tw_fwd, double n_inv, int K1, int L)
 {
@@ -540,15 +542,15 @@ __global__ __launch_bounds__(64) void k_bsk_convert(const uint32_t *__restrict__
 #pragma unroll
     for (int e = 0; e < E; e++) x[0][e] = (double)(int32_t)src[poly * N + G::jA(lane, e)];
     // |x| <= 2^31: far below p/2, so the digit-sized input bound of ntt_forward holds
-    ntt_forward<LOGN, 1>(x, xbuf, TwMem{tw_fwd}, lane);
+    ntt_forward<F, LOGN, 1>(x, xbuf, TwMem{tw_fwd}, lane);
     const size_t dpoly = ((i * K1 + r) * K1 + c) * L + lev;
     double *d = dst + dpoly * N;
 #pragma unroll
-    for (int e = 0; e < E; e++) d[((e >> 1) * 64 + lane) * 2 + (e & 1)] = reduce(mulmod(x[0][e], n_inv));
+    for (int e = 0; e < E; e++) d[((e >> 1) * 64 + lane) * 2 + (e & 1)] = reduce<F>(mulmod<F>(x[0][e], n_inv));
 }
 
 // NTT self-test: forward, scale, inverse; must reproduce the input exactly.
-template <int LOGN>
+template <typename F, int LOGN>
 __global__ __launch_bounds__(64) void k_ntt_roundtrip(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
                                                       const double *__restrict__ tw_fwd,
                                                       const double *__restrict__ tw_inv, double n_inv)
@@ -560,10 +562,10 @@ __global__ __launch_bounds__(64) void k_ntt_roundtrip(const uint32_t *__restrict
     double x[1][E];
 #pragma unroll
     for (int e = 0; e < E; e++) x[0][e] = (double)(int32_t)src[(size_t)blockIdx.x * N + G::jA(lane, e)];
-    ntt_forward<LOGN, 1>(x, xbuf, TwMem{tw_fwd}, lane);
+    ntt_forward<F, LOGN, 1>(x, xbuf, TwMem{tw_fwd}, lane);
 #pragma unroll
-    for (int e = 0; e < E; e++) x[0][e] = reduce(mulmod(x[0][e], n_inv));
-    ntt_inverse<LOGN>(x[0], xbuf, TwMem{tw_inv}, lane);
+    for (int e = 0; e < E; e++) x[0][e] = reduce<F>(mulmod<F>(x[0][e], n_inv));
+    ntt_inverse<F, LOGN>(x[0], xbuf, TwMem{tw_inv}, lane);
 #pragma unroll
     for (int e = 0; e < E; e++) dst[(size_t)blockIdx.x * N + G::jA(lane, e)] = to_torus32(x[0][e]);
 }
@@ -574,21 +576,18 @@ __global__ __launch_bounds__(64) void k_ntt_roundtrip(const uint32_t *__restrict
 namespace {
 
 typedef unsigned __int128 u128;
-uint64_t mulmod_u64(uint64_t a, uint64_t b) { return (uint64_t)((u128)a * b % NTT_P_U64); }
-uint64_t powmod_u64(uint64_t a, uint64_t e)
+uint64_t mulmod_u64(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t)((u128)a * b % p); }
+uint64_t powmod_u64(uint64_t a, uint64_t e, uint64_t p)
 {
     uint64_t r = 1;
     while (e) {
-        if (e & 1) r = mulmod_u64(r, a);
-        a = mulmod_u64(a, a);
+        if (e & 1) r = mulmod_u64(r, a, p);
+        a = mulmod_u64(a, a, p);
         e >>= 1;
     }
     return r;
 }
-double centred(uint64_t v)
-{
-    return v > NTT_P_U64 / 2 ? (double)((int64_t)v - (int64_t)NTT_P_U64) : (double)(int64_t)v;
-}
+double centred(uint64_t v, uint64_t p) { return v > p / 2 ? (double)((int64_t)v - (int64_t)p) : (double)(int64_t)v; }
 int bitrev(int x, int bits)
 {
     int r = 0;
@@ -646,6 +645,7 @@ struct helm_hip_ctx {
     uint32_t *ksk = nullptr;
     uint32_t *tv_bool = nullptr; // one row: all +1/8
     bool have_bsk = false, have_ksk = false;
+    int field = 51; // Fp<51> or Fp<49> (lazy), chosen from the parameter set
     int n_cus = 256;
     int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 occupancy (HELM_HIP_PBS_VARIANT)
     // per-call scratch
@@ -757,14 +757,14 @@ static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
 // the latency build at every size: without the register prefetch each wave serialises
 // ~66 L2 round trips per step and three waves per SIMD do not hide them.  It is kept
 // reachable with HELM_HIP_PBS_VARIANT=3 for profiling only.)
-template <int LOGN, int K, int L>
-static hipError_t launch_pbs_t(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
+template <typename F, int LOGN, int K, int L>
+static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
                                const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
 {
     if constexpr (LOGN == 9) {
-        using Lat = PbsCfg<LOGN, K, L, L, TW_REG, true, 1>;
-        using Bal = PbsCfg<LOGN, K, L, L, TW_LDS, true, 2>;
-        using Occ = PbsCfg<LOGN, K, L, 1, TW_GLOBAL, false, 3>;
+        using Lat = PbsCfg<F, LOGN, K, L, L, TW_REG, true, 1>;
+        using Bal = PbsCfg<F, LOGN, K, L, L, TW_LDS, true, 2>;
+        using Occ = PbsCfg<F, LOGN, K, L, 1, TW_GLOBAL, false, 3>;
         int v = ctx->pbs_variant;
         if (v == 0) {
             const int64_t Cu = ctx->n_cus;
@@ -777,9 +777,19 @@ static hipError_t launch_pbs_t(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
         if (v == 2) return launch_pbs_v<Bal>(ctx, jobs, count, wires, raw, tvs, out_big);
         return launch_pbs_v<Occ>(ctx, jobs, count, wires, raw, tvs, out_big);
     } else {
-        using Big = PbsCfg<LOGN, K, L, L, TW_LDS, true, 1>;
+        using Big = PbsCfg<F, LOGN, K, L, L, TW_LDS, true, 1>;
         return launch_pbs_v<Big>(ctx, jobs, count, wires, raw, tvs, out_big);
     }
+}
+
+template <int LOGN, int K, int L>
+static hipError_t launch_pbs_t(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
+                               const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
+{
+    if constexpr (LOGN == 9) {
+        if (ctx->field == 49) return launch_pbs_f<Fp<49>, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
+    }
+    return launch_pbs_f<Fp<51>, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
 }
 
 static bool pbs_supported(const helm_hip_params &P)
@@ -904,10 +914,8 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         !(P.ks_l >= 1 && (P.ks_l <= 6 || P.ks_l == 8)))
         return fail(HELM_ERR_INVALID, "bad keyswitch decomposition (ks_logB <= 7, ks_l in {1..6,8})");
     // exactness: |sum| <= (k+1) * l * N * (B/2) * 2^31 must stay below p/2
-    {
-        const double bound = (double)(P.k + 1) * P.pbs_l * P.N * (double)(1u << (P.pbs_logB - 1)) * 2147483648.0;
-        if (bound * 1.0001 >= NTT_P / 2) return fail(HELM_ERR_INVALID, "parameter set exceeds the single-prime NTT capacity");
-    }
+    const double bound = (double)(P.k + 1) * P.pbs_l * P.N * (double)(1u << (P.pbs_logB - 1)) * 2147483648.0;
+    if (bound * 1.0001 >= Fp<51>::P / 2) return fail(HELM_ERR_INVALID, "parameter set exceeds the single-prime NTT capacity");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(HELM_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
@@ -930,17 +938,23 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
 
     // twiddle tables: bit-reversed powers of psi (primitive 2N-th root) and of psi^-1
     const int N = P.N, logN = ctx->logN;
-    const uint64_t psi = powmod_u64(NTT_GEN, (NTT_P_U64 - 1) / (2 * (uint64_t)N));
-    const uint64_t psi_inv = powmod_u64(psi, NTT_P_U64 - 2);
+    // the 49-bit prime (no recentring inside transforms) when the set's exact products fit
+    // below its half and a lazy build exists (N = 512); HELM_HIP_FIELD=51 forces the other
+    ctx->field = (N == 512 && bound * 1.002 < Fp<49>::P / 2) ? 49 : 51;
+    if (const char *v = getenv("HELM_HIP_FIELD")) if (atoi(v) == 51) ctx->field = 51;
+    const uint64_t pm = ctx->field == 49 ? Fp<49>::P_U64 : Fp<51>::P_U64;
+    const uint64_t gen = ctx->field == 49 ? Fp<49>::GEN : Fp<51>::GEN;
+    const uint64_t psi = powmod_u64(gen, (pm - 1) / (2 * (uint64_t)N), pm);
+    const uint64_t psi_inv = powmod_u64(psi, pm - 2, pm);
     std::vector<double> tf(N), ti(N);
     uint64_t a = 1, b = 1;
     for (int i = 0; i < N; i++) {
-        tf[bitrev(i, logN)] = centred(a);
-        ti[bitrev(i, logN)] = centred(b);
-        a = mulmod_u64(a, psi);
-        b = mulmod_u64(b, psi_inv);
+        tf[bitrev(i, logN)] = centred(a, pm);
+        ti[bitrev(i, logN)] = centred(b, pm);
+        a = mulmod_u64(a, psi, pm);
+        b = mulmod_u64(b, psi_inv, pm);
     }
-    ctx->n_inv = centred(powmod_u64((uint64_t)N, NTT_P_U64 - 2));
+    ctx->n_inv = centred(powmod_u64((uint64_t)N, pm - 2, pm), pm);
     HIP_TRY(hipMalloc(&ctx->tw_fwd, sizeof(double) * N));
     HIP_TRY(hipMalloc(&ctx->tw_inv, sizeof(double) * N));
     HIP_TRY(hipMemcpy(ctx->tw_fwd, tf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
@@ -1012,11 +1026,14 @@ int helm_hip_load_bootstrap_key(helm_hip_ctx *ctx, const uint32_t *bsk_std, size
     HIP_TRY(hipMalloc(&d_std, n_words * sizeof(uint32_t)));
     if (!ctx->bsk) HIP_TRY(hipMalloc(&ctx->bsk, n_words * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(d_std, bsk_std, n_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    if (P.N == 512)
-        hipLaunchKernelGGL(k_bsk_convert<9>, dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk,
+    if (P.N == 512 && ctx->field == 49)
+        hipLaunchKernelGGL((k_bsk_convert<Fp<49>, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk,
+                           ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
+    else if (P.N == 512)
+        hipLaunchKernelGGL((k_bsk_convert<Fp<51>, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk,
                            ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
     else
-        hipLaunchKernelGGL(k_bsk_convert<10>, dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk,
+        hipLaunchKernelGGL((k_bsk_convert<Fp<51>, 10>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk,
                            ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1435,11 +1452,14 @@ int helm_hip_ntt_roundtrip(helm_hip_ctx *ctx, const uint32_t *poly_in, uint32_t 
     HIP_TRY(hipMalloc(&d_in, (size_t)count * N * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&d_out, (size_t)count * N * sizeof(uint32_t)));
     HIP_TRY(hipMemcpyAsync(d_in, poly_in, (size_t)count * N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    if (N == 512)
-        hipLaunchKernelGGL(k_ntt_roundtrip<9>, dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in, d_out, ctx->tw_fwd,
-                           ctx->tw_inv, ctx->n_inv);
+    if (N == 512 && ctx->field == 49)
+        hipLaunchKernelGGL((k_ntt_roundtrip<Fp<49>, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in, d_out,
+                           ctx->tw_fwd, ctx->tw_inv, ctx->n_inv);
+    else if (N == 512)
+        hipLaunchKernelGGL((k_ntt_roundtrip<Fp<51>, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in, d_out,
+                           ctx->tw_fwd, ctx->tw_inv, ctx->n_inv);
     else
-        hipLaunchKernelGGL(k_ntt_roundtrip<10>, dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in, d_out,
+        hipLaunchKernelGGL((k_ntt_roundtrip<Fp<51>, 10>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in, d_out,
                            ctx->tw_fwd, ctx->tw_inv, ctx->n_inv);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(poly_out, d_out, (size_t)count * N * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

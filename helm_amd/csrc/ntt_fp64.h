@@ -23,31 +23,57 @@
 
 namespace helm {
 
-// p = 0x6060002B00001 = 1695446975119361 = 2^20 * 5 * 323380847 + 1, generator 3.
-// p/2 = 0.7529 * 2^50 exceeds the largest exact coefficient any supported
-// parameter set can produce ((k+1) * l * N * B/2 * 2^31 <= 0.75 * 2^50, checked at
-// context creation) while leaving 2^53 / p = 5.31 of headroom for lazy additions.
-constexpr double NTT_P = 1695446975119361.0;
-constexpr double NTT_PINV = 1.0 / NTT_P;
-constexpr uint64_t NTT_P_U64 = 1695446975119361ull;
-constexpr uint64_t NTT_GEN = 3;
+// Two primes, chosen per context from the parameter set (helm_hip_ctx_create):
+//   Fp51: p = 0x6060002B00001 = 1695446975119361 (p-1 = 2^20 * 5 * 323380847, generator 3).
+//         p/2 = 0.7529 * 2^50 exceeds the largest exact coefficient of every supported set
+//         ((k+1) * l * N * B/2 * 2^31 <= 0.75 * 2^50); 2^53 / p = 5.3 of headroom for lazy
+//         additions, so values are recentred at every block boundary.
+//   Fp49: p = 0x2424DD2F20001 = 635851972411393 (generator 5), for sets whose exact
+//         coefficients stay below p/2 = 0.565 * 2^49 (tfhe boolean DEFAULT: 2^48.17).
+//         2^53 / p = 14.2: a whole forward transform (digits in, <= 7.1p out), the
+//         pointwise sums (<= 3.8p) and their (k+1)-way hand-over sum (<= 11.4p) need no
+//         recentring at all (LAZY) - 11 % fewer fp64 operations per bootstrap.
+template <int ID> struct Fp;
+template <> struct Fp<51> {
+    static constexpr double P = 1695446975119361.0;
+    static constexpr uint64_t P_U64 = 1695446975119361ull;
+    static constexpr uint64_t GEN = 3;
+    static constexpr bool LAZY = false;
+};
+template <> struct Fp<49> {
+    static constexpr double P = 635851972411393.0;
+    static constexpr uint64_t P_U64 = 635851972411393ull;
+    static constexpr uint64_t GEN = 5;
+    static constexpr bool LAZY = true;
+};
 
 // a*w mod p for integers |a| < 2^53, |w| <= p/2.  Result r == a*w (mod p) exactly,
 // |r| <= (0.5 + 0.75 * |a| * 2^-52) * p  (<= 2p for any admissible a).
+template <typename F>
 __device__ __forceinline__ double mulmod(double a, double w)
 {
+    constexpr double PINV = 1.0 / F::P;
     double h = a * w;
     double l = __builtin_fma(a, w, -h);
-    double q = __builtin_rint(h * NTT_PINV);
-    double r = __builtin_fma(-q, NTT_P, h);
+    double q = __builtin_rint(h * PINV);
+    double r = __builtin_fma(-q, F::P, h);
     return r + l;
 }
 
 // a mod p, centred: |result| <= (0.5 + eps) * p.
+template <typename F>
 __device__ __forceinline__ double reduce(double a)
 {
-    double q = __builtin_rint(a * NTT_PINV);
-    return __builtin_fma(-q, NTT_P, a);
+    constexpr double PINV = 1.0 / F::P;
+    double q = __builtin_rint(a * PINV);
+    return __builtin_fma(-q, F::P, a);
+}
+// recentre only where the field has no headroom to skip it
+template <typename F>
+__device__ __forceinline__ double reduce_unless_lazy(double a)
+{
+    if constexpr (F::LAZY) return a;
+    else return reduce<F>(a);
 }
 
 // Exact integer in a double (|v| < 2^51) -> v mod 2^32.
@@ -160,7 +186,7 @@ __device__ __forceinline__ void tw_fill_inverse(TwReg<Geo<LOGN>::NTW> &r, const 
 
 // Fused radix-2 Cooley-Tukey stages on stride bits SB_HI..SB_LO (descending), all of
 // which are register-slot bits (slot bit = stride bit - SHIFT), for M polynomials.
-template <int LOGN, int M, int SHIFT, int SB_HI, int SB_LO, int SLOT0, typename TW>
+template <typename F, int LOGN, int M, int SHIFT, int SB_HI, int SB_LO, int SLOT0, typename TW>
 __device__ __forceinline__ void fwd_block(double (&x)[M][Geo<LOGN>::E], const TW &tw, int jbase)
 {
     constexpr int E = Geo<LOGN>::E, N = Geo<LOGN>::N;
@@ -177,7 +203,7 @@ __device__ __forceinline__ void fwd_block(double (&x)[M][Geo<LOGN>::E], const TW
                 const int e0 = (hi << (eb + 1)) | lo, e1 = e0 | (1 << eb);
 #pragma unroll
                 for (int m = 0; m < M; m++) {
-                    double U = x[m][e0], V = mulmod(x[m][e1], w);
+                    double U = x[m][e0], V = mulmod<F>(x[m][e1], w);
                     x[m][e0] = U + V;
                     x[m][e1] = U - V;
                 }
@@ -187,7 +213,7 @@ __device__ __forceinline__ void fwd_block(double (&x)[M][Geo<LOGN>::E], const TW
 }
 
 // Gentleman-Sande stages on stride bits SB_LO..SB_HI (ascending).
-template <int LOGN, int SHIFT, int SB_LO, int SB_HI, int SLOT0, typename TW>
+template <typename F, int LOGN, int SHIFT, int SB_LO, int SB_HI, int SLOT0, typename TW>
 __device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const TW &tw, int jbase)
 {
     constexpr int E = Geo<LOGN>::E, N = Geo<LOGN>::N;
@@ -198,7 +224,7 @@ __device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const TW &t
         if (sb - SB_LO == 2 && SB_HI - SB_LO == 3) {
             // 4-stage block: the pure-sum path has doubled twice; recentre.
 #pragma unroll
-            for (int e = 0; e < E; e++) x[e] = reduce(x[e]);
+            for (int e = 0; e < E; e++) x[e] = reduce<F>(x[e]);
         }
 #pragma unroll
         for (int hi = 0; hi < (E >> (eb + 1)); hi++) {
@@ -209,7 +235,7 @@ __device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const TW &t
                 const int e0 = (hi << (eb + 1)) | lo, e1 = e0 | (1 << eb);
                 double U = x[e0], V = x[e1];
                 x[e0] = U + V;
-                x[e1] = mulmod(U - V, w);
+                x[e1] = mulmod<F>(U - V, w);
             }
         }
     }
@@ -218,61 +244,61 @@ __device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const TW &t
 // Forward negacyclic NTT of M polynomials held by one wave.
 // in : x[m][e] = coefficient jA(lane,e), |x| <= 0.5p.
 // out: x[m][e] = transform word at position jC(lane,e) of the bit-reversed output,
-//      |x| <= ~3p (not recentred: the pointwise product absorbs it).
+//      |x| <= ~3p (Fp51) / ~7.1p (Fp49, lazy); not recentred: the pointwise product absorbs it.
 // xbuf: wave-private LDS scratch of M * Geo::XPAD doubles.
-template <int LOGN, int M, typename TW>
+template <typename F, int LOGN, int M, typename TW>
 __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double *xbuf, const TW &tw, int lane)
 {
     using G = Geo<LOGN>;
-    fwd_block<LOGN, M, 6, LOGN - 1, LOGN - G::BA, 0>(x, tw, G::jA(lane, 0));
+    fwd_block<F, LOGN, M, 6, LOGN - 1, LOGN - G::BA, 0>(x, tw, G::jA(lane, 0));
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
-        for (int e = 0; e < G::E; e++) xbuf[m * G::XPAD + G::pad1(G::jA(lane, e))] = reduce(x[m][e]);
+        for (int e = 0; e < G::E; e++) xbuf[m * G::XPAD + G::pad1(G::jA(lane, e))] = reduce_unless_lazy<F>(x[m][e]);
     lds_wave_sync();
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
         for (int e = 0; e < G::E; e++) x[m][e] = xbuf[m * G::XPAD + G::pad1(G::jB(lane, e))];
     lds_wave_sync();
-    fwd_block<LOGN, M, G::BC, G::BC + G::BB - 1, G::BC, G::TWA>(x, tw, G::jB(lane, 0));
+    fwd_block<F, LOGN, M, G::BC, G::BC + G::BB - 1, G::BC, G::TWA>(x, tw, G::jB(lane, 0));
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
-        for (int e = 0; e < G::E; e++) xbuf[m * G::XPAD + G::pad2(G::jB(lane, e))] = reduce(x[m][e]);
+        for (int e = 0; e < G::E; e++) xbuf[m * G::XPAD + G::pad2(G::jB(lane, e))] = reduce_unless_lazy<F>(x[m][e]);
     lds_wave_sync();
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
         for (int e = 0; e < G::E; e++) x[m][e] = xbuf[m * G::XPAD + G::pad2(G::jC(lane, e))];
     lds_wave_sync();
-    fwd_block<LOGN, M, 0, G::BC - 1, 0, G::TWA + G::TWB>(x, tw, G::jC(lane, 0));
+    fwd_block<F, LOGN, M, 0, G::BC - 1, 0, G::TWA + G::TWB>(x, tw, G::jC(lane, 0));
 }
 
 // Inverse (without the 1/N factor, which is folded into the bootstrapping key).
 // in : x[e] = transform word at jC(lane,e), |x| <= 0.5p.
 // out: x[e] = coefficient jA(lane,e), exactly centred (|x| <= p/2).
-template <int LOGN, typename TW>
+template <typename F, int LOGN, typename TW>
 __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *xbuf, const TW &tw, int lane)
 {
     using G = Geo<LOGN>;
-    inv_block<LOGN, 0, 0, G::BC - 1, 0>(x, tw, G::jC(lane, 0));
+    inv_block<F, LOGN, 0, 0, G::BC - 1, 0>(x, tw, G::jC(lane, 0));
 #pragma unroll
-    for (int e = 0; e < G::E; e++) xbuf[G::pad2(G::jC(lane, e))] = reduce(x[e]);
+    for (int e = 0; e < G::E; e++) xbuf[G::pad2(G::jC(lane, e))] = reduce<F>(x[e]);
     lds_wave_sync();
 #pragma unroll
     for (int e = 0; e < G::E; e++) x[e] = xbuf[G::pad2(G::jB(lane, e))];
     lds_wave_sync();
-    inv_block<LOGN, G::BC, G::BC, G::BC + G::BB - 1, G::TWC>(x, tw, G::jB(lane, 0));
+    inv_block<F, LOGN, G::BC, G::BC, G::BC + G::BB - 1, G::TWC>(x, tw, G::jB(lane, 0));
 #pragma unroll
-    for (int e = 0; e < G::E; e++) xbuf[G::pad1(G::jB(lane, e))] = reduce(x[e]);
+    for (int e = 0; e < G::E; e++) xbuf[G::pad1(G::jB(lane, e))] = reduce<F>(x[e]);
     lds_wave_sync();
 #pragma unroll
     for (int e = 0; e < G::E; e++) x[e] = xbuf[G::pad1(G::jA(lane, e))];
     lds_wave_sync();
-    inv_block<LOGN, 6, LOGN - G::BA, LOGN - 1, G::TWC + G::TWB>(x, tw, G::jA(lane, 0));
+    inv_block<F, LOGN, 6, LOGN - G::BA, LOGN - 1, G::TWC + G::TWB>(x, tw, G::jA(lane, 0));
 #pragma unroll
-    for (int e = 0; e < G::E; e++) x[e] = reduce(x[e]);
+    for (int e = 0; e < G::E; e++) x[e] = reduce<F>(x[e]);
 }
 
 } // namespace helm
