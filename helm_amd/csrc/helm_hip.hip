@@ -114,15 +114,19 @@ __device__ __forceinline__ void decompose(uint32_t x, int logB, int (&dig)[L])
 // other waves over through LDS (the only two workgroup barriers of the step),
 // inverse-transforms its own sum and accumulates.
 //
-// Builds (struct PbsCfg); latency / balanced are picked per launch from the launch size:
-//   latency    M = L, key words prefetched one step ahead into registers, twiddles in
-//              registers; ~330 registers -> one workgroup per CU.  Narrow levels.
-//   balanced   as above, twiddles from an LDS copy; 256 registers -> two workgroups/CU.
-//   occupancy  M = 1, no prefetch, twiddles from the (L1-resident) global table;
-//              <= 168 registers and ~37 KB LDS -> four workgroups per CU (three waves per
-//              SIMD): the other waves hide every latency.  Wide levels.
+// Builds (struct PbsCfg), picked per launch from the launch size (launch_pbs_f):
+//   latency    M = L: all levels of a polynomial transformed together, key words prefetched
+//              one step ahead into registers, twiddles in registers; ~330 registers -> one
+//              workgroup per CU.  Launches of at most one workgroup per CU.
+//   balanced   as above, twiddles from the LDS lane table; 256 registers -> two per CU.
+//   throughput M = 1: one level at a time (digits produced in the order the signed
+//              decomposition generates them), that level's key words fetched around its
+//              transform, only two partial sums in registers (the third accumulates in LDS),
+//              twiddles from the LDS lane table; 168 registers and 35 KB LDS -> four
+//              workgroups per CU = three waves on every SIMD, which hide each other's LDS
+//              and key latencies.  Wide launches.
 // ------------------------------------------------------------------------------------
-enum { TW_REG = 0, TW_LDS = 1, TW_GLOBAL = 2 };
+enum { TW_REG = 0, TW_LANE = 1 /* lane-major LDS table of forward twiddles, inverse reads it mirrored */ };
 
 template <typename F_, int LOGN_, int K_, int L_, int M_, int TW_, bool PREFETCH_, int MINW_>
 struct PbsCfg {
@@ -134,11 +138,18 @@ struct PbsCfg {
     static constexpr int SLOTS = M > K ? M : K; // exchange slots per wave (also carry the hand-over)
     static constexpr int MAX_SMALL_N = 1024;
     static_assert(L % M == 0, "levels are transformed M at a time");
-    static constexpr size_t X_OFF = 0;                                               // double [K1][SLOTS][XPAD]
-    static constexpr size_t TW_OFF = X_OFF + sizeof(double) * K1 * SLOTS * G::XPAD;  // double [2][N] (TW_LDS)
-    static constexpr size_t ACC_OFF = TW_OFF + (TW == TW_LDS ? sizeof(double) * 2 * G::N : 0); // u32 [K1][N]
-    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint32_t) * K1 * G::N;         // u32 [n+1]
-    static constexpr size_t BYTES = MS_OFF + sizeof(uint32_t) * (MAX_SMALL_N + 1);
+    // slot 0 is the (padded) transform scratch; with M == 1 the other slots only carry the
+    // hand-over and need no padding
+    static constexpr int SLOT_STRIDE = M > 1 ? G::XPAD : G::N;
+    static constexpr int WAVE_STRIDE = G::XPAD + (SLOTS - 1) * SLOT_STRIDE;
+    static constexpr int slot_off(int s) { return s == 0 ? 0 : G::XPAD + (s - 1) * SLOT_STRIDE; }
+    static constexpr int TW_ROWS = TW == TW_LANE ? G::TWB + G::TWC : 0;
+    // the u32 copy of a wave's accumulator polynomial (needed only for the rotated read at
+    // the start of a step) lives in the wave's transform scratch, which is idle then
+    static constexpr size_t X_OFF = 0;                                                // double [K1][WAVE_STRIDE]
+    static constexpr size_t TW_OFF = X_OFF + sizeof(double) * K1 * WAVE_STRIDE;       // double [TW_ROWS][64]
+    static constexpr size_t MS_OFF = TW_OFF + sizeof(double) * TW_ROWS * 64;          // u16 [n+1]
+    static constexpr size_t BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
 };
 
 template <typename C>
@@ -158,8 +169,7 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
     constexpr int N = G::N, E = G::E, K1 = K + 1;
     extern __shared__ __align__(16) unsigned char smem[];
     double *X = reinterpret_cast<double *>(smem + C::X_OFF);
-    uint32_t *ACC = reinterpret_cast<uint32_t *>(smem + C::ACC_OFF);
-    uint32_t *MS = reinterpret_cast<uint32_t *>(smem + C::MS_OFF);
+    uint16_t *MS = reinterpret_cast<uint16_t *>(smem + C::MS_OFF);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int p = __builtin_amdgcn_readfirstlane(tid >> 6); // this wave's polynomial
@@ -179,31 +189,30 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
             uint32_t v;
             if (job.op < 0) v = a0[i];
             else v = gate_lincomb(job.op, job.which, a0 ? a0[i] : 0u, a1 ? a1[i] : 0u, a2 ? a2[i] : 0u, i == n);
-            MS[i] = modswitch(v, LOGN + 1);
+            MS[i] = (uint16_t)modswitch(v, LOGN + 1);
         }
     }
-    // ---- twiddles: registers, an LDS copy of both tables, or the global tables ---------
-    using TwF = typename std::conditional<C::TW == TW_REG, TwReg<G::NTW>, TwMem>::type;
-    TwF twf, twi;
+    // ---- twiddles: registers, or the lane-major LDS table -----------------------------
+    using TwF = typename std::conditional<C::TW == TW_REG, TwReg<G::NTW>, TwLane<LOGN, false>>::type;
+    using TwI = typename std::conditional<C::TW == TW_REG, TwReg<G::NTW>, TwLane<LOGN, true>>::type;
+    TwF twf;
+    TwI twi;
     if constexpr (C::TW == TW_REG) {
         tw_fill_forward<LOGN>(twf, tw_fwd, lane);
         tw_fill_inverse<LOGN>(twi, tw_inv, lane);
-    } else if constexpr (C::TW == TW_LDS) {
-        double *TW = reinterpret_cast<double *>(smem + C::TW_OFF);
-        for (int i = tid; i < N; i += 64 * K1) {
-            TW[i] = tw_fwd[i];
-            TW[N + i] = tw_inv[i];
-        }
-        twf.t = TW;
-        twi.t = TW + N;
     } else {
-        twf.t = tw_fwd;
-        twi.t = tw_inv;
+        double *TW = reinterpret_cast<double *>(smem + C::TW_OFF);
+        for (int r = p; r < C::TW_ROWS; r += K1) TW[r * 64 + lane] = tw_fwd[tw_lane_index<LOGN>(r, lane)];
+        twf.base = TW + lane;
+        twi.base = TW + (63 - lane);
+        twf.fill_uniform(tw_fwd);
+        twi.fill_uniform(tw_fwd);
     }
     __syncthreads();
 
     // ---- accumulator init: (0,...,0, X^{-b~} * tv) ------------------------------------
-    uint32_t *acc_p = ACC + p * N;
+    double *xb = X + (size_t)p * C::WAVE_STRIDE; // this wave's exchange slots
+    uint32_t *acc_p = reinterpret_cast<uint32_t *>(xb);
     uint32_t accr[E];
     {
         const int bt = (int)MS[n];
@@ -223,7 +232,6 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
     }
     lds_wave_sync();
 
-    double *xb = X + (size_t)p * C::SLOTS * G::XPAD; // this wave's exchange slots
     // key words of step i for this wave: [c][lev][e/2][lane] as double2
     const size_t bsk_step = (size_t)K1 * K1 * L * (N / 2); // double2 per LWE coefficient
     const double2 *bsk_p = reinterpret_cast<const double2 *>(bsk) + (size_t)p * K1 * L * (N / 2) + lane;
@@ -250,11 +258,6 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
     while (i < n) {
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
         const double2 *bp_i = bsk_p + (size_t)i * bsk_step;
-        if constexpr (C::TW == TW_GLOBAL) {
-            // keep the (L1-resident) twiddle loads inside the step: hoisted out of the loop
-            // they would pin ~90 registers and defeat the occupancy this build exists for
-            asm volatile("" : "+s"(twf.t), "+s"(twi.t));
-        }
 
         double mine[E];
         if constexpr (M == L) {
@@ -299,13 +302,13 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
 #pragma unroll
                     for (int e = 0; e < E; e++) mine[e] = part[e];
                 } else {
-                    double *dst = xb + (size_t)(c < p ? c : c - 1) * G::XPAD;
+                    double *dst = xb + C::slot_off(c < p ? c : c - 1);
 #pragma unroll
                     for (int e = 0; e < E; e++) dst[e * 64 + lane] = part[e];
                 }
             }
         } else {
-            // ---- one level at a time, least significant first (occupancy build): the
+            // ---- one level at a time, least significant first (throughput build): the
             //      decomposition state is carried in registers, digits are produced in the
             //      order the signed decomposition generates them ---------------------------
             static_assert(M == 1, "level-at-a-time path");
@@ -320,8 +323,16 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
                     state[e] = ((v - accr[e]) + (1u << (31 - rep))) >> (32 - rep);
                 }
             }
-            double part[K1][E];
+            // Key column (p + d) % K1 is handled at distance d: d = 0 is this wave's own sum
+            // (registers), d = 1 stays in registers and is written to the transform scratch
+            // once the last transform is done, d >= 2 is accumulated level by level in its
+            // hand-over slot with ds_add_f64 (exact: integers below 2^53) - three partial
+            // sums never live in registers together.
+            double keep[E];
             const uint32_t mask = (1u << logB) - 1u;
+            int cd[K1]; // wave-uniform column of each distance
+#pragma unroll
+            for (int d = 0; d < K1; d++) cd[d] = p + d >= K1 ? p + d - K1 : p + d;
 #pragma unroll
             for (int lev = L - 1; lev >= 0; lev--) {
                 double x[1][E];
@@ -333,27 +344,51 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
                     state[e] = st + carry;
                     x[0][e] = (double)((int)d - (int)(carry << logB));
                 }
-                ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+                // this level's key words: issued before the transform that hides their latency
+                // (the last column is fetched after the transform: during it the transform's own
+                // temporaries need the registers, and the first two products cover its latency)
+                double2 bwl[K1][E / 2];
+                constexpr int EARLY = K1 > 2 ? 2 : K1;
 #pragma unroll
-                for (int c = 0; c < K1; c++)
+                for (int d = 0; d < EARLY; d++)
+#pragma unroll
+                    for (int e2 = 0; e2 < E / 2; e2++) bwl[d][e2] = bp_i[((cd[d] * L + lev) * (E / 2) + e2) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+                ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int d = EARLY; d < K1; d++)
+#pragma unroll
+                    for (int e2 = 0; e2 < E / 2; e2++) bwl[d][e2] = bp_i[((cd[d] * L + lev) * (E / 2) + e2) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int d = 0; d < K1; d++)
 #pragma unroll
                     for (int e2 = 0; e2 < E / 2; e2++) {
-                        const double2 w = bp_i[((c * L + lev) * (E / 2) + e2) * 64];
+                        const double2 w = bwl[d][e2];
                         const double t0 = mulmod<F>(x[0][2 * e2], w.x), t1 = mulmod<F>(x[0][2 * e2 + 1], w.y);
-                        part[c][2 * e2] = lev == L - 1 ? t0 : part[c][2 * e2] + t0;
-                        part[c][2 * e2 + 1] = lev == L - 1 ? t1 : part[c][2 * e2 + 1] + t1;
+                        if (d == 0) {
+                            mine[2 * e2] = lev == L - 1 ? t0 : mine[2 * e2] + t0;
+                            mine[2 * e2 + 1] = lev == L - 1 ? t1 : mine[2 * e2 + 1] + t1;
+                        } else if (d == 1) {
+                            keep[2 * e2] = lev == L - 1 ? t0 : keep[2 * e2] + t0;
+                            keep[2 * e2 + 1] = lev == L - 1 ? t1 : keep[2 * e2 + 1] + t1;
+                        } else {
+                            double *dst = xb + C::slot_off(d - 1) + lane;
+                            if (lev == L - 1) {
+                                dst[(2 * e2) * 64] = t0;
+                                dst[(2 * e2 + 1) * 64] = t1;
+                            } else {
+                                lds_add(dst + (2 * e2) * 64, t0);
+                                lds_add(dst + (2 * e2 + 1) * 64, t1);
+                            }
+                        }
                     }
             }
+            {
+                double *dst = xb + C::slot_off(0) + lane;
 #pragma unroll
-            for (int c = 0; c < K1; c++) {
-                if (c == p) {
-#pragma unroll
-                    for (int e = 0; e < E; e++) mine[e] = reduce_unless_lazy<F>(part[c][e]);
-                } else {
-                    double *dst = xb + (size_t)(c < p ? c : c - 1) * G::XPAD;
-#pragma unroll
-                    for (int e = 0; e < E; e++) dst[e * 64 + lane] = reduce_unless_lazy<F>(part[c][e]);
-                }
+                for (int e = 0; e < E; e++) dst[e * 64] = keep[e];
             }
         }
         // key words of the next step: in flight during the exchange, the inverse
@@ -362,12 +397,27 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
         if (inext < n) prefetch(inext);
 
         lds_block_sync();
+        if constexpr (M == L) {
 #pragma unroll
-        for (int q = 0; q < K1; q++) {
-            if (q == p) continue;
-            const double *src = X + ((size_t)q * C::SLOTS + (p < q ? p : p - 1)) * G::XPAD;
+            for (int q = 0; q < K1; q++) {
+                if (q == p) continue;
+                const double *src = X + (size_t)q * C::WAVE_STRIDE + C::slot_off(p < q ? p : p - 1);
 #pragma unroll
-            for (int e = 0; e < E; e++) mine[e] += src[e * 64 + lane];
+                for (int e = 0; e < E; e++) mine[e] += src[e * 64 + lane];
+            }
+        } else {
+            // the sum for this wave computed at distance d sits in wave (p - d) mod K1, slot d - 1
+            if constexpr (!F::LAZY) {
+#pragma unroll
+                for (int e = 0; e < E; e++) mine[e] = reduce<F>(mine[e]);
+            }
+#pragma unroll
+            for (int d = 1; d < K1; d++) {
+                const int q = p - d < 0 ? p - d + K1 : p - d;
+                const double *src = X + (size_t)q * C::WAVE_STRIDE + C::slot_off(d - 1);
+#pragma unroll
+                for (int e = 0; e < E; e++) mine[e] += reduce_unless_lazy<F>(src[e * 64 + lane]);
+            }
         }
 #pragma unroll
         for (int e = 0; e < E; e++) mine[e] = reduce<F>(mine[e]);
@@ -647,7 +697,7 @@ struct helm_hip_ctx {
     bool have_bsk = false, have_ksk = false;
     int field = 51; // Fp<51> or Fp<49> (lazy), chosen from the parameter set
     int n_cus = 256;
-    int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 occupancy (HELM_HIP_PBS_VARIANT)
+    int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput (HELM_HIP_PBS_VARIANT)
     // per-call scratch
     DevBuf<PbsJob> d_pbs;
     DevBuf<KsJob> d_ks;
@@ -743,41 +793,44 @@ static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
         if (e != hipSuccess) return e;
         attr_done[ctx->device & 63] = true;
+        if (getenv("HELM_HIP_VERBOSE")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 64 * (C::K + 1),
+                                                               C::BYTES);
+            hipFuncAttributes fa{};
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
+            fprintf(stderr, "[helm_hip] k_pbs M=%d TW=%d MINW=%d: LDS %zu B, regs %d, scratch %zu B, max %d workgroups/CU\n",
+                    C::M, C::TW, C::MINW, (size_t)C::BYTES, fa.numRegs, (size_t)fa.localSizeBytes, nb);
+        }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * (C::K + 1)), C::BYTES, ctx->stream, jobs, wires, raw, tvs,
                        ctx->bsk, ctx->tw_fwd, ctx->tw_inv, out_big, ctx->P.n, ctx->P.pbs_logB);
     return hipGetLastError();
 }
 
-// Build choice.  Measured on MI355X (profiles/r01/microbench_nand_*): per wave of
-// workgroups the latency build takes t1 with one workgroup per CU; the balanced build
-// takes 1.15 t1 alone on a CU and 1.74 t1 when two share it.  The build with the smaller
-// estimate for this launch is used.  (A third, high-occupancy build - one level at a
-// time, no prefetch, 168 registers, four workgroups per CU - measured 1.7x SLOWER than
-// the latency build at every size: without the register prefetch each wave serialises
-// ~66 L2 round trips per step and three waves per SIMD do not hide them.  It is kept
-// reachable with HELM_HIP_PBS_VARIANT=3 for profiling only.)
+// Build choice.  Measured on MI355X, boolean_default (profiles/r01/microbench_nand_*): one
+// launch of B bootstraps takes, by the largest number j of workgroups a CU receives,
+//   latency    4.4 ms per round of 256 (one workgroup per CU)
+//   balanced   4.8 (j = 1), 7.6 (j = 2) ms
+//   throughput 4.9, 7.4, 9.9, 12.4 ms for j = 1..4 (12 waves per CU, three per SIMD), 12.0 ms
+//              per 1,024 in longer launches
+// so a launch that fits one workgroup per CU uses the latency build and every wider one the
+// throughput build.  HELM_HIP_PBS_VARIANT=1|2|3 forces a build (profiling).
 template <typename F, int LOGN, int K, int L>
 static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
                                const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
 {
     if constexpr (LOGN == 9) {
         using Lat = PbsCfg<F, LOGN, K, L, L, TW_REG, true, 1>;
-        using Bal = PbsCfg<F, LOGN, K, L, L, TW_LDS, true, 2>;
-        using Occ = PbsCfg<F, LOGN, K, L, 1, TW_GLOBAL, false, 3>;
+        using Bal = PbsCfg<F, LOGN, K, L, L, TW_LANE, true, 2>;
+        using Thr = PbsCfg<F, LOGN, K, L, 1, TW_LANE, false, 3>;
         int v = ctx->pbs_variant;
-        if (v == 0) {
-            const int64_t Cu = ctx->n_cus;
-            const double lat = (double)((count + Cu - 1) / Cu);
-            const int64_t rem = count % (2 * Cu);
-            const double bal = (double)(count / (2 * Cu)) * 1.74 + (rem == 0 ? 0.0 : rem <= Cu ? 1.15 : 1.74);
-            v = lat <= bal ? 1 : 2;
-        }
+        if (v == 0) v = count <= ctx->n_cus ? 1 : 3;
         if (v == 1) return launch_pbs_v<Lat>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (v == 2) return launch_pbs_v<Bal>(ctx, jobs, count, wires, raw, tvs, out_big);
-        return launch_pbs_v<Occ>(ctx, jobs, count, wires, raw, tvs, out_big);
+        return launch_pbs_v<Thr>(ctx, jobs, count, wires, raw, tvs, out_big);
     } else {
-        using Big = PbsCfg<F, LOGN, K, L, L, TW_LDS, true, 1>;
+        using Big = PbsCfg<F, LOGN, K, L, L, TW_LANE, true, 1>;
         return launch_pbs_v<Big>(ctx, jobs, count, wires, raw, tvs, out_big);
     }
 }

@@ -99,6 +99,12 @@ __device__ __forceinline__ void lds_block_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Wave-private LDS accumulate (ds_add_f64, no return value).
+__device__ __forceinline__ void lds_add(double *p, double v)
+{
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
 // twiddles one lane needs for a block: sum over its stages of E >> (eb+1)
 constexpr int ntw_count(int E, int shift, int sb_lo, int sb_hi)
 {
@@ -137,17 +143,95 @@ struct Geo {
 };
 
 // Twiddle sources.  Twiddle of the butterfly on stride bit sb for coefficient j is
-// table[(N >> (sb+1)) + (j >> (sb+1))] (table = bit-reversed powers of psi).
-// TwMem fetches it (LDS or global table); TwReg holds one lane's twiddles of one
-// direction in registers, filled once per kernel in the order the blocks consume them.
+// table[(N >> (sb+1)) + (j >> (sb+1))] (table = bit-reversed powers of psi).  A source is
+// asked with get(sb, hi, cnt, idx, slot): hi = which of the stage's cnt twiddles of this
+// lane, idx = table index, slot = running count in consumption order.
+//   TwMem    fetches table[idx] (LDS or global table)
+//   TwReg    one lane's twiddles of one direction in registers (filled once per kernel)
+//   TwLane   block A twiddles are the same for every lane (scalar registers); those of
+//            blocks B and C come from a lane-major LDS table [slot][64] of the FORWARD
+//            twiddles: one base address register + immediate offsets.  The inverse
+//            direction reads the same table mirrored: psi^-i = -psi^(N-i), which in the
+//            bit-reversed table is inv[2^s + r] = -fwd[2^(s+1) - 1 - r], i.e. the twiddle
+//            (cnt-1-hi) of lane 63-lane; inv_block absorbs the sign by swapping its
+//            subtraction (MIRROR).
 struct TwMem {
+    static constexpr bool MIRROR = false;
     const double *t;
-    __device__ __forceinline__ double get(int idx, int /*slot*/) const { return t[idx]; }
+    __device__ __forceinline__ double get(int, int, int, int idx, int) const { return t[idx]; }
 };
 template <int NT>
 struct TwReg {
+    static constexpr bool MIRROR = false;
     double v[NT];
-    __device__ __forceinline__ double get(int /*idx*/, int slot) const { return v[slot]; }
+    __device__ __forceinline__ double get(int, int, int, int, int slot) const { return v[slot]; }
+};
+// forward-order slot of twiddle (sb, hi) among one lane's twiddles (block A, then B, then C)
+template <int LOGN>
+constexpr int tw_fwd_slot(int sb, int hi)
+{
+    using G = Geo<LOGN>;
+    int slot = 0;
+    for (int s = LOGN - 1; s >= LOGN - G::BA; s--) {
+        if (s == sb) return slot + hi;
+        slot += G::E >> (s - 6 + 1);
+    }
+    for (int s = G::BC + G::BB - 1; s >= G::BC; s--) {
+        if (s == sb) return slot + hi;
+        slot += G::E >> (s - G::BC + 1);
+    }
+    for (int s = G::BC - 1; s >= 0; s--) {
+        if (s == sb) return slot + hi;
+        slot += G::E >> (s + 1);
+    }
+    return -1;
+}
+// table index of lane-table slot s (0 .. TWB+TWC-1) for a lane
+template <int LOGN>
+__device__ inline int tw_lane_index(int s, int lane)
+{
+    using G = Geo<LOGN>;
+    int slot = 0;
+    for (int sb = G::BC + G::BB - 1; sb >= G::BC; sb--) {
+        const int eb = sb - G::BC, cnt = G::E >> (eb + 1);
+        if (s < slot + cnt) {
+            const int jh = G::jB(lane, 0) | ((s - slot) << (eb + 1 + G::BC));
+            return (G::N >> (sb + 1)) + (jh >> (sb + 1));
+        }
+        slot += cnt;
+    }
+    for (int sb = G::BC - 1; sb >= 0; sb--) {
+        const int cnt = G::E >> (sb + 1);
+        if (s < slot + cnt) {
+            const int jh = G::jC(lane, 0) | ((s - slot) << (sb + 1));
+            return (G::N >> (sb + 1)) + (jh >> (sb + 1));
+        }
+        slot += cnt;
+    }
+    return 0;
+}
+template <int LOGN, bool MIRROR_>
+struct TwLane {
+    static constexpr bool MIRROR = MIRROR_;
+    using G = Geo<LOGN>;
+    const double *base; // LDS table + lane (forward) or + 63 - lane (mirrored)
+    double ua[G::TWA];  // block A: lane-uniform
+    __device__ __forceinline__ double get(int sb, int hi, int cnt, int, int) const
+    {
+        const int fs = tw_fwd_slot<LOGN>(sb, MIRROR ? cnt - 1 - hi : hi);
+        if (fs < G::TWA) return ua[fs];
+        return base[(fs - G::TWA) * 64];
+    }
+    // fill the uniform part from the global forward table (compile-time indices: scalar loads)
+    __device__ __forceinline__ void fill_uniform(const double *__restrict__ table)
+    {
+        int slot = 0;
+#pragma unroll
+        for (int sb = LOGN - 1; sb >= LOGN - G::BA; sb--) {
+#pragma unroll
+            for (int hi = 0; hi < (G::E >> (sb - 6 + 1)); hi++) ua[slot++] = table[(G::N >> (sb + 1)) + hi];
+        }
+    }
 };
 
 // Enumerate (in consumption order) the table indices of a block's twiddles.
@@ -197,7 +281,7 @@ __device__ __forceinline__ void fwd_block(double (&x)[M][Geo<LOGN>::E], const TW
 #pragma unroll
         for (int hi = 0; hi < (E >> (eb + 1)); hi++) {
             const int jh = jbase | (hi << (eb + 1 + SHIFT));
-            const double w = tw.get((N >> (sb + 1)) + (jh >> (sb + 1)), slot++);
+            const double w = tw.get(sb, hi, E >> (eb + 1), (N >> (sb + 1)) + (jh >> (sb + 1)), slot++);
 #pragma unroll
             for (int lo = 0; lo < (1 << eb); lo++) {
                 const int e0 = (hi << (eb + 1)) | lo, e1 = e0 | (1 << eb);
@@ -229,13 +313,13 @@ __device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const TW &t
 #pragma unroll
         for (int hi = 0; hi < (E >> (eb + 1)); hi++) {
             const int jh = jbase | (hi << (eb + 1 + SHIFT));
-            const double w = tw.get((N >> (sb + 1)) + (jh >> (sb + 1)), slot++);
+            const double w = tw.get(sb, hi, E >> (eb + 1), (N >> (sb + 1)) + (jh >> (sb + 1)), slot++);
 #pragma unroll
             for (int lo = 0; lo < (1 << eb); lo++) {
                 const int e0 = (hi << (eb + 1)) | lo, e1 = e0 | (1 << eb);
                 double U = x[e0], V = x[e1];
                 x[e0] = U + V;
-                x[e1] = mulmod<F>(U - V, w);
+                x[e1] = mulmod<F>(TW::MIRROR ? V - U : U - V, w);
             }
         }
     }
