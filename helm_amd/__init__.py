@@ -6,7 +6,8 @@ in-tree native libraries; see include/helm_hip.h for the drop-in C ABI.
 """
 from . import _native  # noqa: F401  (fails loudly if the native libraries are missing)
 from .engine import ClientKey, ServerKey, DeviceWires, Program, named_params  # noqa: F401
-from ._native import HelmError, Params  # noqa: F401
+from ._native import HelmError, Params, SiParams  # noqa: F401
+from .shortint import SiClientKey, SiServerKey, SiWires, si_named_params  # noqa: F401
 from . import verilog_parser, circuit, gates, netlists  # noqa: F401,E402
 from .circuit import Circuit, GateCircuit, EvalCircuit, EncWireMap  # noqa: F401,E402
 from .gates import PtxtType, GateType, Gate  # noqa: F401,E402

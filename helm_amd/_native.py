@@ -37,7 +37,19 @@ class Timing(C.Structure):
                 ("ks_launches", C.c_int64), ("ks_count", C.c_int64)]
 
 
+class SiParams(C.Structure):
+    _fields_ = [(f, C.c_int32) for f in ("n", "k", "N", "pbs_l", "pbs_logB", "ks_l", "ks_logB",
+                                         "message_modulus", "carry_modulus")]
+
+    def as_tuple(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+    def __repr__(self):
+        return "SiParams(" + ", ".join(f"{f}={getattr(self, f)}" for f, _ in self._fields_) + ")"
+
+
 u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
 i32p = C.POINTER(C.c_int32)
 i64p = C.POINTER(C.c_int64)
 u8p = C.POINTER(C.c_uint8)
@@ -87,6 +99,46 @@ HIP_API = {
     "helm_hip_get_timing": (C.c_int, [vp, C.POINTER(Timing), C.c_int]),
 }
 
+# every symbol include/helm_shortint.h declares
+SI_API = {
+    "helm_si_ctx_create": (C.c_int, [C.c_int, C.POINTER(SiParams), C.POINTER(vp)]),
+    "helm_si_ctx_destroy": (C.c_int, [vp]),
+    "helm_si_get_params": (C.c_int, [vp, C.POINTER(SiParams)]),
+    "helm_si_set_stream": (C.c_int, [vp, vp]),
+    "helm_si_sync": (C.c_int, [vp]),
+    "helm_si_load_bootstrap_key": (C.c_int, [vp, u64p, C.c_size_t]),
+    "helm_si_load_keyswitch_key": (C.c_int, [vp, u64p, C.c_size_t]),
+    "helm_si_wires_alloc": (C.c_int, [vp, C.c_int64, C.POINTER(vp)]),
+    "helm_si_wires_free": (C.c_int, [vp, vp]),
+    "helm_si_wires_upload": (C.c_int, [vp, vp, i32p, u64p, C.c_int64]),
+    "helm_si_wires_download": (C.c_int, [vp, vp, i32p, u64p, C.c_int64]),
+    "helm_si_wires_set_trivial": (C.c_int, [vp, vp, i32p, u64p, C.c_int64]),
+    "helm_si_lincomb": (C.c_int, [vp, vp, i32p, i64p, i64p, i32p, C.c_int32, C.c_int64]),
+    "helm_si_make_lut": (C.c_int, [vp, u64p, u64p]),
+    "helm_si_apply_luts": (C.c_int, [vp, vp, i32p, i32p, i32p, C.c_int64, u64p, C.c_int64]),
+    "helm_si_eval_lut_level": (C.c_int, [vp, vp, i32p, i32p, C.c_int32, u64p, i32p, C.c_int64]),
+    "helm_si_keyswitch_batch": (C.c_int, [vp, u64p, u64p, C.c_int64]),
+    "helm_si_pbs_batch": (C.c_int, [vp, u64p, u64p, C.c_int64, i32p, u64p, C.c_int64]),
+    "helm_si_timing_enable": (C.c_int, [vp, C.c_int]),
+    "helm_si_get_timing": (C.c_int, [vp, C.POINTER(Timing), C.c_int]),
+}
+
+SI_CLIENT_API = {
+    "helm_si_client_named_params": (C.c_int, [C.c_char_p, C.POINTER(SiParams), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "helm_si_client_keygen": (C.c_int, [C.POINTER(SiParams), C.c_double, C.c_double, C.c_uint64, C.POINTER(vp)]),
+    "helm_si_client_key_free": (None, [vp]),
+    "helm_si_client_params": (C.c_int, [vp, C.POINTER(SiParams)]),
+    "helm_si_client_bsk_words": (C.c_size_t, [vp]),
+    "helm_si_client_ksk_words": (C.c_size_t, [vp]),
+    "helm_si_client_bsk": (u64p, [vp]),
+    "helm_si_client_ksk": (u64p, [vp]),
+    "helm_si_client_lwe_secret": (u64p, [vp]),
+    "helm_si_client_glwe_secret": (u64p, [vp]),
+    "helm_si_client_encrypt": (C.c_int, [vp, u64p, C.c_int64, u64p]),
+    "helm_si_client_decrypt": (C.c_int, [vp, u64p, C.c_int64, u64p]),
+    "helm_si_client_phase": (C.c_int, [vp, u64p, C.c_int64, C.c_int, u64p]),
+}
+
 CLIENT_API = {
     "helm_client_named_params": (C.c_int, [C.c_char_p, C.POINTER(Params), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "helm_client_last_error": (C.c_char_p, []),
@@ -104,7 +156,7 @@ CLIENT_API = {
     "helm_client_phase": (C.c_int, [vp, u32p, C.c_int64, C.c_int, u32p]),
 }
 
-for _lib, _api in ((hip, HIP_API), (host, CLIENT_API)):
+for _lib, _api in ((hip, HIP_API), (host, CLIENT_API), (hip, SI_API), (host, SI_CLIENT_API)):
     for _name, (_res, _args) in _api.items():
         _fn = getattr(_lib, _name)  # AttributeError here = header/library mismatch
         _fn.restype = _res
@@ -124,6 +176,11 @@ def client_check(rc):
 def as_u32p(a):
     assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(u32p)
+
+
+def as_u64p(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
 
 
 def as_i32p(a):

@@ -1,0 +1,244 @@
+// helm_client64.cpp — CPU key generation, encryption, decryption for the shortint
+// (LUT / arithmetic mode) path: 64-bit torus, ciphertexts under the big key
+// (include/helm_client.h).  Client-side counterpart of tfhe::shortint::{gen_keys,
+// ClientKey} as HELM uses them (reference src/bin/helm.rs:301, src/circuit.rs:982-996,1092).
+#include "../../include/helm_client.h"
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err64;
+int fail64(int code, const std::string &m)
+{
+    g_err64 = m;
+    return code;
+}
+
+// same generator as helm_client.cpp (xoshiro256**, seeded streams)
+struct Rng64 {
+    uint64_t s[4];
+    static uint64_t splitmix(uint64_t &x)
+    {
+        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    explicit Rng64(uint64_t seed, uint64_t stream = 0)
+    {
+        uint64_t x = seed ^ (stream * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull);
+        for (auto &v : s) v = splitmix(x);
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next()
+    {
+        const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0];
+        s[3] ^= s[1];
+        s[1] ^= s[2];
+        s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 45);
+        return r;
+    }
+    double unit() { return ((next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+    bool have_spare = false;
+    double spare = 0;
+    double gauss()
+    {
+        if (have_spare) {
+            have_spare = false;
+            return spare;
+        }
+        const double u = unit(), v = unit();
+        const double r = std::sqrt(-2.0 * std::log(u)), a = 6.283185307179586476925 * v;
+        spare = r * std::sin(a);
+        have_spare = true;
+        return r * std::cos(a);
+    }
+    // torus noise: round(gauss * std * 2^64) mod 2^64
+    uint64_t noise64(double std_dev) { return (uint64_t)(int64_t)std::llround(gauss() * std_dev * 18446744073709551616.0); }
+};
+
+} // namespace
+
+struct helm_si_client_key {
+    helm_si_params P;
+    double lwe_std, glwe_std;
+    std::vector<uint64_t> lwe_sk, glwe_sk, bsk, ksk;
+    uint64_t delta;
+    Rng64 enc_rng{0};
+};
+
+extern "C" {
+
+int helm_si_client_named_params(const char *name, helm_si_params *p, double *lwe_std, double *glwe_std)
+{
+    if (!name || !p || !lwe_std || !glwe_std) return fail64(HELM_ERR_INVALID, "null argument");
+    std::memset(p, 0, sizeof(*p));
+    const std::string s(name);
+    p->k = 1;
+    p->message_modulus = 4;
+    p->carry_modulus = 4;
+    if (s == "shortint_m2c2") {
+        // tfhe 0.4 shortint PARAM_MESSAGE_2_CARRY_2_KS_PBS [recalled, SURVEY.md App. B]
+        p->n = 742; p->N = 2048; p->pbs_l = 1; p->pbs_logB = 23; p->ks_l = 5; p->ks_logB = 3;
+        *lwe_std = 0.000007069849454709433;
+        *glwe_std = 0.00000000000000029403601535432533;
+    } else if (s == "si_toy_512") {
+        p->n = 12; p->N = 512; p->pbs_l = 2; p->pbs_logB = 15; p->ks_l = 4; p->ks_logB = 4;
+        *lwe_std = 1e-9;
+        *glwe_std = 1e-15;
+    } else if (s == "si_toy_1024") {
+        p->n = 10; p->N = 1024; p->pbs_l = 1; p->pbs_logB = 23; p->ks_l = 5; p->ks_logB = 3;
+        *lwe_std = 1e-9;
+        *glwe_std = 1e-15;
+    } else if (s == "si_toy_2048") {
+        p->n = 8; p->N = 2048; p->pbs_l = 1; p->pbs_logB = 23; p->ks_l = 5; p->ks_logB = 3;
+        *lwe_std = 1e-9;
+        *glwe_std = 1e-16;
+    } else if (s == "si_toy_2048_l2") {
+        p->n = 6; p->N = 2048; p->pbs_l = 2; p->pbs_logB = 14; p->ks_l = 3; p->ks_logB = 5;
+        *lwe_std = 1e-9;
+        *glwe_std = 1e-16;
+    } else
+        return fail64(HELM_ERR_INVALID, "unknown shortint parameter set '" + s + "'");
+    return 0;
+}
+
+int helm_si_client_keygen(const helm_si_params *params, double lwe_std, double glwe_std, uint64_t seed,
+                          helm_si_client_key **out)
+{
+    if (!params || !out) return fail64(HELM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const helm_si_params &P = *params;
+    const int t = P.message_modulus * P.carry_modulus;
+    if (P.n < 1 || P.k < 1 || P.N < 2 || (P.N & (P.N - 1)) || P.pbs_l < 1 || P.ks_l < 1 || P.pbs_logB < 1 ||
+        P.ks_logB < 1 || P.pbs_logB * P.pbs_l > 64 || P.ks_logB * P.ks_l > 64 || t < 2 || (t & (t - 1)))
+        return fail64(HELM_ERR_INVALID, "bad parameter set");
+    helm_si_client_key *K = new (std::nothrow) helm_si_client_key();
+    if (!K) return fail64(HELM_ERR_OOM, "key");
+    K->P = P;
+    K->lwe_std = lwe_std;
+    K->glwe_std = glwe_std;
+    K->delta = (1ull << 63) / (uint64_t)t;
+    const int n = P.n, k = P.k, N = P.N, k1 = k + 1, kN = k * N;
+    Rng64 r0(seed, 0x51);
+    K->lwe_sk.resize(n);
+    for (auto &b : K->lwe_sk) b = r0.next() >> 63;
+    K->glwe_sk.resize(kN);
+    for (auto &b : K->glwe_sk) b = r0.next() >> 63;
+    K->enc_rng = Rng64(seed, 0xE1C64);
+
+    // ---- bootstrapping key: GGSW(s_i), [n][l][k+1 rows][k+1 polys][N] -----------------
+    const size_t poly_per_i = (size_t)P.pbs_l * k1 * k1;
+    K->bsk.assign((size_t)n * poly_per_i * N, 0);
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int i = 0; i < n; i++) {
+        Rng64 r(seed, 0x6400000 + (uint64_t)i);
+        std::vector<uint64_t> body(N);
+        for (int j = 0; j < P.pbs_l; j++)
+            for (int row = 0; row < k1; row++) {
+                uint64_t *glwe = K->bsk.data() + (((size_t)i * P.pbs_l + j) * k1 + row) * k1 * N;
+                for (int u = 0; u < N; u++) body[u] = r.noise64(glwe_std);
+                for (int c = 0; c < k; c++) {
+                    uint64_t *A = glwe + (size_t)c * N;
+                    for (int u = 0; u < N; u++) A[u] = r.next();
+                    const uint64_t *S = K->glwe_sk.data() + (size_t)c * N;
+                    for (int u = 0; u < N; u++) {
+                        if (!S[u]) continue;
+                        for (int v = 0; v < N - u; v++) body[v + u] += A[v];
+                        for (int v = N - u; v < N; v++) body[v + u - N] -= A[v];
+                    }
+                }
+                std::memcpy(glwe + (size_t)k * N, body.data(), sizeof(uint64_t) * N);
+                if (K->lwe_sk[i]) glwe[(size_t)row * N] += (uint64_t)1 << (64 - P.pbs_logB * (j + 1));
+            }
+    }
+    // ---- keyswitching key: [k*N][ks_l][n+1] ---------------------------------------------
+    K->ksk.assign((size_t)kN * P.ks_l * (n + 1), 0);
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (int u = 0; u < kN; u++) {
+        Rng64 r(seed, 0x6500000 + (uint64_t)u);
+        for (int j = 0; j < P.ks_l; j++) {
+            uint64_t *ct = K->ksk.data() + ((size_t)u * P.ks_l + j) * (n + 1);
+            uint64_t b = r.noise64(lwe_std);
+            for (int i = 0; i < n; i++) {
+                ct[i] = r.next();
+                if (K->lwe_sk[i]) b += ct[i];
+            }
+            if (K->glwe_sk[u]) b += (uint64_t)1 << (64 - P.ks_logB * (j + 1));
+            ct[n] = b;
+        }
+    }
+    *out = K;
+    return 0;
+}
+
+void helm_si_client_key_free(helm_si_client_key *key) { delete key; }
+
+int helm_si_client_params(const helm_si_client_key *key, helm_si_params *out)
+{
+    if (!key || !out) return fail64(HELM_ERR_INVALID, "null argument");
+    *out = key->P;
+    return 0;
+}
+size_t helm_si_client_bsk_words(const helm_si_client_key *key) { return key ? key->bsk.size() : 0; }
+size_t helm_si_client_ksk_words(const helm_si_client_key *key) { return key ? key->ksk.size() : 0; }
+const uint64_t *helm_si_client_bsk(const helm_si_client_key *key) { return key ? key->bsk.data() : nullptr; }
+const uint64_t *helm_si_client_ksk(const helm_si_client_key *key) { return key ? key->ksk.data() : nullptr; }
+const uint64_t *helm_si_client_lwe_secret(const helm_si_client_key *key) { return key ? key->lwe_sk.data() : nullptr; }
+const uint64_t *helm_si_client_glwe_secret(const helm_si_client_key *key) { return key ? key->glwe_sk.data() : nullptr; }
+
+int helm_si_client_encrypt(helm_si_client_key *key, const uint64_t *values, int64_t count, uint64_t *out)
+{
+    if (!key || !values || !out || count < 0) return fail64(HELM_ERR_INVALID, "bad argument");
+    const int dim = key->P.k * key->P.N;
+    const uint64_t t = (uint64_t)key->P.message_modulus * key->P.carry_modulus;
+    for (int64_t g = 0; g < count; g++) {
+        uint64_t *ct = out + (size_t)g * (dim + 1);
+        uint64_t b = key->enc_rng.noise64(key->glwe_std);
+        for (int i = 0; i < dim; i++) {
+            ct[i] = key->enc_rng.next();
+            if (key->glwe_sk[i]) b += ct[i];
+        }
+        ct[dim] = b + (values[g] % t) * key->delta;
+    }
+    return 0;
+}
+
+int helm_si_client_phase(const helm_si_client_key *key, const uint64_t *lwe, int64_t count, int small, uint64_t *ph)
+{
+    if (!key || !lwe || !ph || count < 0) return fail64(HELM_ERR_INVALID, "bad argument");
+    const int dim = small ? key->P.n : key->P.k * key->P.N;
+    const uint64_t *sk = small ? key->lwe_sk.data() : key->glwe_sk.data();
+    for (int64_t g = 0; g < count; g++) {
+        const uint64_t *ct = lwe + (size_t)g * (dim + 1);
+        uint64_t v = ct[dim];
+        for (int i = 0; i < dim; i++)
+            if (sk[i]) v -= ct[i];
+        ph[g] = v;
+    }
+    return 0;
+}
+
+int helm_si_client_decrypt(const helm_si_client_key *key, const uint64_t *lwe, int64_t count, uint64_t *values)
+{
+    if (!key || !lwe || !values || count < 0) return fail64(HELM_ERR_INVALID, "bad argument");
+    std::vector<uint64_t> ph((size_t)count);
+    if (int rc = helm_si_client_phase(key, lwe, count, 0, ph.data())) return rc;
+    const uint64_t t = (uint64_t)key->P.message_modulus * key->P.carry_modulus;
+    for (int64_t g = 0; g < count; g++) {
+        // round to the nearest multiple of delta; the padding bit wraps into mod 2t, then mod t
+        const uint64_t v = (ph[(size_t)g] + key->delta / 2) / key->delta;
+        values[g] = v % t;
+    }
+    return 0;
+}
+
+} // extern "C"

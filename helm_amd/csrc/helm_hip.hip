@@ -35,6 +35,8 @@ static int fail(int code, const std::string &msg)
     g_err = msg;
     return code;
 }
+// shared with helm_shortint.hip (same library, same helm_hip_last_error())
+int helm_hip_fail_(int code, const std::string &msg) { return fail(code, msg); }
 #define HIP_TRY(expr)                                                                               \
     do {                                                                                            \
         hipError_t e__ = (expr);                                                                    \

@@ -1,0 +1,1089 @@
+// helm_shortint.hip — gfx950 kernels + C ABI (include/helm_shortint.h) of the LUT-mode /
+// arithmetic-mode engine: 64-bit torus, KS_PBS order.  Replaces the tfhe::shortint
+// ServerKey calls HELM issues per LUT gate (reference src/gates.rs:754-785) and, through
+// the radix layer built on the same two primitives, per arithmetic operator
+// (src/gates.rs:306-702):
+//
+//   k_lincomb64     out = sum coef * in + const                      (no bootstrap)
+//   k_keyswitch64   big LWE (k*N) -> small LWE (n), four ciphertexts per key pass
+//   k_pbs64         modulus switch + blind rotate with a per-ciphertext look-up table +
+//                   sample extract.  One workgroup per ciphertext, one wave per
+//                   (accumulator polynomial, CRT prime): the exact negacyclic products of
+//                   a 64-bit torus need ~2^97, i.e. two of the fp64 NTT fields of
+//                   ntt_fp64.h and a CRT lift mod 2^64 after the inverse transforms.
+//   k_bsk_convert64 standard-domain key -> both NTT fields (once per key)
+//
+// There is no CPU fallback in this file.
+#include "../../include/helm_shortint.h"
+#include "ntt_fp64.h"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace helm;
+
+int helm_hip_fail_(int code, const std::string &msg); // helm_hip.hip: sets helm_hip_last_error()
+#define fail helm_hip_fail_
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess)                                                                      \
+            return fail(HELM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));          \
+    } while (0)
+
+namespace {
+
+using F0 = Fp<51>;     // first CRT prime
+using F1 = Fp49Strict; // second CRT prime (recentring kept: long transforms, large digits)
+
+struct Pbs64Job {
+    int32_t in_row;  // row of the small-LWE buffer (n+1 words)
+    int32_t lut;     // row of the look-up-table buffer (N words)
+    int32_t out_row; // row of the destination table (k*N+1 words)
+    int32_t pad;
+};
+
+struct Ks64Job {
+    int32_t in_row;  // row of the big table
+    int32_t out_row; // row of the small-LWE buffer
+};
+
+__device__ __forceinline__ uint32_t modswitch64(uint64_t x, int log2_2N)
+{
+    uint32_t r = (uint32_t)(x >> (64 - log2_2N - 1)) + 1u;
+    return (r >> 1) & ((1u << log2_2N) - 1u);
+}
+
+// exact integer in a double (|v| < 2^51) -> two's complement int64
+__device__ __forceinline__ int64_t to_int64(double v)
+{
+    const double m = v + 6755399441055744.0; // 1.5 * 2^52: mantissa = 2^51 + v
+    const uint32_t lo = (uint32_t)__double2loint(m);
+    const int32_t hi = (int32_t)((uint32_t)__double2hiint(m) & 0xFFFFFu) - 0x80000;
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | lo);
+}
+
+// ------------------------------------------------------------------------------------
+// k_pbs64<LOGN, L>: k = 1.  Waves w = 0..3: polynomial p = w >> 1, field f = w & 1.
+// Per CMUX step, wave (p, f): rotate/subtract polynomial p (u64, LDS), signed-decompose,
+// per level forward NTT in field f and multiply by the two key polynomials of row p; the
+// product for the other polynomial goes to the partner (1-p, f) through this wave's
+// scratch; inverse NTT of the own sum; the two residues of each coefficient meet in the
+// wave that owns that half of the polynomial, which lifts them (CRT) to the exact integer
+// mod 2^64 and accumulates.
+// ------------------------------------------------------------------------------------
+template <int LOGN_, int L_>
+struct Pbs64Cfg {
+    static constexpr int LOGN = LOGN_, L = L_, K = 1, K1 = 2, NW = 4;
+    using G = Geo<LOGN>;
+    static constexpr int MAX_SMALL_N = 1024;
+    static constexpr size_t X_OFF = 0;                                            // double [NW][XPAD]
+    static constexpr size_t TW_OFF = X_OFF + sizeof(double) * NW * G::XPAD;       // double [2][N]
+    static constexpr size_t ACC_OFF = TW_OFF + sizeof(double) * 2 * G::N;         // u64 [K1][N]
+    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint64_t) * K1 * G::N;      // u16 [n+1]
+    static constexpr size_t BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
+};
+
+template <typename C, typename F>
+__device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__restrict__ bsk, int n, int logB,
+                                           double p0inv_mod_p1, int p, int f, int lane)
+{
+    constexpr int LOGN = C::LOGN, L = C::L, K1 = C::K1;
+    using G = Geo<LOGN>;
+    constexpr int N = G::N, E = G::E, H = E / 2;
+    double *X = reinterpret_cast<double *>(smem + C::X_OFF);
+    uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
+    const uint16_t *MS = reinterpret_cast<const uint16_t *>(smem + C::MS_OFF);
+    const int w = p * 2 + f;
+    double *xb = X + (size_t)w * G::XPAD;                       // own scratch
+    const double *x_poly = X + (size_t)((1 - p) * 2 + f) * G::XPAD; // same field, other polynomial
+    const double *x_field = X + (size_t)(p * 2 + (1 - f)) * G::XPAD; // same polynomial, other field
+    uint64_t *acc_p = ACC + (size_t)p * N;
+    TwMem twf{reinterpret_cast<const double *>(smem + C::TW_OFF) + (size_t)f * N};
+    TwMemMirror<LOGN> twi{twf.t};
+
+    // key words of step i for this wave: [i][row p][c][lev][f][e/2][lane] as double2
+    const size_t per_poly = (size_t)2 * (N / 2); // both fields
+    const size_t bsk_step = (size_t)K1 * K1 * L * per_poly;
+    const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * L * 2 + f) * (N / 2) + lane;
+
+    for (int i = 0; i < n; i++) {
+        const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
+        if (a == 0) continue; // uniform over the workgroup: every wave skips the same steps
+        const double2 *bp_i = bsk_w + (size_t)i * bsk_step;
+
+        // ---- rotate / subtract, decomposition state (least significant level first) ----
+        uint64_t state[E];
+        {
+            const int rep = logB * L;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int j = G::jA(lane, e);
+                const int src = (j - a) & (2 * N - 1);
+                uint64_t v = acc_p[src & (N - 1)];
+                if (src >= N) v = 0ull - v;
+                v -= acc_p[j];
+                state[e] = rep >= 64 ? v : (v + (1ull << (63 - rep))) >> (64 - rep);
+            }
+        }
+        double mine[E], other[E];
+        const uint64_t mask = (1ull << logB) - 1ull;
+#pragma unroll
+        for (int lev = L - 1; lev >= 0; lev--) {
+            double x[1][E];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const uint64_t d = state[e] & mask;
+                const uint64_t st = state[e] >> logB;
+                const uint64_t carry = (((d - 1ull) | st) & d) >> (logB - 1);
+                state[e] = st + carry;
+                x[0][e] = (double)((int32_t)(uint32_t)d - (int32_t)((uint32_t)carry << logB));
+            }
+            ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+#pragma unroll
+            for (int c = 0; c < K1; c++) {
+                const double2 *kp = bp_i + (size_t)(c * L + lev) * per_poly;
+#pragma unroll
+                for (int e2 = 0; e2 < E / 2; e2++) {
+                    const double2 kw = kp[e2 * 64];
+                    const double t0 = mulmod<F>(x[0][2 * e2], kw.x), t1 = mulmod<F>(x[0][2 * e2 + 1], kw.y);
+                    if (c == p) {
+                        mine[2 * e2] = lev == L - 1 ? t0 : mine[2 * e2] + t0;
+                        mine[2 * e2 + 1] = lev == L - 1 ? t1 : mine[2 * e2 + 1] + t1;
+                    } else {
+                        other[2 * e2] = lev == L - 1 ? t0 : other[2 * e2] + t0;
+                        other[2 * e2 + 1] = lev == L - 1 ? t1 : other[2 * e2 + 1] + t1;
+                    }
+                }
+            }
+        }
+        // hand the other polynomial's partial sum over through the (now idle) scratch
+#pragma unroll
+        for (int e = 0; e < E; e++) xb[e * 64 + lane] = reduce<F>(other[e]);
+        lds_block_sync();
+#pragma unroll
+        for (int e = 0; e < E; e++) mine[e] = reduce<F>(reduce<F>(mine[e]) + x_poly[e * 64 + lane]);
+        lds_block_sync(); // hand-over slots read: scratch free again
+
+        ntt_inverse<F, LOGN>(mine, xb, twi, lane);
+
+        // ---- CRT: field-f wave lifts slots [f*H, f*H+H); it needs the other field's
+        //      residues for those and provides its own for the other half ----------------
+#pragma unroll
+        for (int e = 0; e < H; e++) xb[e * 64 + lane] = mine[(1 - f) * H + e];
+        lds_block_sync();
+#pragma unroll
+        for (int e = 0; e < H; e++) {
+            const double own = mine[f * H + e], oth = x_field[e * 64 + lane];
+            const double r0 = f == 0 ? own : oth, r1 = f == 0 ? oth : own;
+            // x = r0 + p0 * t,  t = (r1 - r0) * p0^-1 mod p1 : the exact integer (|x| < p0 p1 / 2)
+            const double t = mulmod<F1>(r1 - r0, p0inv_mod_p1);
+            const uint64_t xv = (uint64_t)to_int64(r0) + F0::P_U64 * (uint64_t)to_int64(t);
+            acc_p[G::jA(lane, f * H + e)] += xv;
+        }
+        lds_block_sync(); // accumulator complete before the next step's rotated reads
+    }
+}
+
+template <typename C>
+__global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restrict__ jobs,
+                                                         const uint64_t *__restrict__ small, // rows of n+1
+                                                         const uint64_t *__restrict__ luts,  // rows of N
+                                                         const double *__restrict__ bsk,     // NTT domain, both fields
+                                                         const double *__restrict__ tw0,
+                                                         const double *__restrict__ tw1,
+                                                         uint64_t *__restrict__ out, // rows of k*N+1
+                                                         int n, int logB, double p0inv_mod_p1)
+{
+    constexpr int LOGN = C::LOGN, K = C::K;
+    using G = Geo<LOGN>;
+    constexpr int N = G::N, E = G::E, H = E / 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
+    uint16_t *MS = reinterpret_cast<uint16_t *>(smem + C::MS_OFF);
+    double *TW = reinterpret_cast<double *>(smem + C::TW_OFF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = w >> 1, f = w & 1;
+    const Pbs64Job job = jobs[blockIdx.x];
+    const uint64_t *lwe = small + (size_t)job.in_row * ((size_t)n + 1);
+    for (int i = tid; i <= n; i += 64 * C::NW) MS[i] = (uint16_t)modswitch64(lwe[i], LOGN + 1);
+    for (int i = tid; i < N; i += 64 * C::NW) {
+        TW[i] = tw0[i];
+        TW[N + i] = tw1[i];
+    }
+    __syncthreads();
+    // accumulator: (0, X^{-b~} * lut)
+    {
+        const int bt = (int)MS[n];
+        const uint64_t *tv = luts + (size_t)job.lut * N;
+        for (int j = tid; j < (K + 1) * N; j += 64 * C::NW) {
+            uint64_t v = 0;
+            if (j >= K * N) {
+                const int idx = ((j - K * N) + bt) & (2 * N - 1);
+                v = tv[idx & (N - 1)];
+                if (idx >= N) v = 0ull - v;
+            }
+            ACC[j] = v;
+        }
+    }
+    __syncthreads();
+
+    if (f == 0) pbs64_body<C, F0>(smem, bsk, n, logB, p0inv_mod_p1, p, 0, lane);
+    else pbs64_body<C, F1>(smem, bsk, n, logB, p0inv_mod_p1, p, 1, lane);
+
+    // ---- sample extract (coefficient 0); wave (p, f) writes its half of the slots ------
+    uint64_t *ob = out + (size_t)job.out_row * ((size_t)K * N + 1);
+    const uint64_t *acc_p = ACC + (size_t)p * N;
+    if (p < K) {
+#pragma unroll
+        for (int e = 0; e < H; e++) {
+            const int j = G::jA(lane, f * H + e);
+            const uint64_t v = acc_p[j];
+            if (j == 0) ob[p * N] = v;
+            else ob[p * N + (N - j)] = 0ull - v;
+        }
+    } else if (f == 0 && lane == 0) {
+        ob[K * N] = acc_p[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_keyswitch64: as k_keyswitch of helm_hip.hip, 64-bit words.  Grid (ceil(jobs/4),
+// column chunks of 256); digits of four ciphertexts packed as 4 x int8 per LDS word.
+//   out[c] = (c == n ? body : 0) - sum_t sum_j digit(t,j) * KSK[t][j][c]
+// ------------------------------------------------------------------------------------
+template <int KSL>
+__global__ __launch_bounds__(256) void k_keyswitch64(const Ks64Job *__restrict__ jobs, const uint64_t *__restrict__ big,
+                                                     const uint64_t *__restrict__ ksk, uint64_t *__restrict__ out,
+                                                     int n, int kN, int logB, int count)
+{
+    constexpr int GN = 4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *DIG = reinterpret_cast<uint32_t *>(smem); // [kN * KSL]
+    const int g0 = blockIdx.x * GN;
+    const int ng = min(GN, count - g0);
+    Ks64Job job[GN];
+#pragma unroll
+    for (int g = 0; g < GN; g++) job[g] = jobs[g0 + (g < ng ? g : 0)];
+    const size_t brow = (size_t)kN + 1;
+    const int rep = logB * KSL;
+    const uint64_t mask = (1ull << logB) - 1ull;
+    for (int t = threadIdx.x; t < kN; t += 256) {
+        uint32_t packed[KSL];
+#pragma unroll
+        for (int j = 0; j < KSL; j++) packed[j] = 0;
+#pragma unroll
+        for (int g = 0; g < GN; g++) {
+            if (g < ng) {
+                const uint64_t v = big[brow * (size_t)job[g].in_row + t];
+                uint64_t state = (v + (1ull << (63 - rep))) >> (64 - rep);
+#pragma unroll
+                for (int lev = KSL - 1; lev >= 0; lev--) {
+                    const uint64_t d = state & mask;
+                    state >>= logB;
+                    const uint64_t carry = (((d - 1ull) | state) & d) >> (logB - 1);
+                    state += carry;
+                    const int dig = (int)(uint32_t)d - (int)((uint32_t)carry << logB);
+                    packed[lev] |= ((uint32_t)dig & 0xFFu) << (8 * g);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KSL; j++) DIG[t * KSL + j] = packed[j];
+    }
+    __syncthreads();
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c > n) return;
+    const size_t krow = (size_t)n + 1;
+    uint64_t acc[GN] = {0, 0, 0, 0};
+    const uint64_t *kp = ksk + c;
+    const int rows = kN * KSL;
+#pragma unroll 4
+    for (int r = 0; r < rows; r++) {
+        const uint64_t kw = kp[(size_t)r * krow];
+        const uint32_t pk = DIG[r];
+#pragma unroll
+        for (int g = 0; g < GN; g++) acc[g] += (uint64_t)(int64_t)(int32_t)__builtin_amdgcn_sbfe(pk, 8 * g, 8) * kw;
+    }
+#pragma unroll
+    for (int g = 0; g < GN; g++) {
+        if (g < ng) {
+            const uint64_t body = c == n ? big[brow * (size_t)job[g].in_row + kN] : 0ull;
+            out[krow * (size_t)job[g].out_row + c] = body - acc[g];
+        }
+    }
+}
+
+// out row = sum coef * in rows + const (body only).  One workgroup per output row.
+__global__ __launch_bounds__(256) void k_lincomb64(const int32_t *__restrict__ in_idx, const int64_t *__restrict__ coef,
+                                                   const uint64_t *__restrict__ body_add,
+                                                   const int32_t *__restrict__ out_idx, const uint64_t *__restrict__ src,
+                                                   uint64_t *__restrict__ dst, int terms, int dim)
+{
+    const int g = blockIdx.x;
+    const size_t row = (size_t)dim + 1;
+    uint64_t *o = dst + row * (size_t)(out_idx ? out_idx[g] : g);
+    for (int i = threadIdx.x; i <= dim; i += 256) {
+        uint64_t v = i == dim ? body_add[g] : 0ull;
+        for (int t = 0; t < terms; t++) {
+            const int r = in_idx[(size_t)g * terms + t];
+            if (r >= 0) v += (uint64_t)coef[(size_t)g * terms + t] * src[row * (size_t)r + i];
+        }
+        o[i] = v;
+    }
+}
+
+// a gate of a level must not read a row another gate of the level writes; in-place rows
+// (out == in of the SAME gate) are common in the radix layer, so sums go through a staging
+// buffer first when asked to
+__global__ __launch_bounds__(256) void k_rows64(const uint64_t *__restrict__ src, const int32_t *__restrict__ src_row,
+                                                uint64_t *__restrict__ dst, const int32_t *__restrict__ dst_row,
+                                                int dim)
+{
+    const size_t row = (size_t)dim + 1;
+    const int s = src_row ? src_row[blockIdx.x] : (int)blockIdx.x;
+    const int d = dst_row ? dst_row[blockIdx.x] : (int)blockIdx.x;
+    if (d < 0) return;
+    for (int i = threadIdx.x; i <= dim; i += 256) dst[row * (size_t)d + i] = s < 0 ? 0ull : src[row * (size_t)s + i];
+}
+
+__global__ __launch_bounds__(256) void k_set_trivial64(const int32_t *__restrict__ idx, const uint64_t *__restrict__ body,
+                                                       uint64_t *__restrict__ wires, int dim)
+{
+    const size_t row = (size_t)dim + 1;
+    uint64_t *dst = wires + row * (size_t)idx[blockIdx.x];
+    for (int i = threadIdx.x; i <= dim; i += 256) dst[i] = i == dim ? body[blockIdx.x] : 0ull;
+}
+
+// standard-domain u64 (taken as signed) -> NTT domain of field F, times N^-1, in the lane
+// order k_pbs64 reads: dst[i][r][c][lev][f][e/2][lane][e&1]   (src is [i][lev][r][c][N])
+template <typename F, int LOGN>
+__global__ __launch_bounds__(64) void k_bsk_convert64(const uint64_t *__restrict__ src, double *__restrict__ dst,
+                                                      const double *__restrict__ tw_fwd, double n_inv, double two32,
+                                                      int K1, int L, int f)
+{
+    using G = Geo<LOGN>;
+    constexpr int N = G::N, E = G::E;
+    __shared__ double xbuf[G::XPAD];
+    const int lane = threadIdx.x;
+    const size_t poly = blockIdx.x;
+    const int c = poly % K1;
+    const int r = (poly / K1) % K1;
+    const int lev = (poly / ((size_t)K1 * K1)) % L;
+    const size_t i = poly / ((size_t)K1 * K1 * L);
+    double x[1][E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint64_t v = src[poly * N + G::jA(lane, e)];
+        // v = hi * 2^32 + lo with hi signed: reduce in the field
+        const double hi = (double)(int32_t)(uint32_t)(v >> 32), lo = (double)(uint32_t)v;
+        x[0][e] = reduce<F>(mulmod<F>(hi, two32) + lo);
+    }
+    ntt_forward<F, LOGN, 1>(x, xbuf, TwMem{tw_fwd}, lane);
+    const size_t dpoly = (((i * K1 + r) * K1 + c) * L + lev) * 2 + f;
+    double *d = dst + dpoly * N;
+#pragma unroll
+    for (int e = 0; e < E; e++) d[((e >> 1) * 64 + lane) * 2 + (e & 1)] = reduce<F>(mulmod<F>(x[0][e], n_inv));
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+typedef unsigned __int128 u128;
+uint64_t mulmod_u64(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t)((u128)a * b % p); }
+uint64_t powmod_u64(uint64_t a, uint64_t e, uint64_t p)
+{
+    uint64_t r = 1;
+    while (e) {
+        if (e & 1) r = mulmod_u64(r, a, p);
+        a = mulmod_u64(a, a, p);
+        e >>= 1;
+    }
+    return r;
+}
+double centred(uint64_t v, uint64_t p) { return v > p / 2 ? (double)((int64_t)v - (int64_t)p) : (double)(int64_t)v; }
+int bitrev(int x, int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; i++) {
+        r = (r << 1) | (x & 1);
+        x >>= 1;
+    }
+    return r;
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = std::max(n + n / 2, (size_t)64);
+        if (hipMalloc(&p, want * sizeof(T)) != hipSuccess) return -1;
+        cap = want;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+} // namespace
+
+struct helm_si_wires {
+    helm_si_ctx *owner;
+    uint64_t *d;
+    int64_t n_rows;
+};
+
+struct helm_si_ctx {
+    int device = 0;
+    helm_si_params P{};
+    int logN = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    double *tw[2] = {nullptr, nullptr};
+    double n_inv[2] = {0, 0}, two32[2] = {0, 0};
+    double p0inv_mod_p1 = 0;
+    double *bsk = nullptr;
+    uint64_t *ksk = nullptr;
+    bool have_bsk = false, have_ksk = false;
+    uint64_t delta = 0;
+    // per-call scratch
+    DevBuf<Pbs64Job> d_pbs;
+    DevBuf<Ks64Job> d_ks;
+    DevBuf<uint64_t> d_small, d_luts, d_stage, d_body;
+    DevBuf<int32_t> d_idx, d_idx2;
+    DevBuf<int64_t> d_coef;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pbs, ev_ks, ev_lin;
+    helm_si_timing tacc{};
+};
+
+namespace {
+
+struct Timed {
+    helm_si_ctx *ctx;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> *list;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(helm_si_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> *l) : ctx(c), list(l)
+    {
+        if (ctx->timing) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, ctx->stream);
+        }
+    }
+    ~Timed()
+    {
+        if (ctx->timing) {
+            (void)hipEventRecord(b, ctx->stream);
+            list->push_back({a, b});
+        }
+    }
+};
+
+bool si_supported(const helm_si_params &P)
+{
+    if (P.k != 1) return false;
+    if (!(P.N == 512 || P.N == 1024 || P.N == 2048)) return false;
+    return P.pbs_l == 1 || P.pbs_l == 2;
+}
+
+template <typename C>
+hipError_t launch_pbs64_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
+                          const uint64_t *luts, uint64_t *out)
+{
+    static bool attr_done[64] = {false};
+    auto kern = k_pbs64<C>;
+    if (!attr_done[ctx->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
+        if (e != hipSuccess) return e;
+        attr_done[ctx->device & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, small, luts, ctx->bsk,
+                       ctx->tw[0], ctx->tw[1], out, ctx->P.n, ctx->P.pbs_logB, ctx->p0inv_mod_p1);
+    return hipGetLastError();
+}
+
+hipError_t launch_pbs64(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
+                        const uint64_t *luts, uint64_t *out)
+{
+    const helm_si_params &P = ctx->P;
+#define PBS64_CASE(LN, LV) \
+    if (ctx->logN == LN && P.pbs_l == LV) return launch_pbs64_c<Pbs64Cfg<LN, LV>>(ctx, jobs, count, small, luts, out);
+    PBS64_CASE(9, 1) PBS64_CASE(9, 2) PBS64_CASE(10, 1) PBS64_CASE(10, 2) PBS64_CASE(11, 1) PBS64_CASE(11, 2)
+#undef PBS64_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_ks64(helm_si_ctx *ctx, const Ks64Job *jobs, int64_t count, const uint64_t *big, uint64_t *out)
+{
+    const helm_si_params &P = ctx->P;
+    const int kN = P.k * P.N;
+    dim3 grid((unsigned)((count + 3) / 4), (unsigned)((P.n + 1 + 255) / 256));
+    const size_t lds = (size_t)kN * P.ks_l * sizeof(uint32_t);
+#define KS_CASE(LV)                                                                                                 \
+    case LV: {                                                                                                      \
+        static bool done = false;                                                                                   \
+        if (!done) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_keyswitch64<LV>),                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);             \
+            if (e != hipSuccess) return e;                                                                          \
+            done = true;                                                                                            \
+        }                                                                                                           \
+        hipLaunchKernelGGL(k_keyswitch64<LV>, grid, dim3(256), lds, ctx->stream, jobs, big, ctx->ksk, out, P.n, kN, \
+                           P.ks_logB, (int)count);                                                                  \
+        break;                                                                                                      \
+    }
+    switch (P.ks_l) {
+        KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) KS_CASE(5) KS_CASE(6) KS_CASE(7) KS_CASE(8)
+    default: return hipErrorInvalidValue;
+    }
+#undef KS_CASE
+    return hipGetLastError();
+}
+
+int check_rows(const helm_si_wires *w, const int32_t *idx, int64_t count, bool allow_neg)
+{
+    for (int64_t i = 0; i < count; i++)
+        if (idx[i] >= w->n_rows || (idx[i] < 0 && !(allow_neg && idx[i] == -1)))
+            return fail(HELM_ERR_INVALID, "row index " + std::to_string(idx[i]) + " out of range at position " +
+                                              std::to_string(i));
+    return 0;
+}
+
+template <typename T>
+int upload(helm_si_ctx *ctx, DevBuf<T> &buf, const T *host, size_t n)
+{
+    if (buf.ensure(n)) return fail(HELM_ERR_OOM, "device scratch");
+    HIP_TRY(hipMemcpyAsync(buf.p, host, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+// keyswitch + bootstrap of `count` rows of `src` (big) into rows of `dst` (big)
+int apply_luts_device(helm_si_ctx *ctx, const uint64_t *src, uint64_t *dst, const std::vector<Ks64Job> &ks,
+                      const std::vector<Pbs64Job> &pbs, const uint64_t *luts_host, int64_t n_luts)
+{
+    const helm_si_params &P = ctx->P;
+    if (!ctx->have_bsk || !ctx->have_ksk) return fail(HELM_ERR_STATE, "bootstrapping / keyswitching key not loaded");
+    const int64_t count = (int64_t)pbs.size();
+    if (count == 0) return 0;
+    if (ctx->d_small.ensure((size_t)count * ((size_t)P.n + 1))) return fail(HELM_ERR_OOM, "small-LWE scratch");
+    if (int rc = upload(ctx, ctx->d_ks, ks.data(), ks.size())) return rc;
+    if (int rc = upload(ctx, ctx->d_pbs, pbs.data(), pbs.size())) return rc;
+    if (int rc = upload(ctx, ctx->d_luts, luts_host, (size_t)n_luts * P.N)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // host vectors may go out of scope
+    {
+        Timed t(ctx, &ctx->ev_ks);
+        HIP_TRY(launch_ks64(ctx, ctx->d_ks.p, count, src, ctx->d_small.p));
+    }
+    ctx->tacc.ks_launches++;
+    ctx->tacc.ks_count += count;
+    {
+        Timed t(ctx, &ctx->ev_pbs);
+        HIP_TRY(launch_pbs64(ctx, ctx->d_pbs.p, count, ctx->d_small.p, ctx->d_luts.p, dst));
+    }
+    ctx->tacc.pbs_launches++;
+    ctx->tacc.pbs_count += count;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx **out)
+{
+    if (!params || !out) return fail(HELM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const helm_si_params &P = *params;
+    if (!si_supported(P))
+        return fail(HELM_ERR_INVALID, "unsupported (k,N,pbs_l): built variants are k = 1, N in {512,1024,2048}, pbs_l in {1,2}");
+    if (P.n < 1 || P.n > 1024) return fail(HELM_ERR_INVALID, "n must be in [1,1024]");
+    if (P.pbs_logB < 2 || P.pbs_logB > 30 || P.pbs_logB * P.pbs_l > 64) return fail(HELM_ERR_INVALID, "bad PBS decomposition");
+    if (P.ks_logB < 1 || P.ks_logB > 7 || P.ks_l < 1 || P.ks_l > 8 || P.ks_logB * P.ks_l > 63)
+        return fail(HELM_ERR_INVALID, "bad keyswitch decomposition (ks_logB <= 7, ks_l <= 8)");
+    const int t = P.message_modulus * P.carry_modulus;
+    if (P.message_modulus < 2 || P.carry_modulus < 1 || (t & (t - 1)) || t > P.N / 2)
+        return fail(HELM_ERR_INVALID, "message_modulus * carry_modulus must be a power of two <= N/2");
+    // exactness: |sum| <= (k+1) * l * N * (B/2) * 2^63 must stay below p0 * p1 / 2
+    {
+        const long double bound = (long double)(P.k + 1) * P.pbs_l * P.N * (long double)(1ull << (P.pbs_logB - 1)) *
+                                  9223372036854775808.0L;
+        if (bound * 1.001L >= (long double)F0::P * (long double)F1::P / 2)
+            return fail(HELM_ERR_INVALID, "parameter set exceeds the two-prime NTT capacity");
+        // per-field operands: digits must be far below p
+        if ((double)(1ull << (P.pbs_logB - 1)) * 4 >= F1::P / 2) return fail(HELM_ERR_INVALID, "pbs_logB too large");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(HELM_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail(HELM_ERR_NO_DEVICE, "device_id out of range");
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(HELM_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    helm_si_ctx *ctx = new (std::nothrow) helm_si_ctx();
+    if (!ctx) return fail(HELM_ERR_OOM, "ctx");
+    ctx->device = device_id;
+    ctx->P = P;
+    while ((1 << ctx->logN) < P.N) ctx->logN++;
+    ctx->delta = (1ull << 63) / (uint64_t)t;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    const uint64_t pm[2] = {F0::P_U64, F1::P_U64}, gen[2] = {F0::GEN, F1::GEN};
+    const int N = P.N, logN = ctx->logN;
+    for (int f = 0; f < 2; f++) {
+        const uint64_t psi = powmod_u64(gen[f], (pm[f] - 1) / (2 * (uint64_t)N), pm[f]);
+        std::vector<double> tf(N);
+        uint64_t a = 1;
+        for (int i = 0; i < N; i++) {
+            tf[bitrev(i, logN)] = centred(a, pm[f]);
+            a = mulmod_u64(a, psi, pm[f]);
+        }
+        ctx->n_inv[f] = centred(powmod_u64((uint64_t)N, pm[f] - 2, pm[f]), pm[f]);
+        ctx->two32[f] = centred((1ull << 32) % pm[f], pm[f]);
+        HIP_TRY(hipMalloc(&ctx->tw[f], sizeof(double) * N));
+        HIP_TRY(hipMemcpy(ctx->tw[f], tf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    }
+    ctx->p0inv_mod_p1 = centred(powmod_u64(pm[0] % pm[1], pm[1] - 2, pm[1]), pm[1]);
+    *out = ctx;
+    return 0;
+}
+
+int helm_si_ctx_destroy(helm_si_ctx *ctx)
+{
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto *l : {&ctx->ev_pbs, &ctx->ev_ks, &ctx->ev_lin})
+        for (auto &p : *l) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    (void)hipFree(ctx->tw[0]);
+    (void)hipFree(ctx->tw[1]);
+    (void)hipFree(ctx->bsk);
+    (void)hipFree(ctx->ksk);
+    ctx->d_pbs.release();
+    ctx->d_ks.release();
+    ctx->d_small.release();
+    ctx->d_luts.release();
+    ctx->d_stage.release();
+    ctx->d_body.release();
+    ctx->d_idx.release();
+    ctx->d_idx2.release();
+    ctx->d_coef.release();
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return 0;
+}
+
+int helm_si_get_params(const helm_si_ctx *ctx, helm_si_params *out)
+{
+    if (!ctx || !out) return fail(HELM_ERR_INVALID, "null argument");
+    *out = ctx->P;
+    return 0;
+}
+
+int helm_si_set_stream(helm_si_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return 0;
+}
+
+int helm_si_sync(helm_si_ctx *ctx)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int helm_si_load_bootstrap_key(helm_si_ctx *ctx, const uint64_t *bsk_std, size_t n_words)
+{
+    if (!ctx || !bsk_std) return fail(HELM_ERR_INVALID, "null argument");
+    const helm_si_params &P = ctx->P;
+    const size_t K1 = P.k + 1;
+    const size_t polys = (size_t)P.n * P.pbs_l * K1 * K1;
+    if (n_words != polys * P.N)
+        return fail(HELM_ERR_INVALID, "bootstrapping key: expected " + std::to_string(polys * P.N) + " words, got " +
+                                          std::to_string(n_words));
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint64_t *d_std = nullptr;
+    HIP_TRY(hipMalloc(&d_std, n_words * sizeof(uint64_t)));
+    if (!ctx->bsk) HIP_TRY(hipMalloc(&ctx->bsk, n_words * 2 * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(d_std, bsk_std, n_words * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+#define CONV(LN)                                                                                                     \
+    if (ctx->logN == LN) {                                                                                           \
+        hipLaunchKernelGGL((k_bsk_convert64<F0, LN>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk, \
+                           ctx->tw[0], ctx->n_inv[0], ctx->two32[0], (int)K1, P.pbs_l, 0);                           \
+        hipLaunchKernelGGL((k_bsk_convert64<F1, LN>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk, \
+                           ctx->tw[1], ctx->n_inv[1], ctx->two32[1], (int)K1, P.pbs_l, 1);                           \
+    }
+    CONV(9) CONV(10) CONV(11)
+#undef CONV
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_std));
+    ctx->have_bsk = true;
+    return 0;
+}
+
+int helm_si_load_keyswitch_key(helm_si_ctx *ctx, const uint64_t *ksk, size_t n_words)
+{
+    if (!ctx || !ksk) return fail(HELM_ERR_INVALID, "null argument");
+    const helm_si_params &P = ctx->P;
+    const size_t want = (size_t)P.k * P.N * P.ks_l * ((size_t)P.n + 1);
+    if (n_words != want)
+        return fail(HELM_ERR_INVALID, "keyswitching key: expected " + std::to_string(want) + " words, got " +
+                                          std::to_string(n_words));
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->ksk) HIP_TRY(hipMalloc(&ctx->ksk, want * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpyAsync(ctx->ksk, ksk, want * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->have_ksk = true;
+    return 0;
+}
+
+int helm_si_wires_alloc(helm_si_ctx *ctx, int64_t n_rows, helm_si_wires **out)
+{
+    if (!ctx || !out || n_rows <= 0) return fail(HELM_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    helm_si_wires *w = new (std::nothrow) helm_si_wires();
+    if (!w) return fail(HELM_ERR_OOM, "wires");
+    w->owner = ctx;
+    w->n_rows = n_rows;
+    const size_t bytes = (size_t)n_rows * ((size_t)ctx->P.k * ctx->P.N + 1) * sizeof(uint64_t);
+    if (hipMalloc(&w->d, bytes) != hipSuccess) {
+        delete w;
+        return fail(HELM_ERR_OOM, "ciphertext table of " + std::to_string(bytes) + " bytes");
+    }
+    HIP_TRY(hipMemsetAsync(w->d, 0, bytes, ctx->stream));
+    *out = w;
+    return 0;
+}
+
+int helm_si_wires_free(helm_si_ctx *ctx, helm_si_wires *w)
+{
+    if (!w) return 0;
+    if (!ctx || w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(w->d);
+    delete w;
+    return 0;
+}
+
+int helm_si_wires_upload(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx, const uint64_t *lwe_host, int64_t count)
+{
+    if (!ctx || !w || !idx || !lwe_host || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
+    if (w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (count == 0) return 0;
+    if (int rc = check_rows(w, idx, count, false)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int dim = ctx->P.k * ctx->P.N;
+    if (int rc = upload(ctx, ctx->d_stage, lwe_host, (size_t)count * (dim + 1))) return rc;
+    if (int rc = upload(ctx, ctx->d_idx, idx, (size_t)count)) return rc;
+    hipLaunchKernelGGL(k_rows64, dim3((unsigned)count), dim3(256), 0, ctx->stream, ctx->d_stage.p, (const int32_t *)nullptr,
+                       w->d, ctx->d_idx.p, dim);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int helm_si_wires_download(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx, uint64_t *lwe_host, int64_t count)
+{
+    if (!ctx || !w || !idx || !lwe_host || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
+    if (w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (count == 0) return 0;
+    if (int rc = check_rows(w, idx, count, false)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int dim = ctx->P.k * ctx->P.N;
+    if (ctx->d_stage.ensure((size_t)count * (dim + 1))) return fail(HELM_ERR_OOM, "staging");
+    if (int rc = upload(ctx, ctx->d_idx, idx, (size_t)count)) return rc;
+    hipLaunchKernelGGL(k_rows64, dim3((unsigned)count), dim3(256), 0, ctx->stream, w->d, ctx->d_idx.p, ctx->d_stage.p,
+                       (const int32_t *)nullptr, dim);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(lwe_host, ctx->d_stage.p, (size_t)count * (dim + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int helm_si_wires_set_trivial(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx, const uint64_t *value, int64_t count)
+{
+    if (!ctx || !w || !idx || !value || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
+    if (w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (count == 0) return 0;
+    if (int rc = check_rows(w, idx, count, false)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint64_t> body((size_t)count);
+    for (int64_t g = 0; g < count; g++) body[(size_t)g] = value[g] * ctx->delta;
+    if (int rc = upload(ctx, ctx->d_body, body.data(), body.size())) return rc;
+    if (int rc = upload(ctx, ctx->d_idx, idx, (size_t)count)) return rc;
+    hipLaunchKernelGGL(k_set_trivial64, dim3((unsigned)count), dim3(256), 0, ctx->stream, ctx->d_idx.p, ctx->d_body.p, w->d,
+                       ctx->P.k * ctx->P.N);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int helm_si_lincomb(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, const int64_t *coef,
+                    const int64_t *const_add, const int32_t *out_idx, int32_t terms, int64_t count)
+{
+    if (!ctx || !w || !in_idx || !coef || !out_idx || terms < 1 || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
+    if (w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (count == 0) return 0;
+    if (int rc = check_rows(w, in_idx, count * terms, true)) return rc;
+    if (int rc = check_rows(w, out_idx, count, false)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int dim = ctx->P.k * ctx->P.N;
+    std::vector<uint64_t> body((size_t)count, 0);
+    if (const_add)
+        for (int64_t g = 0; g < count; g++) body[(size_t)g] = (uint64_t)const_add[g] * ctx->delta;
+    if (int rc = upload(ctx, ctx->d_body, body.data(), body.size())) return rc;
+    if (int rc = upload(ctx, ctx->d_idx, in_idx, (size_t)count * terms)) return rc;
+    if (int rc = upload(ctx, ctx->d_idx2, out_idx, (size_t)count)) return rc;
+    if (int rc = upload(ctx, ctx->d_coef, coef, (size_t)count * terms)) return rc;
+    // sums are staged (rows 0..count-1) and then scattered, so that a gate may overwrite a
+    // row another gate of the same call still reads
+    if (ctx->d_stage.ensure((size_t)count * (dim + 1))) return fail(HELM_ERR_OOM, "staging");
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // host vectors may go out of scope
+    {
+        Timed t(ctx, &ctx->ev_lin);
+        hipLaunchKernelGGL(k_lincomb64, dim3((unsigned)count), dim3(256), 0, ctx->stream, ctx->d_idx.p, ctx->d_coef.p,
+                           ctx->d_body.p, (const int32_t *)nullptr, w->d, ctx->d_stage.p, terms, dim);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_rows64, dim3((unsigned)count), dim3(256), 0, ctx->stream, ctx->d_stage.p,
+                           (const int32_t *)nullptr, w->d, ctx->d_idx2.p, dim);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int helm_si_make_lut(const helm_si_ctx *ctx, const uint64_t *f_values, uint64_t *tv)
+{
+    if (!ctx || !f_values || !tv) return fail(HELM_ERR_INVALID, "null argument");
+    const int N = ctx->P.N, t = ctx->P.message_modulus * ctx->P.carry_modulus;
+    const int box = N / t, half = box / 2;
+    std::vector<uint64_t> acc((size_t)N);
+    for (int v = 0; v < t; v++)
+        for (int j = 0; j < box; j++) acc[(size_t)v * box + j] = f_values[v] * ctx->delta;
+    for (int j = 0; j < half; j++) acc[(size_t)j] = 0ull - acc[(size_t)j];
+    for (int j = 0; j < N; j++) tv[j] = acc[(size_t)((j + half) % N)]; // rotate_left(half)
+    return 0;
+}
+
+int helm_si_apply_luts(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, const int32_t *lut_idx,
+                       const int32_t *out_idx, int64_t count, const uint64_t *luts, int64_t n_luts)
+{
+    if (!ctx || !w || !in_idx || !lut_idx || !out_idx || !luts || count < 0 || n_luts <= 0)
+        return fail(HELM_ERR_INVALID, "bad argument");
+    if (w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (count == 0) return 0;
+    if (int rc = check_rows(w, in_idx, count, false)) return rc;
+    if (int rc = check_rows(w, out_idx, count, false)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<Ks64Job> ks((size_t)count);
+    std::vector<Pbs64Job> pbs((size_t)count);
+    for (int64_t g = 0; g < count; g++) {
+        if (lut_idx[g] < 0 || lut_idx[g] >= n_luts) return fail(HELM_ERR_INVALID, "lut_idx out of range");
+        ks[(size_t)g] = Ks64Job{in_idx[g], (int32_t)g};
+        pbs[(size_t)g] = Pbs64Job{(int32_t)g, lut_idx[g], out_idx[g], 0};
+    }
+    // every keyswitch finishes (kernel boundary) before any bootstrap writes its output row
+    return apply_luts_device(ctx, w->d, w->d, ks, pbs, luts, n_luts);
+}
+
+int helm_si_eval_lut_level(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *arity, const int32_t *in_idx,
+                           int32_t max_in, const uint64_t *table, const int32_t *out_idx, int64_t count)
+{
+    if (!ctx || !w || !arity || !in_idx || !table || !out_idx || max_in < 1 || count < 0)
+        return fail(HELM_ERR_INVALID, "bad argument");
+    if (w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (count == 0) return 0;
+    if (int rc = check_rows(w, out_idx, count, false)) return rc;
+    const helm_si_params &P = ctx->P;
+    const int t = P.message_modulus * P.carry_modulus;
+    // ---- linear part of every gate: packed operand (LUT gates), copy or negation ---------
+    std::vector<int32_t> lin_in((size_t)count * max_in, -1);
+    std::vector<int64_t> lin_coef((size_t)count * max_in, 0);
+    std::vector<int32_t> pbs_gate; // gates that bootstrap
+    std::map<std::pair<int, uint64_t>, int32_t> lut_of;
+    std::vector<uint64_t> luts;
+    std::vector<int32_t> lut_idx;
+    for (int64_t g = 0; g < count; g++) {
+        const int ar = arity[g];
+        if (ar < 0 || ar > max_in) return fail(HELM_ERR_INVALID, "gate " + std::to_string(g) + ": bad arity");
+        const int32_t *in = in_idx + (size_t)g * max_in;
+        for (int q = 0; q < std::max(ar, 1); q++)
+            if (in[q] < 0 || in[q] >= w->n_rows)
+                return fail(HELM_ERR_INVALID, "gate " + std::to_string(g) + ": operand row out of range");
+        if (ar == 0) { // DFF / copy (circuit.rs:1063-1069)
+            lin_in[(size_t)g * max_in] = in[0];
+            lin_coef[(size_t)g * max_in] = 1;
+        } else if (ar == 1) { // gates.rs:765-770
+            lin_in[(size_t)g * max_in] = in[0];
+            lin_coef[(size_t)g * max_in] = table[g] == 0 ? 1 : -1;
+        } else {
+            if ((1 << ar) > t)
+                return fail(HELM_ERR_INVALID, "gate " + std::to_string(g) + ": " + std::to_string(ar) +
+                                                  " inputs do not fit the plaintext space of " + std::to_string(t));
+            for (int q = 0; q < ar; q++) { // gates.rs:773-778 (ar = 2: x * 2 + y)
+                lin_in[(size_t)g * max_in + q] = in[q];
+                lin_coef[(size_t)g * max_in + q] = (int64_t)1 << (ar - 1 - q);
+            }
+            const std::pair<int, uint64_t> key(ar, table[g]);
+            auto it = lut_of.find(key);
+            if (it == lut_of.end()) {
+                std::vector<uint64_t> f((size_t)t, 0);
+                for (int v = 0; v < t; v++) {
+                    // arity 2: table[(x&1)*2 + (y&1)] with v = 2x + y (gates.rs:750-752); else table[v] & 1
+                    const int idx = ar == 2 ? (((v >> 1) & 1) * 2 + (v & 1)) : (v & ((1 << ar) - 1));
+                    f[(size_t)v] = (table[g] >> idx) & 1ull;
+                }
+                const int32_t id = (int32_t)(luts.size() / P.N);
+                luts.resize(luts.size() + P.N);
+                helm_si_make_lut(ctx, f.data(), luts.data() + (size_t)id * P.N);
+                it = lut_of.emplace(key, id).first;
+            }
+            pbs_gate.push_back((int32_t)g);
+            lut_idx.push_back(it->second);
+        }
+    }
+    // bootstrapped gates first (pack, then KS + PBS in place), copies / negations after them:
+    // the order the boolean engine uses, which only matters for a DFF that latches a wire
+    // produced in its own (last) level
+    std::vector<int32_t> sub_in, sub_out;
+    std::vector<int64_t> sub_coef;
+    auto gather = [&](bool want_pbs) {
+        sub_in.clear();
+        sub_out.clear();
+        sub_coef.clear();
+        for (int64_t g = 0; g < count; g++) {
+            if ((arity[g] >= 2) != want_pbs) continue;
+            sub_in.insert(sub_in.end(), lin_in.begin() + g * max_in, lin_in.begin() + (g + 1) * max_in);
+            sub_coef.insert(sub_coef.end(), lin_coef.begin() + g * max_in, lin_coef.begin() + (g + 1) * max_in);
+            sub_out.push_back(out_idx[g]);
+        }
+    };
+    if (!pbs_gate.empty()) {
+        gather(true);
+        if (int rc = helm_si_lincomb(ctx, w, sub_in.data(), sub_coef.data(), nullptr, sub_out.data(), max_in,
+                                     (int64_t)sub_out.size()))
+            return rc;
+        if (int rc = helm_si_apply_luts(ctx, w, sub_out.data(), lut_idx.data(), sub_out.data(), (int64_t)sub_out.size(),
+                                        luts.data(), (int64_t)(luts.size() / P.N)))
+            return rc;
+    }
+    gather(false);
+    if (!sub_out.empty())
+        if (int rc = helm_si_lincomb(ctx, w, sub_in.data(), sub_coef.data(), nullptr, sub_out.data(), max_in,
+                                     (int64_t)sub_out.size()))
+            return rc;
+    return 0;
+}
+
+int helm_si_keyswitch_batch(helm_si_ctx *ctx, const uint64_t *in_big, uint64_t *out_small, int64_t count)
+{
+    if (!ctx || !in_big || !out_small || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
+    if (!ctx->have_ksk) return fail(HELM_ERR_STATE, "keyswitching key not loaded");
+    if (count == 0) return 0;
+    const helm_si_params &P = ctx->P;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t row = (size_t)P.n + 1, brow = (size_t)P.k * P.N + 1;
+    std::vector<Ks64Job> jobs((size_t)count);
+    for (int64_t g = 0; g < count; g++) jobs[(size_t)g] = Ks64Job{(int32_t)g, (int32_t)g};
+    if (int rc = upload(ctx, ctx->d_stage, in_big, (size_t)count * brow)) return rc;
+    if (int rc = upload(ctx, ctx->d_ks, jobs.data(), jobs.size())) return rc;
+    if (ctx->d_small.ensure((size_t)count * row)) return fail(HELM_ERR_OOM, "small-LWE scratch");
+    {
+        Timed t(ctx, &ctx->ev_ks);
+        HIP_TRY(launch_ks64(ctx, ctx->d_ks.p, count, ctx->d_stage.p, ctx->d_small.p));
+    }
+    HIP_TRY(hipMemcpyAsync(out_small, ctx->d_small.p, (size_t)count * row * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int helm_si_pbs_batch(helm_si_ctx *ctx, const uint64_t *in_small, const uint64_t *luts, int64_t n_luts,
+                      const int32_t *lut_idx, uint64_t *out_big, int64_t count)
+{
+    if (!ctx || !in_small || !luts || !lut_idx || !out_big || count < 0 || n_luts <= 0)
+        return fail(HELM_ERR_INVALID, "bad argument");
+    if (!ctx->have_bsk) return fail(HELM_ERR_STATE, "bootstrapping key not loaded");
+    if (count == 0) return 0;
+    const helm_si_params &P = ctx->P;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t row = (size_t)P.n + 1, brow = (size_t)P.k * P.N + 1;
+    std::vector<Pbs64Job> jobs((size_t)count);
+    for (int64_t g = 0; g < count; g++) {
+        if (lut_idx[g] < 0 || lut_idx[g] >= n_luts) return fail(HELM_ERR_INVALID, "lut_idx out of range");
+        jobs[(size_t)g] = Pbs64Job{(int32_t)g, lut_idx[g], (int32_t)g, 0};
+    }
+    if (int rc = upload(ctx, ctx->d_small, in_small, (size_t)count * row)) return rc;
+    if (int rc = upload(ctx, ctx->d_luts, luts, (size_t)n_luts * P.N)) return rc;
+    if (int rc = upload(ctx, ctx->d_pbs, jobs.data(), jobs.size())) return rc;
+    if (ctx->d_stage.ensure((size_t)count * brow)) return fail(HELM_ERR_OOM, "staging");
+    {
+        Timed t(ctx, &ctx->ev_pbs);
+        HIP_TRY(launch_pbs64(ctx, ctx->d_pbs.p, count, ctx->d_small.p, ctx->d_luts.p, ctx->d_stage.p));
+    }
+    ctx->tacc.pbs_launches++;
+    ctx->tacc.pbs_count += count;
+    HIP_TRY(hipMemcpyAsync(out_big, ctx->d_stage.p, (size_t)count * brow * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int helm_si_timing_enable(helm_si_ctx *ctx, int enable)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");
+    ctx->timing = enable != 0;
+    return 0;
+}
+
+int helm_si_get_timing(helm_si_ctx *ctx, helm_si_timing *out, int reset)
+{
+    if (!ctx || !out) return fail(HELM_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    auto drain = [](std::vector<std::pair<hipEvent_t, hipEvent_t>> &l, double &acc) {
+        for (auto &p : l) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) acc += ms;
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        l.clear();
+    };
+    drain(ctx->ev_pbs, ctx->tacc.pbs_ms);
+    drain(ctx->ev_ks, ctx->tacc.ks_ms);
+    drain(ctx->ev_lin, ctx->tacc.linear_ms);
+    *out = ctx->tacc;
+    if (reset) ctx->tacc = helm_si_timing{};
+    return 0;
+}
+
+} // extern "C"

@@ -47,6 +47,15 @@ template <> struct Fp<49> {
     static constexpr bool LAZY = true;
 };
 
+// The 49-bit prime with recentring kept (transforms of more than 9 stages, or inputs
+// larger than boolean digits, would outgrow the lazy bound).
+struct Fp49Strict {
+    static constexpr double P = Fp<49>::P;
+    static constexpr uint64_t P_U64 = Fp<49>::P_U64;
+    static constexpr uint64_t GEN = Fp<49>::GEN;
+    static constexpr bool LAZY = false;
+};
+
 // a*w mod p for integers |a| < 2^53, |w| <= p/2.  Result r == a*w (mod p) exactly,
 // |r| <= (0.5 + 0.75 * |a| * 2^-52) * p  (<= 2p for any admissible a).
 template <typename F>
@@ -159,6 +168,16 @@ struct TwMem {
     static constexpr bool MIRROR = false;
     const double *t;
     __device__ __forceinline__ double get(int, int, int, int idx, int) const { return t[idx]; }
+};
+// inverse twiddles read from the FORWARD index table (see TwLane for the identity)
+template <int LOGN>
+struct TwMemMirror {
+    static constexpr bool MIRROR = true;
+    const double *t;
+    __device__ __forceinline__ double get(int sb, int, int, int idx, int) const
+    {
+        return t[3 * ((1 << LOGN) >> (sb + 1)) - 1 - idx];
+    }
 };
 template <int NT>
 struct TwReg {

@@ -1,0 +1,237 @@
+"""Shortint (LUT / arithmetic mode) object layer over include/helm_shortint.h:
+SiClientKey (CPU), SiServerKey (GPU engine context with keys resident in HBM),
+SiWires (HBM-resident table of big-LWE ciphertexts).
+
+Mirrors the roles of tfhe::shortint::{ClientKey, ServerKey} as HELM uses them
+(reference src/bin/helm.rs:301, src/circuit.rs:75-79, src/gates.rs:754-785).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nv
+from ._native import SiParams, Timing, hip, host, hip_check, client_check
+
+
+def si_named_params(name):
+    """-> (SiParams, lwe_noise_std, glwe_noise_std)"""
+    p = SiParams()
+    a, b = C.c_double(), C.c_double()
+    rc = host.helm_si_client_named_params(name.encode(), C.byref(p), C.byref(a), C.byref(b))
+    if rc != 0:
+        raise nv.HelmError(f"unknown shortint parameter set {name!r}")
+    return p, a.value, b.value
+
+
+class SiClientKey:
+    def __init__(self, params, lwe_std, glwe_std, seed=1):
+        self.params = params
+        h = nv.vp()
+        rc = host.helm_si_client_keygen(C.byref(params), lwe_std, glwe_std, seed, C.byref(h))
+        if rc != 0:
+            raise nv.HelmError(f"helm_si_client_keygen failed ({rc})")
+        self._h = h
+        self.dim = params.k * params.N
+        self.t = params.message_modulus * params.carry_modulus
+        self.delta = (1 << 63) // self.t
+
+    @classmethod
+    def generate(cls, name="shortint_m2c2", seed=1):
+        p, a, b = si_named_params(name)
+        return cls(p, a, b, seed)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            host.helm_si_client_key_free(self._h)
+            self._h = None
+
+    def _view(self, fn, count):
+        return np.ctypeslib.as_array(fn(self._h), shape=(count,))
+
+    @property
+    def bsk(self):
+        return self._view(host.helm_si_client_bsk, host.helm_si_client_bsk_words(self._h))
+
+    @property
+    def ksk(self):
+        return self._view(host.helm_si_client_ksk, host.helm_si_client_ksk_words(self._h))
+
+    @property
+    def lwe_secret(self):
+        return self._view(host.helm_si_client_lwe_secret, self.params.n)
+
+    @property
+    def glwe_secret(self):
+        return self._view(host.helm_si_client_glwe_secret, self.dim)
+
+    def encrypt(self, values):
+        """int or sequence -> [count, k*N+1] uint64 (ClientKey::encrypt(u64))."""
+        scalar = np.isscalar(values)
+        v = np.ascontiguousarray(np.atleast_1d(np.asarray(values)).astype(np.uint64))
+        out = np.zeros((len(v), self.dim + 1), dtype=np.uint64)
+        rc = host.helm_si_client_encrypt(self._h, nv.as_u64p(v), len(v), nv.as_u64p(out))
+        assert rc == 0
+        return out[0] if scalar else out
+
+    def decrypt_message_and_carry(self, lwe):
+        a = np.ascontiguousarray(lwe, dtype=np.uint64)
+        one = a.ndim == 1
+        a2 = a.reshape(-1, self.dim + 1)
+        out = np.zeros(len(a2), dtype=np.uint64)
+        rc = host.helm_si_client_decrypt(self._h, nv.as_u64p(a2), len(a2), nv.as_u64p(out))
+        assert rc == 0
+        return int(out[0]) if one else out
+
+    def decrypt(self, lwe):
+        """ClientKey::decrypt: the message part (mod message_modulus)."""
+        v = self.decrypt_message_and_carry(lwe)
+        return v % self.params.message_modulus
+
+    def phase(self, lwe, small=False):
+        dim = self.params.n if small else self.dim
+        a2 = np.ascontiguousarray(lwe, dtype=np.uint64).reshape(-1, dim + 1)
+        out = np.zeros(len(a2), dtype=np.uint64)
+        rc = host.helm_si_client_phase(self._h, nv.as_u64p(a2), len(a2), int(small), nv.as_u64p(out))
+        assert rc == 0
+        return out
+
+
+class SiServerKey:
+    """GPU engine context (64-bit torus) with both keys resident in HBM."""
+
+    def __init__(self, client_key=None, params=None, bsk=None, ksk=None, device=0):
+        self.params = client_key.params if client_key is not None else params
+        h = nv.vp()
+        hip_check(hip.helm_si_ctx_create(device, C.byref(self.params), C.byref(h)))
+        self._h = h
+        self.dim = self.params.k * self.params.N
+        if client_key is not None:
+            bsk, ksk = client_key.bsk, client_key.ksk
+        if bsk is not None:
+            bsk = np.ascontiguousarray(bsk, dtype=np.uint64).reshape(-1)
+            hip_check(hip.helm_si_load_bootstrap_key(self._h, nv.as_u64p(bsk), bsk.size))
+        if ksk is not None:
+            ksk = np.ascontiguousarray(ksk, dtype=np.uint64).reshape(-1)
+            hip_check(hip.helm_si_load_keyswitch_key(self._h, nv.as_u64p(ksk), ksk.size))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            hip.helm_si_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def sync(self):
+        hip_check(hip.helm_si_sync(self._h))
+
+    def set_stream(self, stream_ptr):
+        hip_check(hip.helm_si_set_stream(self._h, nv.vp(stream_ptr)))
+
+    def wires(self, n_rows):
+        return SiWires(self, n_rows)
+
+    def make_lut(self, f):
+        """generate_lookup_table(f): f is a callable or a value table over [0, msg*carry)."""
+        t = self.params.message_modulus * self.params.carry_modulus
+        vals = np.array([f(v) for v in range(t)] if callable(f) else list(f), dtype=np.uint64)
+        assert len(vals) == t
+        out = np.zeros(self.params.N, dtype=np.uint64)
+        hip_check(hip.helm_si_make_lut(self._h, nv.as_u64p(vals), nv.as_u64p(out)))
+        return out
+
+    def keyswitch_batch(self, big):
+        p = self.params
+        big = np.ascontiguousarray(big, dtype=np.uint64).reshape(-1, self.dim + 1)
+        out = np.zeros((len(big), p.n + 1), dtype=np.uint64)
+        hip_check(hip.helm_si_keyswitch_batch(self._h, nv.as_u64p(big), nv.as_u64p(out), len(big)))
+        return out
+
+    def pbs_batch(self, small, luts, lut_idx=None):
+        p = self.params
+        small = np.ascontiguousarray(small, dtype=np.uint64).reshape(-1, p.n + 1)
+        luts = np.ascontiguousarray(luts, dtype=np.uint64).reshape(-1, p.N)
+        if lut_idx is None:
+            lut_idx = np.zeros(len(small), dtype=np.int32)
+        lut_idx = np.ascontiguousarray(lut_idx, dtype=np.int32)
+        out = np.zeros((len(small), self.dim + 1), dtype=np.uint64)
+        hip_check(hip.helm_si_pbs_batch(self._h, nv.as_u64p(small), nv.as_u64p(luts), len(luts), nv.as_i32p(lut_idx),
+                                        nv.as_u64p(out), len(small)))
+        return out
+
+    def timing_enable(self, on=True):
+        hip_check(hip.helm_si_timing_enable(self._h, int(on)))
+
+    def timing(self, reset=False):
+        t = Timing()
+        hip_check(hip.helm_si_get_timing(self._h, C.byref(t), int(reset)))
+        return t
+
+
+class SiWires:
+    """HBM-resident ciphertext table: rows of k*N+1 uint64."""
+
+    def __init__(self, server_key, n_rows):
+        self.sk = server_key
+        self.n_rows = int(n_rows)
+        h = nv.vp()
+        hip_check(hip.helm_si_wires_alloc(server_key._h, self.n_rows, C.byref(h)))
+        self._h = h
+
+    def free(self):
+        if getattr(self, "_h", None) and getattr(self.sk, "_h", None):
+            hip.helm_si_wires_free(self.sk._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        self.free()
+
+    def upload(self, idx, lwe):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        lwe = np.ascontiguousarray(lwe, dtype=np.uint64).reshape(len(idx), self.sk.dim + 1)
+        hip_check(hip.helm_si_wires_upload(self.sk._h, self._h, nv.as_i32p(idx), nv.as_u64p(lwe), len(idx)))
+
+    def download(self, idx=None):
+        if idx is None:
+            idx = np.arange(self.n_rows)
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        out = np.zeros((len(idx), self.sk.dim + 1), dtype=np.uint64)
+        hip_check(hip.helm_si_wires_download(self.sk._h, self._h, nv.as_i32p(idx), nv.as_u64p(out), len(idx)))
+        return out
+
+    def set_trivial(self, idx, values):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(values), idx.shape).astype(np.uint64))
+        hip_check(hip.helm_si_wires_set_trivial(self.sk._h, self._h, nv.as_i32p(idx), nv.as_u64p(v), len(idx)))
+
+    def lincomb(self, in_idx, coef, out_idx, const_add=None):
+        """out[g] = sum_t coef[g,t] * row in_idx[g,t] + const_add[g] * delta."""
+        in_idx = np.ascontiguousarray(np.atleast_2d(in_idx), dtype=np.int32)
+        coef = np.ascontiguousarray(np.atleast_2d(coef), dtype=np.int64)
+        out_idx = np.ascontiguousarray(out_idx, dtype=np.int32)
+        assert in_idx.shape == coef.shape and in_idx.shape[0] == len(out_idx)
+        ca = None
+        if const_add is not None:
+            ca = np.ascontiguousarray(np.broadcast_to(np.asarray(const_add), out_idx.shape).astype(np.int64))
+        hip_check(hip.helm_si_lincomb(self.sk._h, self._h, nv.as_i32p(in_idx), nv.as_i64p(coef),
+                                      nv.as_i64p(ca) if ca is not None else None, nv.as_i32p(out_idx),
+                                      in_idx.shape[1], len(out_idx)))
+
+    def apply_luts(self, in_idx, luts, out_idx, lut_idx=None):
+        in_idx = np.ascontiguousarray(in_idx, dtype=np.int32)
+        out_idx = np.ascontiguousarray(out_idx, dtype=np.int32)
+        luts = np.ascontiguousarray(luts, dtype=np.uint64).reshape(-1, self.sk.params.N)
+        if lut_idx is None:
+            lut_idx = np.zeros(len(in_idx), dtype=np.int32)
+        lut_idx = np.ascontiguousarray(lut_idx, dtype=np.int32)
+        hip_check(hip.helm_si_apply_luts(self.sk._h, self._h, nv.as_i32p(in_idx), nv.as_i32p(lut_idx),
+                                         nv.as_i32p(out_idx), len(in_idx), nv.as_u64p(luts), len(luts)))
+
+    def eval_lut_level(self, arity, in_idx, table, out_idx):
+        """gates::lut() for a level: in_idx [count, max_in] (-1 padded), table = truth tables as bit masks."""
+        arity = np.ascontiguousarray(arity, dtype=np.int32)
+        in_idx = np.ascontiguousarray(np.atleast_2d(in_idx), dtype=np.int32)
+        table = np.ascontiguousarray(table, dtype=np.uint64)
+        out_idx = np.ascontiguousarray(out_idx, dtype=np.int32)
+        hip_check(hip.helm_si_eval_lut_level(self.sk._h, self._h, nv.as_i32p(arity), nv.as_i32p(in_idx),
+                                             in_idx.shape[1], nv.as_u64p(table), nv.as_i32p(out_idx), len(arity)))

@@ -20,6 +20,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "helm_hip.h"
+#include "helm_shortint.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -58,6 +59,32 @@ int helm_client_encrypt_bool(helm_client_key *key, const uint8_t *bits, int64_t 
 int helm_client_decrypt_bool(const helm_client_key *key, const uint32_t *lwe, int64_t count, uint8_t *bits_out);
 /* Raw phases b - <a,s> (noise measurements). big != 0: ciphertexts under the k*N key. */
 int helm_client_phase(const helm_client_key *key, const uint32_t *lwe, int64_t count, int big, uint32_t *phase_out);
+
+/* ---- shortint (LUT / arithmetic mode) client: 64-bit torus, KS_PBS order ------------
+ * tfhe::shortint::gen_keys(PARAM_...)              reference src/bin/helm.rs:301
+ * ClientKey::encrypt(u64) / decrypt                reference src/circuit.rs:982-996, 1092
+ * Ciphertexts are encrypted under the BIG key (k*N words + body). */
+typedef struct helm_si_client_key helm_si_client_key;
+/* "shortint_m2c2": PARAM_MESSAGE_2_CARRY_2_KS_PBS [recalled; the 3-bit-capable
+ * class tests/circuit_test.rs:287 needs]; "si_toy_*": small sets for exact oracle comparisons. */
+int helm_si_client_named_params(const char *name, helm_si_params *params, double *lwe_noise_std,
+                                double *glwe_noise_std);
+int helm_si_client_keygen(const helm_si_params *params, double lwe_noise_std, double glwe_noise_std,
+                          uint64_t seed, helm_si_client_key **out);
+void helm_si_client_key_free(helm_si_client_key *key);
+int helm_si_client_params(const helm_si_client_key *key, helm_si_params *out);
+size_t helm_si_client_bsk_words(const helm_si_client_key *key);
+size_t helm_si_client_ksk_words(const helm_si_client_key *key);
+const uint64_t *helm_si_client_bsk(const helm_si_client_key *key); /* [n][pbs_l][k+1][k+1][N] */
+const uint64_t *helm_si_client_ksk(const helm_si_client_key *key); /* [k*N][ks_l][n+1]       */
+const uint64_t *helm_si_client_lwe_secret(const helm_si_client_key *key);  /* n   words of 0/1 */
+const uint64_t *helm_si_client_glwe_secret(const helm_si_client_key *key); /* k*N words of 0/1 */
+/* value v (taken mod message_modulus*carry_modulus) -> big LWE with body += v * delta */
+int helm_si_client_encrypt(helm_si_client_key *key, const uint64_t *values, int64_t count, uint64_t *lwe_out);
+/* round(phase / delta) mod (message_modulus*carry_modulus): message AND carry;
+ * ClientKey::decrypt is this value mod message_modulus */
+int helm_si_client_decrypt(const helm_si_client_key *key, const uint64_t *lwe, int64_t count, uint64_t *values_out);
+int helm_si_client_phase(const helm_si_client_key *key, const uint64_t *lwe, int64_t count, int small, uint64_t *phase_out);
 
 #ifdef __cplusplus
 }

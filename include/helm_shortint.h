@@ -1,0 +1,123 @@
+/*
+ * helm_shortint.h — C ABI of the MI355X-native LUT-mode / arithmetic-mode engine
+ * (64-bit torus, "shortint" ciphertexts: message + carry bits under one padding bit).
+ *
+ * Reference interfaces this replaces (all arithmetic inside the `tfhe` 0.4.1 crate,
+ * Cargo.toml:18, absent from the tree):
+ *   src/gates.rs:754-785      gates::lut(): tfhe::shortint::ServerKey::
+ *                             {smart_evaluate_bivariate_function, smart_neg,
+ *                              smart_scalar_left_shift, add, create_trivial,
+ *                              generate_lookup_table, apply_lookup_table}
+ *   src/circuit.rs:1032-1083  LutCircuit::evaluate_encrypted: per level,
+ *                             gates.par_iter_mut() -> one lut() per gate
+ *   src/circuit.rs:970-1000   encrypt_inputs (client_key.encrypt(u64), create_trivial(0))
+ *   src/gates.rs:306-702      arithmetic-mode operators (FheUint8..128 = radix of shortint
+ *                             blocks): served by the same two device primitives below
+ *
+ * Shape of the replacement.  Ciphertexts live in a device-resident table of "big" LWE
+ * rows (k*N mask words + body, uint64) - tfhe's KS_PBS order: apply_lookup_table =
+ * keyswitch big->small, then programmable bootstrap small->big.  Two level-batched
+ * primitives carry every operator of both modes:
+ *   helm_si_lincomb()      out = sum_t coef[t] * in[t] + const        (no bootstrap)
+ *   helm_si_apply_luts()   out = PBS_lut( KS( in ) )                  (one bootstrap)
+ * and helm_si_eval_lut_level() is gates::lut() for a whole netlist level.
+ *
+ * Conventions as in helm_hip.h: 0 / negative helm_status, helm_hip_last_error(),
+ * caller owns host buffers, one context per device + host thread, stream-asynchronous
+ * with helm_si_sync(), no CPU fallback.
+ *
+ * Layouts (all words uint64_t, arithmetic mod 2^64)
+ *   big LWE / wire row   k*N mask words + body
+ *   bootstrapping key    [n][pbs_l][k+1][k+1][N]      (as helm_hip.h, 64-bit)
+ *   keyswitching key     [k*N][ks_l][n+1]
+ *   encoding             value v in [0, message_modulus*carry_modulus) -> v * delta,
+ *                        delta = 2^63 / (message_modulus * carry_modulus)
+ *                        (the one citable line: src/gates.rs:851)
+ *   look-up table        test polynomial of N words: box v of N/(msg*carry) coefficients
+ *                        = f(v) * delta, rotated left by half a box, wrapped part negated
+ */
+#ifndef HELM_SHORTINT_H
+#define HELM_SHORTINT_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "helm_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct helm_si_ctx helm_si_ctx;
+typedef struct helm_si_wires helm_si_wires;
+
+/* tfhe::shortint::ClassicPBSParameters as HELM picks them (src/bin/helm.rs:301,
+ * tests/circuit_test.rs:287), runtime values. */
+typedef struct {
+    int32_t n, k, N;
+    int32_t pbs_l, pbs_logB;
+    int32_t ks_l, ks_logB;
+    int32_t message_modulus, carry_modulus;
+} helm_si_params;
+
+/* Replaces shortint ServerKey construction (helm.rs:301: gen_keys(PARAM_...)). */
+int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx **out);
+int helm_si_ctx_destroy(helm_si_ctx *ctx);
+int helm_si_get_params(const helm_si_ctx *ctx, helm_si_params *out);
+int helm_si_set_stream(helm_si_ctx *ctx, void *hip_stream);
+int helm_si_sync(helm_si_ctx *ctx);
+int helm_si_load_bootstrap_key(helm_si_ctx *ctx, const uint64_t *bsk_std, size_t n_words);
+int helm_si_load_keyswitch_key(helm_si_ctx *ctx, const uint64_t *ksk, size_t n_words);
+
+/* Device-resident ciphertext table (replaces HashMap<String, Arc<RwLock<CtxtShortInt>>>,
+ * circuit.rs:1046-1049).  Rows of k*N+1 words. */
+int helm_si_wires_alloc(helm_si_ctx *ctx, int64_t n_rows, helm_si_wires **out);
+int helm_si_wires_free(helm_si_ctx *ctx, helm_si_wires *w);
+int helm_si_wires_upload(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx, const uint64_t *lwe_host,
+                         int64_t count);
+int helm_si_wires_download(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx, uint64_t *lwe_host,
+                           int64_t count);
+/* ServerKey::create_trivial(value) (circuit.rs:978): zero mask, body = value * delta. */
+int helm_si_wires_set_trivial(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx, const uint64_t *value,
+                              int64_t count);
+
+/* out[g] = sum_{t<terms} coef[g*terms+t] * row in_idx[g*terms+t]  +  const_add[g] * delta
+ * (in_idx = -1: term skipped).  Replaces unchecked add / sub / scalar_mul /
+ * scalar_left_shift / neg / scalar_add of tfhe::shortint (gates.rs:769,776-778). */
+int helm_si_lincomb(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, const int64_t *coef,
+                    const int64_t *const_add, const int32_t *out_idx, int32_t terms, int64_t count);
+
+/* Look-up tables as test polynomials (n_luts rows of N words), see layout above.
+ * helm_si_make_lut() is ServerKey::generate_lookup_table(f) with f given as its value
+ * table over [0, message_modulus*carry_modulus). */
+int helm_si_make_lut(const helm_si_ctx *ctx, const uint64_t *f_values, uint64_t *test_poly_out);
+/* out[g] = apply_lookup_table(row in_idx[g], luts[lut_idx[g]])  (gates.rs:783): keyswitch
+ * then programmable bootstrap, `count` ciphertexts in one batched dispatch. */
+int helm_si_apply_luts(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, const int32_t *lut_idx,
+                       const int32_t *out_idx, int64_t count, const uint64_t *luts, int64_t n_luts);
+
+/* One netlist level of LUT gates = gates::lut() per gate (gates.rs:754-785):
+ *   arity 1  : table all zero -> copy, else -> negation (smart_neg)
+ *   arity 2  : bivariate f(x,y) = table[(x&1)*2 + (y&1)]
+ *   arity >=3: pack sum in_i << (arity-1-i) (first input = MSB, gates.rs:159-167),
+ *              f(x) = table[x] & 1
+ * arity 0 with table 0: DFF / copy of in_idx[g*max_in] (circuit.rs:1063-1069).
+ * table[g] holds the truth table as bits (bit i = entry i), in_idx is [count][max_in]. */
+int helm_si_eval_lut_level(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *arity, const int32_t *in_idx,
+                           int32_t max_in, const uint64_t *table, const int32_t *out_idx, int64_t count);
+
+/* Primitive forms on host buffers (tests).  small: count x (n+1); big: count x (k*N+1). */
+int helm_si_keyswitch_batch(helm_si_ctx *ctx, const uint64_t *in_big, uint64_t *out_small, int64_t count);
+int helm_si_pbs_batch(helm_si_ctx *ctx, const uint64_t *in_small, const uint64_t *luts, int64_t n_luts,
+                      const int32_t *lut_idx, uint64_t *out_big, int64_t count);
+
+typedef struct {
+    double pbs_ms, ks_ms, linear_ms;
+    int64_t pbs_launches, pbs_count, ks_launches, ks_count;
+} helm_si_timing;
+int helm_si_timing_enable(helm_si_ctx *ctx, int enable);
+int helm_si_get_timing(helm_si_ctx *ctx, helm_si_timing *out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HELM_SHORTINT_H */

@@ -22,7 +22,7 @@ class Params(C.Structure):
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so", "liborc64.so"])
 
 
 def lib():
@@ -137,3 +137,98 @@ def decompose(x, logB, l):
 
 def max_threads():
     return int(lib().orc_max_threads())
+
+
+# ---------------------------------------------------------------------------------------
+# shortint (LUT / arithmetic mode) oracle: oracle/shortint_oracle.c
+# ---------------------------------------------------------------------------------------
+class Params64(C.Structure):
+    _fields_ = [(f, C.c_int32) for f in ("n", "k", "N", "pbs_l", "pbs_logB", "ks_l", "ks_logB",
+                                         "message_modulus", "carry_modulus")]
+
+
+_LIB64 = None
+
+
+def lib64():
+    global _LIB64
+    if _LIB64 is None:
+        path = os.path.join(_HERE, "liborc64.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "liborc64.so"])
+        L = C.CDLL(path)
+        u64p = C.POINTER(C.c_uint64)
+        i32p = C.POINTER(C.c_int32)
+        P = C.POINTER(Params64)
+        L.orc64_make_lut.argtypes = [P, u64p, u64p]
+        L.orc64_bootstrap.argtypes = [P, u64p, u64p, u64p, u64p]
+        L.orc64_keyswitch.argtypes = [P, u64p, u64p, u64p]
+        L.orc64_apply_lut.argtypes = [P, u64p, u64p, u64p, u64p, u64p]
+        L.orc64_eval_lut_level.argtypes = [P, u64p, u64p, u64p, i32p, i32p, C.c_int, u64p, i32p, C.c_int]
+        L.orc64_decrypt.restype = C.c_uint64
+        L.orc64_decrypt.argtypes = [P, u64p, u64p]
+        L.orc64_modswitch.restype = C.c_uint64
+        L.orc64_modswitch.argtypes = [C.c_uint64, C.c_int]
+        L.orc64_decompose.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+        _LIB64 = L
+    return _LIB64
+
+
+def _u64(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+class Oracle64:
+    """Server-side shortint evaluation with a given (bsk, ksk) in the standard-domain
+    layouts documented in include/helm_shortint.h."""
+
+    def __init__(self, params9, bsk_std, ksk):
+        self.p = Params64(*[int(x) for x in params9])
+        self.bsk = np.ascontiguousarray(bsk_std, dtype=np.uint64)
+        self.ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
+        self.dim = self.p.k * self.p.N
+        self.t = self.p.message_modulus * self.p.carry_modulus
+        self.delta = (1 << 63) // self.t
+
+    def make_lut(self, f):
+        vals = np.array([f(v) for v in range(self.t)] if callable(f) else list(f), dtype=np.uint64)
+        out = np.zeros(self.p.N, dtype=np.uint64)
+        lib64().orc64_make_lut(C.byref(self.p), _u64(vals), _u64(out))
+        return out
+
+    def keyswitch(self, big):
+        big = np.ascontiguousarray(big, dtype=np.uint64)
+        out = np.zeros(self.p.n + 1, dtype=np.uint64)
+        lib64().orc64_keyswitch(C.byref(self.p), _u64(self.ksk), _u64(big), _u64(out))
+        return out
+
+    def bootstrap(self, small, lut):
+        small = np.ascontiguousarray(small, dtype=np.uint64)
+        lut = np.ascontiguousarray(lut, dtype=np.uint64)
+        out = np.zeros(self.dim + 1, dtype=np.uint64)
+        lib64().orc64_bootstrap(C.byref(self.p), _u64(self.bsk), _u64(small), _u64(lut), _u64(out))
+        return out
+
+    def apply_lut(self, big, lut):
+        big = np.ascontiguousarray(big, dtype=np.uint64)
+        lut = np.ascontiguousarray(lut, dtype=np.uint64)
+        out = np.zeros(self.dim + 1, dtype=np.uint64)
+        lib64().orc64_apply_lut(C.byref(self.p), _u64(self.bsk), _u64(self.ksk), _u64(big), _u64(lut), _u64(out))
+        return out
+
+    def eval_lut_level(self, wires, arity, in_idx, table, out_idx):
+        """In place on `wires` ([rows, k*N+1] uint64)."""
+        assert wires.dtype == np.uint64 and wires.flags["C_CONTIGUOUS"]
+        arity = np.ascontiguousarray(arity, dtype=np.int32)
+        in_idx = np.ascontiguousarray(np.atleast_2d(in_idx), dtype=np.int32)
+        table = np.ascontiguousarray(table, dtype=np.uint64)
+        out_idx = np.ascontiguousarray(out_idx, dtype=np.int32)
+        lib64().orc64_eval_lut_level(C.byref(self.p), _u64(self.bsk), _u64(self.ksk), _u64(wires), _i32(arity),
+                                     _i32(in_idx), in_idx.shape[1], _u64(table), _i32(out_idx), len(arity))
+
+    def decrypt(self, glwe_sk_bits, ct):
+        """message and carry"""
+        sk = np.ascontiguousarray(glwe_sk_bits, dtype=np.uint64)
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        return int(lib64().orc64_decrypt(C.byref(self.p), _u64(sk), _u64(ct)))

@@ -1,0 +1,142 @@
+"""LUT-mode primitives on the GPU (include/helm_shortint.h) against the shortint oracle:
+bit-exact keyswitch, programmable bootstrap and whole LUT gates on the toy parameter sets
+(every (N, pbs_l) kernel build), truth tables of gates::lut() (reference src/gates.rs:754-785,
+tests/circuit_test.rs:287-310), and the full PARAM_MESSAGE_2_CARRY_2 set."""
+import numpy as np
+import pytest
+
+import helm_amd
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+TOYS = ["si_toy_512", "si_toy_1024", "si_toy_2048", "si_toy_2048_l2"]
+
+
+@pytest.fixture(scope="module", params=TOYS)
+def toy(request):
+    ck = helm_amd.SiClientKey.generate(request.param, seed=3)
+    sk = helm_amd.SiServerKey(ck)
+    orc = oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk)
+    yield ck, sk, orc
+    sk.close()
+
+
+def test_keyswitch_batch_bit_exact(toy):
+    ck, sk, orc = toy
+    cts = ck.encrypt(np.arange(7) % ck.t)
+    got = sk.keyswitch_batch(cts)
+    for g in range(len(cts)):
+        assert np.array_equal(got[g], orc.keyswitch(cts[g]))
+    # the small ciphertexts still carry the message
+    ph = ck.phase(got, small=True)
+    assert np.array_equal(((ph + ck.delta // 2) // ck.delta) % ck.t, np.arange(7) % ck.t)
+
+
+def test_pbs_batch_bit_exact(toy):
+    ck, sk, orc = toy
+    vals = np.arange(ck.t, dtype=np.uint64)
+    small = sk.keyswitch_batch(ck.encrypt(vals))
+    luts = np.stack([orc.make_lut(lambda x: (5 * x + 3) % ck.t), orc.make_lut(lambda x: x & 1)])
+    assert np.array_equal(luts[0], sk.make_lut(lambda x: (5 * x + 3) % ck.t))  # generate_lookup_table parity
+    idx = (np.arange(ck.t) % 2).astype(np.int32)
+    got = sk.pbs_batch(small, luts, idx)
+    for g in range(ck.t):
+        want = orc.bootstrap(small[g], luts[idx[g]])
+        assert np.array_equal(got[g], want), f"ciphertext {g}"
+    dec = ck.decrypt_message_and_carry(got)
+    assert list(dec) == [((5 * v + 3) % ck.t) if i == 0 else (v & 1) for v, i in zip(range(ck.t), idx)]
+
+
+def test_lut_level_bit_exact_and_truth_tables(toy):
+    ck, sk, orc = toy
+    rng = np.random.default_rng(11)
+    # inputs: rows 0..3 hold bits, gates of every arity gates::lut() distinguishes
+    bits = np.array([1, 0, 1, 1], dtype=np.uint64)
+    gates = [  # (arity, inputs, table)
+        (3, [0, 1, 2], 0x96), (3, [0, 1, 2], 0xE8), (3, [3, 2, 1], 0x1B), (4, [0, 1, 2, 3], 0x6996),
+        (2, [0, 1], 0x6), (2, [2, 3], 0x8), (2, [1, 0], 0xD), (1, [0], 0x0), (1, [2], 0x2), (0, [3], 0x0),
+    ]
+    n_in, count, max_in = len(bits), len(gates), 4
+    arity = np.array([g[0] for g in gates], dtype=np.int32)
+    in_idx = np.full((count, max_in), -1, dtype=np.int32)
+    for g, (_, ins, _) in enumerate(gates):
+        in_idx[g, :len(ins)] = ins
+    table = np.array([g[2] for g in gates], dtype=np.uint64)
+    out_idx = np.arange(n_in, n_in + count, dtype=np.int32)
+    host = np.zeros((n_in + count, ck.dim + 1), dtype=np.uint64)
+    host[:n_in] = ck.encrypt(bits)
+    w = sk.wires(n_in + count)
+    w.upload(np.arange(n_in), host[:n_in])
+    w.eval_lut_level(arity, in_idx, table, out_idx)
+    got = w.download()
+    orc.eval_lut_level(host, arity, in_idx, table, out_idx)
+    assert np.array_equal(got, host)
+    dec = ck.decrypt_message_and_carry(got[n_in:])
+    for g, (ar, ins, tb) in enumerate(gates):
+        x = [int(bits[i]) for i in ins]
+        if ar >= 3:
+            want = (tb >> sum(b << (ar - 1 - q) for q, b in enumerate(x))) & 1  # first input = MSB (gates.rs:159-167)
+        elif ar == 2:
+            want = (tb >> (x[0] * 2 + x[1])) & 1
+        elif ar == 1:
+            want = x[0] if tb == 0 else (-x[0]) % ck.t  # smart_neg (gates.rs:769)
+        else:
+            want = x[0]
+        assert int(dec[g]) == want, f"gate {g}"
+    del rng
+
+
+def test_lincomb_and_apply_luts_in_place(toy):
+    ck, sk, orc = toy
+    w = sk.wires(8)
+    w.upload([0, 1, 2], ck.encrypt([1, 2, 3]))
+    w.set_trivial([3], [2])
+    # row 4 = 2*r0 + r1 + 3 ; row 0 = r0 + r2 (in place) ; row 5 = -r3 + 1
+    w.lincomb([[0, 1], [0, 2], [3, -1]], [[2, 1], [1, 1], [-1, 0]], [4, 0, 5], const_add=[3, 0, 1])
+    assert list(ck.decrypt_message_and_carry(w.download([4, 0, 5]))) == [7, 4, (-2 + 1) % ck.t]
+    lut = sk.make_lut(lambda x: (x * x) % ck.t)
+    w.apply_luts([4, 0], lut, [4, 6])
+    assert list(ck.decrypt_message_and_carry(w.download([4, 6]))) == [49 % ck.t, 16 % ck.t]
+
+
+def test_errors():
+    p, a, b = helm_amd.si_named_params("si_toy_512")
+    bad = helm_amd.SiParams(*p.as_tuple())
+    bad.k = 2
+    with pytest.raises(helm_amd.HelmError, match="unsupported"):
+        helm_amd.SiServerKey(params=bad)
+    sk = helm_amd.SiServerKey(params=p)
+    w = sk.wires(4)
+    with pytest.raises(helm_amd.HelmError, match="not loaded"):
+        w.apply_luts([0], np.zeros(p.N, dtype=np.uint64), [1])
+    with pytest.raises(helm_amd.HelmError, match="out of range"):
+        w.lincomb([[9]], [[1]], [0])
+    sk.close()
+
+
+def test_full_parameter_set_m2c2():
+    """PARAM_MESSAGE_2_CARRY_2_KS_PBS: one bootstrap bit-exact against the O(N^2) oracle, every
+    plaintext value through a LUT, and the 3-input packing of gates::lut()."""
+    ck = helm_amd.SiClientKey.generate("shortint_m2c2", seed=1)
+    sk = helm_amd.SiServerKey(ck)
+    orc = oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk)
+    vals = np.arange(ck.t, dtype=np.uint64)
+    cts = ck.encrypt(vals)
+    w = sk.wires(64)
+    w.upload(np.arange(ck.t), cts)
+    lut = sk.make_lut(lambda x: (7 * x + 5) % ck.t)
+    w.apply_luts(np.arange(ck.t), lut, np.arange(ck.t) + ck.t)
+    got = w.download(np.arange(ck.t) + ck.t)
+    assert list(ck.decrypt_message_and_carry(got)) == [(7 * v + 5) % ck.t for v in range(ck.t)]
+    # determinism + bit-exactness of one full-size bootstrap (12.4 G exact u64 multiply-adds on the CPU)
+    assert np.array_equal(got[5], orc.apply_lut(cts[5], lut))
+    # 8 x majority / parity of three encrypted bits
+    bits = np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], dtype=np.uint64)
+    w.upload(np.arange(32, 56), ck.encrypt(bits.reshape(-1)))
+    in_idx = np.arange(32, 56, dtype=np.int32).reshape(8, 3)
+    for tb, fn in ((0xE8, lambda a, b, c: (a + b + c) >= 2), (0x96, lambda a, b, c: (a + b + c) & 1)):
+        w.eval_lut_level(np.full(8, 3, np.int32), in_idx, np.full(8, tb, np.uint64), np.arange(56, 64))
+        dec = ck.decrypt(w.download(np.arange(56, 64)))
+        assert list(dec) == [int(fn(*r)) for r in bits.tolist()]
+    sk.close()
