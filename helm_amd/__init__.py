@@ -9,7 +9,8 @@ from .engine import ClientKey, ServerKey, DeviceWires, Program, named_params  # 
 from ._native import HelmError, Params, SiParams  # noqa: F401
 from .shortint import SiClientKey, SiServerKey, SiWires, si_named_params  # noqa: F401
 from . import verilog_parser, circuit, gates, netlists  # noqa: F401,E402
-from .circuit import Circuit, GateCircuit, EvalCircuit, EncWireMap  # noqa: F401,E402
+from .circuit import (Circuit, GateCircuit, EvalCircuit, EncWireMap, LutCircuit, ArithCircuit,  # noqa: F401,E402
+                      SiEncWireMap)
 from .gates import PtxtType, GateType, Gate  # noqa: F401,E402
 
 
@@ -17,3 +18,9 @@ def gen_keys(name="boolean_default", seed=1, device=0):
     """tfhe::boolean::gen_keys() (reference src/bin/helm.rs:241) -> (client_key, server_key)."""
     ck = ClientKey.generate(name, seed)
     return ck, ServerKey(ck, device=device)
+
+
+def gen_keys_shortint(name="shortint_m2c2", seed=1, device=0):
+    """tfhe::shortint::gen_keys(PARAM_...) (reference src/bin/helm.rs:301) -> (client_key, server_key)."""
+    ck = SiClientKey.generate(name, seed)
+    return ck, SiServerKey(ck, device=device)

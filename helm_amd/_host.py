@@ -1,7 +1,7 @@
 """ctypes bindings of include/helm_host.h (libhelm_host.so)."""
 import ctypes as C
 
-from ._native import host, vp, u32p, HelmError, Params  # noqa: F401
+from ._native import host, vp, u32p, u64p, HelmError, Params  # noqa: F401
 
 cp = C.c_char_p
 cpp = C.POINTER(C.c_void_p)  # char** returned as raw pointer so we can free it
@@ -41,6 +41,24 @@ HOST_API = {
     "helm_host_gate_circuit_decrypt_outputs": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
     "helm_host_gate_circuit_log": (vp, [vp]),
     "helm_host_gate_circuit_pbs_per_cycle": (C.c_int64, [vp]),
+    "helm_host_si_circuit_new": (C.c_int, [C.c_int, vp, vp, vp, C.POINTER(vp)]),
+    "helm_host_si_circuit_free": (None, [vp]),
+    "helm_host_si_circuit_encrypt_inputs": (C.c_int, [vp, cp, cp, C.POINTER(vp)]),
+    "helm_host_si_circuit_evaluate_encrypted": (C.c_int, [vp, vp, C.c_int64, cp, C.POINTER(vp)]),
+    "helm_host_si_circuit_init_ready": (C.c_int, [vp, C.POINTER(vp)]),
+    "helm_host_si_circuit_evaluate_ready": (C.c_int, [vp, vp, vp]),
+    "helm_host_si_circuit_decrypt_outputs": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
+    "helm_host_si_circuit_log": (vp, [vp]),
+    "helm_host_si_circuit_pbs_per_cycle": (C.c_int64, [vp]),
+    "helm_host_si_circuit_pbs_rounds_per_cycle": (C.c_int64, [vp]),
+    "helm_host_si_enc_map_new": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "helm_host_si_enc_map_free": (None, [vp]),
+    "helm_host_si_enc_map_blocks": (C.c_int, [vp]),
+    "helm_host_si_enc_map_row_words": (C.c_int, [vp]),
+    "helm_host_si_enc_map_insert": (C.c_int, [vp, cp, u64p]),
+    "helm_host_si_enc_map_get": (C.c_int, [vp, cp, u64p]),
+    "helm_host_si_enc_map_contains_key": (C.c_int, [vp, cp]),
+    "helm_host_si_enc_map_keys": (vp, [vp]),
 }
 for _name, (_res, _args) in HOST_API.items():
     _fn = getattr(host, _name)

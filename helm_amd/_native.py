@@ -113,6 +113,7 @@ SI_API = {
     "helm_si_wires_upload": (C.c_int, [vp, vp, i32p, u64p, C.c_int64]),
     "helm_si_wires_download": (C.c_int, [vp, vp, i32p, u64p, C.c_int64]),
     "helm_si_wires_set_trivial": (C.c_int, [vp, vp, i32p, u64p, C.c_int64]),
+    "helm_si_wires_copy": (C.c_int, [vp, vp, i32p, vp, i32p, C.c_int64]),
     "helm_si_lincomb": (C.c_int, [vp, vp, i32p, i64p, i64p, i32p, C.c_int32, C.c_int64]),
     "helm_si_make_lut": (C.c_int, [vp, u64p, u64p]),
     "helm_si_apply_luts": (C.c_int, [vp, vp, i32p, i32p, i32p, C.c_int64, u64p, C.c_int64]),

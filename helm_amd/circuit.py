@@ -146,3 +146,101 @@ class GateCircuit(EvalCircuit):
 
     def pbs_per_cycle(self):
         return int(H.host.helm_host_gate_circuit_pbs_per_cycle(self._h))
+
+
+class SiEncWireMap:
+    """HashMap<String, CtxtShortInt> / HashMap<String, FheType> whose values live in an HBM table of
+    big-LWE rows: `blocks` rows per wire (1 in LUT mode, 4..64 for FheUint8..128)."""
+
+    def __init__(self, server_key=None, blocks=1, _handle=None):
+        if _handle is None:
+            h = H.vp()
+            H.check(H.host.helm_host_si_enc_map_new(server_key._h, int(blocks), C.byref(h)))
+            _handle = h
+        self._h = _handle
+        self.blocks = int(H.host.helm_host_si_enc_map_blocks(self._h))
+        self.row_words = int(H.host.helm_host_si_enc_map_row_words(self._h))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            H.host.helm_host_si_enc_map_free(self._h)
+            self._h = None
+
+    def insert(self, wire, ct):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64).reshape(self.blocks, self.row_words)
+        H.check(H.host.helm_host_si_enc_map_insert(self._h, wire.encode(), nv.as_u64p(ct)))
+
+    __setitem__ = insert
+
+    def __getitem__(self, wire):
+        out = np.zeros((self.blocks, self.row_words), dtype=np.uint64)
+        H.check(H.host.helm_host_si_enc_map_get(self._h, wire.encode(), nv.as_u64p(out)))
+        return out[0] if self.blocks == 1 else out
+
+    def contains_key(self, wire):
+        return bool(H.host.helm_host_si_enc_map_contains_key(self._h, wire.encode()))
+
+    __contains__ = contains_key
+
+    def keys(self):
+        return [k for k in H.take(H.host.helm_host_si_enc_map_keys(self._h)).splitlines() if k]
+
+    def __len__(self):
+        return len(self.keys())
+
+
+class _SiCircuit(EvalCircuit):
+    MODE = 0
+
+    def __init__(self, client_key, server_key, circuit):
+        h = H.vp()
+        H.check(H.host.helm_host_si_circuit_new(self.MODE, client_key._h, server_key._h, circuit._h, C.byref(h)))
+        self._h = h
+        self._ck, self._sk, self.circuit = client_key, server_key, circuit  # keep alive
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            H.host.helm_host_si_circuit_free(self._h)
+            self._h = None
+
+    def _map(self, fn, *args):
+        h = H.vp()
+        H.check(fn(self._h, *args, C.byref(h)))
+        return SiEncWireMap(_handle=h)
+
+    def encrypt_inputs(self, wire_set, input_wire_map):
+        return self._map(H.host.helm_host_si_circuit_encrypt_inputs, H.nl(sorted(wire_set)),
+                         map_to_text(input_wire_map).encode())
+
+    def evaluate_encrypted(self, enc_wire_map, current_cycle, ptxt_type="bool"):
+        return self._map(H.host.helm_host_si_circuit_evaluate_encrypted, enc_wire_map._h, int(current_cycle),
+                         ptxt_type.encode())
+
+    def init_ready(self):
+        return self._map(H.host.helm_host_si_circuit_init_ready)
+
+    def evaluate_ready(self, enc_wire_map, valid_outputs):
+        H.check(H.host.helm_host_si_circuit_evaluate_ready(self._h, enc_wire_map._h, valid_outputs._h))
+
+    def decrypt_outputs(self, enc_wire_map, verbose=False):
+        return text_to_map(H.out_text(H.host.helm_host_si_circuit_decrypt_outputs, self._h, enc_wire_map._h,
+                                      int(verbose)))
+
+    def log(self):
+        return H.take(H.host.helm_host_si_circuit_log(self._h))
+
+    def pbs_per_cycle(self):
+        return int(H.host.helm_host_si_circuit_pbs_per_cycle(self._h))
+
+    def pbs_rounds_per_cycle(self):
+        return int(H.host.helm_host_si_circuit_pbs_rounds_per_cycle(self._h))
+
+
+class LutCircuit(_SiCircuit):
+    """reference src/circuit.rs:75-79, 969-1120"""
+    MODE = 0
+
+
+class ArithCircuit(_SiCircuit):
+    """reference src/circuit.rs:81-85, 1112-1500"""
+    MODE = 1

@@ -829,6 +829,24 @@ int helm_si_wires_download(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *id
     return 0;
 }
 
+int helm_si_wires_copy(helm_si_ctx *ctx, helm_si_wires *src, const int32_t *src_idx, helm_si_wires *dst,
+                       const int32_t *dst_idx, int64_t count)
+{
+    if (!ctx || !src || !dst || !src_idx || !dst_idx || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
+    if (src->owner != ctx || dst->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (count == 0) return 0;
+    if (int rc = check_rows(src, src_idx, count, false)) return rc;
+    if (int rc = check_rows(dst, dst_idx, count, false)) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = upload(ctx, ctx->d_idx, src_idx, (size_t)count)) return rc;
+    if (int rc = upload(ctx, ctx->d_idx2, dst_idx, (size_t)count)) return rc;
+    hipLaunchKernelGGL(k_rows64, dim3((unsigned)count), dim3(256), 0, ctx->stream, src->d, ctx->d_idx.p, dst->d,
+                       ctx->d_idx2.p, ctx->P.k * ctx->P.N);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int helm_si_wires_set_trivial(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx, const uint64_t *value, int64_t count)
 {
     if (!ctx || !w || !idx || !value || count < 0) return fail(HELM_ERR_INVALID, "bad argument");

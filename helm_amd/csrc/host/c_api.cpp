@@ -12,6 +12,12 @@ struct helm_netlist { verilog_parser::Netlist nl; };
 struct helm_circuit { Circuit c; };
 struct helm_gate_circuit { std::unique_ptr<GateCircuit> gc; };
 struct helm_enc_map { std::unique_ptr<EncWireMap> m; };
+struct helm_si_enc_map { std::unique_ptr<SiEncWireMap> m; };
+struct helm_si_circuit {
+    std::unique_ptr<LutCircuit> lut;
+    std::unique_ptr<ArithCircuit> arith;
+    EvalCircuit<SiEncWireMap> *ec() { return lut ? static_cast<EvalCircuit<SiEncWireMap> *>(lut.get()) : arith.get(); }
+};
 
 namespace {
 thread_local std::string g_err;
@@ -250,6 +256,86 @@ int helm_host_enc_map_get(const helm_enc_map *m, const char *wire, uint32_t *lwe
 }
 int helm_host_enc_map_contains_key(const helm_enc_map *m, const char *wire) { return m->m->contains_key(wire) ? 1 : 0; }
 char *helm_host_enc_map_keys(const helm_enc_map *m)
+{
+    std::ostringstream os;
+    for (auto &k : m->m->keys()) os << k << '\n';
+    return dup(os.str());
+}
+
+
+int helm_host_si_circuit_new(int mode, helm_si_client_key *client_key, helm_si_ctx *server_key,
+                             const helm_circuit *circuit, helm_si_circuit **out)
+{
+    return guard([&] {
+        if (!client_key || !server_key || !circuit) throw Panic("null argument");
+        auto *c = new helm_si_circuit();
+        try {
+            if (mode == 0) c->lut = std::make_unique<LutCircuit>(client_key, server_key, circuit->c);
+            else c->arith = std::make_unique<ArithCircuit>(client_key, server_key, circuit->c);
+        } catch (...) {
+            delete c;
+            throw;
+        }
+        *out = c;
+    });
+}
+void helm_host_si_circuit_free(helm_si_circuit *c) { delete c; }
+int helm_host_si_circuit_encrypt_inputs(helm_si_circuit *c, const char *wire_set, const char *input_wire_map,
+                                        helm_si_enc_map **out)
+{
+    return guard([&] { *out = new helm_si_enc_map{c->ec()->encrypt_inputs(to_set(wire_set), parse_map(input_wire_map))}; });
+}
+int helm_host_si_circuit_evaluate_encrypted(helm_si_circuit *c, const helm_si_enc_map *enc_wire_map,
+                                            int64_t current_cycle, const char *ptxt_type, helm_si_enc_map **out)
+{
+    return guard([&] {
+        *out = new helm_si_enc_map{c->ec()->evaluate_encrypted(*enc_wire_map->m, (size_t)current_cycle, ptxt_type ? ptxt_type : "bool")};
+    });
+}
+int helm_host_si_circuit_init_ready(helm_si_circuit *c, helm_si_enc_map **out)
+{
+    return guard([&] { *out = new helm_si_enc_map{c->ec()->init_ready()}; });
+}
+int helm_host_si_circuit_evaluate_ready(helm_si_circuit *c, const helm_si_enc_map *enc_wire_map, helm_si_enc_map *valid_outputs)
+{
+    return guard([&] { c->ec()->evaluate_ready(*enc_wire_map->m, *valid_outputs->m); });
+}
+int helm_host_si_circuit_decrypt_outputs(helm_si_circuit *c, const helm_si_enc_map *enc_wire_map, int verbose, char **out_map)
+{
+    return guard([&] { *out_map = dup(map_text(c->ec()->decrypt_outputs(*enc_wire_map->m, verbose != 0))); });
+}
+char *helm_host_si_circuit_log(helm_si_circuit *c) { return dup(c->lut ? c->lut->log() : c->arith->log()); }
+int64_t helm_host_si_circuit_pbs_per_cycle(const helm_si_circuit *c)
+{
+    return c->lut ? c->lut->pbs_per_cycle() : c->arith->pbs_per_cycle();
+}
+int64_t helm_host_si_circuit_pbs_rounds_per_cycle(const helm_si_circuit *c)
+{
+    return c->lut ? 0 : c->arith->pbs_rounds_per_cycle();
+}
+int helm_host_si_enc_map_new(helm_si_ctx *server_key, int blocks, helm_si_enc_map **out)
+{
+    return guard([&] {
+        if (!server_key || blocks < 1) throw Panic("bad argument");
+        *out = new helm_si_enc_map{std::make_unique<SiEncWireMap>(server_key, blocks)};
+    });
+}
+void helm_host_si_enc_map_free(helm_si_enc_map *m) { delete m; }
+int helm_host_si_enc_map_blocks(const helm_si_enc_map *m) { return m->m->blocks(); }
+int helm_host_si_enc_map_row_words(const helm_si_enc_map *m) { return m->m->row_words(); }
+int helm_host_si_enc_map_insert(helm_si_enc_map *m, const char *wire, const uint64_t *lwe)
+{
+    return guard([&] { m->m->insert(wire, lwe); });
+}
+int helm_host_si_enc_map_get(const helm_si_enc_map *m, const char *wire, uint64_t *lwe_out)
+{
+    return guard([&] {
+        auto v = m->m->get(wire);
+        std::memcpy(lwe_out, v.data(), v.size() * sizeof(uint64_t));
+    });
+}
+int helm_host_si_enc_map_contains_key(const helm_si_enc_map *m, const char *wire) { return m->m->contains_key(wire) ? 1 : 0; }
+char *helm_host_si_enc_map_keys(const helm_si_enc_map *m)
 {
     std::ostringstream os;
     for (auto &k : m->m->keys()) os << k << '\n';

@@ -23,6 +23,7 @@
 
 #include "../../../include/helm_client.h"
 #include "../../../include/helm_hip.h"
+#include "../../../include/helm_shortint.h"
 
 namespace helm {
 
@@ -210,6 +211,121 @@ class GateCircuit : public EvalCircuit<EncWireMap> {
     std::vector<std::string> prog_keys_;
     std::vector<int> prog_rows_;
     int64_t pbs_count_ = 0;
+    std::string log_;
+};
+
+// ---------------------------------------------------------------------------------------
+// LUT mode and arithmetic mode (include/helm_shortint.h)
+// ---------------------------------------------------------------------------------------
+
+// Device-resident replacement of HashMap<String, CtxtShortInt> / HashMap<String, FheType>
+// (circuit.rs:1046-1049, 1312-1315): wire name -> first of `blocks` consecutive rows of a
+// big-LWE table (1 row per shortint wire, 4..64 per FheUint8..128 wire).
+class SiEncWireMap {
+  public:
+    SiEncWireMap(helm_si_ctx *ctx, int blocks);
+    ~SiEncWireMap();
+    SiEncWireMap(const SiEncWireMap &) = delete;
+    SiEncWireMap &operator=(const SiEncWireMap &) = delete;
+    bool contains_key(const std::string &k) const { return index_.count(k) != 0; }
+    size_t len() const { return index_.size(); }
+    int blocks() const { return blocks_; }
+    int row_words() const { return dim_ + 1; }
+    std::vector<std::string> keys() const;
+    int row(const std::string &k) const;                    // first row; throws Panic if absent
+    std::vector<uint64_t> get(const std::string &k) const;  // download `blocks` ciphertexts
+    void insert(const std::string &k, const uint64_t *lwe); // upload (adds the key if new)
+    std::unique_ptr<SiEncWireMap> clone(int64_t scratch_rows) const;
+    void reserve_keys(const std::vector<std::string> &names, int64_t scratch_rows);
+    int scratch(int64_t rows); // first row of a scratch region behind the named rows
+    helm_si_wires *table() const { return wires_; }
+
+  private:
+    void grow(int64_t rows);
+    helm_si_ctx *ctx_;
+    int blocks_, dim_ = 0;
+    helm_si_wires *wires_ = nullptr;
+    int64_t cap_ = 0;
+    std::unordered_map<std::string, int> index_;
+};
+
+// reference src/circuit.rs:75-79, 969-1120
+class LutCircuit : public EvalCircuit<SiEncWireMap> {
+  public:
+    LutCircuit(helm_si_client_key *client_key, helm_si_ctx *server_key, Circuit circuit);
+    std::unique_ptr<SiEncWireMap> encrypt_inputs(const std::set<std::string> &wire_set,
+                                                 const std::map<std::string, PtxtType> &input_wire_map) override;
+    std::unique_ptr<SiEncWireMap> evaluate_encrypted(const SiEncWireMap &enc_wire_map, size_t current_cycle,
+                                                     const std::string &ptxt_type) override;
+    std::unique_ptr<SiEncWireMap> init_ready() override;
+    void evaluate_ready(const SiEncWireMap &enc_wire_map, SiEncWireMap &valid_outputs) override;
+    std::map<std::string, PtxtType> decrypt_outputs(const SiEncWireMap &enc_wire_map, bool verbose) override;
+    int64_t pbs_per_cycle() const { return pbs_count_; }
+    std::string log() { std::string s; s.swap(log_); return s; }
+
+  private:
+    helm_si_client_key *client_key_;
+    helm_si_ctx *server_key_;
+    Circuit circuit_;
+    helm_si_params P_{};
+    int64_t pbs_count_ = 0;
+    std::string log_;
+};
+
+// One integer operator of a level: rows a, b, out are the first rows of radix integers.
+struct RadixOp {
+    enum Kind { Copy, Add, Sub, Mul, AddScalar, SubScalar, MulScalar } kind = Copy;
+    int a = -1, b = -1, out = -1;
+    unsigned __int128 scalar = 0;
+};
+
+// Level-batched FheUintN operators (add, sub, mul and their scalar forms, copy) over the two
+// device primitives helm_si_lincomb / helm_si_apply_luts.
+class RadixEngine {
+  public:
+    RadixEngine(helm_si_ctx *ctx, int blocks);
+    int64_t scratch_rows(const std::vector<RadixOp> &ops) const;
+    void run_level(helm_si_wires *w, const std::vector<RadixOp> &ops, int scratch);
+    void propagate(helm_si_wires *w, const std::vector<int32_t> &bases, int scratch);
+    int64_t pbs_count() const { return pbs_count_; }
+    int64_t pbs_rounds() const { return pbs_rounds_; }
+
+  private:
+    void lincomb(helm_si_wires *w, const std::vector<int32_t> &in_idx, const std::vector<int64_t> &coef,
+                 const std::vector<int64_t> &cadd, const std::vector<int32_t> &out, int terms);
+    void apply(helm_si_wires *w, const std::vector<int32_t> &in, const std::vector<int32_t> &lut,
+               const std::vector<int32_t> &out);
+    helm_si_ctx *ctx_;
+    int nb_;
+    helm_si_params P_{};
+    std::vector<uint64_t> luts_;
+    int lut_msg_ = 0, lut_carry_ = 0, lut_state_ = 0, lut_state0_ = 0, lut_comb_ = 0, lut_mul_lo_ = 0, lut_mul_hi_ = 0;
+    int64_t pbs_count_ = 0, pbs_rounds_ = 0;
+};
+
+// reference src/circuit.rs:81-85, 1112-1500
+class ArithCircuit : public EvalCircuit<SiEncWireMap> {
+  public:
+    ArithCircuit(helm_si_client_key *client_key, helm_si_ctx *server_key, Circuit circuit);
+    std::unique_ptr<SiEncWireMap> encrypt_inputs(const std::set<std::string> &wire_set,
+                                                 const std::map<std::string, PtxtType> &input_wire_map) override;
+    std::unique_ptr<SiEncWireMap> evaluate_encrypted(const SiEncWireMap &enc_wire_map, size_t current_cycle,
+                                                     const std::string &ptxt_type) override;
+    std::unique_ptr<SiEncWireMap> init_ready() override;
+    void evaluate_ready(const SiEncWireMap &enc_wire_map, SiEncWireMap &valid_outputs) override;
+    std::map<std::string, PtxtType> decrypt_outputs(const SiEncWireMap &enc_wire_map, bool verbose) override;
+    int64_t pbs_per_cycle() const { return pbs_count_; }
+    int64_t pbs_rounds_per_cycle() const { return pbs_rounds_; }
+    std::string log() { std::string s; s.swap(log_); return s; }
+
+  private:
+    void encrypt_value(SiEncWireMap &m, const std::string &wire, unsigned __int128 value);
+    helm_si_client_key *client_key_;
+    helm_si_ctx *server_key_;
+    Circuit circuit_;
+    helm_si_params P_{};
+    std::string global_ptxt_type_;
+    int64_t pbs_count_ = 0, pbs_rounds_ = 0;
     std::string log_;
 };
 

@@ -1,0 +1,857 @@
+// shortint_circuit.cpp — SiEncWireMap, RadixEngine, LutCircuit and ArithCircuit: the
+// encrypted evaluators of LUT mode and arithmetic mode over include/helm_shortint.h.
+//
+//   LutCircuit    reference src/circuit.rs:75-79, 393-401, 969-1120 (impl EvalCircuit<CtxtShortInt>)
+//                 + gates::lut(), src/gates.rs:754-785 -> helm_si_eval_lut_level per level
+//   ArithCircuit  reference src/circuit.rs:81-85, 403-411, 1112-1500 (impl EvalCircuit<FheType>)
+//                 + Gate::evaluate_encrypted_{add,sub,mul,copy}_block(_plain),
+//                 src/gates.rs:306-702 -> RadixEngine (FheUint8..128 = radix integers of
+//                 2-bit-message shortint blocks, least significant block first)
+//
+// The radix algorithms inside tfhe's FheUintN operators live in the absent `tfhe` crate;
+// the ones here are level-batched restatements with the same results mod 2^bits (what the
+// reference's tests pin: tests/gates_test.rs:127-310, tests/circuit_test.rs:349-368).
+#include "helm_host.hpp"
+
+#include <algorithm>
+#include <sstream>
+
+namespace helm {
+
+static void si_ok(int rc, const char *what)
+{
+    if (rc != 0) throw Panic(std::string(what) + ": " + helm_hip_last_error());
+}
+
+// ---------------------------------------------------------------------------------------
+// SiEncWireMap
+// ---------------------------------------------------------------------------------------
+SiEncWireMap::SiEncWireMap(helm_si_ctx *ctx, int blocks) : ctx_(ctx), blocks_(blocks)
+{
+    helm_si_params P;
+    si_ok(helm_si_get_params(ctx, &P), "get_params");
+    dim_ = P.k * P.N;
+}
+
+SiEncWireMap::~SiEncWireMap()
+{
+    if (wires_) helm_si_wires_free(ctx_, wires_);
+}
+
+std::vector<std::string> SiEncWireMap::keys() const
+{
+    std::vector<std::string> k;
+    k.reserve(index_.size());
+    for (auto &kv : index_) k.push_back(kv.first);
+    std::sort(k.begin(), k.end());
+    return k;
+}
+
+int SiEncWireMap::row(const std::string &k) const
+{
+    auto it = index_.find(k);
+    if (it == index_.end()) throw Panic("wire \"" + k + "\" not in the encrypted wire map");
+    return it->second;
+}
+
+void SiEncWireMap::grow(int64_t rows)
+{
+    if (rows <= cap_) return;
+    const int64_t want = std::max<int64_t>(rows, std::max<int64_t>(16, cap_ * 2));
+    helm_si_wires *nw = nullptr;
+    si_ok(helm_si_wires_alloc(ctx_, want, &nw), "wires_alloc");
+    if (wires_) {
+        const int64_t used = std::min<int64_t>(cap_, (int64_t)index_.size() * blocks_);
+        if (used > 0) {
+            std::vector<int32_t> idx((size_t)used);
+            for (int64_t i = 0; i < used; i++) idx[(size_t)i] = (int32_t)i;
+            si_ok(helm_si_wires_copy(ctx_, wires_, idx.data(), nw, idx.data(), used), "wires_copy");
+        }
+        helm_si_wires_free(ctx_, wires_);
+    }
+    wires_ = nw;
+    cap_ = want;
+}
+
+void SiEncWireMap::reserve_keys(const std::vector<std::string> &names, int64_t scratch_rows)
+{
+    std::vector<const std::string *> fresh;
+    std::unordered_map<std::string, int> seen;
+    for (auto &nm : names)
+        if (!index_.count(nm) && !seen.count(nm)) {
+            seen[nm] = 1;
+            fresh.push_back(&nm);
+        }
+    grow(((int64_t)index_.size() + (int64_t)fresh.size()) * blocks_ + scratch_rows);
+    for (auto *nm : fresh) {
+        const int r = (int)index_.size() * blocks_;
+        index_[*nm] = r;
+    }
+}
+
+int SiEncWireMap::scratch(int64_t rows)
+{
+    const int64_t base = (int64_t)index_.size() * blocks_;
+    grow(base + rows);
+    return (int)base;
+}
+
+std::vector<uint64_t> SiEncWireMap::get(const std::string &k) const
+{
+    const int32_t r = row(k);
+    std::vector<int32_t> idx((size_t)blocks_);
+    for (int b = 0; b < blocks_; b++) idx[(size_t)b] = r + b;
+    std::vector<uint64_t> out((size_t)blocks_ * (dim_ + 1));
+    si_ok(helm_si_wires_download(ctx_, wires_, idx.data(), out.data(), blocks_), "wires_download");
+    return out;
+}
+
+void SiEncWireMap::insert(const std::string &k, const uint64_t *lwe)
+{
+    auto it = index_.find(k);
+    int32_t r;
+    if (it == index_.end()) {
+        r = (int32_t)index_.size() * blocks_;
+        grow(r + blocks_);
+        index_[k] = r;
+    } else
+        r = it->second;
+    std::vector<int32_t> idx((size_t)blocks_);
+    for (int b = 0; b < blocks_; b++) idx[(size_t)b] = r + b;
+    si_ok(helm_si_wires_upload(ctx_, wires_, idx.data(), lwe, blocks_), "wires_upload");
+}
+
+std::unique_ptr<SiEncWireMap> SiEncWireMap::clone(int64_t scratch_rows) const
+{
+    auto m = std::make_unique<SiEncWireMap>(ctx_, blocks_);
+    const int64_t used = (int64_t)index_.size() * blocks_;
+    m->grow(used + scratch_rows);
+    if (used > 0) {
+        std::vector<int32_t> idx((size_t)used);
+        for (int64_t i = 0; i < used; i++) idx[(size_t)i] = (int32_t)i;
+        si_ok(helm_si_wires_copy(ctx_, wires_, idx.data(), m->wires_, idx.data(), used), "wires_copy");
+    }
+    m->index_ = index_;
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------
+// LutCircuit
+// ---------------------------------------------------------------------------------------
+LutCircuit::LutCircuit(helm_si_client_key *client_key, helm_si_ctx *server_key, Circuit circuit)
+    : client_key_(client_key), server_key_(server_key), circuit_(std::move(circuit))
+{
+    si_ok(helm_si_get_params(server_key, &P_), "get_params");
+}
+
+// reference src/circuit.rs:970-1000
+std::unique_ptr<SiEncWireMap> LutCircuit::encrypt_inputs(const std::set<std::string> &wire_set,
+                                                         const std::map<std::string, PtxtType> &input_wire_map)
+{
+    auto m = std::make_unique<SiEncWireMap>(server_key_, 1);
+    std::vector<std::string> names(wire_set.begin(), wire_set.end());
+    names.insert(names.end(), circuit_.input_wires().begin(), circuit_.input_wires().end());
+    names.insert(names.end(), circuit_.dff_outputs().begin(), circuit_.dff_outputs().end());
+    m->reserve_keys(names, 0);
+    {
+        std::vector<int32_t> idx;
+        for (auto &w : wire_set) idx.push_back(m->row(w));
+        std::vector<uint64_t> zeros(idx.size(), 0);
+        if (!idx.empty())
+            si_ok(helm_si_wires_set_trivial(server_key_, m->table(), idx.data(), zeros.data(), (int64_t)idx.size()),
+                  "wires_set_trivial");
+    }
+    std::vector<int32_t> idx;
+    std::vector<uint64_t> vals;
+    const bool dummy = input_wire_map.empty() || input_wire_map.count("dummy");
+    for (auto &input_wire : circuit_.input_wires()) {
+        uint64_t v = 0;
+        if (!dummy) {
+            auto it = input_wire_map.find(input_wire);
+            if (it == input_wire_map.end()) throw Panic("\n Input wire \"" + input_wire + "\" not found in input wires!");
+            if (it->second.kind != PtxtType::Bool) throw Panic("internal error: entered unreachable code");
+            v = it->second.as_bool() ? 1 : 0;
+        }
+        idx.push_back(m->row(input_wire));
+        vals.push_back(v);
+    }
+    for (auto &w : circuit_.dff_outputs()) {
+        idx.push_back(m->row(w));
+        vals.push_back(0);
+    }
+    if (!idx.empty()) {
+        const size_t row = (size_t)P_.k * P_.N + 1;
+        std::vector<uint64_t> cts(idx.size() * row);
+        if (helm_si_client_encrypt(client_key_, vals.data(), (int64_t)vals.size(), cts.data())) throw Panic("encrypt failed");
+        si_ok(helm_si_wires_upload(server_key_, m->table(), idx.data(), cts.data(), (int64_t)idx.size()), "wires_upload");
+    }
+    return m;
+}
+
+// reference src/circuit.rs:1002-1011
+std::unique_ptr<SiEncWireMap> LutCircuit::init_ready()
+{
+    auto m = std::make_unique<SiEncWireMap>(server_key_, 1);
+    m->reserve_keys(circuit_.output_wires(), 0);
+    std::vector<int32_t> idx;
+    for (auto &w : circuit_.output_wires()) idx.push_back(m->row(w));
+    std::vector<uint64_t> zeros(idx.size(), 0);
+    if (!idx.empty())
+        si_ok(helm_si_wires_set_trivial(server_key_, m->table(), idx.data(), zeros.data(), (int64_t)idx.size()),
+              "wires_set_trivial");
+    return m;
+}
+
+// reference src/circuit.rs:1013-1030: valid = enc * READY + valid * (1 - READY), here one
+// 3-input look-up (enc, valid, READY) -> READY ? enc : valid per output.
+void LutCircuit::evaluate_ready(const SiEncWireMap &enc_wire_map, SiEncWireMap &valid_outputs)
+{
+    std::vector<std::string> keys;
+    for (auto &k : valid_outputs.keys())
+        if (enc_wire_map.contains_key(k)) keys.push_back(k);
+    if (keys.empty()) return;
+    if (!enc_wire_map.contains_key("READY")) throw Panic("called `Option::unwrap()` on a `None` value (READY)");
+    SiEncWireMap tmp(server_key_, 1);
+    std::vector<std::string> names = {"READY"};
+    for (auto &k : keys) {
+        names.push_back("t:" + k);
+        names.push_back("e:" + k);
+    }
+    tmp.reserve_keys(names, 0);
+    tmp.insert("READY", enc_wire_map.get("READY").data());
+    std::vector<int32_t> arity, in_idx, out;
+    std::vector<uint64_t> table;
+    for (auto &k : keys) {
+        tmp.insert("t:" + k, enc_wire_map.get(k).data());
+        tmp.insert("e:" + k, valid_outputs.get(k).data());
+        arity.push_back(3);
+        in_idx.push_back(tmp.row("t:" + k));
+        in_idx.push_back(tmp.row("e:" + k));
+        in_idx.push_back(tmp.row("READY"));
+        table.push_back(0xE4); // index = enc*4 + valid*2 + READY
+        out.push_back(tmp.row("e:" + k));
+    }
+    si_ok(helm_si_eval_lut_level(server_key_, tmp.table(), arity.data(), in_idx.data(), 3, table.data(), out.data(),
+                                 (int64_t)arity.size()),
+          "eval_lut_level");
+    for (auto &k : keys) valid_outputs.insert(k, tmp.get("e:" + k).data());
+}
+
+// reference src/circuit.rs:1032-1083
+std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap &enc_wire_map, size_t /*cycle*/,
+                                                             const std::string & /*ptxt_type*/)
+{
+    if (!circuit_.gates_empty()) throw Panic("assertion failed: self.circuit.gates.is_empty()");
+    if (!circuit_.get_ordered_gates().empty()) throw Panic("assertion failed: self.circuit.ordered_gates.is_empty()");
+    auto eval_values = enc_wire_map.clone(0);
+    const size_t total_levels = circuit_.level_map().size();
+    pbs_count_ = 0;
+    for (auto &kv : circuit_.level_map()) {
+        const auto &gates = kv.second;
+        int max_in = 1;
+        for (auto &g : gates) max_in = std::max<int>(max_in, (int)g.get_input_wires().size());
+        std::vector<int32_t> arity, in_idx((size_t)gates.size() * max_in, -1), out;
+        std::vector<uint64_t> table;
+        for (size_t gi = 0; gi < gates.size(); gi++) {
+            const Gate &g = gates[gi];
+            const auto &ins = g.get_input_wires();
+            for (size_t q = 0; q < ins.size(); q++) in_idx[gi * max_in + q] = eval_values->row(ins[q]);
+            if (g.get_gate_type() == GateType::Lut) {
+                if (!g.get_lut_const()) throw Panic("Lut const not provided");
+                if (ins.size() > 6) throw Panic("LUT with more than 6 inputs does not fit the truth-table word");
+                uint64_t bits = 0;
+                for (size_t i = 0; i < g.get_lut_const()->size() && i < 64; i++)
+                    if ((*g.get_lut_const())[i] & 1) bits |= 1ull << i;
+                arity.push_back((int32_t)ins.size());
+                table.push_back(bits);
+                if (ins.size() >= 2) pbs_count_++;
+            } else { // evaluate_encrypted_dff: the output is a copy of the first input (circuit.rs:1067)
+                if (ins.empty()) throw Panic("gate \"" + g.get_gate_name() + "\" has no input");
+                arity.push_back(0);
+                table.push_back(0);
+            }
+            out.push_back(eval_values->row(g.get_output_wire()));
+        }
+        if (!gates.empty())
+            si_ok(helm_si_eval_lut_level(server_key_, eval_values->table(), arity.data(), in_idx.data(), max_in,
+                                         table.data(), out.data(), (int64_t)gates.size()),
+                  "eval_lut_level");
+        std::ostringstream os;
+        os << "  Evaluated gates in level [" << kv.first << "/" << total_levels << "]\n";
+        log_ += os.str();
+    }
+    si_ok(helm_si_sync(server_key_), "sync");
+    return eval_values;
+}
+
+// reference src/circuit.rs:1085-1110
+std::map<std::string, PtxtType> LutCircuit::decrypt_outputs(const SiEncWireMap &enc_wire_map, bool verbose)
+{
+    std::map<std::string, PtxtType> out;
+    for (auto &w : circuit_.output_wires()) {
+        auto ct = enc_wire_map.get(w);
+        uint64_t v = 0;
+        if (helm_si_client_decrypt(client_key_, ct.data(), 1, &v)) throw Panic("decrypt failed");
+        PtxtType p;
+        p.kind = PtxtType::U64;
+        p.value = v % (uint64_t)P_.message_modulus; // ClientKey::decrypt: the message part
+        out[w] = p;
+    }
+    size_t i = 0;
+    for (auto &kv : out) {
+        if (i > 10 && !verbose) {
+            log_ += "[!] More than ten output_wires, pass `--verbose` to see output.\n";
+            break;
+        }
+        log_ += " " + kv.first + ": " + kv.second.to_string() + "\n";
+        i++;
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------
+// RadixEngine: level-batched radix-integer operators on rows of one ciphertext table.
+// An integer = `nb` consecutive rows (block 0 least significant), every block a shortint
+// with a 2-bit message (message_modulus 4) and value below 16.
+// ---------------------------------------------------------------------------------------
+RadixEngine::RadixEngine(helm_si_ctx *ctx, int nb) : ctx_(ctx), nb_(nb)
+{
+    si_ok(helm_si_get_params(ctx, &P_), "get_params");
+    if (P_.message_modulus != 4 || P_.carry_modulus != 4)
+        throw Panic("the radix layer needs message_modulus = carry_modulus = 4 (PARAM_MESSAGE_2_CARRY_2)");
+    const int t = 16;
+    auto add_lut = [&](auto f) {
+        std::vector<uint64_t> vals((size_t)t);
+        for (int v = 0; v < t; v++) vals[(size_t)v] = (uint64_t)f(v);
+        const size_t at = luts_.size();
+        luts_.resize(at + (size_t)P_.N);
+        si_ok(helm_si_make_lut(ctx_, vals.data(), luts_.data() + at), "make_lut");
+        return (int)(at / (size_t)P_.N);
+    };
+    lut_msg_ = add_lut([](int v) { return v & 3; });
+    lut_carry_ = add_lut([](int v) { return v >> 2; });
+    // carry state of a block sum x <= 7: 0 none, 1 generates, 2 propagates an incoming carry
+    lut_state_ = add_lut([](int v) { return v >= 4 ? 1 : v == 3 ? 2 : 0; });
+    lut_state0_ = add_lut([](int v) { return v >= 4 ? 1 : 0; }); // block 0: nothing comes in
+    // prefix combine, packed hi * 4 + lo: a propagating block takes the state below it
+    lut_comb_ = add_lut([](int v) { return (v >> 2) == 2 ? (v & 3) : (v >> 2); });
+    // products of two 2-bit messages, packed a * 4 + b
+    lut_mul_lo_ = add_lut([](int v) { return ((v >> 2) * (v & 3)) & 3; });
+    lut_mul_hi_ = add_lut([](int v) { return ((v >> 2) * (v & 3)) >> 2; });
+}
+
+void RadixEngine::lincomb(helm_si_wires *w, const std::vector<int32_t> &in_idx, const std::vector<int64_t> &coef,
+                          const std::vector<int64_t> &cadd, const std::vector<int32_t> &out, int terms)
+{
+    if (out.empty()) return;
+    si_ok(helm_si_lincomb(ctx_, w, in_idx.data(), coef.data(), cadd.empty() ? nullptr : cadd.data(), out.data(), terms,
+                          (int64_t)out.size()),
+          "lincomb");
+}
+
+void RadixEngine::apply(helm_si_wires *w, const std::vector<int32_t> &in, const std::vector<int32_t> &lut,
+                        const std::vector<int32_t> &out)
+{
+    if (in.empty()) return;
+    si_ok(helm_si_apply_luts(ctx_, w, in.data(), lut.data(), out.data(), (int64_t)in.size(), luts_.data(),
+                             (int64_t)(luts_.size() / (size_t)P_.N)),
+          "apply_luts");
+    pbs_count_ += (int64_t)in.size();
+    pbs_rounds_++;
+}
+
+// Full carry propagation of integers whose block sums are <= 6 (block 0: <= 7): carry
+// states, Hillis-Steele prefix over them (log2 nb rounds of one bootstrap per block), final
+// message extraction.  `scratch` needs 2 * nb rows per integer.
+void RadixEngine::propagate(helm_si_wires *w, const std::vector<int32_t> &bases, int scratch)
+{
+    const int G = (int)bases.size();
+    if (G == 0) return;
+    auto S = [&](int g, int buf, int i) { return scratch + (g * 2 + buf) * nb_ + i; };
+    std::vector<int32_t> in, lut, out;
+    for (int g = 0; g < G; g++)
+        for (int i = 0; i + 1 < nb_; i++) { // the top block's carry is dropped (mod 2^bits)
+            in.push_back(bases[(size_t)g] + i);
+            lut.push_back(i == 0 ? lut_state0_ : lut_state_);
+            out.push_back(S(g, 0, i));
+        }
+    apply(w, in, lut, out);
+    int cur = 0;
+    for (int d = 1; d < nb_ - 1; d <<= 1) {
+        // s'[i] = comb(s[i], s[i-d]) for i >= d (packed 4 * s[i] + s[i-d]); s'[i] = s[i] below
+        std::vector<int32_t> li, lo;
+        std::vector<int64_t> lc;
+        in.clear();
+        lut.clear();
+        out.clear();
+        for (int g = 0; g < G; g++)
+            for (int i = 0; i + 1 < nb_; i++) {
+                li.push_back(S(g, cur, i));
+                lc.push_back(i >= d ? 4 : 1);
+                li.push_back(i >= d ? S(g, cur, i - d) : -1);
+                lc.push_back(i >= d ? 1 : 0);
+                lo.push_back(S(g, cur ^ 1, i));
+                if (i >= d) {
+                    in.push_back(S(g, cur ^ 1, i));
+                    lut.push_back(lut_comb_);
+                    out.push_back(S(g, cur ^ 1, i));
+                }
+            }
+        lincomb(w, li, lc, {}, lo, 2);
+        apply(w, in, lut, out);
+        cur ^= 1;
+    }
+    // block i += carry out of block i-1 (state == 1), then keep the message
+    std::vector<int32_t> li, lo;
+    std::vector<int64_t> lc;
+    in.clear();
+    lut.clear();
+    out.clear();
+    for (int g = 0; g < G; g++)
+        for (int i = 0; i < nb_; i++) {
+            li.push_back(bases[(size_t)g] + i);
+            lc.push_back(1);
+            li.push_back(i > 0 ? S(g, cur, i - 1) : -1);
+            lc.push_back(i > 0 ? 1 : 0);
+            lo.push_back(bases[(size_t)g] + i);
+            in.push_back(bases[(size_t)g] + i);
+            lut.push_back(lut_msg_);
+            out.push_back(bases[(size_t)g] + i);
+        }
+    lincomb(w, li, lc, {}, lo, 2);
+    apply(w, in, lut, out);
+}
+
+int64_t RadixEngine::scratch_rows(const std::vector<RadixOp> &ops) const
+{
+    int64_t rows = 0;
+    for (auto &op : ops) {
+        rows += 2 * nb_; // propagate states
+        // partial-product vectors (2 nb - 1) plus the message / carry vectors of the reduction
+        // rounds (about 1.5 nb): 4 nb + 4 vectors of nb rows bound both
+        if (op.kind == RadixOp::Mul || op.kind == RadixOp::MulScalar) rows += (int64_t)(4 * nb_ + 4) * nb_;
+        if (op.kind == RadixOp::AddScalar || op.kind == RadixOp::SubScalar) rows += nb_;
+    }
+    return rows;
+}
+
+// One netlist level of integer operators (independent of each other), batched stage by stage.
+void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops, int scratch)
+{
+    // ---- stage 1: block sums of add / sub, operand rows of the multiplications --------------
+    struct Term { int base; int low; int maxv; }; // blocks below `low` are zero; block values <= maxv
+    struct MulState { std::vector<Term> terms; int out; };
+    std::vector<MulState> muls;
+    std::vector<int32_t> prop_bases; // integers waiting for the final propagation
+    int sp = scratch;
+    auto take = [&](int rows) { const int b = sp; sp += rows; return b; };
+
+    {
+        std::vector<int32_t> li, lo;
+        std::vector<int64_t> lc, ca;
+        std::vector<int32_t> triv_idx;
+        std::vector<uint64_t> triv_val;
+        for (auto &op : ops) {
+            switch (op.kind) {
+            case RadixOp::Copy:
+                for (int i = 0; i < nb_; i++) {
+                    li.push_back(op.a + i); lc.push_back(1); li.push_back(-1); lc.push_back(0);
+                    lo.push_back(op.out + i); ca.push_back(0);
+                }
+                break;
+            case RadixOp::Add: case RadixOp::Sub: case RadixOp::AddScalar: case RadixOp::SubScalar: {
+                // a + b, or a + ~b + 1 with ~b digit = 3 - b_i (two's complement, mod 2^bits)
+                const bool sub = op.kind == RadixOp::Sub || op.kind == RadixOp::SubScalar;
+                const bool scalar = op.kind == RadixOp::AddScalar || op.kind == RadixOp::SubScalar;
+                for (int i = 0; i < nb_; i++) {
+                    int64_t c = 0;
+                    li.push_back(op.a + i); lc.push_back(1);
+                    if (scalar) {
+                        const int digit = (int)((op.scalar >> (2 * i)) & 3);
+                        li.push_back(-1); lc.push_back(0);
+                        c = sub ? 3 - digit : digit;
+                    } else {
+                        li.push_back(op.b + i); lc.push_back(sub ? -1 : 1);
+                        c = sub ? 3 : 0;
+                    }
+                    if (sub && i == 0) c += 1;
+                    lo.push_back(op.out + i); ca.push_back(c);
+                }
+                prop_bases.push_back(op.out);
+                break;
+            }
+            case RadixOp::Mul: case RadixOp::MulScalar:
+                break; // below
+            }
+        }
+        lincomb(w, li, lc, ca, lo, 2);
+        (void)triv_idx;
+        (void)triv_val;
+    }
+
+    // ---- multiplications: partial products ----------------------------------------------------
+    {
+        std::vector<int32_t> li, lo, in, lut, out;
+        std::vector<int64_t> lc;
+        std::vector<int32_t> zero_rows;
+        for (auto &op : ops) {
+            if (op.kind == RadixOp::MulScalar) {
+                // sum_j s_j * (a << j blocks): block values <= 3 * s_j, no bootstrap needed here
+                MulState ms;
+                ms.out = op.out;
+                for (int j = 0; j < nb_; j++) {
+                    const int digit = (int)((op.scalar >> (2 * j)) & 3);
+                    if (!digit) continue;
+                    const int base = take(nb_);
+                    for (int k = 0; k < nb_; k++) {
+                        li.push_back(k >= j ? op.a + (k - j) : -1); lc.push_back(k >= j ? digit : 0);
+                        li.push_back(-1); lc.push_back(0);
+                        lo.push_back(base + k);
+                    }
+                    ms.terms.push_back(Term{base, j, 3 * digit});
+                }
+                muls.push_back(std::move(ms));
+            } else if (op.kind == RadixOp::Mul) {
+                // term L_j: block k = lo(a_{k-j} * b_j), term H_j: block k = hi(a_{k-1-j} * b_j)
+                MulState ms;
+                ms.out = op.out;
+                for (int j = 0; j < nb_; j++) {
+                    const int Lb = take(nb_), Hb = j + 1 < nb_ ? take(nb_) : -1;
+                    for (int k = 0; k < nb_; k++) {
+                        if (k >= j) { // packed operand 4 * a_{k-j} + b_j, in place in the L row
+                            li.push_back(op.a + (k - j)); lc.push_back(4);
+                            li.push_back(op.b + j); lc.push_back(1);
+                            lo.push_back(Lb + k);
+                        } else
+                            zero_rows.push_back(Lb + k);
+                        if (Hb >= 0 && k <= j) zero_rows.push_back(Hb + k);
+                    }
+                    ms.terms.push_back(Term{Lb, j, 3});
+                    if (Hb >= 0) ms.terms.push_back(Term{Hb, j + 1, 3});
+                }
+                muls.push_back(std::move(ms));
+            }
+        }
+        lincomb(w, li, lc, {}, lo, 2);
+        // bootstraps: hi first (reads the packed operand in the L row), then lo in place
+        size_t mi = 0;
+        std::vector<int32_t> in2, lut2, out2;
+        for (auto &op : ops) {
+            if (op.kind == RadixOp::MulScalar) { mi++; continue; }
+            if (op.kind != RadixOp::Mul) continue;
+            MulState &ms = muls[mi++];
+            size_t ti = 0;
+            for (int j = 0; j < nb_; j++) {
+                const int Lb = ms.terms[ti++].base, Hb = j + 1 < nb_ ? ms.terms[ti++].base : -1;
+                for (int k = j; k < nb_; k++) {
+                    if (Hb >= 0 && k + 1 < nb_) { in.push_back(Lb + k); lut.push_back(lut_mul_hi_); out.push_back(Hb + k + 1); }
+                    in2.push_back(Lb + k); lut2.push_back(lut_mul_lo_); out2.push_back(Lb + k);
+                }
+            }
+        }
+        if (!zero_rows.empty()) {
+            std::vector<uint64_t> z(zero_rows.size(), 0);
+            si_ok(helm_si_wires_set_trivial(ctx_, w, zero_rows.data(), z.data(), (int64_t)zero_rows.size()), "set_trivial");
+        }
+        apply(w, in, lut, out);
+        apply(w, in2, lut2, out2);
+    }
+
+    // ---- multiplications: reduce the terms (sums of <= 15 per block, then message + carry) ----
+    for (;;) {
+        std::vector<int32_t> li, lo, in, lut, out, zero_rows;
+        std::vector<int64_t> lc;
+        bool any = false;
+        const int T = 5;
+        for (auto &ms : muls) {
+            auto need_reduce = [&]() {
+                if (ms.terms.size() > 2) return true;
+                int s = 0;
+                for (auto &t : ms.terms) s += t.maxv;
+                return s > 6;
+            };
+            if (!need_reduce()) continue;
+            any = true;
+            std::sort(ms.terms.begin(), ms.terms.end(), [](const Term &x, const Term &y) { return x.low < y.low; });
+            std::vector<Term> next;
+            size_t q = 0;
+            while (q < ms.terms.size()) {
+                // greedy group: sum of the block bounds <= 15
+                size_t e = q;
+                int s = 0;
+                while (e < ms.terms.size() && e - q < (size_t)T && s + ms.terms[e].maxv <= 15) s += ms.terms[e++].maxv;
+                if (e - q == 1 && s <= 3) { // nothing to merge with: passes through
+                    next.push_back(ms.terms[q]);
+                    q = e;
+                    continue;
+                }
+                const int low = ms.terms[q].low;
+                const int Mb = take(nb_), Cb = low + 1 < nb_ ? take(nb_) : -1;
+                for (int k = 0; k < nb_; k++) {
+                    if (k < low) { zero_rows.push_back(Mb + k); if (Cb >= 0) zero_rows.push_back(Cb + k); continue; }
+                    if (Cb >= 0 && k == low) zero_rows.push_back(Cb + k);
+                    for (size_t u = q; u < q + (size_t)T; u++) {
+                        const bool on = u < e && k >= ms.terms[u].low;
+                        li.push_back(on ? ms.terms[u].base + k : -1);
+                        lc.push_back(on ? 1 : 0);
+                    }
+                    lo.push_back(Mb + k);
+                    if (Cb >= 0 && k + 1 < nb_) { in.push_back(Mb + k); lut.push_back(lut_carry_); out.push_back(Cb + k + 1); }
+                }
+                next.push_back(Term{Mb, low, 3});
+                if (Cb >= 0) next.push_back(Term{Cb, low + 1, 3});
+                q = e;
+            }
+            // message extraction after the carries have been read
+            ms.terms.swap(next);
+        }
+        if (!any) break;
+        lincomb(w, li, lc, {}, lo, T);
+        if (!zero_rows.empty()) {
+            std::vector<uint64_t> z(zero_rows.size(), 0);
+            si_ok(helm_si_wires_set_trivial(ctx_, w, zero_rows.data(), z.data(), (int64_t)zero_rows.size()), "set_trivial");
+        }
+        apply(w, in, lut, out);
+        // message in place: every summed row
+        std::vector<int32_t> min_, mlut, mout;
+        for (auto r : lo) { min_.push_back(r); mlut.push_back(lut_msg_); mout.push_back(r); }
+        apply(w, min_, mlut, mout);
+    }
+    // ---- multiplications: last addition ---------------------------------------------------------
+    {
+        std::vector<int32_t> li, lo;
+        std::vector<int64_t> lc;
+        for (auto &ms : muls) {
+            int s = 0;
+            for (auto &t : ms.terms) s += t.maxv;
+            for (int k = 0; k < nb_; k++) {
+                for (size_t u = 0; u < 2; u++) {
+                    const bool on = u < ms.terms.size() && k >= ms.terms[u].low;
+                    li.push_back(on ? ms.terms[u].base + k : -1);
+                    lc.push_back(on ? 1 : 0);
+                }
+                lo.push_back(ms.out + k);
+            }
+            if (s > 3) prop_bases.push_back(ms.out);
+        }
+        lincomb(w, li, lc, {}, lo, 2);
+    }
+    // ---- carry propagation of everything that needs it -------------------------------------------
+    propagate(w, prop_bases, take(2 * nb_ * (int)prop_bases.size()));
+}
+
+// ---------------------------------------------------------------------------------------
+// ArithCircuit
+// ---------------------------------------------------------------------------------------
+static bool is_numeric_string(const std::string &s) // reference src/circuit.rs:100-102
+{
+    if (s.empty()) return false;
+    for (char c : s)
+        if (c < '0' || c > '9') return false;
+    return true;
+}
+
+static int blocks_of(const std::string &ptxt_type)
+{
+    if (ptxt_type == "u8") return 4;
+    if (ptxt_type == "u16") return 8;
+    if (ptxt_type == "u32") return 16;
+    if (ptxt_type == "u64") return 32;
+    if (ptxt_type == "u128") return 64;
+    throw Panic("internal error: entered unreachable code");
+}
+
+static PtxtType::Kind kind_of(const std::string &ptxt_type)
+{
+    if (ptxt_type == "u8") return PtxtType::U8;
+    if (ptxt_type == "u16") return PtxtType::U16;
+    if (ptxt_type == "u32") return PtxtType::U32;
+    if (ptxt_type == "u64") return PtxtType::U64;
+    return PtxtType::U128;
+}
+
+ArithCircuit::ArithCircuit(helm_si_client_key *client_key, helm_si_ctx *server_key, Circuit circuit)
+    : client_key_(client_key), server_key_(server_key), circuit_(std::move(circuit))
+{
+    si_ok(helm_si_get_params(server_key, &P_), "get_params");
+}
+
+void ArithCircuit::encrypt_value(SiEncWireMap &m, const std::string &wire, unsigned __int128 value)
+{
+    const int nb = m.blocks();
+    std::vector<uint64_t> digits((size_t)nb);
+    for (int i = 0; i < nb; i++) digits[(size_t)i] = (uint64_t)((value >> (2 * i)) & 3);
+    std::vector<uint64_t> cts((size_t)nb * ((size_t)P_.k * P_.N + 1));
+    if (helm_si_client_encrypt(client_key_, digits.data(), nb, cts.data())) throw Panic("encrypt failed");
+    m.insert(wire, cts.data());
+}
+
+// reference src/circuit.rs:1113-1190
+std::unique_ptr<SiEncWireMap> ArithCircuit::encrypt_inputs(const std::set<std::string> &wire_set,
+                                                           const std::map<std::string, PtxtType> &input_wire_map)
+{
+    if (input_wire_map.empty()) throw Panic("called `Option::unwrap()` on a `None` value");
+    switch (input_wire_map.begin()->second.kind) {
+    case PtxtType::U8: global_ptxt_type_ = "u8"; break;
+    case PtxtType::U16: global_ptxt_type_ = "u16"; break;
+    case PtxtType::U32: global_ptxt_type_ = "u32"; break;
+    case PtxtType::U64: global_ptxt_type_ = "u64"; break;
+    case PtxtType::U128: global_ptxt_type_ = "u128"; break;
+    default: throw Panic("internal error: entered unreachable code");
+    }
+    const int nb = blocks_of(global_ptxt_type_);
+    auto m = std::make_unique<SiEncWireMap>(server_key_, nb);
+    std::vector<std::string> names(wire_set.begin(), wire_set.end()); // FheType::None: rows exist, zero
+    names.insert(names.end(), circuit_.input_wires().begin(), circuit_.input_wires().end());
+    names.insert(names.end(), circuit_.dff_outputs().begin(), circuit_.dff_outputs().end());
+    m->reserve_keys(names, 0);
+    const bool dummy = input_wire_map.count("dummy") != 0;
+    for (auto &input_wire : circuit_.input_wires()) {
+        unsigned __int128 v = 0;
+        if (!dummy) {
+            auto it = input_wire_map.find(input_wire);
+            if (it == input_wire_map.end()) throw Panic("\n Input wire \"" + input_wire + "\" not found in input wires!");
+            v = it->second.value;
+        }
+        encrypt_value(*m, input_wire, v);
+    }
+    for (auto &w : circuit_.dff_outputs()) encrypt_value(*m, w, 0);
+    return m;
+}
+
+// reference src/circuit.rs:1192-1216: trivial zeros
+std::unique_ptr<SiEncWireMap> ArithCircuit::init_ready()
+{
+    const int nb = blocks_of(global_ptxt_type_.empty() ? "u32" : global_ptxt_type_);
+    auto m = std::make_unique<SiEncWireMap>(server_key_, nb);
+    m->reserve_keys(circuit_.output_wires(), 0);
+    std::vector<int32_t> idx;
+    for (auto &w : circuit_.output_wires())
+        for (int b = 0; b < nb; b++) idx.push_back(m->row(w) + b);
+    std::vector<uint64_t> zeros(idx.size(), 0);
+    if (!idx.empty())
+        si_ok(helm_si_wires_set_trivial(server_key_, m->table(), idx.data(), zeros.data(), (int64_t)idx.size()),
+              "wires_set_trivial");
+    return m;
+}
+
+// reference src/circuit.rs:1218-1297 multiplies by READY; arithmetic netlists carry no READY
+// wire in any of the reference's runs or tests, so this mirrors the no-READY outcome.
+void ArithCircuit::evaluate_ready(const SiEncWireMap &enc_wire_map, SiEncWireMap &)
+{
+    if (!enc_wire_map.contains_key("READY")) throw Panic("called `Option::unwrap()` on a `None` value (READY)");
+    throw Panic("READY-latched outputs are not implemented for arithmetic circuits");
+}
+
+// reference src/circuit.rs:1299-1454
+std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMap &enc_wire_map, size_t /*cycle*/,
+                                                               const std::string &ptxt_type)
+{
+    if (!circuit_.gates_empty()) throw Panic("assertion failed: self.circuit.gates.is_empty()");
+    if (!circuit_.get_ordered_gates().empty()) throw Panic("assertion failed: self.circuit.ordered_gates.is_empty()");
+    const int nb = blocks_of(ptxt_type);
+    if (nb != enc_wire_map.blocks()) throw Panic("ptxt_type does not match the encrypted inputs");
+    const int bits = 2 * nb;
+    const unsigned __int128 vmask = bits >= 128 ? ~(unsigned __int128)0 : (((unsigned __int128)1 << bits) - 1);
+    RadixEngine eng(server_key_, nb);
+    // plan every level first: the scratch region is sized once
+    std::vector<std::vector<RadixOp>> plan;
+    auto eval_values = enc_wire_map.clone(0);
+    int64_t max_scratch = 0;
+    for (auto &kv : circuit_.level_map()) {
+        std::vector<RadixOp> ops;
+        for (auto &g : kv.second) {
+            const auto &ins = g.get_input_wires();
+            RadixOp op{};
+            op.out = eval_values->row(g.get_output_wire());
+            bool is_ptxt_op = false;
+            for (auto &w : ins) is_ptxt_op |= is_numeric_string(w);
+            const GateType t = g.get_gate_type();
+            if (is_ptxt_op) { // circuit.rs:1336-1387: ct (op) scalar, whatever the operand order
+                op.a = -1;
+                for (auto &w : ins) {
+                    if (is_numeric_string(w)) {
+                        unsigned __int128 x = 0;
+                        bool overflow = false;
+                        for (char c : w) {
+                            x = x * 10 + (unsigned)(c - '0');
+                            if (x > vmask) overflow = true;
+                        }
+                        op.scalar = overflow ? 0 : x; // parse::<uN>().unwrap_or(0)
+                    } else
+                        op.a = eval_values->row(w);
+                }
+                if (op.a < 0) throw Panic("Empty ctxt operand!");
+                if (t == GateType::Add) op.kind = RadixOp::AddScalar;
+                else if (t == GateType::Sub) op.kind = RadixOp::SubScalar;
+                else if (t == GateType::Mult) op.kind = RadixOp::MulScalar;
+                else if (t == GateType::Div || t == GateType::Shl || t == GateType::Shr)
+                    throw Panic("gate \"" + g.get_gate_name() + "\": div / shl / shr are not implemented in this build");
+                else throw Panic("internal error: entered unreachable code");
+            } else {
+                if (ins.empty()) throw Panic("gate \"" + g.get_gate_name() + "\" has no input");
+                op.a = eval_values->row(ins[0]);
+                op.b = ins.size() > 1 ? eval_values->row(ins[1]) : -1;
+                if (t == GateType::Copy) op.kind = RadixOp::Copy;
+                else if (ins.size() < 2) throw Panic("index out of bounds: the len is 1 but the index is 1");
+                else if (t == GateType::Add) op.kind = RadixOp::Add;
+                else if (t == GateType::Sub) op.kind = RadixOp::Sub;
+                else if (t == GateType::Div || t == GateType::Shl || t == GateType::Shr)
+                    throw Panic("gate \"" + g.get_gate_name() + "\": div / shl / shr are not implemented in this build");
+                else op.kind = RadixOp::Mul; // default arm (circuit.rs:1429-1435)
+            }
+            ops.push_back(op);
+        }
+        max_scratch = std::max(max_scratch, eng.scratch_rows(ops));
+        plan.push_back(std::move(ops));
+    }
+    const int scratch = eval_values->scratch(max_scratch);
+    const size_t total_levels = circuit_.level_map().size();
+    size_t li = 0;
+    for (auto &kv : circuit_.level_map()) {
+        eng.run_level(eval_values->table(), plan[li++], scratch);
+        std::ostringstream os;
+        os << "  Evaluated gates in level [" << kv.first << "/" << total_levels << "]\n";
+        log_ += os.str();
+    }
+    si_ok(helm_si_sync(server_key_), "sync");
+    pbs_count_ = eng.pbs_count();
+    pbs_rounds_ = eng.pbs_rounds();
+    return eval_values;
+}
+
+// reference src/circuit.rs:1456-1483
+std::map<std::string, PtxtType> ArithCircuit::decrypt_outputs(const SiEncWireMap &enc_wire_map, bool verbose)
+{
+    std::map<std::string, PtxtType> out;
+    const int nb = enc_wire_map.blocks();
+    const int bits = 2 * nb;
+    const char *names[] = {"u8", "u16", "u32", "u64", "u128"};
+    std::string pt = "u32";
+    for (auto *n : names)
+        if (blocks_of(n) == nb) pt = n;
+    for (auto &w : circuit_.output_wires()) {
+        auto ct = enc_wire_map.get(w);
+        std::vector<uint64_t> vals((size_t)nb);
+        if (helm_si_client_decrypt(client_key_, ct.data(), nb, vals.data())) throw Panic("decrypt failed");
+        unsigned __int128 v = 0;
+        for (int i = nb - 1; i >= 0; i--) v = (v << 2) + vals[(size_t)i]; // carries included, wrapping
+        if (bits < 128) v &= (((unsigned __int128)1 << bits) - 1);
+        PtxtType p;
+        p.kind = kind_of(pt);
+        p.value = v;
+        out[w] = p;
+    }
+    size_t i = 0;
+    for (auto &kv : out) {
+        if (i > 10 && !verbose) {
+            log_ += "[!] More than ten output_wires, pass `--verbose` to see output.\n";
+            break;
+        }
+        log_ += " " + kv.first + ": " + kv.second.to_string() + "\n";
+        i++;
+    }
+    return out;
+}
+
+} // namespace helm

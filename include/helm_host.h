@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include "helm_client.h"
 #include "helm_hip.h"
+#include "helm_shortint.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -83,6 +84,36 @@ int helm_host_gate_circuit_decrypt_outputs(helm_gate_circuit *gc, const helm_enc
 /* progress / output lines the reference prints (circuit.rs:542, 562-573); drains the buffer */
 char *helm_host_gate_circuit_log(helm_gate_circuit *gc);
 int64_t helm_host_gate_circuit_pbs_per_cycle(const helm_gate_circuit *gc);
+
+/* ---- LUT mode / arithmetic mode (include/helm_shortint.h) ------------------------------
+ * LutCircuit (circuit.rs:969-1120) and ArithCircuit (circuit.rs:1112-1500); `mode` 0 = LUT,
+ * 1 = arithmetic.  Encrypted maps hold `blocks` big-LWE rows per wire (1 for LUT mode). */
+typedef struct helm_si_circuit helm_si_circuit;
+typedef struct helm_si_enc_map helm_si_enc_map;
+int helm_host_si_circuit_new(int mode, helm_si_client_key *client_key, helm_si_ctx *server_key,
+                             const helm_circuit *circuit, helm_si_circuit **out);
+void helm_host_si_circuit_free(helm_si_circuit *c);
+int helm_host_si_circuit_encrypt_inputs(helm_si_circuit *c, const char *wire_set, const char *input_wire_map,
+                                        helm_si_enc_map **out);
+int helm_host_si_circuit_evaluate_encrypted(helm_si_circuit *c, const helm_si_enc_map *enc_wire_map,
+                                            int64_t current_cycle, const char *ptxt_type, helm_si_enc_map **out);
+int helm_host_si_circuit_init_ready(helm_si_circuit *c, helm_si_enc_map **out);
+int helm_host_si_circuit_evaluate_ready(helm_si_circuit *c, const helm_si_enc_map *enc_wire_map,
+                                        helm_si_enc_map *valid_outputs);
+int helm_host_si_circuit_decrypt_outputs(helm_si_circuit *c, const helm_si_enc_map *enc_wire_map, int verbose,
+                                         char **out_map);
+char *helm_host_si_circuit_log(helm_si_circuit *c);
+/* bootstraps of the last evaluate_encrypted, and (arithmetic) the number of batched rounds */
+int64_t helm_host_si_circuit_pbs_per_cycle(const helm_si_circuit *c);
+int64_t helm_host_si_circuit_pbs_rounds_per_cycle(const helm_si_circuit *c);
+int helm_host_si_enc_map_new(helm_si_ctx *server_key, int blocks, helm_si_enc_map **out);
+void helm_host_si_enc_map_free(helm_si_enc_map *m);
+int helm_host_si_enc_map_blocks(const helm_si_enc_map *m);
+int helm_host_si_enc_map_row_words(const helm_si_enc_map *m);
+int helm_host_si_enc_map_insert(helm_si_enc_map *m, const char *wire, const uint64_t *lwe);
+int helm_host_si_enc_map_get(const helm_si_enc_map *m, const char *wire, uint64_t *lwe_out);
+int helm_host_si_enc_map_contains_key(const helm_si_enc_map *m, const char *wire);
+char *helm_host_si_enc_map_keys(const helm_si_enc_map *m);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,9 @@ int helm_si_wires_upload(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx,
                          int64_t count);
 int helm_si_wires_download(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx, uint64_t *lwe_host,
                            int64_t count);
+/* Row copy between two tables of the same context (Ciphertext::clone, circuit.rs:1046-1049). */
+int helm_si_wires_copy(helm_si_ctx *ctx, helm_si_wires *src, const int32_t *src_idx, helm_si_wires *dst,
+                       const int32_t *dst_idx, int64_t count);
 /* ServerKey::create_trivial(value) (circuit.rs:978): zero mask, body = value * delta. */
 int helm_si_wires_set_trivial(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx, const uint64_t *value,
                               int64_t count);

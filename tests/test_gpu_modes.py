@@ -1,0 +1,147 @@
+"""LUT mode and arithmetic mode end to end on the GPU through the host front end, mirroring
+reference tests/circuit_test.rs:266-311 (encrypted 8-bit LUT adder: every wire equals the
+plaintext evaluation), :313-370 (chi-squared in arithmetic mode) and tests/gates_test.rs:127-310
+(FheUint16 add / sub / mul known answers)."""
+import os
+
+import numpy as np
+import pytest
+
+import helm_amd
+from helm_amd import ArithCircuit, Circuit, EvalCircuit, LutCircuit, PtxtType, verilog_parser
+from helm_amd._host import Panic
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+NET = os.path.join(HERE, "netlists")
+
+
+@pytest.fixture(scope="module")
+def keys():
+    ck, sk = helm_amd.gen_keys_shortint("shortint_m2c2", seed=1)  # the 3-bit-capable class of circuit_test.rs:287
+    yield ck, sk
+    sk.close()
+
+
+def _circuit(path_or_text, is_arith=False, is_text=False):
+    rd = verilog_parser.read_verilog_text if is_text else verilog_parser.read_verilog_file
+    gates_set, wire_set, input_wires, output_wires, dffs, _, _ = rd(path_or_text, is_arith)
+    c = Circuit(gates_set, input_wires, output_wires, dffs)
+    c.sort_circuit()
+    c.compute_levels()
+    return c, wire_set, input_wires, output_wires
+
+
+def test_encrypted_8_bit_adder_lut(keys):  # circuit_test.rs:266-311
+    client_key, server_key = keys
+    circuit, wire_set, input_wires, output_wires = _circuit(f"{NET}/8-bit-adder-lut-3-1.v")
+    a, b, cin = 0xB7, 0x6E, 1
+    inputs = {f"a[{i}]": PtxtType.Bool((a >> i) & 1) for i in range(8)}
+    inputs.update({f"b[{i}]": PtxtType.Bool((b >> i) & 1) for i in range(8)})
+    inputs["cin"] = PtxtType.Bool(cin)
+    ptxt = circuit.initialize_wire_map(wire_set, inputs, "bool")
+    ptxt = circuit.evaluate(ptxt)
+    lc = LutCircuit(client_key, server_key, circuit)
+    enc = EvalCircuit.encrypt_inputs(lc, wire_set, inputs)
+    enc = EvalCircuit.evaluate_encrypted(lc, enc, 1, "bool")
+    assert lc.pbs_per_cycle() == 16
+    for wire, want in ptxt.items():  # every wire, as the reference test does
+        assert client_key.decrypt(enc[wire]) == int(bool(want)), wire
+    out = EvalCircuit.decrypt_outputs(lc, enc, True)
+    total = sum(out[f"sum[{i}]"].value << i for i in range(8)) + (out["cout"].value << 8)
+    assert total == a + b + cin
+    assert all(v.kind == "U64" for v in out.values())
+    assert "Evaluated gates in level [1/" in lc.log()
+
+
+def test_lut_sequential_ready_latch(keys):
+    """2-bit counter out of LUTs and DFFs, READY-latched outputs (circuit.rs:1002-1030)."""
+    client_key, server_key = keys
+    text = """input en;
+output q0, READY;
+dff g0(d0, q0);
+dff g1(d1, q1);
+lut g2(0x6, q0, en, d0);
+lut g3(0x8, q0, en, c0);
+lut g4(0x6, q1, c0, d1);
+lut g5(0xAA, q1, q1, q1, READY);
+"""
+    circuit, wire_set, input_wires, output_wires = _circuit(text, is_text=True)
+    lc = LutCircuit(client_key, server_key, circuit)
+    enc = lc.encrypt_inputs(wire_set, {"en": PtxtType.Bool(True), "q0": PtxtType.Bool(False), "q1": PtxtType.Bool(False)})
+    ready = lc.init_ready()
+    state = []
+    for _ in range(3):
+        enc = lc.evaluate_encrypted(enc, 1, "bool")
+        lc.evaluate_ready(enc, ready)
+        state.append((client_key.decrypt(enc["q0"]), client_key.decrypt(enc["q1"])))
+    assert state == [(1, 0), (0, 1), (1, 1)]
+    assert lc.decrypt_outputs(ready, True)["READY"].value == 1
+
+
+@pytest.mark.parametrize("x,y", [(10, 20), (20, 30), (30, 40)])
+def test_fheuint16_known_answers(keys, x, y):  # gates_test.rs:127-310 (K-7)
+    client_key, server_key = keys
+    text = """input [15:0] A, B;
+output [15:0] S, D, P, Q, R;
+add g0(A, B, S);
+sub g1(B, A, D);
+mult g2(A, B, P);
+add g3(A, 7, Q);
+sub g4(B, 3, R);
+"""
+    circuit, wire_set, input_wires, output_wires = _circuit(text, is_arith=True, is_text=True)
+    ac = ArithCircuit(client_key, server_key, circuit)
+    enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U16(x), "B": PtxtType.U16(y)})
+    enc = ac.evaluate_encrypted(enc, 1, "u16")
+    out = ac.decrypt_outputs(enc, True)
+    assert out["S"] == PtxtType.U16(x + y)
+    assert out["D"] == PtxtType.U16(y - x)
+    assert out["P"] == PtxtType.U16(x * y)
+    assert out["Q"] == PtxtType.U16(x + 7)
+    assert out["R"] == PtxtType.U16(y - 3)
+
+
+def test_radix_wraparound_u8(keys):
+    client_key, server_key = keys
+    text = """input [7:0] A, B;
+output [7:0] S, D, P, C, M;
+add g0(A, B, S);
+sub g1(A, B, D);
+mult g2(A, B, P);
+copy g3(A, C);
+mult g4(A, 27, M);
+"""
+    circuit, wire_set, _, _ = _circuit(text, is_arith=True, is_text=True)
+    ac = ArithCircuit(client_key, server_key, circuit)
+    for a, b in ((200, 100), (3, 250), (255, 255), (0, 0)):
+        enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U8(a), "B": PtxtType.U8(b)})
+        out = ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, "u8"), True)
+        assert out["S"].value == (a + b) % 256 and out["D"].value == (a - b) % 256
+        assert out["P"].value == (a * b) % 256 and out["C"].value == a and out["M"].value == (a * 27) % 256
+
+
+def test_chi_squared_u32(keys):  # circuit_test.rs:313-370, inputs K-5 (2, 7, 9)
+    client_key, server_key = keys
+    circuit, wire_set, input_wires, output_wires = _circuit(f"{NET}/chi_squared_arith.v", is_arith=True)
+    inputs = verilog_parser.read_input_wires(os.path.join(HERE, "golden", "chi_squared_arith_1.inputs.csv"), "u32")
+    ac = ArithCircuit(client_key, server_key, circuit)
+    enc = EvalCircuit.encrypt_inputs(ac, wire_set, inputs)
+    enc = EvalCircuit.evaluate_encrypted(ac, enc, 1, "u32")
+    out = EvalCircuit.decrypt_outputs(ac, enc, True)
+    n0, n1, n2 = 2, 7, 9
+    M = 1 << 32
+    want = {"alpha": ((4 * n0 * n2 - n1 * n1) ** 2) % M, "beta1": (2 * (2 * n0 + n1) ** 2) % M,
+            "beta2": ((2 * n0 + n1) * (2 * n2 + n1)) % M, "beta3": (2 * (2 * n2 + n1) ** 2) % M}
+    assert {k: v.value for k, v in out.items()} == want == {"alpha": 529, "beta1": 242, "beta2": 275, "beta3": 1250}
+    assert all(v.kind == "U32" for v in out.values())
+    assert ac.pbs_per_cycle() > 0 and ac.pbs_rounds_per_cycle() > 0
+
+
+def test_arith_rejects_unimplemented_ops(keys):
+    client_key, server_key = keys
+    circuit, wire_set, _, _ = _circuit("input [7:0] A, B;\noutput [7:0] Y;\ndiv g0(A, B, Y);\n", is_arith=True, is_text=True)
+    ac = ArithCircuit(client_key, server_key, circuit)
+    enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U8(9), "B": PtxtType.U8(2)})
+    with pytest.raises(Panic, match="not implemented"):
+        ac.evaluate_encrypted(enc, 1, "u8")
