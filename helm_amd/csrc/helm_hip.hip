@@ -25,6 +25,8 @@
 #include <vector>
 
 using namespace helm;
+struct helm_hip_wires;
+struct helm_hip_program;
 
 // ------------------------------------------------------------------------------------
 // error plumbing
@@ -709,6 +711,10 @@ struct helm_hip_ctx {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pbs, ev_ks, ev_lin;
     helm_hip_timing tacc{};
+    // wire tables and programs created from this context: released with it, so that a handle
+    // freed after its context (host-language destructors run in any order) is harmless
+    std::vector<helm_hip_wires *> child_wires;
+    std::vector<helm_hip_program *> child_progs;
 };
 
 struct helm_hip_program {
@@ -1031,6 +1037,24 @@ int helm_hip_ctx_destroy(helm_hip_ctx *ctx)
             (void)hipEventDestroy(p.first);
             (void)hipEventDestroy(p.second);
         }
+    for (auto *w : ctx->child_wires) {
+        (void)hipFree(w->d);
+        w->d = nullptr;
+        w->owner = nullptr;
+    }
+    for (auto *pr : ctx->child_progs) {
+        (void)hipFree(pr->d_pbs);
+        (void)hipFree(pr->d_ks);
+        (void)hipFree(pr->d_lin);
+        pr->d_pbs = nullptr;
+        pr->d_ks = nullptr;
+        pr->d_lin = nullptr;
+        pr->s_pbs.release();
+        pr->s_ks.release();
+        pr->s_lin.release();
+        pr->s_rows.release();
+        pr->owner = nullptr;
+    }
     (void)hipFree(ctx->tw_fwd);
     (void)hipFree(ctx->tw_inv);
     (void)hipFree(ctx->bsk);
@@ -1127,6 +1151,7 @@ int helm_hip_wires_alloc(helm_hip_ctx *ctx, int64_t n_wires, helm_hip_wires **ou
         return fail(HELM_ERR_OOM, "wire table of " + std::to_string(bytes) + " bytes");
     }
     HIP_TRY(hipMemsetAsync(w->d, 0, bytes, ctx->stream));
+    ctx->child_wires.push_back(w);
     *out = w;
     return 0;
 }
@@ -1134,10 +1159,15 @@ int helm_hip_wires_alloc(helm_hip_ctx *ctx, int64_t n_wires, helm_hip_wires **ou
 int helm_hip_wires_free(helm_hip_ctx *ctx, helm_hip_wires *w)
 {
     if (!w) return 0;
+    if (!w->owner) { // its context is gone and took the device memory with it
+        delete w;
+        return 0;
+    }
     if (!ctx || w->owner != ctx) return fail(HELM_ERR_STATE, "wire table belongs to another context");
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(w->d);
+    ctx->child_wires.erase(std::remove(ctx->child_wires.begin(), ctx->child_wires.end(), w), ctx->child_wires.end());
     delete w;
     return 0;
 }
@@ -1310,6 +1340,7 @@ int helm_hip_program_create(helm_hip_ctx *ctx, const int32_t *opcode, const int3
         HIP_TRY(hipMalloc(&pr->d_lin, all_lin.size() * sizeof(LinJob)));
         HIP_TRY(hipMemcpy(pr->d_lin, all_lin.data(), all_lin.size() * sizeof(LinJob), hipMemcpyHostToDevice));
     }
+    ctx->child_progs.push_back(pr);
     *prog = pr;
     return 0;
 }
@@ -1317,7 +1348,12 @@ int helm_hip_program_create(helm_hip_ctx *ctx, const int32_t *opcode, const int3
 int helm_hip_program_destroy(helm_hip_ctx *ctx, helm_hip_program *prog)
 {
     if (!prog) return 0;
+    if (!prog->owner) {
+        delete prog;
+        return 0;
+    }
     if (!ctx || prog->owner != ctx) return fail(HELM_ERR_STATE, "program belongs to another context");
+    ctx->child_progs.erase(std::remove(ctx->child_progs.begin(), ctx->child_progs.end(), prog), ctx->child_progs.end());
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(prog->d_pbs);

@@ -472,6 +472,7 @@ struct helm_si_ctx {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pbs, ev_ks, ev_lin;
     helm_si_timing tacc{};
+    std::vector<helm_si_wires *> child_wires; // released with the context (see helm_hip.hip)
 };
 
 namespace {
@@ -678,6 +679,11 @@ int helm_si_ctx_destroy(helm_si_ctx *ctx)
             (void)hipEventDestroy(p.first);
             (void)hipEventDestroy(p.second);
         }
+    for (auto *w : ctx->child_wires) {
+        (void)hipFree(w->d);
+        w->d = nullptr;
+        w->owner = nullptr;
+    }
     (void)hipFree(ctx->tw[0]);
     (void)hipFree(ctx->tw[1]);
     (void)hipFree(ctx->bsk);
@@ -778,6 +784,7 @@ int helm_si_wires_alloc(helm_si_ctx *ctx, int64_t n_rows, helm_si_wires **out)
         return fail(HELM_ERR_OOM, "ciphertext table of " + std::to_string(bytes) + " bytes");
     }
     HIP_TRY(hipMemsetAsync(w->d, 0, bytes, ctx->stream));
+    ctx->child_wires.push_back(w);
     *out = w;
     return 0;
 }
@@ -785,10 +792,15 @@ int helm_si_wires_alloc(helm_si_ctx *ctx, int64_t n_rows, helm_si_wires **out)
 int helm_si_wires_free(helm_si_ctx *ctx, helm_si_wires *w)
 {
     if (!w) return 0;
+    if (!w->owner) { // its context is gone and took the device memory with it
+        delete w;
+        return 0;
+    }
     if (!ctx || w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(w->d);
+    ctx->child_wires.erase(std::remove(ctx->child_wires.begin(), ctx->child_wires.end(), w), ctx->child_wires.end());
     delete w;
     return 0;
 }

@@ -24,6 +24,8 @@ def _declared(header, prefix):
 @pytest.mark.parametrize("header,prefix,lib,table", [
     ("helm_hip.h", "helm_hip_", nv.hip, nv.HIP_API),
     ("helm_client.h", "helm_client_", nv.host, nv.CLIENT_API),
+    ("helm_client.h", "helm_si_client_", nv.host, nv.SI_CLIENT_API),
+    ("helm_shortint.h", "helm_si_", nv.hip, nv.SI_API),
     ("helm_host.h", "helm_host_", nv.host, _host.HOST_API),
 ])
 def test_every_declared_symbol_is_exported_and_bound(header, prefix, lib, table):
@@ -37,7 +39,7 @@ def test_every_declared_symbol_is_exported_and_bound(header, prefix, lib, table)
 
 
 def test_no_torch_types_in_the_abi():
-    for h in ("helm_hip.h", "helm_client.h", "helm_host.h"):
+    for h in ("helm_hip.h", "helm_shortint.h", "helm_client.h", "helm_host.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
         assert "torch" not in text.lower() and "at::" not in text and "#include <hip" not in text
 
@@ -49,6 +51,7 @@ def test_product_package_never_touches_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "liborc" not in src, f
                 assert "tfhe_oracle" not in src.replace("oracle/tfhe_oracle.c header", ""), f
+                assert "shortint_oracle" not in src and "orc64_" not in src, f
 
 
 def test_parameter_validation_needs_no_device():
@@ -68,12 +71,42 @@ def test_parameter_validation_needs_no_device():
     assert nv.hip.helm_hip_ctx_create(0, None, C.byref(h)) == -1
 
 
+def test_shortint_parameter_validation_needs_no_device():
+    p, _, _ = helm_amd.si_named_params("shortint_m2c2")
+    assert p.as_tuple() == (742, 1, 2048, 1, 23, 5, 3, 4, 4)
+    h = nv.vp()
+    for field, value, msg in (("k", 2, b"unsupported"), ("N", 4096, b"unsupported"), ("pbs_logB", 31, b"decomposition"),
+                              ("message_modulus", 3, b"power of two"), ("ks_logB", 9, b"keyswitch")):
+        bad = helm_amd.SiParams.from_buffer_copy(p)
+        setattr(bad, field, value)
+        assert nv.hip.helm_si_ctx_create(0, C.byref(bad), C.byref(h)) == -1, field
+        assert msg in nv.hip.helm_hip_last_error(), (field, nv.hip.helm_hip_last_error())
+    bad = helm_amd.SiParams.from_buffer_copy(p)
+    bad.pbs_l, bad.pbs_logB = 2, 28  # 2 * 2 * 2048 * 2^27 * 2^63 exceeds the two-prime CRT range
+    assert nv.hip.helm_si_ctx_create(0, C.byref(bad), C.byref(h)) == -1
+    assert b"capacity" in nv.hip.helm_hip_last_error()
+
+
+def test_shortint_client_roundtrip():
+    for name in ("si_toy_512", "shortint_m2c2"):
+        ck = helm_amd.SiClientKey.generate(name, seed=4)
+        vals = np.arange(ck.t, dtype=np.uint64)
+        ct = ck.encrypt(vals)
+        assert ct.shape == (ck.t, ck.dim + 1)
+        assert np.array_equal(ck.decrypt_message_and_carry(ct), vals)
+        assert np.array_equal(ck.decrypt(ct), vals % ck.params.message_modulus)
+        assert ck.bsk.size == ck.params.n * ck.params.pbs_l * 4 * ck.params.N
+        assert ck.ksk.size == ck.dim * ck.params.ks_l * (ck.params.n + 1)
+
+
 def test_no_cpu_fallback(have_gpu):
     if have_gpu:
         pytest.skip("GPU present: covered by the gpu tests")
     ck = helm_amd.ClientKey.generate("toy", seed=1)
     with pytest.raises(helm_amd.HelmError, match="no HIP device|no CPU fallback|-2"):
         helm_amd.ServerKey(ck)
+    with pytest.raises(helm_amd.HelmError, match="no HIP device|no CPU fallback|-2"):
+        helm_amd.SiServerKey(helm_amd.SiClientKey.generate("si_toy_512", seed=1))
 
 
 def test_client_roundtrip_and_noise():

@@ -146,3 +146,36 @@ def test_full_parameter_sets(name):
     for g in sub:
         assert np.array_equal(got[2 + g], ref[2 + g]), f"gate {g} differs from the oracle"
     sk.close()
+
+
+def test_handles_outlive_their_context():
+    """Wire tables, programs and circuits freed AFTER their context (destructor order of a host
+    language is arbitrary) must be harmless: the context releases their device memory."""
+    import gc as _gc
+    from helm_amd import Circuit, GateCircuit, PtxtType, verilog_parser
+    ck = helm_amd.ClientKey.generate("toy", seed=1)
+    sk = helm_amd.ServerKey(ck)
+    w = sk.wires(8)
+    w.upload([0, 1], ck.encrypt([True, False]))
+    prog = helm_amd.Program(sk, [oracle.AND], [0], [1], [-1], [2], [0, 1])
+    prog.run(w)
+    gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_text(
+        "input a, b;\noutput y;\nand g0(a, b, y);\n", False)
+    c = Circuit(gates, inputs, outputs, dffs)
+    c.sort_circuit()
+    c.compute_levels()
+    g = GateCircuit(ck, sk, c)
+    enc = g.evaluate_encrypted(g.encrypt_inputs(wire_set, {"a": PtxtType.Bool(True), "b": PtxtType.Bool(True)}), 1, "bool")
+    assert ck.decrypt(enc["y"])
+    sck = helm_amd.SiClientKey.generate("si_toy_512", seed=1)
+    ssk = helm_amd.SiServerKey(sck)
+    sw = ssk.wires(4)
+    sk.close()
+    ssk.close()
+    h_w, h_p, h_sw = w._h, prog._h, sw._h
+    from helm_amd import _native as nv
+    assert nv.hip.helm_hip_wires_free(None, h_w) == 0 and nv.hip.helm_hip_program_destroy(None, h_p) == 0
+    assert nv.hip.helm_si_wires_free(None, h_sw) == 0
+    w._h = prog._h = sw._h = None
+    del enc, g
+    _gc.collect()
