@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=4, help="AES blocks per GPU evaluated together")
+    ap.add_argument("--blocks", type=int, default=16, help="AES blocks per GPU evaluated together")
     ap.add_argument("--params", default="boolean_default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-levels", type=int, default=2, help="netlist levels (1 block) timed on the CPU oracle")
@@ -155,14 +155,17 @@ def main():
     avg_launch_s = tm.pbs_ms / launches * 1e-3
     algo_bytes = bsk_bytes + avg_pbs_per_launch * io_bytes
     achieved_gbs = algo_bytes / avg_launch_s / 1e9
-    # fp64 lane-operations of one bootstrap, counted from the kernel's instruction stream
-    # (DESIGN.md "k_pbs"): per CMUX step and wave: forward NTTs, pointwise, inverse NTT
+    # fp64 lane-operations of one bootstrap (DESIGN.md "k_pbs"): per CMUX step and wave, forward
+    # transforms (8 per butterfly), pointwise multiply-accumulate (6 + 1 per word), inverse
+    # transform (8 per butterfly + 4 recentrings of 3) and the hand-over sums; the 49-bit field
+    # needs no recentring inside forward transforms and products
     logN = int(np.log2(p.N))
     E = p.N // 64
     bfly = E // 2 * logN
-    dp_fwd = p.pbs_l * (bfly * 8 + 2 * E * 3)
-    dp_mac = K1 * E * (p.pbs_l * 7 + 3)
-    dp_inv = bfly * 8 + 3 * E * 3 + E * (p.k + 3)
+    lazy = p.N == 512  # field chosen by helm_hip_ctx_create for boolean_default
+    dp_fwd = p.pbs_l * (bfly * 8 + (0 if lazy else 2 * E * 3))
+    dp_mac = K1 * E * (p.pbs_l * 7 - 1) + (0 if lazy else K1 * E * 3)
+    dp_inv = bfly * 8 + 4 * E * 3 + E * p.k
     dp_ops_per_pbs = p.n * K1 * 64 * (dp_fwd + dp_mac + dp_inv)
     fp64_tops = dp_ops_per_pbs * tm.pbs_count / (tm.pbs_ms * 1e-3) / 1e12
 
@@ -177,7 +180,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32 torus (exact NTT in f64 FMA over a 51-bit prime)",
+        "dtype": "u32 torus (exact NTT in f64 FMA over a 49-bit prime)",
         "data": "synthetic: generated AES-128 netlist (stand-in for HELM's), seeded random keys/plaintexts, "
                 "fresh encryptions resident in HBM",
         "config": {
@@ -207,6 +210,21 @@ def main():
                       "frac": round(fp64_tops / 39.3, 4), "dp_lane_ops_per_bootstrap": int(dp_ops_per_pbs)},
         "setup_s": {"keygen_upload": round(t_keys, 2)},
     }
+
+    # ---- wall-clock of ONE AES-128 evaluation (latency; levels are 80-256 gates wide, so the
+    #      GPU is far from full: this is the n-step blind-rotation chain, 207 levels deep) ------
+    if world == 1:
+        o1 = build_program_arrays(circuit, wire_names, 1)
+        prog1 = helm_amd.Program(sk, *o1[:6])
+        prog1.run(wires)
+        sync_all()
+        t0 = time.perf_counter()
+        prog1.run(wires)
+        sync_all()
+        t1 = time.perf_counter() - t0
+        result["single_block"] = {"wall_s": round(t1, 4), "gate_bootstraps_per_s": round(prog1.total_pbs() / t1, 1),
+                                  "bootstraps": int(prog1.total_pbs())}
+        prog1.destroy()
 
     # ---- CPU baseline: the oracle (a port, not tfhe-rs) on this box's host cores --------
     if world == 1 and not args.no_cpu_baseline:

@@ -109,6 +109,11 @@ __device__ __forceinline__ void decompose(uint32_t x, int logB, int (&dig)[L])
     }
 }
 
+// Diagnostic clock stamps (HELM_HIP_CLOCK_PROBE=1): workgroup 0 records s_memtime (shader
+// clock) and s_memrealtime (100 MHz) around its blind rotation; the ratio is the clock the
+// chip actually holds under this kernel's load.  Written to a buffer nothing else reads.
+__device__ unsigned long long g_clock_probe[4];
+
 // ------------------------------------------------------------------------------------
 // k_pbs: one workgroup = one bootstrap; wave p owns accumulator polynomial p.
 //
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
                                                                   const double *__restrict__ tw_fwd,
                                                                   const double *__restrict__ tw_inv,
                                                                   uint32_t *__restrict__ out_big, // rows of K*N+1
-                                                                  int n, int logB)
+                                                                  int n, int logB, int probe)
 {
     constexpr int LOGN = C::LOGN, K = C::K, L = C::L, M = C::M;
     using F = typename C::F;
@@ -256,6 +261,11 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
         return i;
     };
 
+    const bool stamp = probe && blockIdx.x == 0 && tid == 0;
+    if (stamp) {
+        g_clock_probe[0] = __builtin_amdgcn_s_memtime();
+        g_clock_probe[1] = __builtin_amdgcn_s_memrealtime();
+    }
     // ---- blind rotation: acc += BSK_i (x) (X^{a_i} acc - acc) -------------------------
     int i = next_nonzero(0);
     if (i < n) prefetch(i);
@@ -437,6 +447,10 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
         i = inext;
     }
 
+    if (stamp) {
+        g_clock_probe[2] = __builtin_amdgcn_s_memtime();
+        g_clock_probe[3] = __builtin_amdgcn_s_memrealtime();
+    }
     // ---- sample extract (coefficient 0): wave p writes its own polynomial -------------
     uint32_t *ob = out_big + (size_t)blockIdx.x * ((size_t)K * N + 1);
     if (p < K) {
@@ -701,6 +715,7 @@ struct helm_hip_ctx {
     bool have_bsk = false, have_ksk = false;
     int field = 51; // Fp<51> or Fp<49> (lazy), chosen from the parameter set
     int n_cus = 256;
+    int clock_probe = 0;     // HELM_HIP_CLOCK_PROBE: print the in-kernel clock of every k_pbs launch
     int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput (HELM_HIP_PBS_VARIANT)
     // per-call scratch
     DevBuf<PbsJob> d_pbs;
@@ -812,8 +827,16 @@ static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * (C::K + 1)), C::BYTES, ctx->stream, jobs, wires, raw, tvs,
-                       ctx->bsk, ctx->tw_fwd, ctx->tw_inv, out_big, ctx->P.n, ctx->P.pbs_logB);
-    return hipGetLastError();
+                       ctx->bsk, ctx->tw_fwd, ctx->tw_inv, out_big, ctx->P.n, ctx->P.pbs_logB, ctx->clock_probe);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && ctx->clock_probe) {
+        unsigned long long v[4];
+        (void)hipStreamSynchronize(ctx->stream);
+        if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_clock_probe), sizeof(v)) == hipSuccess && v[3] > v[1])
+            fprintf(stderr, "[helm_hip] k_pbs M=%d x%lld: in-kernel clock %.3f GHz (%.3f ms of blind rotation)\n", C::M,
+                    (long long)count, (double)(v[2] - v[0]) / (double)(v[3] - v[1]) * 0.1, (double)(v[3] - v[1]) * 1e-5);
+    }
+    return e;
 }
 
 // Build choice.  Measured on MI355X, boolean_default (profiles/r01/microbench_nand_*): one
@@ -993,6 +1016,7 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
     ctx->P = P;
     ctx->n_cus = prop.multiProcessorCount;
     if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) ctx->pbs_variant = atoi(v);
+    if (const char *v = getenv("HELM_HIP_CLOCK_PROBE")) ctx->clock_probe = atoi(v);
     while ((1 << ctx->logN) < P.N) ctx->logN++;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
