@@ -1,0 +1,45 @@
+"""Generates tests/golden/shortint_toy.npz: a tiny 64-bit-torus parameter set (n=3, N=512, k=1,
+message = carry = 4), its keys, four input ciphertexts and the expected output ciphertext of one
+LUT gate of every kind gates::lut() distinguishes (reference src/gates.rs:754-785), produced by
+the CPU oracle (oracle/shortint_oracle.c: schoolbook products in wrapping u64 arithmetic).
+
+tests/test_oracle_shortint.py re-derives the same ciphertexts with an independent numpy
+restatement; the GPU tests compare the HIP path with them.  The reference (Rust + un-vendored tfhe
+crate) cannot run here, so these vectors pin both paths to the schoolbook definition, not to
+tfhe-rs bits (ciphertext-level parity with tfhe-rs is unpinned, see the oracle's header).
+
+Run from the repo root:  python tests/golden/make_golden_shortint.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import helm_amd  # noqa: E402
+import oracle  # noqa: E402
+
+p = helm_amd.SiParams(n=3, k=1, N=512, pbs_l=1, pbs_logB=23, ks_l=2, ks_logB=8, message_modulus=4, carry_modulus=4)
+ck = helm_amd.SiClientKey(p, 1e-9, 1e-16, seed=2025)
+orc = oracle.Oracle64(p.as_tuple(), ck.bsk, ck.ksk)
+bits = np.array([1, 0, 1, 1], dtype=np.uint64)
+gates = [(3, [0, 1, 2], 0x96), (3, [3, 1, 0], 0xE8), (4, [0, 1, 2, 3], 0x7EE8), (2, [0, 1], 0x6), (2, [2, 3], 0x8),
+         (1, [0], 0x0), (1, [2], 0x2), (0, [3], 0x0)]
+n_in, max_in = len(bits), 4
+arity = np.array([g[0] for g in gates], dtype=np.int32)
+in_idx = np.full((len(gates), max_in), -1, dtype=np.int32)
+for g, (_, ins, _) in enumerate(gates):
+    in_idx[g, :len(ins)] = ins
+table = np.array([g[2] for g in gates], dtype=np.uint64)
+out_idx = np.arange(n_in, n_in + len(gates), dtype=np.int32)
+wires = np.zeros((n_in + len(gates), ck.dim + 1), dtype=np.uint64)
+wires[:n_in] = ck.encrypt(bits)
+inputs = wires[:n_in].copy()
+orc.eval_lut_level(wires, arity, in_idx, table, out_idx)
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "shortint_toy.npz"),
+                    params=np.array(p.as_tuple(), dtype=np.int32), lwe_sk=ck.lwe_secret.copy(),
+                    glwe_sk=ck.glwe_secret.copy(), bsk=ck.bsk.copy(), ksk=ck.ksk.copy(), bits=bits, inputs=inputs,
+                    arity=arity, in_idx=in_idx, table=table, expected=wires[n_in:])
+print("wrote shortint_toy.npz:", len(gates), "gates; decrypted:",
+      [orc.decrypt(ck.glwe_secret, wires[n_in + g]) for g in range(len(gates))])

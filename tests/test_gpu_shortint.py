@@ -140,3 +140,17 @@ def test_full_parameter_set_m2c2():
         dec = ck.decrypt(w.download(np.arange(56, 64)))
         assert list(dec) == [int(fn(*r)) for r in bits.tolist()]
     sk.close()
+
+
+def test_golden_vectors_on_gpu():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shortint_toy.npz"))
+    p = helm_amd.SiParams(*[int(x) for x in g["params"]])
+    sk = helm_amd.SiServerKey(params=p, bsk=g["bsk"], ksk=g["ksk"])
+    n_in = len(g["inputs"])
+    w = sk.wires(n_in + len(g["arity"]))
+    w.upload(np.arange(n_in), g["inputs"])
+    out_idx = np.arange(n_in, n_in + len(g["arity"]), dtype=np.int32)
+    w.eval_lut_level(g["arity"], g["in_idx"], g["table"], out_idx)
+    assert np.array_equal(w.download(out_idx), g["expected"])
+    sk.close()

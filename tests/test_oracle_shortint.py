@@ -98,3 +98,100 @@ def test_8_bit_lut_adder_every_wire(toy):  # circuit_test.rs:266-311
         orc.eval_lut_level(wires, ar, ii, tb, [row[g.output_wire] for g in gs])
     for w, want in ptxt.items():
         assert int(ck.decrypt(wires[row[w]])) == int(bool(want)), w
+
+
+# ---------------------------------------------------------------------------------------
+# committed golden vectors + an independent numpy restatement of apply_lookup_table
+# ---------------------------------------------------------------------------------------
+def _np_decompose(x, logB, l):
+    """closest-representable balanced digits of uint64 array x -> list of int64 arrays, level 1 first"""
+    rep = logB * l
+    state = ((x + np.uint64(1 << (63 - rep))) >> np.uint64(64 - rep)).astype(np.uint64)
+    out = [None] * l
+    for lev in range(l - 1, -1, -1):
+        d = state & np.uint64((1 << logB) - 1)
+        state = state >> np.uint64(logB)
+        carry = (((d - np.uint64(1)) | state) & d) >> np.uint64(logB - 1)
+        state = state + carry
+        out[lev] = d.astype(np.int64) - (carry.astype(np.int64) << logB)
+    return out
+
+
+def _np_negacyclic(d, row):
+    """(sum_a d[a] X^a) * row  mod X^N + 1, wrapping uint64"""
+    N = len(row)
+    acc = np.zeros(N, dtype=np.uint64)
+    du = d.astype(np.uint64)  # two's complement: wrapping arithmetic is a ring homomorphism
+    for a in np.nonzero(d)[0]:
+        t = du[a] * row
+        acc[a:] += t[:N - a]
+        acc[:a] -= t[N - a:]
+    return acc
+
+
+def _np_apply_lut(P, bsk, ksk, ct, tv):
+    n, k, N, l, logB, ksl, kslogB = P[:7]
+    kN = k * N
+    ksk = ksk.reshape(kN, ksl, n + 1)
+    small = np.zeros(n + 1, dtype=np.uint64)
+    small[n] = ct[kN]
+    digs = _np_decompose(ct[:kN], kslogB, ksl)
+    for j in range(ksl):
+        small -= (digs[j].astype(np.uint64)[:, None] * ksk[:, j, :]).sum(axis=0, dtype=np.uint64)
+    ms = lambda x: ((int(x) >> (64 - (N.bit_length()) - 1)) + 1 >> 1) & (2 * N - 1)
+    rot = lambda poly, a: np.array([poly[(j - a) % (2 * N)] if (j - a) % (2 * N) < N else
+                                    np.uint64(0) - poly[(j - a) % (2 * N) - N] for j in range(N)], dtype=np.uint64)
+    acc = np.zeros((k + 1, N), dtype=np.uint64)
+    acc[k] = rot(tv, (2 * N - ms(small[n])) % (2 * N))
+    bsk = bsk.reshape(n, l, k + 1, k + 1, N)
+    for i in range(n):
+        a = ms(small[i])
+        if a == 0:
+            continue
+        diff = np.stack([rot(acc[r], a) - acc[r] for r in range(k + 1)])
+        for r in range(k + 1):
+            digs = _np_decompose(diff[r], logB, l)
+            for j in range(l):
+                for c in range(k + 1):
+                    acc[c] += _np_negacyclic(digs[j], bsk[i, j, r, c])
+    out = np.zeros(kN + 1, dtype=np.uint64)
+    for r in range(k):
+        out[r * N] = acc[r][0]
+        out[r * N + 1:(r + 1) * N] = np.uint64(0) - acc[r][:0:-1]
+    out[kN] = acc[k][0]
+    return out
+
+
+def test_golden_vectors_two_independent_routes():
+    g = np.load(os.path.join(HERE, "golden", "shortint_toy.npz"))
+    P = [int(x) for x in g["params"]]
+    orc = oracle.Oracle64(P, g["bsk"], g["ksk"])
+    n_in = len(g["inputs"])
+    wires = np.zeros((n_in + len(g["arity"]), P[1] * P[2] + 1), dtype=np.uint64)
+    wires[:n_in] = g["inputs"]
+    out_idx = np.arange(n_in, len(wires), dtype=np.int32)
+    orc.eval_lut_level(wires, g["arity"], g["in_idx"], g["table"], out_idx)
+    assert np.array_equal(wires[n_in:], g["expected"])  # the C oracle reproduces the committed vectors
+    # numpy route for the three gate kinds that bootstrap: pack, look-up table, keyswitch, blind rotate
+    t, delta = P[7] * P[8], (1 << 63) // (P[7] * P[8])
+    with np.errstate(over="ignore"):
+        for gi in (0, 2, 3):
+            ar, ins, tb = int(g["arity"][gi]), g["in_idx"][gi], int(g["table"][gi])
+            packed = np.zeros_like(wires[0])
+            for q in range(ar):
+                packed += np.uint64(1 << (ar - 1 - q)) * g["inputs"][ins[q]]
+            f = [(tb >> ((((v >> 1) & 1) * 2 + (v & 1)) if ar == 2 else (v & ((1 << ar) - 1)))) & 1 for v in range(t)]
+            box = P[2] // t
+            acc = np.repeat(np.array(f, dtype=np.uint64) * np.uint64(delta), box)
+            acc[:box // 2] = np.uint64(0) - acc[:box // 2]
+            tv = np.roll(acc, -(box // 2))
+            assert np.array_equal(tv, orc.make_lut(f))
+            assert np.array_equal(_np_apply_lut(P, g["bsk"], g["ksk"], packed, tv), g["expected"][gi]), gi
+    # and they decrypt to the truth tables
+    bits = [int(b) for b in g["bits"]]
+    for gi in range(len(g["arity"])):
+        ar, ins, tb = int(g["arity"][gi]), g["in_idx"][gi], int(g["table"][gi])
+        x = [bits[i] for i in ins[:max(ar, 1)]]
+        want = ((tb >> sum(b << (ar - 1 - q) for q, b in enumerate(x))) & 1) if ar >= 2 else \
+            (x[0] if (ar == 0 or tb == 0) else (-x[0]) % t)
+        assert orc.decrypt(g["glwe_sk"], g["expected"][gi]) == want, gi
