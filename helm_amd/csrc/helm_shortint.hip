@@ -40,8 +40,10 @@ int helm_hip_fail_(int code, const std::string &msg); // helm_hip.hip: sets helm
 
 namespace {
 
-using F0 = Fp<51>;     // first CRT prime
-using F1 = Fp49Strict; // second CRT prime (recentring kept: long transforms, large digits)
+// CRT pair: two 49-bit primes whose 2^53 / p = 14.2 headroom lets a whole forward transform (up to
+// 11 stages, digits below 2^23), the pointwise products and their sums run without recentring
+using F0 = Fp<49>;
+using F1 = Fp49b;
 
 struct Pbs64Job {
     int32_t in_row;  // row of the small-LWE buffer (n+1 words)
@@ -85,8 +87,10 @@ struct Pbs64Cfg {
     using G = Geo<LOGN>;
     static constexpr int MAX_SMALL_N = 1024;
     static constexpr size_t X_OFF = 0;                                            // double [NW][XPAD]
-    static constexpr size_t TW_OFF = X_OFF + sizeof(double) * NW * G::XPAD;       // double [2][N]
-    static constexpr size_t ACC_OFF = TW_OFF + sizeof(double) * 2 * G::N;         // u64 [K1][N]
+    // twiddles per field: index table for blocks A, B (N >> BC entries) + lane table for block C
+    static constexpr int TW_IDX = G::N >> G::BC, TW_FIELD = TW_IDX + G::TWC * 64;
+    static constexpr size_t TW_OFF = X_OFF + sizeof(double) * NW * G::XPAD;       // double [2][TW_FIELD]
+    static constexpr size_t ACC_OFF = TW_OFF + sizeof(double) * 2 * TW_FIELD;     // u64 [K1][N]
     static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint64_t) * K1 * G::N;      // u16 [n+1]
     static constexpr size_t BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
 };
@@ -106,8 +110,9 @@ __device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__
     const double *x_poly = X + (size_t)((1 - p) * 2 + f) * G::XPAD; // same field, other polynomial
     const double *x_field = X + (size_t)(p * 2 + (1 - f)) * G::XPAD; // same polynomial, other field
     uint64_t *acc_p = ACC + (size_t)p * N;
-    TwMem twf{reinterpret_cast<const double *>(smem + C::TW_OFF) + (size_t)f * N};
-    TwMemMirror<LOGN> twi{twf.t};
+    const double *twt = reinterpret_cast<const double *>(smem + C::TW_OFF) + (size_t)f * C::TW_FIELD;
+    TwHybrid<LOGN, false> twf{twt, twt + C::TW_IDX + lane};
+    TwHybrid<LOGN, true> twi{twt, twt + C::TW_IDX + (63 - lane)};
 
     // key words of step i for this wave: [i][row p][c][lev][f][e/2][lane] as double2
     const size_t per_poly = (size_t)2 * (N / 2); // both fields
@@ -119,8 +124,9 @@ __device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__
         if (a == 0) continue; // uniform over the workgroup: every wave skips the same steps
         const double2 *bp_i = bsk_w + (size_t)i * bsk_step;
 
-        // ---- rotate / subtract, decomposition state (least significant level first) ----
-        uint64_t state[E];
+        // ---- rotate / subtract, decomposition state (least significant level first; the
+        //      rounded value has logB * L <= 32 bits) --------------------------------------------
+        uint32_t state[E];
         {
             const int rep = logB * L;
 #pragma unroll
@@ -130,30 +136,38 @@ __device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__
                 uint64_t v = acc_p[src & (N - 1)];
                 if (src >= N) v = 0ull - v;
                 v -= acc_p[j];
-                state[e] = rep >= 64 ? v : (v + (1ull << (63 - rep))) >> (64 - rep);
+                state[e] = (uint32_t)((v + (1ull << (63 - rep))) >> (64 - rep));
             }
         }
         double mine[E], other[E];
-        const uint64_t mask = (1ull << logB) - 1ull;
+        const uint32_t mask = (1u << logB) - 1u;
 #pragma unroll
         for (int lev = L - 1; lev >= 0; lev--) {
             double x[1][E];
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const uint64_t d = state[e] & mask;
-                const uint64_t st = state[e] >> logB;
-                const uint64_t carry = (((d - 1ull) | st) & d) >> (logB - 1);
+                const uint32_t d = state[e] & mask;
+                const uint32_t st = state[e] >> logB;
+                const uint32_t carry = (((d - 1u) | st) & d) >> (logB - 1);
                 state[e] = st + carry;
-                x[0][e] = (double)((int32_t)(uint32_t)d - (int32_t)((uint32_t)carry << logB));
+                x[0][e] = (double)((int32_t)d - (int32_t)(carry << logB));
             }
+            // key words: the first column is fetched before the transform (which hides its
+            // latency), the second after it (hidden by the first column's products)
+            double2 kw[K1][E / 2];
+#pragma unroll
+            for (int e2 = 0; e2 < E / 2; e2++) kw[0][e2] = (bp_i + (size_t)(0 * L + lev) * per_poly)[e2 * 64];
+            __builtin_amdgcn_sched_barrier(0);
             ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e2 = 0; e2 < E / 2; e2++) kw[1][e2] = (bp_i + (size_t)(1 * L + lev) * per_poly)[e2 * 64];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < K1; c++) {
-                const double2 *kp = bp_i + (size_t)(c * L + lev) * per_poly;
 #pragma unroll
                 for (int e2 = 0; e2 < E / 2; e2++) {
-                    const double2 kw = kp[e2 * 64];
-                    const double t0 = mulmod<F>(x[0][2 * e2], kw.x), t1 = mulmod<F>(x[0][2 * e2 + 1], kw.y);
+                    const double t0 = mulmod<F>(x[0][2 * e2], kw[c][e2].x), t1 = mulmod<F>(x[0][2 * e2 + 1], kw[c][e2].y);
                     if (c == p) {
                         mine[2 * e2] = lev == L - 1 ? t0 : mine[2 * e2] + t0;
                         mine[2 * e2 + 1] = lev == L - 1 ? t1 : mine[2 * e2 + 1] + t1;
@@ -216,9 +230,14 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
     const Pbs64Job job = jobs[blockIdx.x];
     const uint64_t *lwe = small + (size_t)job.in_row * ((size_t)n + 1);
     for (int i = tid; i <= n; i += 64 * C::NW) MS[i] = (uint16_t)modswitch64(lwe[i], LOGN + 1);
-    for (int i = tid; i < N; i += 64 * C::NW) {
+    for (int i = tid; i < C::TW_IDX; i += 64 * C::NW) {
         TW[i] = tw0[i];
-        TW[N + i] = tw1[i];
+        TW[C::TW_FIELD + i] = tw1[i];
+    }
+    for (int r = w; r < G::TWC; r += C::NW) { // lane-table rows of block C (slots TWB.. of tw_lane_index)
+        const int idx = tw_lane_index<LOGN>(G::TWB + r, lane);
+        TW[C::TW_IDX + r * 64 + lane] = tw0[idx];
+        TW[C::TW_FIELD + C::TW_IDX + r * 64 + lane] = tw1[idx];
     }
     __syncthreads();
     // accumulator: (0, X^{-b~} * lut)
@@ -617,7 +636,8 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
     if (!si_supported(P))
         return fail(HELM_ERR_INVALID, "unsupported (k,N,pbs_l): built variants are k = 1, N in {512,1024,2048}, pbs_l in {1,2}");
     if (P.n < 1 || P.n > 1024) return fail(HELM_ERR_INVALID, "n must be in [1,1024]");
-    if (P.pbs_logB < 2 || P.pbs_logB > 30 || P.pbs_logB * P.pbs_l > 64) return fail(HELM_ERR_INVALID, "bad PBS decomposition");
+    if (P.pbs_logB < 2 || P.pbs_logB > 30 || P.pbs_logB * P.pbs_l > 32)
+        return fail(HELM_ERR_INVALID, "bad PBS decomposition (pbs_logB * pbs_l <= 32: every tfhe shortint set)");
     if (P.ks_logB < 1 || P.ks_logB > 7 || P.ks_l < 1 || P.ks_l > 8 || P.ks_logB * P.ks_l > 63)
         return fail(HELM_ERR_INVALID, "bad keyswitch decomposition (ks_logB <= 7, ks_l <= 8)");
     const int t = P.message_modulus * P.carry_modulus;

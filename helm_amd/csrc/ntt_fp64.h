@@ -47,6 +47,16 @@ template <> struct Fp<49> {
     static constexpr bool LAZY = true;
 };
 
+// A second lazy 49-bit prime (0x24007A8500001, generator 5): with Fp<49> it forms the CRT pair
+// of the 64-bit-torus kernels (p * q / 2 = 2^97.35 covers their exact products); an 11-stage
+// forward transform of digits below 2^23 stays under 9.6 q < 2^53 without recentring.
+struct Fp49b {
+    static constexpr double P = 633351586185217.0;
+    static constexpr uint64_t P_U64 = 633351586185217ull;
+    static constexpr uint64_t GEN = 5;
+    static constexpr bool LAZY = true;
+};
+
 // The 49-bit prime with recentring kept (transforms of more than 9 stages, or inputs
 // larger than boolean digits, would outgrow the lazy bound).
 struct Fp49Strict {
@@ -250,6 +260,25 @@ struct TwLane {
 #pragma unroll
             for (int hi = 0; hi < (G::E >> (sb - 6 + 1)); hi++) ua[slot++] = table[(G::N >> (sb + 1)) + hi];
         }
+    }
+};
+
+// Index table for blocks A and B (entries below N >> BC: few, read with few distinct
+// addresses per instruction) + lane-major table for block C, whose per-lane indices stride
+// by E through an index table (E-way bank conflicts for E = 16, 32).
+template <int LOGN, bool MIRROR_>
+struct TwHybrid {
+    static constexpr bool MIRROR = MIRROR_;
+    using G = Geo<LOGN>;
+    const double *t;    // LDS index table, entries [0, N >> BC)
+    const double *base; // LDS lane table of block C [TWC][64] + lane (forward) or + 63 - lane (mirrored)
+    __device__ __forceinline__ double get(int sb, int hi, int cnt, int idx, int) const
+    {
+        if (sb < G::BC) {
+            const int fs = tw_fwd_slot<LOGN>(sb, MIRROR ? cnt - 1 - hi : hi) - G::TWA - G::TWB;
+            return base[fs * 64];
+        }
+        return t[MIRROR ? 3 * (G::N >> (sb + 1)) - 1 - idx : idx];
     }
 };
 

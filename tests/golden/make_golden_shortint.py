@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 import helm_amd  # noqa: E402
 import oracle  # noqa: E402
 
-p = helm_amd.SiParams(n=3, k=1, N=512, pbs_l=1, pbs_logB=23, ks_l=2, ks_logB=8, message_modulus=4, carry_modulus=4)
+p = helm_amd.SiParams(n=3, k=1, N=512, pbs_l=1, pbs_logB=23, ks_l=3, ks_logB=5, message_modulus=4, carry_modulus=4)
 ck = helm_amd.SiClientKey(p, 1e-9, 1e-16, seed=2025)
 orc = oracle.Oracle64(p.as_tuple(), ck.bsk, ck.ksk)
 bits = np.array([1, 0, 1, 1], dtype=np.uint64)
