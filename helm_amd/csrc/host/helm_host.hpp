@@ -274,7 +274,7 @@ class LutCircuit : public EvalCircuit<SiEncWireMap> {
 
 // One integer operator of a level: rows a, b, out are the first rows of radix integers.
 struct RadixOp {
-    enum Kind { Copy, Add, Sub, Mul, AddScalar, SubScalar, MulScalar } kind = Copy;
+    enum Kind { Copy, Add, Sub, Mul, Div, Shl, Shr, AddScalar, SubScalar, MulScalar, DivScalar, ShlScalar, ShrScalar } kind = Copy;
     int a = -1, b = -1, out = -1;
     unsigned __int128 scalar = 0;
 };
@@ -286,7 +286,8 @@ class RadixEngine {
     RadixEngine(helm_si_ctx *ctx, int blocks);
     int64_t scratch_rows(const std::vector<RadixOp> &ops) const;
     void run_level(helm_si_wires *w, const std::vector<RadixOp> &ops, int scratch);
-    void propagate(helm_si_wires *w, const std::vector<int32_t> &bases, int scratch);
+    void propagate(helm_si_wires *w, const std::vector<int32_t> &bases, int scratch, int width,
+                   const std::vector<int32_t> *carry_out_rows);
     int64_t pbs_count() const { return pbs_count_; }
     int64_t pbs_rounds() const { return pbs_rounds_; }
 
@@ -295,11 +296,15 @@ class RadixEngine {
                  const std::vector<int64_t> &cadd, const std::vector<int32_t> &out, int terms);
     void apply(helm_si_wires *w, const std::vector<int32_t> &in, const std::vector<int32_t> &lut,
                const std::vector<int32_t> &out);
+    void shift_scalar(helm_si_wires *w, const std::vector<RadixOp> &ops);
+    void shift_encrypted(helm_si_wires *w, const std::vector<RadixOp> &ops, int &scratch_pos);
+    void divide(helm_si_wires *w, const std::vector<RadixOp> &ops, int &scratch_pos);
     helm_si_ctx *ctx_;
     int nb_;
     helm_si_params P_{};
     std::vector<uint64_t> luts_;
     int lut_msg_ = 0, lut_carry_ = 0, lut_state_ = 0, lut_state0_ = 0, lut_comb_ = 0, lut_mul_lo_ = 0, lut_mul_hi_ = 0;
+    int lut_bit0_ = 0, lut_bit1_ = 0, lut_shl1_ = 0, lut_shr1_ = 0, lut_sel_ = 0;
     int64_t pbs_count_ = 0, pbs_rounds_ = 0;
 };
 

@@ -338,6 +338,12 @@ RadixEngine::RadixEngine(helm_si_ctx *ctx, int nb) : ctx_(ctx), nb_(nb)
     // products of two 2-bit messages, packed a * 4 + b
     lut_mul_lo_ = add_lut([](int v) { return ((v >> 2) * (v & 3)) & 3; });
     lut_mul_hi_ = add_lut([](int v) { return ((v >> 2) * (v & 3)) >> 2; });
+    lut_bit0_ = add_lut([](int v) { return v & 1; });
+    lut_bit1_ = add_lut([](int v) { return (v >> 1) & 1; });
+    // one-bit shifts of a block x with its neighbour y, packed 4 * x + y
+    lut_shl1_ = add_lut([](int v) { return (((v >> 2) << 1) & 3) | ((v & 3) >> 1); });
+    lut_shr1_ = add_lut([](int v) { return ((v >> 2) >> 1) | (((v & 3) & 1) << 1); });
+    lut_sel_ = add_lut([](int v) { return (v >> 2) ? (v & 3) : 0; }); // 4 * c + x -> c ? x : 0
 }
 
 void RadixEngine::lincomb(helm_si_wires *w, const std::vector<int32_t> &in_idx, const std::vector<int64_t> &coef,
@@ -360,24 +366,28 @@ void RadixEngine::apply(helm_si_wires *w, const std::vector<int32_t> &in, const 
     pbs_rounds_++;
 }
 
-// Full carry propagation of integers whose block sums are <= 6 (block 0: <= 7): carry
-// states, Hillis-Steele prefix over them (log2 nb rounds of one bootstrap per block), final
-// message extraction.  `scratch` needs 2 * nb rows per integer.
-void RadixEngine::propagate(helm_si_wires *w, const std::vector<int32_t> &bases, int scratch)
+// Full carry propagation of integers of `W` blocks whose block sums are <= 6 (block 0: <= 7):
+// carry states, Hillis-Steele prefix over them (log2 W rounds of one bootstrap per block), final
+// message extraction.  `scratch` needs 2 * W rows per integer.  With `flags` (one row per
+// integer) the carry OUT of the top block is kept there (0 / 1) instead of being dropped.
+void RadixEngine::propagate(helm_si_wires *w, const std::vector<int32_t> &bases, int scratch, int W,
+                            const std::vector<int32_t> *flags)
 {
     const int G = (int)bases.size();
     if (G == 0) return;
-    auto S = [&](int g, int buf, int i) { return scratch + (g * 2 + buf) * nb_ + i; };
+    if (W <= 0) W = nb_;
+    const int NS = flags ? W : W - 1; // blocks whose carry state matters
+    auto S = [&](int g, int buf, int i) { return scratch + (g * 2 + buf) * W + i; };
     std::vector<int32_t> in, lut, out;
     for (int g = 0; g < G; g++)
-        for (int i = 0; i + 1 < nb_; i++) { // the top block's carry is dropped (mod 2^bits)
+        for (int i = 0; i < NS; i++) {
             in.push_back(bases[(size_t)g] + i);
             lut.push_back(i == 0 ? lut_state0_ : lut_state_);
             out.push_back(S(g, 0, i));
         }
     apply(w, in, lut, out);
     int cur = 0;
-    for (int d = 1; d < nb_ - 1; d <<= 1) {
+    for (int d = 1; d < NS; d <<= 1) {
         // s'[i] = comb(s[i], s[i-d]) for i >= d (packed 4 * s[i] + s[i-d]); s'[i] = s[i] below
         std::vector<int32_t> li, lo;
         std::vector<int64_t> lc;
@@ -385,7 +395,7 @@ void RadixEngine::propagate(helm_si_wires *w, const std::vector<int32_t> &bases,
         lut.clear();
         out.clear();
         for (int g = 0; g < G; g++)
-            for (int i = 0; i + 1 < nb_; i++) {
+            for (int i = 0; i < NS; i++) {
                 li.push_back(S(g, cur, i));
                 lc.push_back(i >= d ? 4 : 1);
                 li.push_back(i >= d ? S(g, cur, i - d) : -1);
@@ -407,8 +417,8 @@ void RadixEngine::propagate(helm_si_wires *w, const std::vector<int32_t> &bases,
     in.clear();
     lut.clear();
     out.clear();
-    for (int g = 0; g < G; g++)
-        for (int i = 0; i < nb_; i++) {
+    for (int g = 0; g < G; g++) {
+        for (int i = 0; i < W; i++) {
             li.push_back(bases[(size_t)g] + i);
             lc.push_back(1);
             li.push_back(i > 0 ? S(g, cur, i - 1) : -1);
@@ -418,8 +428,232 @@ void RadixEngine::propagate(helm_si_wires *w, const std::vector<int32_t> &bases,
             lut.push_back(lut_msg_);
             out.push_back(bases[(size_t)g] + i);
         }
+        if (flags) { // the prefix state of the top block is 0 or 1: the carry out
+            li.push_back(S(g, cur, W - 1));
+            lc.push_back(1);
+            li.push_back(-1);
+            lc.push_back(0);
+            lo.push_back((*flags)[(size_t)g]);
+        }
+    }
     lincomb(w, li, lc, {}, lo, 2);
     apply(w, in, lut, out);
+}
+
+// Shift by a plaintext amount (src/gates.rs:602-700, scalar forms): whole blocks move for free,
+// an odd amount costs one bivariate look-up per block on the pair (4 * x + y).
+void RadixEngine::shift_scalar(helm_si_wires *w, const std::vector<RadixOp> &ops)
+{
+    std::vector<int32_t> li, lo, in, lut, out;
+    std::vector<int64_t> lc;
+    for (auto &op : ops) {
+        const bool left = op.kind == RadixOp::ShlScalar;
+        if (!left && op.kind != RadixOp::ShrScalar) continue;
+        const int s = (int)(op.scalar % (unsigned)(2 * nb_)), q = s >> 1, r = s & 1;
+        for (int i = 0; i < nb_; i++) {
+            const int xi = left ? i - q : i + q, yi = left ? xi - 1 : xi + 1; // y: the neighbour bits come from
+            const bool xok = xi >= 0 && xi < nb_, yok = yi >= 0 && yi < nb_;
+            li.push_back(xok ? op.a + xi : -1);
+            lc.push_back(xok ? (r ? 4 : 1) : 0);
+            li.push_back(r && yok ? op.a + yi : -1);
+            lc.push_back(r && yok ? 1 : 0);
+            lo.push_back(op.out + i);
+            if (r) {
+                in.push_back(op.out + i);
+                lut.push_back(left ? lut_shl1_ : lut_shr1_);
+                out.push_back(op.out + i);
+            }
+        }
+    }
+    // operands may alias outputs (out == a): lincomb stages every sum before writing any row
+    lincomb(w, li, lc, {}, lo, 2);
+    apply(w, in, lut, out);
+}
+
+// Shift by an encrypted amount (mod bits): the amount's bits select, stage by stage, between the
+// value and the value shifted by 2^t (a barrel shifter); a selection is two look-ups per block,
+// sel(c, x) = c ? x : 0 on 4 * c + x, summed.
+void RadixEngine::shift_encrypted(helm_si_wires *w, const std::vector<RadixOp> &ops, int &sp)
+{
+    std::vector<const RadixOp *> sh;
+    for (auto &op : ops)
+        if (op.kind == RadixOp::Shl || op.kind == RadixOp::Shr) sh.push_back(&op);
+    if (sh.empty()) return;
+    const int G = (int)sh.size();
+    int nbits = 0;
+    while ((1 << nbits) < 2 * nb_) nbits++;
+    auto take = [&](int rows) { const int b = sp; sp += rows; return b; };
+    const int bits0 = take(G * nbits), cur0 = take(G * nb_), shf0 = take(G * nb_), selA0 = take(G * nb_), selB0 = take(G * nb_);
+    auto BIT = [&](int g, int t) { return bits0 + g * nbits + t; };
+    std::vector<int32_t> li, lo, in, lut, out;
+    std::vector<int64_t> lc, ca;
+    // bits of the amount; working copy of the value
+    for (int g = 0; g < G; g++) {
+        for (int t = 0; t < nbits; t++) {
+            in.push_back(sh[(size_t)g]->b + (t >> 1));
+            lut.push_back((t & 1) ? lut_bit1_ : lut_bit0_);
+            out.push_back(BIT(g, t));
+        }
+        for (int i = 0; i < nb_; i++) {
+            li.push_back(sh[(size_t)g]->a + i); lc.push_back(1); li.push_back(-1); lc.push_back(0);
+            lo.push_back(cur0 + g * nb_ + i);
+        }
+    }
+    lincomb(w, li, lc, {}, lo, 2);
+    apply(w, in, lut, out);
+    for (int t = 0; t < nbits; t++) {
+        // candidate: the value shifted by 2^t bits
+        li.clear(); lc.clear(); lo.clear(); in.clear(); lut.clear(); out.clear();
+        for (int g = 0; g < G; g++) {
+            const bool left = sh[(size_t)g]->kind == RadixOp::Shl;
+            const int q = t == 0 ? 0 : 1 << (t - 1), r = t == 0 ? 1 : 0;
+            for (int i = 0; i < nb_; i++) {
+                const int xi = left ? i - q : i + q, yi = left ? xi - 1 : xi + 1;
+                const bool xok = xi >= 0 && xi < nb_, yok = yi >= 0 && yi < nb_;
+                li.push_back(xok ? cur0 + g * nb_ + xi : -1);
+                lc.push_back(xok ? (r ? 4 : 1) : 0);
+                li.push_back(r && yok ? cur0 + g * nb_ + yi : -1);
+                lc.push_back(r && yok ? 1 : 0);
+                lo.push_back(shf0 + g * nb_ + i);
+                if (r) { in.push_back(shf0 + g * nb_ + i); lut.push_back(left ? lut_shl1_ : lut_shr1_); out.push_back(shf0 + g * nb_ + i); }
+            }
+        }
+        lincomb(w, li, lc, {}, lo, 2);
+        apply(w, in, lut, out);
+        // cur = bit ? shifted : cur
+        li.clear(); lc.clear(); lo.clear(); ca.clear(); in.clear(); lut.clear(); out.clear();
+        for (int g = 0; g < G; g++)
+            for (int i = 0; i < nb_; i++) {
+                li.push_back(BIT(g, t)); lc.push_back(4); li.push_back(shf0 + g * nb_ + i); lc.push_back(1);
+                lo.push_back(selA0 + g * nb_ + i); ca.push_back(0);
+                li.push_back(BIT(g, t)); lc.push_back(-4); li.push_back(cur0 + g * nb_ + i); lc.push_back(1);
+                lo.push_back(selB0 + g * nb_ + i); ca.push_back(4);
+                in.push_back(selA0 + g * nb_ + i); lut.push_back(lut_sel_); out.push_back(selA0 + g * nb_ + i);
+                in.push_back(selB0 + g * nb_ + i); lut.push_back(lut_sel_); out.push_back(selB0 + g * nb_ + i);
+            }
+        lincomb(w, li, lc, ca, lo, 2);
+        apply(w, in, lut, out);
+        li.clear(); lc.clear(); lo.clear();
+        for (int g = 0; g < G; g++)
+            for (int i = 0; i < nb_; i++) {
+                li.push_back(selA0 + g * nb_ + i); lc.push_back(1); li.push_back(selB0 + g * nb_ + i); lc.push_back(1);
+                lo.push_back(cur0 + g * nb_ + i);
+            }
+        lincomb(w, li, lc, {}, lo, 2);
+    }
+    li.clear(); lc.clear(); lo.clear();
+    for (int g = 0; g < G; g++)
+        for (int i = 0; i < nb_; i++) {
+            li.push_back(cur0 + g * nb_ + i); lc.push_back(1); li.push_back(-1); lc.push_back(0);
+            lo.push_back(sh[(size_t)g]->out + i);
+        }
+    lincomb(w, li, lc, {}, lo, 2);
+}
+
+// Unsigned division (quotient), restoring: for every numerator bit, most significant first,
+// R = 2R + bit; D = R - B with its carry out (1 <=> R >= B); R = carry ? D : R; the carry is the
+// quotient bit.  R has one block more than the operands (2R + 1 < 2B).  A zero divisor yields
+// the all-ones quotient, as tfhe's.
+void RadixEngine::divide(helm_si_wires *w, const std::vector<RadixOp> &ops, int &sp)
+{
+    std::vector<const RadixOp *> dv;
+    for (auto &op : ops)
+        if (op.kind == RadixOp::Div || op.kind == RadixOp::DivScalar) dv.push_back(&op);
+    if (dv.empty()) return;
+    const int G = (int)dv.size(), W = nb_ + 1, bits = 2 * nb_;
+    auto take = [&](int rows) { const int b = sp; sp += rows; return b; };
+    const int abit0 = take(G * bits), qbit0 = take(G * bits), B0 = take(G * W), R0 = take(G * W), D0 = take(G * W),
+              selA0 = take(G * W), selB0 = take(G * W), st0 = take(2 * W * G);
+    std::vector<int32_t> li, lo, in, lut, out, idx;
+    std::vector<int64_t> lc, ca;
+    std::vector<uint64_t> val;
+    // divisor widened by one zero block (plaintext divisors as trivial ciphertexts), R = 0
+    for (int g = 0; g < G; g++)
+        for (int i = 0; i < W; i++) {
+            const bool scalar = dv[(size_t)g]->kind == RadixOp::DivScalar;
+            if (scalar || i == nb_) {
+                idx.push_back(B0 + g * W + i);
+                val.push_back(i < nb_ ? (uint64_t)((dv[(size_t)g]->scalar >> (2 * i)) & 3) : 0);
+            } else {
+                li.push_back(dv[(size_t)g]->b + i); lc.push_back(1); li.push_back(-1); lc.push_back(0);
+                lo.push_back(B0 + g * W + i);
+            }
+            idx.push_back(R0 + g * W + i);
+            val.push_back(0);
+        }
+    lincomb(w, li, lc, {}, lo, 2);
+    si_ok(helm_si_wires_set_trivial(ctx_, w, idx.data(), val.data(), (int64_t)idx.size()), "set_trivial");
+    // bits of the numerators
+    for (int g = 0; g < G; g++)
+        for (int t = 0; t < bits; t++) {
+            in.push_back(dv[(size_t)g]->a + (t >> 1));
+            lut.push_back((t & 1) ? lut_bit1_ : lut_bit0_);
+            out.push_back(abit0 + g * bits + t);
+        }
+    apply(w, in, lut, out);
+    std::vector<int32_t> dbase((size_t)G), flags((size_t)G);
+    for (int t = bits - 1; t >= 0; t--) {
+        // R = 2R + a_t : pairs (4 * R_i + R_{i-1}) -> ((x << 1) & 3) | (y >> 1), then + bit on block 0
+        li.clear(); lc.clear(); lo.clear(); in.clear(); lut.clear(); out.clear();
+        for (int g = 0; g < G; g++)
+            for (int i = 0; i < W; i++) {
+                li.push_back(R0 + g * W + i); lc.push_back(4);
+                li.push_back(i > 0 ? R0 + g * W + i - 1 : -1); lc.push_back(i > 0 ? 1 : 0);
+                lo.push_back(D0 + g * W + i);
+                in.push_back(D0 + g * W + i); lut.push_back(lut_shl1_); out.push_back(R0 + g * W + i);
+            }
+        lincomb(w, li, lc, {}, lo, 2);
+        apply(w, in, lut, out);
+        // D = R + a_t (block 0) + ~B + 1 : block sums, then propagation with the carry out
+        li.clear(); lc.clear(); lo.clear(); ca.clear();
+        for (int g = 0; g < G; g++) {
+            // fold the incoming bit into R first (it is needed again if the subtraction is undone)
+            li.push_back(R0 + g * W); lc.push_back(1); li.push_back(abit0 + g * bits + t); lc.push_back(1);
+            lo.push_back(R0 + g * W); ca.push_back(0);
+        }
+        lincomb(w, li, lc, ca, lo, 2);
+        li.clear(); lc.clear(); lo.clear(); ca.clear();
+        for (int g = 0; g < G; g++) {
+            for (int i = 0; i < W; i++) {
+                li.push_back(R0 + g * W + i); lc.push_back(1); li.push_back(B0 + g * W + i); lc.push_back(-1);
+                lo.push_back(D0 + g * W + i); ca.push_back(i == 0 ? 4 : 3);
+            }
+            dbase[(size_t)g] = D0 + g * W;
+            flags[(size_t)g] = qbit0 + g * bits + t;
+        }
+        lincomb(w, li, lc, ca, lo, 2);
+        propagate(w, dbase, st0, W, &flags);
+        // R = q ? D : R
+        li.clear(); lc.clear(); lo.clear(); ca.clear(); in.clear(); lut.clear(); out.clear();
+        for (int g = 0; g < G; g++)
+            for (int i = 0; i < W; i++) {
+                const int q = qbit0 + g * bits + t;
+                li.push_back(q); lc.push_back(4); li.push_back(D0 + g * W + i); lc.push_back(1);
+                lo.push_back(selA0 + g * W + i); ca.push_back(0);
+                li.push_back(q); lc.push_back(-4); li.push_back(R0 + g * W + i); lc.push_back(1);
+                lo.push_back(selB0 + g * W + i); ca.push_back(4);
+                in.push_back(selA0 + g * W + i); lut.push_back(lut_sel_); out.push_back(selA0 + g * W + i);
+                in.push_back(selB0 + g * W + i); lut.push_back(lut_sel_); out.push_back(selB0 + g * W + i);
+            }
+        lincomb(w, li, lc, ca, lo, 2);
+        apply(w, in, lut, out);
+        li.clear(); lc.clear(); lo.clear();
+        for (int g = 0; g < G; g++)
+            for (int i = 0; i < W; i++) {
+                li.push_back(selA0 + g * W + i); lc.push_back(1); li.push_back(selB0 + g * W + i); lc.push_back(1);
+                lo.push_back(R0 + g * W + i);
+            }
+        lincomb(w, li, lc, {}, lo, 2);
+    }
+    // quotient blocks from the quotient bits
+    li.clear(); lc.clear(); lo.clear();
+    for (int g = 0; g < G; g++)
+        for (int i = 0; i < nb_; i++) {
+            li.push_back(qbit0 + g * bits + 2 * i); lc.push_back(1);
+            li.push_back(qbit0 + g * bits + 2 * i + 1); lc.push_back(2);
+            lo.push_back(dv[(size_t)g]->out + i);
+        }
+    lincomb(w, li, lc, {}, lo, 2);
 }
 
 int64_t RadixEngine::scratch_rows(const std::vector<RadixOp> &ops) const
@@ -431,6 +665,8 @@ int64_t RadixEngine::scratch_rows(const std::vector<RadixOp> &ops) const
         // rounds (about 1.5 nb): 4 nb + 4 vectors of nb rows bound both
         if (op.kind == RadixOp::Mul || op.kind == RadixOp::MulScalar) rows += (int64_t)(4 * nb_ + 4) * nb_;
         if (op.kind == RadixOp::AddScalar || op.kind == RadixOp::SubScalar) rows += nb_;
+        if (op.kind == RadixOp::Shl || op.kind == RadixOp::Shr) rows += 4 * nb_ + 8;
+        if (op.kind == RadixOp::Div || op.kind == RadixOp::DivScalar) rows += 4 * 2 * nb_ + 7 * (nb_ + 1);
     }
     return rows;
 }
@@ -480,8 +716,8 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops, i
                 prop_bases.push_back(op.out);
                 break;
             }
-            case RadixOp::Mul: case RadixOp::MulScalar:
-                break; // below
+            default:
+                break; // multiplications, shifts, divisions: below
             }
         }
         lincomb(w, li, lc, ca, lo, 2);
@@ -637,7 +873,11 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops, i
         lincomb(w, li, lc, {}, lo, 2);
     }
     // ---- carry propagation of everything that needs it -------------------------------------------
-    propagate(w, prop_bases, take(2 * nb_ * (int)prop_bases.size()));
+    propagate(w, prop_bases, take(2 * nb_ * (int)prop_bases.size()), nb_, nullptr);
+    // ---- shifts and divisions (own round structure) ----------------------------------------------
+    shift_scalar(w, ops);
+    shift_encrypted(w, ops, sp);
+    divide(w, ops, sp);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -785,8 +1025,9 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
                 if (t == GateType::Add) op.kind = RadixOp::AddScalar;
                 else if (t == GateType::Sub) op.kind = RadixOp::SubScalar;
                 else if (t == GateType::Mult) op.kind = RadixOp::MulScalar;
-                else if (t == GateType::Div || t == GateType::Shl || t == GateType::Shr)
-                    throw Panic("gate \"" + g.get_gate_name() + "\": div / shl / shr are not implemented in this build");
+                else if (t == GateType::Div) op.kind = RadixOp::DivScalar;
+                else if (t == GateType::Shl) op.kind = RadixOp::ShlScalar;
+                else if (t == GateType::Shr) op.kind = RadixOp::ShrScalar;
                 else throw Panic("internal error: entered unreachable code");
             } else {
                 if (ins.empty()) throw Panic("gate \"" + g.get_gate_name() + "\" has no input");
@@ -796,8 +1037,9 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
                 else if (ins.size() < 2) throw Panic("index out of bounds: the len is 1 but the index is 1");
                 else if (t == GateType::Add) op.kind = RadixOp::Add;
                 else if (t == GateType::Sub) op.kind = RadixOp::Sub;
-                else if (t == GateType::Div || t == GateType::Shl || t == GateType::Shr)
-                    throw Panic("gate \"" + g.get_gate_name() + "\": div / shl / shr are not implemented in this build");
+                else if (t == GateType::Div) op.kind = RadixOp::Div;
+                else if (t == GateType::Shl) op.kind = RadixOp::Shl;
+                else if (t == GateType::Shr) op.kind = RadixOp::Shr;
                 else op.kind = RadixOp::Mul; // default arm (circuit.rs:1429-1435)
             }
             ops.push_back(op);

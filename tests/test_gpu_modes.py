@@ -138,10 +138,34 @@ def test_chi_squared_u32(keys):  # circuit_test.rs:313-370, inputs K-5 (2, 7, 9)
     assert ac.pbs_per_cycle() > 0 and ac.pbs_rounds_per_cycle() > 0
 
 
-def test_arith_rejects_unimplemented_ops(keys):
+def test_shifts_and_division_u8(keys):  # gates.rs:386-452, 488-700 (div, shl, shr and their plain forms)
     client_key, server_key = keys
-    circuit, wire_set, _, _ = _circuit("input [7:0] A, B;\noutput [7:0] Y;\ndiv g0(A, B, Y);\n", is_arith=True, is_text=True)
+    text = """input [7:0] A, B;
+output [7:0] Q, QS, L3, R3, L2, R1, LV, RV;
+div g0(A, B, Q);
+div g1(A, 7, QS);
+shl g2(A, 3, L3);
+shr g3(A, 3, R3);
+shl g4(A, 2, L2);
+shr g5(A, 1, R1);
+shl g6(A, B, LV);
+shr g7(A, B, RV);
+"""
+    circuit, wire_set, _, _ = _circuit(text, is_arith=True, is_text=True)
     ac = ArithCircuit(client_key, server_key, circuit)
-    enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U8(9), "B": PtxtType.U8(2)})
-    with pytest.raises(Panic, match="not implemented"):
-        ac.evaluate_encrypted(enc, 1, "u8")
+    for a, b in ((201, 13), (77, 3), (5, 0)):
+        enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U8(a), "B": PtxtType.U8(b)})
+        out = {k: v.value for k, v in ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, "u8"), True).items()}
+        assert out["Q"] == (a // b if b else 255), (a, b, out)  # x / 0 = all ones, as tfhe's
+        assert out["QS"] == a // 7
+        assert out["L3"] == (a << 3) % 256 and out["R3"] == a >> 3 and out["L2"] == (a << 2) % 256 and out["R1"] == a >> 1
+        assert out["LV"] == (a << (b % 8)) % 256 and out["RV"] == a >> (b % 8), (a, b, out)
+
+
+def test_division_u16(keys):
+    client_key, server_key = keys
+    circuit, wire_set, _, _ = _circuit("input [15:0] A, B;\noutput [15:0] Q;\ndiv g0(A, B, Q);\n", is_arith=True, is_text=True)
+    ac = ArithCircuit(client_key, server_key, circuit)
+    enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U16(51234), "B": PtxtType.U16(321)})
+    out = ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, "u16"), True)
+    assert out["Q"] == PtxtType.U16(51234 // 321)
