@@ -737,6 +737,7 @@ struct helm_hip_program {
     int64_t n_levels;
     std::vector<int64_t> off;
     std::vector<int32_t> op, in0, in1, in2, out;
+    int64_t max_row = -1; // largest wire index any gate reads or writes
     // device copies of the full job lists, with per-level offsets
     PbsJob *d_pbs = nullptr;
     KsJob *d_ks = nullptr;
@@ -1330,6 +1331,16 @@ int helm_hip_program_create(helm_hip_ctx *ctx, const int32_t *opcode, const int3
     pr->in1.assign(in1, in1 + total);
     pr->in2.assign(in2, in2 + total);
     pr->out.assign(out, out + total);
+    for (int64_t i = 0; i < total; i++) {
+        const int32_t v[4] = {in0[i], in1[i], in2[i], out[i]};
+        for (int q = 0; q < 4; q++) {
+            if (v[q] < -1 || (q == 3 && v[q] < 0)) {
+                delete pr;
+                return fail(HELM_ERR_INVALID, "gate " + std::to_string(i) + ": bad wire index " + std::to_string(v[q]));
+            }
+            pr->max_row = std::max<int64_t>(pr->max_row, v[q]);
+        }
+    }
     pr->plans.resize(n_levels);
     std::vector<PbsJob> all_pbs;
     std::vector<KsJob> all_ks;
@@ -1391,16 +1402,14 @@ int helm_hip_program_destroy(helm_hip_ctx *ctx, helm_hip_program *prog)
     return 0;
 }
 
+// O(1): the index range of a program is established once, at creation (a level call must not
+// cost a pass over the whole netlist: 207 levels x millions of gates on a multi-GPU batch)
 static int check_program(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w)
 {
     if (!ctx || !prog || !w) return fail(HELM_ERR_INVALID, "null argument");
     if (prog->owner != ctx || w->owner != ctx) return fail(HELM_ERR_STATE, "handle belongs to another context");
-    for (size_t i = 0; i < prog->out.size(); i++) {
-        const int32_t v[4] = {prog->in0[i], prog->in1[i], prog->in2[i], prog->out[i]};
-        for (int q = 0; q < 4; q++)
-            if (v[q] >= w->n_wires || v[q] < -1 || (q == 3 && v[q] < 0))
-                return fail(HELM_ERR_INVALID, "program references wire " + std::to_string(v[q]) + " outside the table");
-    }
+    if (prog->max_row >= w->n_wires)
+        return fail(HELM_ERR_INVALID, "program references wire " + std::to_string(prog->max_row) + " outside the table");
     return 0;
 }
 
