@@ -241,19 +241,23 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
     }
     lds_wave_sync();
 
-    // key words of step i for this wave: [c][lev][e/2][lane] as double2
-    const size_t bsk_step = (size_t)K1 * K1 * L * (N / 2); // double2 per LWE coefficient
-    const double2 *bsk_p = reinterpret_cast<const double2 *>(bsk) + (size_t)p * K1 * L * (N / 2) + lane;
+    // key words of step i for this wave: [i][p][c][lev][e/2][lane] as double2, byte offsets
+    const unsigned poly_bytes = (unsigned)(N / 2) * 16u;                 // one key polynomial
+    const unsigned step_bytes = (unsigned)(K1 * K1 * L) * poly_bytes;    // one LWE coefficient
+    const unsigned row_off = (unsigned)(p * K1 * L) * poly_bytes;        // this wave's GGSW row
+    KeyBuf kb;
+    kb.init(bsk, (size_t)n * step_bytes, lane);
     double2 bw[C::PREFETCH ? K1 : 1][C::PREFETCH ? L : 1][C::PREFETCH ? E / 2 : 1];
     auto prefetch = [&](int i) {
         if constexpr (C::PREFETCH) {
-            const double2 *bp = bsk_p + (size_t)i * bsk_step;
+            const unsigned so = (unsigned)i * step_bytes + row_off;
 #pragma unroll
             for (int c = 0; c < K1; c++)
 #pragma unroll
                 for (int lev = 0; lev < L; lev++)
 #pragma unroll
-                    for (int e2 = 0; e2 < E / 2; e2++) bw[c][lev][e2] = bp[((c * L + lev) * (E / 2) + e2) * 64];
+                    for (int e2 = 0; e2 < E / 2; e2++)
+                        bw[c][lev][e2] = kb.load(so + (unsigned)(c * L + lev) * poly_bytes, e2 * 1024);
         }
     };
     auto next_nonzero = [&](int i) {
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
     if (i < n) prefetch(i);
     while (i < n) {
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
-        const double2 *bp_i = bsk_p + (size_t)i * bsk_step;
+        const unsigned so_i = (unsigned)i * step_bytes + row_off;
 
         double mine[E];
         if constexpr (M == L) {
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
                     for (int lev = 0; lev < L; lev++) {
                         double2 w;
                         if constexpr (C::PREFETCH) w = bw[c][lev][e2];
-                        else w = bp_i[((c * L + lev) * (E / 2) + e2) * 64];
+                        else w = kb.load(so_i + (unsigned)(c * L + lev) * poly_bytes, e2 * 1024);
                         s0 += mulmod<F>(x[lev][2 * e2], w.x);
                         s1 += mulmod<F>(x[lev][2 * e2 + 1], w.y);
                     }
@@ -366,14 +370,14 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
 #pragma unroll
                 for (int d = 0; d < EARLY; d++)
 #pragma unroll
-                    for (int e2 = 0; e2 < E / 2; e2++) bwl[d][e2] = bp_i[((cd[d] * L + lev) * (E / 2) + e2) * 64];
+                    for (int e2 = 0; e2 < E / 2; e2++) bwl[d][e2] = kb.load(so_i + (unsigned)(cd[d] * L + lev) * poly_bytes, e2 * 1024);
                 __builtin_amdgcn_sched_barrier(0);
                 ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int d = EARLY; d < K1; d++)
 #pragma unroll
-                    for (int e2 = 0; e2 < E / 2; e2++) bwl[d][e2] = bp_i[((cd[d] * L + lev) * (E / 2) + e2) * 64];
+                    for (int e2 = 0; e2 < E / 2; e2++) bwl[d][e2] = kb.load(so_i + (unsigned)(cd[d] * L + lev) * poly_bytes, e2 * 1024);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int d = 0; d < K1; d++)

@@ -118,6 +118,29 @@ __device__ __forceinline__ void lds_block_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Key words are read with buffer loads: one resource descriptor (scalar registers) for the whole
+// bootstrapping key, a scalar byte offset per (step, row, column, level), one lane-offset
+// register and an immediate per word - no per-load 64-bit vector address arithmetic.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+struct KeyBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int lane16; // lane * 16 bytes
+    __device__ __forceinline__ void init(const void *base, size_t bytes, int lane)
+    {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0,
+                                                 (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes), 0x00020000);
+        lane16 = lane * 16;
+    }
+    // double2 at byte offset soff (wave-uniform) + imm (compile-time) + lane * 16
+    __device__ __forceinline__ double2 load(unsigned soff, int imm) const
+    {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16 + imm, (int)soff, 0);
+        double2 d;
+        __builtin_memcpy(&d, &v, 16);
+        return d;
+    }
+};
+
 // Wave-private LDS accumulate (ds_add_f64, no return value).
 __device__ __forceinline__ void lds_add(double *p, double v)
 {
