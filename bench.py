@@ -45,8 +45,10 @@ def main():
     ap.add_argument("--blocks", type=int, default=16, help="AES blocks per GPU evaluated together")
     ap.add_argument("--params", default="boolean_default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-levels", type=int, default=2, help="netlist levels (1 block) timed on the CPU oracle")
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the LUT-mode / arithmetic-mode side measurements")
+    ap.add_argument("--cpu-levels", type=int, default=8, help="at most this many netlist levels (1 block) on the CPU oracle")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="stop the CPU sample after this much time")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every logical CPU of the box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -239,14 +241,15 @@ def main():
         rows = [index[f"key[{i}]"] for i in range(128)] + [index[f"pt[{i}]"] for i in range(128)]
         del bits  # the oracle must see the very ciphertexts the GPU evaluated
         host[rows] = wires.download(np.array(rows, np.int32))
-        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-        L = min(args.cpu_levels, len(o_off) - 1)
-        n_pbs = 0
+        ncpu = os.cpu_count() or 1
+        threads = max(1, min(args.cpu_threads or ncpu, ncpu))
+        n_pbs, L = 0, 0
         t0 = time.perf_counter()
-        for l in range(L):
-            s = slice(o_off[l], o_off[l + 1])
+        while L < min(args.cpu_levels, len(o_off) - 1) and (L < 1 or time.perf_counter() - t0 < args.cpu_seconds):
+            s = slice(o_off[L], o_off[L + 1])
             orc.eval_level(host, o_ops[s], o_i0[s], o_i1[s], o_i2[s], o_out[s], nthreads=threads)
             n_pbs += int(np.sum(o_ops[s] != oracle.NOT))
+            L += 1
         cpu_s = time.perf_counter() - t0
         gpu_rows = wires.download(o_out[:o_off[L]])
         same = bool(np.array_equal(gpu_rows, host[o_out[:o_off[L]]]))
@@ -259,9 +262,53 @@ def main():
         }
         if not same:
             raise SystemExit("GPU ciphertexts differ from the CPU oracle on the sampled levels")
+    # ---- the other two modes of the reference, same GPU, outside the timed region: 3-input LUT
+    #      gates (BASELINE config 3's primitive) and the chi-squared u32 netlist (config 5) ------
+    if world == 1 and not args.no_other_modes:
+        try:
+            result["other_modes"] = other_modes(local_rank)
+        except Exception as e:  # the headline line must survive a failure here
+            result["other_modes"] = {"error": repr(e)}
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def other_modes(device):
+    import helm_amd
+    from helm_amd import ArithCircuit, Circuit, PtxtType, verilog_parser
+    ck, sk = helm_amd.gen_keys_shortint("shortint_m2c2", seed=1, device=device)
+    B = 1024
+    bits = np.random.default_rng(0).integers(0, 2, size=3 * B).astype(np.uint64)
+    w = sk.wires(4 * B)
+    w.upload(np.arange(3 * B), ck.encrypt(bits))
+    in_idx = np.arange(3 * B, dtype=np.int32).reshape(3, B).T.copy()
+    ar, tb, out = np.full(B, 3, np.int32), np.full(B, 0xE8, np.uint64), np.arange(3 * B, 4 * B, dtype=np.int32)
+    w.eval_lut_level(ar, in_idx, tb, out)
+    sk.sync()
+    t0 = time.perf_counter()
+    w.eval_lut_level(ar, in_idx, tb, out)
+    sk.sync()
+    dt = time.perf_counter() - t0
+    ok = bool(np.array_equal(ck.decrypt(w.download(out)), (bits[:B] + bits[B:2 * B] + bits[2 * B:]) >= 2))
+    res = {"lut_mode": {"workload": f"{B} independent 3-input LUT gates (keyswitch + programmable bootstrap), "
+                                    "PARAM_MESSAGE_2_CARRY_2", "luts_per_s": round(B / dt, 1), "decrypt_ok": ok}}
+    g, ws, i, o, d, _, _ = verilog_parser.read_verilog_file(os.path.join(ROOT, "tests", "netlists", "chi_squared_arith.v"), True)
+    c = Circuit(g, i, o, d)
+    c.sort_circuit()
+    c.compute_levels()
+    ac = ArithCircuit(ck, sk, c)
+    enc = ac.encrypt_inputs(ws, {"N0": PtxtType.U32(2), "N1": PtxtType.U32(7), "N2": PtxtType.U32(9)})
+    ac.evaluate_encrypted(enc, 1, "u32")
+    t0 = time.perf_counter()
+    outm = ac.evaluate_encrypted(enc, 1, "u32")
+    dt = time.perf_counter() - t0
+    dec = {k: int(v.value) for k, v in ac.decrypt_outputs(outm, True).items()}
+    res["arith_mode"] = {"workload": "chi_squared_arith.v, u32 (16 radix blocks per integer)", "wall_s": round(dt, 4),
+                         "bootstraps": ac.pbs_per_cycle(), "batched_rounds": ac.pbs_rounds_per_cycle(),
+                         "decrypt_ok": dec == {"alpha": 529, "beta1": 242, "beta2": 275, "beta3": 1250}}
+    sk.close()
+    return res
 
 
 if __name__ == "__main__":

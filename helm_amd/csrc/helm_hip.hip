@@ -866,6 +866,9 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
         if (v == 2) return launch_pbs_v<Bal>(ctx, jobs, count, wires, raw, tvs, out_big);
         return launch_pbs_v<Thr>(ctx, jobs, count, wires, raw, tvs, out_big);
     } else {
+        // N = 1024 (k = 1): two waves per bootstrap, 422 registers: two workgroups per CU put one
+        // wave on every SIMD (82.6 k gates/s on helm_cuda; a one-level-at-a-time build with 256
+        // registers spilled and measured 73 k)
         using Big = PbsCfg<F, LOGN, K, L, L, TW_LANE, true, 1>;
         return launch_pbs_v<Big>(ctx, jobs, count, wires, raw, tvs, out_big);
     }
