@@ -182,6 +182,20 @@ struct Geo {
     // LDS paddings making both sides of each transpose bank-conflict free.
     __device__ static __forceinline__ int pad1(int j) { return j + ((j >> (LOGN - 3)) << 3); }
     __device__ static __forceinline__ int pad2(int j) { return j + (j >> LOGE); }
+    // The same padded indices as (per-lane base) + (compile-time offset of slot e), so that every
+    // transpose access is one address register plus an immediate:
+    //   pad1(jA) = baseA(lane) + offA1(e)    pad1(jB) = baseB(lane) + offB1(e)
+    //   pad2(jB) = baseB(lane) + offB2(e)    pad2(jC) = baseC(lane) + e
+    __device__ static __forceinline__ int baseA(int lane) { return lane; }
+    __device__ static __forceinline__ int baseB(int lane)
+    {
+        return ((lane >> BC) << (LOGN - 3)) + ((lane >> BC) << 3) + (lane & ((1 << BC) - 1));
+    }
+    __device__ static __forceinline__ int baseC(int lane) { return lane * (E + 1); }
+    static constexpr int offA1(int e) { return (e << 6) + ((e >> (LOGN - 9)) << 3); }
+    static constexpr int offB1(int e) { return e << BC; }
+    static constexpr int offB2(int e) { return (e << BC) + (e >> (LOGE - BC)); }
+    static_assert(BC == 3, "the base/offset forms assume 8-lane groups in layout B");
 };
 
 // Twiddle sources.  Twiddle of the butterfly on stride bit sb for coefficient j is
@@ -406,26 +420,27 @@ __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double
 {
     using G = Geo<LOGN>;
     fwd_block<F, LOGN, M, 6, LOGN - 1, LOGN - G::BA, 0>(x, tw, G::jA(lane, 0));
+    double *pA = xbuf + G::baseA(lane), *pB = xbuf + G::baseB(lane), *pC = xbuf + G::baseC(lane);
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
-        for (int e = 0; e < G::E; e++) xbuf[m * G::XPAD + G::pad1(G::jA(lane, e))] = reduce_unless_lazy<F>(x[m][e]);
+        for (int e = 0; e < G::E; e++) pA[m * G::XPAD + G::offA1(e)] = reduce_unless_lazy<F>(x[m][e]);
     lds_wave_sync();
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
-        for (int e = 0; e < G::E; e++) x[m][e] = xbuf[m * G::XPAD + G::pad1(G::jB(lane, e))];
+        for (int e = 0; e < G::E; e++) x[m][e] = pB[m * G::XPAD + G::offB1(e)];
     lds_wave_sync();
     fwd_block<F, LOGN, M, G::BC, G::BC + G::BB - 1, G::BC, G::TWA>(x, tw, G::jB(lane, 0));
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
-        for (int e = 0; e < G::E; e++) xbuf[m * G::XPAD + G::pad2(G::jB(lane, e))] = reduce_unless_lazy<F>(x[m][e]);
+        for (int e = 0; e < G::E; e++) pB[m * G::XPAD + G::offB2(e)] = reduce_unless_lazy<F>(x[m][e]);
     lds_wave_sync();
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
-        for (int e = 0; e < G::E; e++) x[m][e] = xbuf[m * G::XPAD + G::pad2(G::jC(lane, e))];
+        for (int e = 0; e < G::E; e++) x[m][e] = pC[m * G::XPAD + e];
     lds_wave_sync();
     fwd_block<F, LOGN, M, 0, G::BC - 1, 0, G::TWA + G::TWB>(x, tw, G::jC(lane, 0));
 }
@@ -438,18 +453,19 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *x
 {
     using G = Geo<LOGN>;
     inv_block<F, LOGN, 0, 0, G::BC - 1, 0>(x, tw, G::jC(lane, 0));
+    double *pA = xbuf + G::baseA(lane), *pB = xbuf + G::baseB(lane), *pC = xbuf + G::baseC(lane);
 #pragma unroll
-    for (int e = 0; e < G::E; e++) xbuf[G::pad2(G::jC(lane, e))] = reduce<F>(x[e]);
+    for (int e = 0; e < G::E; e++) pC[e] = reduce<F>(x[e]);
     lds_wave_sync();
 #pragma unroll
-    for (int e = 0; e < G::E; e++) x[e] = xbuf[G::pad2(G::jB(lane, e))];
+    for (int e = 0; e < G::E; e++) x[e] = pB[G::offB2(e)];
     lds_wave_sync();
     inv_block<F, LOGN, G::BC, G::BC, G::BC + G::BB - 1, G::TWC>(x, tw, G::jB(lane, 0));
 #pragma unroll
-    for (int e = 0; e < G::E; e++) xbuf[G::pad1(G::jB(lane, e))] = reduce<F>(x[e]);
+    for (int e = 0; e < G::E; e++) pB[G::offB1(e)] = reduce<F>(x[e]);
     lds_wave_sync();
 #pragma unroll
-    for (int e = 0; e < G::E; e++) x[e] = xbuf[G::pad1(G::jA(lane, e))];
+    for (int e = 0; e < G::E; e++) x[e] = pA[G::offA1(e)];
     lds_wave_sync();
     inv_block<F, LOGN, 6, LOGN - G::BA, LOGN - 1, G::TWC + G::TWB>(x, tw, G::jA(lane, 0));
 #pragma unroll
