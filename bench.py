@@ -48,7 +48,9 @@ def main():
     ap.add_argument("--no-other-modes", action="store_true", help="skip the LUT-mode / arithmetic-mode side measurements")
     ap.add_argument("--cpu-levels", type=int, default=8, help="at most this many netlist levels (1 block) on the CPU oracle")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="stop the CPU sample after this much time")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every logical CPU of the box")
+    ap.add_argument("--cpu-threads", type=int, default=32,
+                    help="OpenMP threads of the CPU sample (0 = every logical CPU); measured on the 1-GPU box, whose CPU "
+                         "share is 16 cores: 16 -> 192, 32 -> 212, 64 -> 213, 128 -> 160, 256 -> 123 gates/s")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
