@@ -101,11 +101,13 @@ __device__ __forceinline__ void decompose(uint32_t x, int logB, int (&dig)[L])
     const uint32_t mask = (1u << logB) - 1u;
 #pragma unroll
     for (int lev = L - 1; lev >= 0; lev--) {
-        uint32_t d = state & mask;
+        const uint32_t d = state & mask;
         state >>= logB;
-        uint32_t carry = (((d - 1u) | state) & d) >> (logB - 1);
-        state += carry;
-        dig[lev] = (int)d - (int)(carry << logB);
+        // -carry straight from the deciding bit (one signed bit-field extract), then
+        // state -= (-carry), digit = d + ((-carry) << logB) (one shift-add)
+        const int nc = __builtin_amdgcn_sbfe(((d - 1u) | state) & d, logB - 1, 1);
+        state -= (uint32_t)nc;
+        dig[lev] = (int)d + (int)((uint32_t)nc << logB);
     }
 }
 
@@ -150,11 +152,14 @@ struct PbsCfg {
     // slot 0 is the (padded) transform scratch; with M == 1 the other slots only carry the
     // hand-over and need no padding
     static constexpr int SLOT_STRIDE = M > 1 ? G::XPAD : G::N;
-    static constexpr int WAVE_STRIDE = G::XPAD + (SLOTS - 1) * SLOT_STRIDE;
+    // the u32 copy of a wave's accumulator polynomial lives in the wave's (then idle) exchange
+    // slots, unrolled negacyclically over 3N - 64 entries (+acc, -acc, +acc) so that the rotated
+    // read of slot e is one address register + 256 e bytes, sign included
+    static constexpr int ACC3 = 3 * G::N - 64;
+    static constexpr int WAVE_STRIDE_X = G::XPAD + (SLOTS - 1) * SLOT_STRIDE;
+    static constexpr int WAVE_STRIDE = WAVE_STRIDE_X > (ACC3 + 1) / 2 ? WAVE_STRIDE_X : (ACC3 + 1) / 2;
     static constexpr int slot_off(int s) { return s == 0 ? 0 : G::XPAD + (s - 1) * SLOT_STRIDE; }
     static constexpr int TW_ROWS = TW == TW_LANE ? G::TWB + G::TWC : 0;
-    // the u32 copy of a wave's accumulator polynomial (needed only for the rotated read at
-    // the start of a step) lives in the wave's transform scratch, which is idle then
     static constexpr size_t X_OFF = 0;                                                // double [K1][WAVE_STRIDE]
     static constexpr size_t TW_OFF = X_OFF + sizeof(double) * K1 * WAVE_STRIDE;       // double [TW_ROWS][64]
     static constexpr size_t MS_OFF = TW_OFF + sizeof(double) * TW_ROWS * 64;          // u16 [n+1]
@@ -236,9 +241,18 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
                 if (idx >= N) v = 0u - v;
             }
             accr[e] = v;
-            acc_p[j] = v;
         }
     }
+    auto acc_store = [&]() { // acc3[j] = v, acc3[j + N] = -v, acc3[j + 2N] = v (j < N - 64)
+        uint32_t *aw = acc_p + lane;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            aw[64 * e] = accr[e];
+            aw[64 * e + N] = 0u - accr[e];
+            if (e < E - 1) aw[64 * e + 2 * N] = accr[e];
+        }
+    };
+    acc_store();
     lds_wave_sync();
 
     // key words of step i for this wave: [i][p][c][lev][e/2][lane] as double2, byte offsets
@@ -283,12 +297,12 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
             double x[L][E];
             {
                 uint32_t rot[E];
+                const uint32_t *ar = acc_p + ((lane - a) & (2 * N - 1)); // (X^a acc)[jA(lane, e)] = ar[64 e]
 #pragma unroll
-                for (int e = 0; e < E; e++) rot[e] = acc_p[(G::jA(lane, e) - a) & (N - 1)];
+                for (int e = 0; e < E; e++) rot[e] = ar[64 * e];
 #pragma unroll
                 for (int e = 0; e < E; e++) {
-                    const int src = (G::jA(lane, e) - a) & (2 * N - 1);
-                    const uint32_t v = src >= N ? 0u - rot[e] : rot[e];
+                    const uint32_t v = rot[e];
                     int dig[L];
                     decompose<L>(v - accr[e], logB, dig);
 #pragma unroll
@@ -333,13 +347,9 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
             uint32_t state[E];
             {
                 const int rep = logB * L;
+                const uint32_t *ar = acc_p + ((lane - a) & (2 * N - 1)); // (X^a acc)[jA(lane, e)] = ar[64 e]
 #pragma unroll
-                for (int e = 0; e < E; e++) {
-                    const int src = (G::jA(lane, e) - a) & (2 * N - 1);
-                    uint32_t v = acc_p[src & (N - 1)];
-                    if (src >= N) v = 0u - v;
-                    state[e] = ((v - accr[e]) + (1u << (31 - rep))) >> (32 - rep);
-                }
+                for (int e = 0; e < E; e++) state[e] = ((ar[64 * e] - accr[e]) + (1u << (31 - rep))) >> (32 - rep);
             }
             // Key column (p + d) % K1 is handled at distance d: d = 0 is this wave's own sum
             // (registers), d = 1 stays in registers and is written to the transform scratch
@@ -356,11 +366,11 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
                 double x[1][E];
 #pragma unroll
                 for (int e = 0; e < E; e++) {
-                    uint32_t d = state[e] & mask;
-                    uint32_t st = state[e] >> logB;
-                    const uint32_t carry = (((d - 1u) | st) & d) >> (logB - 1);
-                    state[e] = st + carry;
-                    x[0][e] = (double)((int)d - (int)(carry << logB));
+                    const uint32_t d = state[e] & mask;
+                    const uint32_t st = state[e] >> logB;
+                    const int nc = __builtin_amdgcn_sbfe(((d - 1u) | st) & d, logB - 1, 1); // -carry
+                    state[e] = st - (uint32_t)nc;
+                    x[0][e] = (double)((int)d + (int)((uint32_t)nc << logB));
                 }
                 // this level's key words: issued before the transform that hides their latency
                 // (the last column is fetched after the transform: during it the transform's own
@@ -443,10 +453,8 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
 
         ntt_inverse<F, LOGN>(mine, xb, twi, lane);
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            accr[e] += to_torus32(mine[e]);
-            acc_p[G::jA(lane, e)] = accr[e];
-        }
+        for (int e = 0; e < E; e++) accr[e] += to_torus32(mine[e]);
+        acc_store();
         lds_wave_sync();
         i = inext;
     }
