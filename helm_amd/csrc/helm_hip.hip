@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
         return i;
     };
 
-    const bool stamp = probe && blockIdx.x == 0 && tid == 0;
+    const bool stamp = (probe & 1) && blockIdx.x == 0 && tid == 0;
     if (stamp) {
         g_clock_probe[0] = __builtin_amdgcn_s_memtime();
         g_clock_probe[1] = __builtin_amdgcn_s_memrealtime();
@@ -288,6 +288,13 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
     int i = next_nonzero(0);
     if (i < n) prefetch(i);
     while (i < n) {
+        if (probe & 2) {
+            // experiment (HELM_HIP_PRIO_ROTATE): the CU arbitrates VALU issue oldest-first, so the four
+            // workgroups of a CU drift apart; rotate a raised priority through them instead
+            const int pr = ((i >> 4) + (int)(blockIdx.x >> 8)) & 3;
+            if (pr == 0) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
         const unsigned so_i = (unsigned)i * step_bytes + row_off;
 
@@ -842,7 +849,7 @@ static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * (C::K + 1)), C::BYTES, ctx->stream, jobs, wires, raw, tvs,
                        ctx->bsk, ctx->tw_fwd, ctx->tw_inv, out_big, ctx->P.n, ctx->P.pbs_logB, ctx->clock_probe);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess && ctx->clock_probe) {
+    if (e == hipSuccess && (ctx->clock_probe & 1)) {
         unsigned long long v[4];
         (void)hipStreamSynchronize(ctx->stream);
         if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_clock_probe), sizeof(v)) == hipSuccess && v[3] > v[1])
@@ -1033,6 +1040,7 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
     ctx->n_cus = prop.multiProcessorCount;
     if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) ctx->pbs_variant = atoi(v);
     if (const char *v = getenv("HELM_HIP_CLOCK_PROBE")) ctx->clock_probe = atoi(v);
+    if (const char *v = getenv("HELM_HIP_PRIO_ROTATE")) ctx->clock_probe |= atoi(v) ? 2 : 0;
     while ((1 << ctx->logN) < P.N) ctx->logN++;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
