@@ -486,6 +486,228 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
 }
 
 // ------------------------------------------------------------------------------------
+// k_pbs_wide: one workgroup of (k+1)*L waves per bootstrap - one wave per (polynomial, level).
+// For launches that leave CUs partly empty (<= one bootstrap per CU: a single netlist's levels)
+// the chain of n CMUX steps is the whole cost, so the step is spread over every SIMD of the CU:
+// wave (r, lev) rotates / subtracts polynomial r, keeps digit `lev` of the decomposition,
+// transforms it (one NTT instead of L), multiplies by its k+1 key polynomials and adds the
+// products into per-column accumulators in LDS (ds_add_f64: exact integer sums, any order);
+// the lev = 0 wave of polynomial c then recentres column c, inverse-transforms, lifts and
+// updates the accumulator copy every wave of the polynomial reads in the next step.
+// ------------------------------------------------------------------------------------
+#ifdef HELM_WIDE_STAMPS
+__device__ unsigned long long g_wide_stamps[16 * 6];
+#endif
+template <typename F_, int LOGN_, int K_, int L_>
+struct WideCfg {
+    using F = F_;
+    static constexpr int LOGN = LOGN_, K = K_, L = L_, K1 = K_ + 1, NW = (K_ + 1) * L_;
+    using G = Geo<LOGN>;
+    static constexpr int MAX_SMALL_N = 1024;
+    static constexpr int ACC3 = (3 * G::N - 64 + 1) / 2 * 2; // u32 entries per polynomial (see PbsCfg)
+    static constexpr int TW_ROWS = G::TWB + G::TWC;
+    static constexpr size_t X_OFF = 0;                                              // double [NW][XPAD]
+    static constexpr size_t COL_OFF = X_OFF + sizeof(double) * NW * G::XPAD;        // double [K1][N]
+    static constexpr size_t TW_OFF = COL_OFF + sizeof(double) * K1 * G::N;          // double [TW_ROWS][64]
+    static constexpr size_t ACC_OFF = TW_OFF + sizeof(double) * TW_ROWS * 64;       // u32 [K1][ACC3]
+    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint32_t) * K1 * ACC3;        // u16 [n+1]
+    static constexpr size_t BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
+};
+
+template <typename C>
+__global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__restrict__ jobs,
+                                                            const uint32_t *__restrict__ wires,
+                                                            const uint32_t *__restrict__ raw_in,
+                                                            const uint32_t *__restrict__ tvs,
+                                                            const double *__restrict__ bsk,
+                                                            const double *__restrict__ tw_fwd,
+                                                            uint32_t *__restrict__ out_big, int n, int logB)
+{
+    constexpr int LOGN = C::LOGN, K = C::K, L = C::L, K1 = C::K1, NW = C::NW;
+    using F = typename C::F;
+    using G = Geo<LOGN>;
+    constexpr int N = G::N, E = G::E;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *X = reinterpret_cast<double *>(smem + C::X_OFF);
+    double *COL = reinterpret_cast<double *>(smem + C::COL_OFF);
+    double *TW = reinterpret_cast<double *>(smem + C::TW_OFF);
+    uint32_t *ACC = reinterpret_cast<uint32_t *>(smem + C::ACC_OFF);
+    uint16_t *MS = reinterpret_cast<uint16_t *>(smem + C::MS_OFF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = w / L, lev = w - r * L; // polynomial (GGSW row) and decomposition level of this wave
+    const PbsJob job = jobs[blockIdx.x];
+    const size_t row = (size_t)n + 1;
+    {
+        const uint32_t *a0 = nullptr, *a1 = nullptr, *a2 = nullptr;
+        if (job.op < 0) a0 = raw_in + row * (size_t)job.in0;
+        else {
+            if (job.in0 >= 0) a0 = wires + row * (size_t)job.in0;
+            if (job.in1 >= 0) a1 = wires + row * (size_t)job.in1;
+            if (job.in2 >= 0) a2 = wires + row * (size_t)job.in2;
+        }
+        for (int i = tid; i <= n; i += 64 * NW) {
+            uint32_t v;
+            if (job.op < 0) v = a0[i];
+            else v = gate_lincomb(job.op, job.which, a0 ? a0[i] : 0u, a1 ? a1[i] : 0u, a2 ? a2[i] : 0u, i == n);
+            MS[i] = (uint16_t)modswitch(v, LOGN + 1);
+        }
+    }
+    for (int q = w; q < C::TW_ROWS; q += NW) TW[q * 64 + lane] = tw_fwd[tw_lane_index<LOGN>(q, lane)];
+    for (int j = tid; j < K1 * N; j += 64 * NW) COL[j] = 0.0;
+    TwLane<LOGN, false> twf;
+    TwLane<LOGN, true> twi;
+    twf.base = TW + lane;
+    twi.base = TW + (63 - lane);
+    twf.fill_uniform(tw_fwd);
+    twi.fill_uniform(tw_fwd);
+    __syncthreads();
+
+    // accumulator (0, ..., 0, X^{-b~} tv): the lev = 0 wave of polynomial r owns it (registers)
+    // and publishes the negacyclically unrolled u32 copy every wave of the polynomial reads
+    uint32_t *acc_r = ACC + (size_t)r * C::ACC3;
+    uint32_t accr[E];
+    auto acc_store = [&]() {
+        uint32_t *aw = acc_r + lane;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            aw[64 * e] = accr[e];
+            aw[64 * e + N] = 0u - accr[e];
+            if (e < E - 1) aw[64 * e + 2 * N] = accr[e];
+        }
+    };
+    if (lev == 0) {
+        const int bt = (int)MS[n];
+        const uint32_t *tv = tvs + (size_t)job.tv * N;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            uint32_t v = 0;
+            if (r == K) {
+                const int idx = (G::jA(lane, e) + bt) & (2 * N - 1);
+                v = tv[idx & (N - 1)];
+                if (idx >= N) v = 0u - v;
+            }
+            accr[e] = v;
+        }
+        acc_store();
+    }
+    __syncthreads();
+
+    double *xb = X + (size_t)w * G::XPAD;
+    const unsigned poly_bytes = (unsigned)(N / 2) * 16u;
+    const unsigned step_bytes = (unsigned)(K1 * K1 * L) * poly_bytes;
+    const unsigned wave_off = (unsigned)(r * K1 * L + lev) * poly_bytes; // + c * L * poly_bytes per column
+    KeyBuf kb;
+    kb.init(bsk, (size_t)n * step_bytes, lane);
+    const uint32_t mask = (1u << logB) - 1u;
+    const int rep = logB * L;
+
+#ifdef HELM_WIDE_STAMPS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, t0, t1;
+#define STAMP(k)                                   \
+    t1 = __builtin_amdgcn_s_memtime();             \
+    __builtin_amdgcn_s_waitcnt(0xC07F);            \
+    ph[k] += t1 - t0;                              \
+    t0 = t1;
+#else
+#define STAMP(k)
+#endif
+    for (int i = 0; i < n; i++) {
+        const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
+        if (a == 0) continue; // uniform over the workgroup
+#ifdef HELM_WIDE_STAMPS
+        t0 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+        // this step's key words (k+1 polynomials of this wave's row and level)
+        double2 kw[K1][E / 2];
+        const unsigned so = (unsigned)i * step_bytes + wave_off;
+#pragma unroll
+        for (int c = 0; c < K1; c++)
+#pragma unroll
+            for (int e2 = 0; e2 < E / 2; e2++) kw[c][e2] = kb.load(so + (unsigned)(c * L) * poly_bytes, e2 * 1024);
+        // rotate / subtract, run the signed decomposition down to this wave's level
+        double x[1][E];
+        {
+            const uint32_t *ar = acc_r + ((lane - a) & (2 * N - 1));
+            const uint32_t *ac = acc_r + lane;
+            uint32_t st[E];
+            int dig[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) st[e] = ((ar[64 * e] - ac[64 * e]) + (1u << (31 - rep))) >> (32 - rep);
+            // the carry chain runs from the least significant level down to this wave's own
+#pragma unroll
+            for (int l = L - 1; l >= 0; l--) {
+                if (l >= lev) {
+#pragma unroll
+                    for (int e = 0; e < E; e++) {
+                        const uint32_t d = st[e] & mask;
+                        st[e] >>= logB;
+                        const int nc = __builtin_amdgcn_sbfe(((d - 1u) | st[e]) & d, logB - 1, 1);
+                        st[e] -= (uint32_t)nc;
+                        dig[e] = (int)d + (int)((uint32_t)nc << logB);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) x[0][e] = (double)dig[e];
+        }
+        STAMP(0) // loads issued, rotation, decomposition
+        ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+        STAMP(1) // forward transform
+#pragma unroll
+        for (int c = 0; c < K1; c++) {
+            double *col = COL + (size_t)c * N + lane;
+#pragma unroll
+            for (int e2 = 0; e2 < E / 2; e2++) {
+                // (k+1) L products meet in a column: <= 11.3 p in the lazy field (2^53 = 14.2 p); the
+                // 51-bit field recentres each first (<= 4.5 p of its 5.3 p)
+                lds_add_wg(col + (2 * e2) * 64, reduce_unless_lazy<F>(mulmod<F>(x[0][2 * e2], kw[c][e2].x)));
+                lds_add_wg(col + (2 * e2 + 1) * 64, reduce_unless_lazy<F>(mulmod<F>(x[0][2 * e2 + 1], kw[c][e2].y)));
+            }
+        }
+        STAMP(2) // products
+        lds_block_sync(); // every product of the step is in its column
+        STAMP(3) // barrier 1
+        if (lev == 0) {
+            double mine[E];
+            double *col = COL + (size_t)r * N + lane;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                mine[e] = reduce<F>(col[e * 64]);
+                col[e * 64] = 0.0;
+            }
+            ntt_inverse<F, LOGN>(mine, xb, twi, lane);
+#pragma unroll
+            for (int e = 0; e < E; e++) accr[e] += to_torus32(mine[e]);
+            acc_store();
+        }
+        STAMP(4) // inverse side (lev = 0) or nothing
+        lds_block_sync(); // accumulator copies published, columns cleared
+        STAMP(5) // barrier 2
+    }
+#ifdef HELM_WIDE_STAMPS
+    if (blockIdx.x == 0 && lane == 0)
+        for (int q = 0; q < 6; q++) g_wide_stamps[w * 6 + q] = ph[q];
+#endif
+
+    uint32_t *ob = out_big + (size_t)blockIdx.x * ((size_t)K * N + 1);
+    if (lev == 0) {
+        if (r < K) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int j = G::jA(lane, e);
+                if (j == 0) ob[r * N] = accr[e];
+                else ob[r * N + (N - j)] = 0u - accr[e];
+            }
+        } else if (lane == 0) {
+            ob[K * N] = accr[0];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // k_keyswitch: grid (ceil(jobs / 4), column chunks); 256 threads; one output column per
 // thread, FOUR gates per workgroup so that every key word fetched (from L2 / Infinity
 // Cache: the key is 12 MB and shared by all gates) feeds four multiply-adds.
@@ -734,6 +956,7 @@ struct helm_hip_ctx {
     bool have_bsk = false, have_ksk = false;
     int field = 51; // Fp<51> or Fp<49> (lazy), chosen from the parameter set
     int n_cus = 256;
+    int narrow_variant = 4;  // build for launches of at most one workgroup per CU: 4 wide, 1 latency (HELM_HIP_NARROW)
     int clock_probe = 0;     // HELM_HIP_CLOCK_PROBE: print the in-kernel clock of every k_pbs launch
     int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput (HELM_HIP_PBS_VARIANT)
     // per-call scratch
@@ -859,14 +1082,49 @@ static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
     return e;
 }
 
+template <typename C>
+static hipError_t launch_pbs_wide(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
+                                  const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
+{
+    static bool attr_done[64] = {false};
+    auto kern = k_pbs_wide<C>;
+    if (!attr_done[ctx->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
+        if (e != hipSuccess) return e;
+        attr_done[ctx->device & 63] = true;
+        if (getenv("HELM_HIP_VERBOSE")) {
+            hipFuncAttributes fa{};
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
+            fprintf(stderr, "[helm_hip] k_pbs_wide: %d waves, LDS %zu B, regs %d, scratch %zu B\n", C::NW, (size_t)C::BYTES,
+                    fa.numRegs, (size_t)fa.localSizeBytes);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, wires, raw, tvs, ctx->bsk,
+                       ctx->tw_fwd, out_big, ctx->P.n, ctx->P.pbs_logB);
+#ifdef HELM_WIDE_STAMPS
+    {
+        unsigned long long v[16 * 6];
+        (void)hipStreamSynchronize(ctx->stream);
+        if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_wide_stamps), sizeof(v)) == hipSuccess)
+            for (int w = 0; w < C::NW; w++)
+                fprintf(stderr, "[wide] wave %d (r %d lev %d): prep %llu fwd %llu mac %llu bar1 %llu inv %llu bar2 %llu cycles/step\n", w,
+                        w / C::L, w % C::L, v[w * 6] / 722, v[w * 6 + 1] / 722, v[w * 6 + 2] / 722, v[w * 6 + 3] / 722,
+                        v[w * 6 + 4] / 722, v[w * 6 + 5] / 722);
+    }
+#endif
+    return hipGetLastError();
+}
+
 // Build choice.  Measured on MI355X, boolean_default (profiles/r01/microbench_nand_*): one
 // launch of B bootstraps takes, by the largest number j of workgroups a CU receives,
 //   latency    4.4 ms per round of 256 (one workgroup per CU)
 //   balanced   4.8 (j = 1), 7.6 (j = 2) ms
 //   throughput 4.9, 7.4, 9.9, 12.4 ms for j = 1..4 (12 waves per CU, three per SIMD), 12.0 ms
 //              per 1,024 in longer launches
-// so a launch that fits one workgroup per CU uses the latency build and every wider one the
-// throughput build.  HELM_HIP_PBS_VARIANT=1|2|3 forces a build (profiling).
+//   wide       3.7 - 3.9 ms per round of <= 256 ((k+1) L = 9 waves per bootstrap: k_pbs_wide)
+// so a launch that fits one workgroup per CU uses the wide kernel (HELM_HIP_NARROW=1: the latency
+// build) and every wider one the throughput build.  HELM_HIP_PBS_VARIANT=1|2|3|4 forces a build.
 template <typename F, int LOGN, int K, int L>
 static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
                                const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
@@ -876,7 +1134,8 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
         using Bal = PbsCfg<F, LOGN, K, L, L, TW_LANE, true, 2>;
         using Thr = PbsCfg<F, LOGN, K, L, 1, TW_LANE, false, 3>;
         int v = ctx->pbs_variant;
-        if (v == 0) v = count <= ctx->n_cus ? 1 : 3;
+        if (v == 0) v = count <= ctx->n_cus ? ctx->narrow_variant : 3;
+        if (v == 4) return launch_pbs_wide<WideCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (v == 1) return launch_pbs_v<Lat>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (v == 2) return launch_pbs_v<Bal>(ctx, jobs, count, wires, raw, tvs, out_big);
         return launch_pbs_v<Thr>(ctx, jobs, count, wires, raw, tvs, out_big);
@@ -1039,6 +1298,7 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
     ctx->P = P;
     ctx->n_cus = prop.multiProcessorCount;
     if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) ctx->pbs_variant = atoi(v);
+    if (const char *v = getenv("HELM_HIP_NARROW")) ctx->narrow_variant = atoi(v) == 4 ? 4 : 1;
     if (const char *v = getenv("HELM_HIP_CLOCK_PROBE")) ctx->clock_probe = atoi(v);
     if (const char *v = getenv("HELM_HIP_PRIO_ROTATE")) ctx->clock_probe |= atoi(v) ? 2 : 0;
     while ((1 << ctx->logN) < P.N) ctx->logN++;

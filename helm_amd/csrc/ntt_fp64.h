@@ -147,6 +147,12 @@ __device__ __forceinline__ void lds_add(double *p, double v)
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+// LDS accumulate shared by the waves of a workgroup (atomic ds_add_f64).
+__device__ __forceinline__ void lds_add_wg(double *p, double v)
+{
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // twiddles one lane needs for a block: sum over its stages of E >> (eb+1)
 constexpr int ntw_count(int E, int shift, int sb_lo, int sb_hi)
 {
