@@ -115,6 +115,27 @@ __device__ __forceinline__ void decompose(uint32_t x, int logB, int (&dig)[L])
 // clock) and s_memrealtime (100 MHz) around its blind rotation; the ratio is the clock the
 // chip actually holds under this kernel's load.  Written to a buffer nothing else reads.
 __device__ unsigned long long g_clock_probe[4];
+#ifdef HELM_WIDE_STAMPS
+// per-phase cycle totals (diagnostic build only): [workgroup 0 | last workgroup][wave][phase]
+__device__ unsigned long long g_wide_stamps[2 * 16 * 6];
+#define STAMP_DECL unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1;
+#define STAMP_BEGIN                        \
+    t0 = __builtin_amdgcn_s_memtime();     \
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#define STAMP(k)                           \
+    t1 = __builtin_amdgcn_s_memtime();     \
+    __builtin_amdgcn_s_waitcnt(0xC07F);    \
+    ph[k] += t1 - t0;                      \
+    t0 = t1;
+#define STAMP_END(wave)                                                                          \
+    if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane == 0)                           \
+        for (int q = 0; q < 6; q++) g_wide_stamps[((blockIdx.x ? 1 : 0) * 16 + (wave)) * 6 + q] = ph[q];
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN
+#define STAMP(k)
+#define STAMP_END(wave)
+#endif
 
 // ------------------------------------------------------------------------------------
 // k_pbs: one workgroup = one bootstrap; wave p owns accumulator polynomial p.
@@ -287,7 +308,9 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
     // ---- blind rotation: acc += BSK_i (x) (X^{a_i} acc - acc) -------------------------
     int i = next_nonzero(0);
     if (i < n) prefetch(i);
+    STAMP_DECL
     while (i < n) {
+        STAMP_BEGIN
         if (probe & 2) {
             // experiment (HELM_HIP_PRIO_ROTATE): the CU arbitrates VALU issue oldest-first, so the four
             // workgroups of a CU drift apart; rotate a raised priority through them instead
@@ -430,8 +453,10 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
         // transform and the next step's forward transforms
         const int inext = next_nonzero(i + 1);
         if (inext < n) prefetch(inext);
+        STAMP(0) // rotation, decomposition, forward transforms, products, hand-over written
 
         lds_block_sync();
+        STAMP(1) // barrier 1
         if constexpr (M == L) {
 #pragma unroll
             for (int q = 0; q < K1; q++) {
@@ -456,15 +481,20 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
         }
 #pragma unroll
         for (int e = 0; e < E; e++) mine[e] = reduce<F>(mine[e]);
+        STAMP(2) // hand-over read and summed
         lds_block_sync(); // every hand-over slot has been read: the slots are free again
+        STAMP(3) // barrier 2
 
         ntt_inverse<F, LOGN>(mine, xb, twi, lane);
+        STAMP(4) // inverse transform
 #pragma unroll
         for (int e = 0; e < E; e++) accr[e] += to_torus32(mine[e]);
         acc_store();
         lds_wave_sync();
+        STAMP(5) // lift, accumulate, publish
         i = inext;
     }
+    STAMP_END(p)
 
     if (stamp) {
         g_clock_probe[2] = __builtin_amdgcn_s_memtime();
@@ -495,9 +525,6 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
 // the lev = 0 wave of polynomial c then recentres column c, inverse-transforms, lifts and
 // updates the accumulator copy every wave of the polynomial reads in the next step.
 // ------------------------------------------------------------------------------------
-#ifdef HELM_WIDE_STAMPS
-__device__ unsigned long long g_wide_stamps[16 * 6];
-#endif
 template <typename F_, int LOGN_, int K_, int L_>
 struct WideCfg {
     using F = F_;
@@ -603,23 +630,11 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
     const uint32_t mask = (1u << logB) - 1u;
     const int rep = logB * L;
 
-#ifdef HELM_WIDE_STAMPS
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, t0, t1;
-#define STAMP(k)                                   \
-    t1 = __builtin_amdgcn_s_memtime();             \
-    __builtin_amdgcn_s_waitcnt(0xC07F);            \
-    ph[k] += t1 - t0;                              \
-    t0 = t1;
-#else
-#define STAMP(k)
-#endif
+    STAMP_DECL
     for (int i = 0; i < n; i++) {
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
         if (a == 0) continue; // uniform over the workgroup
-#ifdef HELM_WIDE_STAMPS
-        t0 = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
+        STAMP_BEGIN
         // this step's key words (k+1 polynomials of this wave's row and level)
         double2 kw[K1][E / 2];
         const unsigned so = (unsigned)i * step_bytes + wave_off;
@@ -687,10 +702,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
         lds_block_sync(); // accumulator copies published, columns cleared
         STAMP(5) // barrier 2
     }
-#ifdef HELM_WIDE_STAMPS
-    if (blockIdx.x == 0 && lane == 0)
-        for (int q = 0; q < 6; q++) g_wide_stamps[w * 6 + q] = ph[q];
-#endif
+    STAMP_END(w)
 
     uint32_t *ob = out_big + (size_t)blockIdx.x * ((size_t)K * N + 1);
     if (lev == 0) {
@@ -1072,6 +1084,7 @@ static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * (C::K + 1)), C::BYTES, ctx->stream, jobs, wires, raw, tvs,
                        ctx->bsk, ctx->tw_fwd, ctx->tw_inv, out_big, ctx->P.n, ctx->P.pbs_logB, ctx->clock_probe);
     hipError_t e = hipGetLastError();
+    print_stamps(ctx, C::K + 1, "k_pbs: work | bar1 | sum | bar2 | inverse | publish");
     if (e == hipSuccess && (ctx->clock_probe & 1)) {
         unsigned long long v[4];
         (void)hipStreamSynchronize(ctx->stream);
@@ -1080,6 +1093,26 @@ static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
                     (long long)count, (double)(v[2] - v[0]) / (double)(v[3] - v[1]) * 0.1, (double)(v[3] - v[1]) * 1e-5);
     }
     return e;
+}
+
+static void print_stamps(helm_hip_ctx *ctx, int waves, const char *what)
+{
+#ifdef HELM_WIDE_STAMPS
+    unsigned long long v[2 * 16 * 6];
+    (void)hipStreamSynchronize(ctx->stream);
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_wide_stamps), sizeof(v)) != hipSuccess) return;
+    for (int b = 0; b < 2; b++)
+        for (int w = 0; w < waves; w++) {
+            const unsigned long long *q = v + (b * 16 + w) * 6;
+            fprintf(stderr, "[stamps %s] %s workgroup, wave %d: %llu %llu %llu %llu %llu %llu cycles/step\n", what,
+                    b ? "last" : "first", w, q[0] / ctx->P.n, q[1] / ctx->P.n, q[2] / ctx->P.n, q[3] / ctx->P.n, q[4] / ctx->P.n,
+                    q[5] / ctx->P.n);
+        }
+#else
+    (void)ctx;
+    (void)waves;
+    (void)what;
+#endif
 }
 
 template <typename C>
@@ -1102,17 +1135,7 @@ static hipError_t launch_pbs_wide(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, wires, raw, tvs, ctx->bsk,
                        ctx->tw_fwd, out_big, ctx->P.n, ctx->P.pbs_logB);
-#ifdef HELM_WIDE_STAMPS
-    {
-        unsigned long long v[16 * 6];
-        (void)hipStreamSynchronize(ctx->stream);
-        if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_wide_stamps), sizeof(v)) == hipSuccess)
-            for (int w = 0; w < C::NW; w++)
-                fprintf(stderr, "[wide] wave %d (r %d lev %d): prep %llu fwd %llu mac %llu bar1 %llu inv %llu bar2 %llu cycles/step\n", w,
-                        w / C::L, w % C::L, v[w * 6] / 722, v[w * 6 + 1] / 722, v[w * 6 + 2] / 722, v[w * 6 + 3] / 722,
-                        v[w * 6 + 4] / 722, v[w * 6 + 5] / 722);
-    }
-#endif
+    print_stamps(ctx, C::NW, "wide: prep | fwd | products | bar1 | inverse | bar2");
     return hipGetLastError();
 }
 
