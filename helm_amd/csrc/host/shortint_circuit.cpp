@@ -685,8 +685,6 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops, i
     {
         std::vector<int32_t> li, lo;
         std::vector<int64_t> lc, ca;
-        std::vector<int32_t> triv_idx;
-        std::vector<uint64_t> triv_val;
         for (auto &op : ops) {
             switch (op.kind) {
             case RadixOp::Copy:
@@ -721,8 +719,6 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops, i
             }
         }
         lincomb(w, li, lc, ca, lo, 2);
-        (void)triv_idx;
-        (void)triv_val;
     }
 
     // ---- multiplications: partial products ----------------------------------------------------
