@@ -1,0 +1,73 @@
+"""Two ranks, ONE GPU: the multi-GPU driver (helm_amd/distributed.py) with the real GPU level
+executor (helm_hip_program_run_level_shard / _scatter_level) on both ranks and torch.distributed's
+gloo backend carrying the all-gather of the device staging buffers.  RCCL needs one GPU per rank
+(the driver runs that at round end); this covers everything else of the N > 1 path on the one-GPU
+box: sharded levels, replicated levels, staging / scatter on device memory, and that every rank
+ends with the wire table a single-process evaluation produces."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, blocks, result_dir):
+    import helm_amd
+    from helm_amd import Circuit, verilog_parser
+    from helm_amd.distributed import GpuLevelExecutor, ShardedRunner, level_arrays
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    ck = helm_amd.ClientKey.generate("toy_k2", seed=5)
+    sk = helm_amd.ServerKey(ck, device=0)
+    sk.set_stream(torch.cuda.current_stream().cuda_stream)
+    gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_file(
+        os.path.join(HERE, "netlists", "alu-c880-class.v"), False)
+    c = Circuit(gates, inputs, outputs, dffs)
+    c.sort_circuit()
+    c.compute_levels()
+    names = list(inputs) + sorted(wire_set)
+    index = {w: i for i, w in enumerate(names)}
+    ops, i0, i1, i2, out, off = level_arrays(c, index)
+    nw, nl = len(names), len(off) - 1
+    tile = lambda a: np.concatenate([np.concatenate([np.where(a[off[l]:off[l + 1]] >= 0, a[off[l]:off[l + 1]] + b * nw, -1)
+                                                     for b in range(blocks)]) for l in range(nl)]).astype(np.int32)
+    opsT = np.concatenate([np.tile(ops[off[l]:off[l + 1]], blocks) for l in range(nl)]).astype(np.int32)
+    offT = (off * blocks).astype(np.int64)
+    prog = helm_amd.Program(sk, opsT, tile(i0), tile(i1), tile(i2), tile(out), offT)
+    rng = np.random.default_rng(3)
+    bits = rng.integers(0, 2, size=(blocks, len(inputs))).astype(bool)
+    wires = sk.wires(nw * blocks)
+    rows = np.concatenate([b * nw + np.arange(len(inputs)) for b in range(blocks)]).astype(np.int32)
+    wires.upload(rows, ck.encrypt(bits.reshape(-1)))
+    runner = ShardedRunner(GpuLevelExecutor(prog, wires), rank, world, dist, replicate_below=64)
+    runner.run()
+    torch.cuda.synchronize()
+    dist.barrier()
+    got = wires.download()
+    # single-process reference on a fresh table (same ciphertexts: the client RNG is seeded)
+    ref = sk.wires(nw * blocks)
+    ref.upload(rows, got[rows])
+    prog.run(ref)
+    sk.sync()
+    np.save(os.path.join(result_dir, f"rank{rank}.npy"), np.array([
+        int(np.array_equal(got, ref.download())), len(runner.sharded_levels), nl], dtype=np.int64))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, 6, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        same, sharded, nl = np.load(tmp_path / f"rank{r}.npy")
+        assert same == 1, f"rank {r}: sharded evaluation differs from the single-process one"
+        assert 0 < sharded <= nl
