@@ -68,9 +68,17 @@ def main():
     from helm_amd.distributed import GpuLevelExecutor, ShardedRunner
     from helm_amd.netlists import aes128, aes128_reference_encrypt
 
+    # rehearsal of the N > 1 path on a one-GPU box: HELM_BENCH_REHEARSE=1 puts every rank on cuda:0 and
+    # carries the collectives over gloo (RCCL needs one GPU per rank); never used for reported numbers
+    rehearse = os.environ.get("HELM_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- keys (identical on every rank: same seed) and engine --------------------------
     t0 = time.time()
@@ -186,7 +194,7 @@ def main():
         "vs_baseline": None,
         "dtype": "u32 torus (exact NTT in f64 FMA over a 49-bit prime)",
         "data": "synthetic: generated AES-128 netlist (stand-in for HELM's), seeded random keys/plaintexts, "
-                "fresh encryptions resident in HBM",
+                "fresh encryptions resident in HBM" + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearse else ""),
         "config": {
             "workload": f"AES-128 gates-mode netlist, {args.blocks} block(s) per GPU evaluated level-synchronously",
             "params": args.params, "n": p.n, "k": p.k, "N": p.N, "pbs_l": p.pbs_l, "pbs_logB": p.pbs_logB,

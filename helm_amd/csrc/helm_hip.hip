@@ -1410,7 +1410,10 @@ int helm_hip_get_params(const helm_hip_ctx *ctx, helm_hip_params *out)
 int helm_hip_set_stream(helm_hip_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");
-    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    // NULL is HIP's null (legacy default) stream - what torch.cuda.current_stream() is unless the caller
+    // switched streams - NOT "back to the context's own stream": collectives the caller orders on that
+    // stream must see the engine's kernels on it
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     return 0;
 }
 

@@ -732,7 +732,10 @@ int helm_si_get_params(const helm_si_ctx *ctx, helm_si_params *out)
 int helm_si_set_stream(helm_si_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");
-    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    // NULL is HIP's null (legacy default) stream - what torch.cuda.current_stream() is unless the caller
+    // switched streams - NOT "back to the context's own stream": collectives the caller orders on that
+    // stream must see the engine's kernels on it
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     return 0;
 }
 

@@ -103,8 +103,9 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
 int helm_hip_ctx_destroy(helm_hip_ctx *ctx);
 /* The parameter set the context was created with. */
 int helm_hip_get_params(const helm_hip_ctx *ctx, helm_hip_params *out);
-/* Run on an existing hipStream_t (e.g. the host framework's current stream); NULL = the
- * context's own stream. */
+/* Run on an existing hipStream_t (e.g. the host framework's current stream, so that collectives
+ * ordered on it see the engine's kernels).  NULL = HIP's null (legacy default) stream.  A fresh
+ * context runs on a non-blocking stream of its own. */
 int helm_hip_set_stream(helm_hip_ctx *ctx, void *hip_stream);
 int helm_hip_sync(helm_hip_ctx *ctx);
 

@@ -27,8 +27,11 @@ def _worker(rank, world, port, blocks, result_dir):
     ck = helm_amd.ClientKey.generate("toy_k2", seed=5)
     sk = helm_amd.ServerKey(ck, device=0)
     sk.set_stream(torch.cuda.current_stream().cuda_stream)
-    gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_file(
-        os.path.join(HERE, "netlists", "alu-c880-class.v"), False)
+    # the AES netlist: 207 levels, several hundred gates wide with `blocks` copies - launches long enough
+    # that a collective not ordered behind the engine's kernels reads stale staging rows (this test
+    # caught exactly that: helm_hip_set_stream(NULL) used to mean "the context's own stream")
+    from helm_amd.netlists import aes128
+    gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_text(aes128(), False)
     c = Circuit(gates, inputs, outputs, dffs)
     c.sort_circuit()
     c.compute_levels()
@@ -46,7 +49,7 @@ def _worker(rank, world, port, blocks, result_dir):
     wires = sk.wires(nw * blocks)
     rows = np.concatenate([b * nw + np.arange(len(inputs)) for b in range(blocks)]).astype(np.int32)
     wires.upload(rows, ck.encrypt(bits.reshape(-1)))
-    runner = ShardedRunner(GpuLevelExecutor(prog, wires), rank, world, dist, replicate_below=64)
+    runner = ShardedRunner(GpuLevelExecutor(prog, wires), rank, world, dist)
     runner.run()
     torch.cuda.synchronize()
     dist.barrier()
@@ -66,7 +69,7 @@ def test_two_ranks_on_one_gpu(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, 6, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, 4, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         same, sharded, nl = np.load(tmp_path / f"rank{r}.npy")
         assert same == 1, f"rank {r}: sharded evaluation differs from the single-process one"
