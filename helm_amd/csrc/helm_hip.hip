@@ -1522,6 +1522,12 @@ int helm_hip_wires_upload(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t *i
     if (w->owner != ctx) return fail(HELM_ERR_STATE, "wire table belongs to another context");
     if (count == 0) return 0;
     if (int rc = check_idx(w, idx, count, false)) return rc;
+    {
+        std::vector<int32_t> sorted(idx, idx + count);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+            return fail(HELM_ERR_INVALID, "upload names the same wire twice");
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t row = (size_t)ctx->P.n + 1;
     uint32_t *d_rows = nullptr;
@@ -1606,7 +1612,9 @@ int helm_hip_eval_gate_level(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->d_pbs.ensure(pl.pbs.size()) || ctx->d_ks.ensure(pl.ks.size()) || ctx->d_lin.ensure(pl.lin.size()))
         return fail(HELM_ERR_OOM, "job buffers");
-    // the previous level may still be reading the job buffers: same stream => ordered
+    // the previous level may still be reading the job buffers, and a host-to-device copy from
+    // pageable memory is not guaranteed to queue behind it: drain the stream first
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (!pl.pbs.empty())
         HIP_TRY(hipMemcpyAsync(ctx->d_pbs.p, pl.pbs.data(), pl.pbs.size() * sizeof(PbsJob), hipMemcpyHostToDevice, ctx->stream));
     if (!pl.ks.empty())
@@ -1773,6 +1781,7 @@ int helm_hip_program_run_level_shard(helm_hip_ctx *ctx, helm_hip_program *prog, 
         return rc;
     if (prog->s_pbs.ensure(pl.pbs.size()) || prog->s_ks.ensure(pl.ks.size()) || prog->s_lin.ensure(pl.lin.size()))
         return fail(HELM_ERR_OOM, "shard job buffers");
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // the previous level's shard may still read these buffers (see eval_gate_level)
     if (!pl.pbs.empty())
         HIP_TRY(hipMemcpyAsync(prog->s_pbs.p, pl.pbs.data(), pl.pbs.size() * sizeof(PbsJob), hipMemcpyHostToDevice, ctx->stream));
     if (!pl.ks.empty())
@@ -1797,6 +1806,7 @@ int helm_hip_program_scatter_level(helm_hip_ctx *ctx, helm_hip_program *prog, he
     std::vector<int32_t> rows((size_t)(chunk * world), -1);
     for (int64_t g = 0; g < cnt; g++) rows[(size_t)g] = prog->out[(size_t)(b + g)]; // chunks are contiguous: row g = gate g
     if (prog->s_rows.ensure(rows.size())) return fail(HELM_ERR_OOM, "scatter rows");
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // previous scatter may still read s_rows
     HIP_TRY(hipMemcpyAsync(prog->s_rows.p, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)rows.size()), dim3(256), 0, ctx->stream,

@@ -588,6 +588,15 @@ int check_rows(const helm_si_wires *w, const int32_t *idx, int64_t count, bool a
     return 0;
 }
 
+// Per-context scratch is refilled from pageable host memory by every call; such a copy is not
+// guaranteed to queue behind kernels still reading the previous contents, so callers drain the
+// stream (drain()) before their first upload.
+int drain(helm_si_ctx *ctx)
+{
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 template <typename T>
 int upload(helm_si_ctx *ctx, DevBuf<T> &buf, const T *host, size_t n)
 {
@@ -604,6 +613,7 @@ int apply_luts_device(helm_si_ctx *ctx, const uint64_t *src, uint64_t *dst, cons
     if (!ctx->have_bsk || !ctx->have_ksk) return fail(HELM_ERR_STATE, "bootstrapping / keyswitching key not loaded");
     const int64_t count = (int64_t)pbs.size();
     if (count == 0) return 0;
+    if (int rc = drain(ctx)) return rc;
     if (ctx->d_small.ensure((size_t)count * ((size_t)P.n + 1))) return fail(HELM_ERR_OOM, "small-LWE scratch");
     if (int rc = upload(ctx, ctx->d_ks, ks.data(), ks.size())) return rc;
     if (int rc = upload(ctx, ctx->d_pbs, pbs.data(), pbs.size())) return rc;
@@ -834,7 +844,14 @@ int helm_si_wires_upload(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx,
     if (w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
     if (count == 0) return 0;
     if (int rc = check_rows(w, idx, count, false)) return rc;
+    {
+        std::vector<int32_t> sorted(idx, idx + count);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+            return fail(HELM_ERR_INVALID, "upload names the same row twice");
+    }
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = drain(ctx)) return rc;
     const int dim = ctx->P.k * ctx->P.N;
     if (int rc = upload(ctx, ctx->d_stage, lwe_host, (size_t)count * (dim + 1))) return rc;
     if (int rc = upload(ctx, ctx->d_idx, idx, (size_t)count)) return rc;
@@ -852,6 +869,7 @@ int helm_si_wires_download(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *id
     if (count == 0) return 0;
     if (int rc = check_rows(w, idx, count, false)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = drain(ctx)) return rc;
     const int dim = ctx->P.k * ctx->P.N;
     if (ctx->d_stage.ensure((size_t)count * (dim + 1))) return fail(HELM_ERR_OOM, "staging");
     if (int rc = upload(ctx, ctx->d_idx, idx, (size_t)count)) return rc;
@@ -873,6 +891,7 @@ int helm_si_wires_copy(helm_si_ctx *ctx, helm_si_wires *src, const int32_t *src_
     if (int rc = check_rows(src, src_idx, count, false)) return rc;
     if (int rc = check_rows(dst, dst_idx, count, false)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = drain(ctx)) return rc;
     if (int rc = upload(ctx, ctx->d_idx, src_idx, (size_t)count)) return rc;
     if (int rc = upload(ctx, ctx->d_idx2, dst_idx, (size_t)count)) return rc;
     hipLaunchKernelGGL(k_rows64, dim3((unsigned)count), dim3(256), 0, ctx->stream, src->d, ctx->d_idx.p, dst->d,
@@ -889,6 +908,7 @@ int helm_si_wires_set_trivial(helm_si_ctx *ctx, helm_si_wires *w, const int32_t 
     if (count == 0) return 0;
     if (int rc = check_rows(w, idx, count, false)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = drain(ctx)) return rc;
     std::vector<uint64_t> body((size_t)count);
     for (int64_t g = 0; g < count; g++) body[(size_t)g] = value[g] * ctx->delta;
     if (int rc = upload(ctx, ctx->d_body, body.data(), body.size())) return rc;
@@ -909,6 +929,7 @@ int helm_si_lincomb(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, c
     if (int rc = check_rows(w, in_idx, count * terms, true)) return rc;
     if (int rc = check_rows(w, out_idx, count, false)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = drain(ctx)) return rc;
     const int dim = ctx->P.k * ctx->P.N;
     std::vector<uint64_t> body((size_t)count, 0);
     if (const_add)
@@ -1063,6 +1084,7 @@ int helm_si_keyswitch_batch(helm_si_ctx *ctx, const uint64_t *in_big, uint64_t *
     if (count == 0) return 0;
     const helm_si_params &P = ctx->P;
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = drain(ctx)) return rc;
     const size_t row = (size_t)P.n + 1, brow = (size_t)P.k * P.N + 1;
     std::vector<Ks64Job> jobs((size_t)count);
     for (int64_t g = 0; g < count; g++) jobs[(size_t)g] = Ks64Job{(int32_t)g, (int32_t)g};
@@ -1088,6 +1110,7 @@ int helm_si_pbs_batch(helm_si_ctx *ctx, const uint64_t *in_small, const uint64_t
     if (count == 0) return 0;
     const helm_si_params &P = ctx->P;
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = drain(ctx)) return rc;
     const size_t row = (size_t)P.n + 1, brow = (size_t)P.k * P.N + 1;
     std::vector<Pbs64Job> jobs((size_t)count);
     for (int64_t g = 0; g < count; g++) {

@@ -166,9 +166,18 @@ std::unique_ptr<EncWireMap> GateCircuit::encrypt_inputs(const std::set<std::stri
         idx.push_back(m->row(input_wire));
         bits.push_back(v ? 1 : 0);
     }
+    // DFF outputs are also input wires (verilog_parser.rs:225-227); the reference inserts them a
+    // second time with encrypt(false), which wins (circuit.rs:474-476).  One upload must not carry
+    // the same row twice (rows are written concurrently): override in place.
     for (auto &w : circuit_.dff_outputs()) {
-        idx.push_back(m->row(w));
-        bits.push_back(0);
+        const int32_t r = m->row(w);
+        size_t q = 0;
+        while (q < idx.size() && idx[q] != r) q++;
+        if (q < idx.size()) bits[q] = 0;
+        else {
+            idx.push_back(r);
+            bits.push_back(0);
+        }
     }
     if (!idx.empty()) {
         std::vector<uint32_t> cts(idx.size() * (size_t)(n_ + 1));

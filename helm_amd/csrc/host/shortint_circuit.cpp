@@ -175,9 +175,17 @@ std::unique_ptr<SiEncWireMap> LutCircuit::encrypt_inputs(const std::set<std::str
         idx.push_back(m->row(input_wire));
         vals.push_back(v);
     }
+    // DFF outputs are input wires too; the reference's second insert (encrypt(0), circuit.rs:995-997)
+    // wins.  One upload must not carry the same row twice (rows are written concurrently).
     for (auto &w : circuit_.dff_outputs()) {
-        idx.push_back(m->row(w));
-        vals.push_back(0);
+        const int32_t r = m->row(w);
+        size_t q = 0;
+        while (q < idx.size() && idx[q] != r) q++;
+        if (q < idx.size()) vals[q] = 0;
+        else {
+            idx.push_back(r);
+            vals.push_back(0);
+        }
     }
     if (!idx.empty()) {
         const size_t row = (size_t)P_.k * P_.N + 1;

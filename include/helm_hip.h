@@ -120,7 +120,8 @@ int helm_hip_load_keyswitch_key(helm_hip_ctx *ctx, const uint32_t *ksk, size_t n
 /* Replaces the HashMap<String, Arc<RwLock<Ciphertext>>> of circuit.rs:517-520. */
 int helm_hip_wires_alloc(helm_hip_ctx *ctx, int64_t n_wires, helm_hip_wires **out);
 int helm_hip_wires_free(helm_hip_ctx *ctx, helm_hip_wires *w);
-/* lwe_host: count rows of n+1 words; row r goes to / comes from wire idx[r]. */
+/* lwe_host: count rows of n+1 words; row r goes to / comes from wire idx[r].  An upload must not
+ * name the same wire twice (rows are written concurrently): HELM_ERR_INVALID. */
 int helm_hip_wires_upload(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t *idx,
                           const uint32_t *lwe_host, int64_t count);
 int helm_hip_wires_download(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t *idx,

@@ -179,3 +179,20 @@ def test_handles_outlive_their_context():
     w._h = prog._h = sw._h = None
     del enc, g
     _gc.collect()
+
+
+def test_upload_rejects_duplicate_rows():
+    """Rows of one upload are written concurrently: naming a wire twice is an error, not a race
+    (a DFF output listed both as input and as state used to reach the table twice)."""
+    ck = helm_amd.ClientKey.generate("toy", seed=1)
+    sk = helm_amd.ServerKey(ck)
+    w = sk.wires(4)
+    with pytest.raises(helm_amd.HelmError, match="twice"):
+        w.upload([1, 2, 1], ck.encrypt([True, False, True]))
+    sck = helm_amd.SiClientKey.generate("si_toy_512", seed=1)
+    ssk = helm_amd.SiServerKey(sck)
+    sw = ssk.wires(4)
+    with pytest.raises(helm_amd.HelmError, match="twice"):
+        sw.upload([0, 0], sck.encrypt([1, 2]))
+    sk.close()
+    ssk.close()
