@@ -731,18 +731,22 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
 template <int KSL>
 __global__ __launch_bounds__(256) void k_keyswitch(const KsJob *__restrict__ jobs, const uint32_t *__restrict__ big,
                                                    const uint32_t *__restrict__ ksk, uint32_t *__restrict__ out,
-                                                   int n, int kN, int logB, int count)
+                                                   int n, int kN, int logB, int count, int t_chunk)
 {
+    // blockIdx.z selects a slice of t_chunk input coefficients (narrow launches: the k*N*ks_l key rows
+    // are split over several workgroups whose partial sums meet in `out` by atomic add - wrapping
+    // integer adds, any order; the rows are zeroed beforehand).  gridDim.z == 1: plain stores.
     constexpr int G = 4;
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *DIG = reinterpret_cast<uint32_t *>(smem); // [kN * KSL] words, byte g = digit of gate g
+    uint32_t *DIG = reinterpret_cast<uint32_t *>(smem); // [t_chunk * KSL] words, byte g = digit of gate g
     const int g0 = blockIdx.x * G;
     const int ng = min(G, count - g0);
+    const int t0 = blockIdx.z * t_chunk, t1 = min(kN, t0 + t_chunk);
     KsJob job[G];
 #pragma unroll
     for (int g = 0; g < G; g++) job[g] = jobs[g0 + (g < ng ? g : 0)];
     const size_t brow = (size_t)kN + 1;
-    for (int t = threadIdx.x; t < kN; t += 256) {
+    for (int t = t0 + threadIdx.x; t < t1; t += 256) {
         uint32_t packed[KSL];
 #pragma unroll
         for (int j = 0; j < KSL; j++) packed[j] = 0;
@@ -758,15 +762,15 @@ __global__ __launch_bounds__(256) void k_keyswitch(const KsJob *__restrict__ job
             }
         }
 #pragma unroll
-        for (int j = 0; j < KSL; j++) DIG[t * KSL + j] = packed[j];
+        for (int j = 0; j < KSL; j++) DIG[(t - t0) * KSL + j] = packed[j];
     }
     __syncthreads();
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c > n) return;
     const size_t krow = (size_t)n + 1;
     uint32_t acc[G] = {0, 0, 0, 0};
-    const uint32_t *kp = ksk + c;
-    const int rows = kN * KSL;
+    const uint32_t *kp = ksk + (size_t)t0 * KSL * krow + c;
+    const int rows = (t1 - t0) * KSL;
 #pragma unroll 8
     for (int r = 0; r < rows; r++) {
         const uint32_t w = kp[(size_t)r * krow];
@@ -778,13 +782,22 @@ __global__ __launch_bounds__(256) void k_keyswitch(const KsJob *__restrict__ job
     for (int g = 0; g < G; g++) {
         if (g < ng) {
             uint32_t body = 0;
-            if (c == n) {
+            if (c == n && blockIdx.z == 0) {
                 body = big[brow * (size_t)job[g].big0 + kN] + job[g].add_body;
                 if (job[g].big1 >= 0) body += big[brow * (size_t)job[g].big1 + kN];
             }
-            out[krow * (size_t)job[g].out + c] = body - acc[g];
+            uint32_t *dst = out + krow * (size_t)job[g].out + c;
+            if (gridDim.z == 1) *dst = body - acc[g];
+            else atomicAdd(dst, body - acc[g]);
         }
     }
+}
+
+// rows named by the keyswitch jobs <- 0 (before a row-split keyswitch accumulates into them)
+__global__ __launch_bounds__(256) void k_ks_zero(const KsJob *__restrict__ jobs, uint32_t *__restrict__ out, int n)
+{
+    uint32_t *dst = out + ((size_t)n + 1) * (size_t)jobs[blockIdx.x].out;
+    for (int i = threadIdx.x; i <= n; i += 256) dst[i] = 0u;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1207,12 +1220,22 @@ static hipError_t launch_ks(helm_hip_ctx *ctx, const KsJob *jobs, int64_t count,
 {
     const helm_hip_params &P = ctx->P;
     const int kN = P.k * P.N;
-    dim3 grid((unsigned)((count + 3) / 4), (unsigned)((P.n + 1 + 255) / 256));
-    const size_t lds = (size_t)kN * P.ks_l * sizeof(uint32_t);
+    const unsigned gx = (unsigned)((count + 3) / 4), gy = (unsigned)((P.n + 1 + 255) / 256);
+    // narrow launches: split the key rows until ~2 workgroups per CU exist (at most 16 slices)
+    int slices = 1;
+    while (slices < 16 && (int64_t)gx * gy * slices < 2 * (int64_t)ctx->n_cus && kN / (slices * 2) >= 64) slices *= 2;
+    const int t_chunk = (kN + slices - 1) / slices;
+    dim3 grid(gx, gy, (unsigned)slices);
+    const size_t lds = (size_t)t_chunk * P.ks_l * sizeof(uint32_t);
+    if (slices > 1) {
+        hipLaunchKernelGGL(k_ks_zero, dim3((unsigned)count), dim3(256), 0, ctx->stream, jobs, out, P.n);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
 #define KS_CASE(LV)                                                                                       \
     case LV:                                                                                              \
         hipLaunchKernelGGL(k_keyswitch<LV>, grid, dim3(256), lds, ctx->stream, jobs, big, ctx->ksk, out, P.n, kN, \
-                           P.ks_logB, (int)count);                                                        \
+                           P.ks_logB, (int)count, t_chunk);                                               \
         break;
     switch (P.ks_l) {
         KS_CASE(1) KS_CASE(2) KS_CASE(3) KS_CASE(4) KS_CASE(5) KS_CASE(6) KS_CASE(8)

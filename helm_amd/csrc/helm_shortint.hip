@@ -283,20 +283,23 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
 template <int KSL>
 __global__ __launch_bounds__(256) void k_keyswitch64(const Ks64Job *__restrict__ jobs, const uint64_t *__restrict__ big,
                                                      const uint64_t *__restrict__ ksk, uint64_t *__restrict__ out,
-                                                     int n, int kN, int logB, int count)
+                                                     int n, int kN, int logB, int count, int t_chunk)
 {
+    // blockIdx.z: slice of t_chunk input coefficients (see k_keyswitch of helm_hip.hip); with more
+    // than one slice the partial sums meet in `out` (zeroed beforehand) by 64-bit atomic add
     constexpr int GN = 4;
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *DIG = reinterpret_cast<uint32_t *>(smem); // [kN * KSL]
+    uint32_t *DIG = reinterpret_cast<uint32_t *>(smem); // [t_chunk * KSL]
     const int g0 = blockIdx.x * GN;
     const int ng = min(GN, count - g0);
+    const int t0 = blockIdx.z * t_chunk, t1 = min(kN, t0 + t_chunk);
     Ks64Job job[GN];
 #pragma unroll
     for (int g = 0; g < GN; g++) job[g] = jobs[g0 + (g < ng ? g : 0)];
     const size_t brow = (size_t)kN + 1;
     const int rep = logB * KSL;
     const uint64_t mask = (1ull << logB) - 1ull;
-    for (int t = threadIdx.x; t < kN; t += 256) {
+    for (int t = t0 + threadIdx.x; t < t1; t += 256) {
         uint32_t packed[KSL];
 #pragma unroll
         for (int j = 0; j < KSL; j++) packed[j] = 0;
@@ -317,15 +320,15 @@ __global__ __launch_bounds__(256) void k_keyswitch64(const Ks64Job *__restrict__
             }
         }
 #pragma unroll
-        for (int j = 0; j < KSL; j++) DIG[t * KSL + j] = packed[j];
+        for (int j = 0; j < KSL; j++) DIG[(t - t0) * KSL + j] = packed[j];
     }
     __syncthreads();
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c > n) return;
     const size_t krow = (size_t)n + 1;
     uint64_t acc[GN] = {0, 0, 0, 0};
-    const uint64_t *kp = ksk + c;
-    const int rows = kN * KSL;
+    const uint64_t *kp = ksk + (size_t)t0 * KSL * krow + c;
+    const int rows = (t1 - t0) * KSL;
 #pragma unroll 4
     for (int r = 0; r < rows; r++) {
         const uint64_t kw = kp[(size_t)r * krow];
@@ -336,8 +339,10 @@ __global__ __launch_bounds__(256) void k_keyswitch64(const Ks64Job *__restrict__
 #pragma unroll
     for (int g = 0; g < GN; g++) {
         if (g < ng) {
-            const uint64_t body = c == n ? big[brow * (size_t)job[g].in_row + kN] : 0ull;
-            out[krow * (size_t)job[g].out_row + c] = body - acc[g];
+            const uint64_t body = (c == n && blockIdx.z == 0) ? big[brow * (size_t)job[g].in_row + kN] : 0ull;
+            uint64_t *dst = out + krow * (size_t)job[g].out_row + c;
+            if (gridDim.z == 1) *dst = body - acc[g];
+            else atomicAdd(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)(body - acc[g]));
         }
     }
 }
@@ -482,6 +487,7 @@ struct helm_si_ctx {
     uint64_t *ksk = nullptr;
     bool have_bsk = false, have_ksk = false;
     uint64_t delta = 0;
+    int n_cus = 256;
     // per-call scratch
     DevBuf<Pbs64Job> d_pbs;
     DevBuf<Ks64Job> d_ks;
@@ -554,10 +560,19 @@ hipError_t launch_pbs64(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, c
 
 hipError_t launch_ks64(helm_si_ctx *ctx, const Ks64Job *jobs, int64_t count, const uint64_t *big, uint64_t *out)
 {
+    // `out` is the small-LWE scratch: rows 0..count-1 (job g writes row g)
     const helm_si_params &P = ctx->P;
     const int kN = P.k * P.N;
-    dim3 grid((unsigned)((count + 3) / 4), (unsigned)((P.n + 1 + 255) / 256));
-    const size_t lds = (size_t)kN * P.ks_l * sizeof(uint32_t);
+    const unsigned gx = (unsigned)((count + 3) / 4), gy = (unsigned)((P.n + 1 + 255) / 256);
+    int slices = 1;
+    while (slices < 16 && (int64_t)gx * gy * slices < 2 * (int64_t)ctx->n_cus && kN / (slices * 2) >= 64) slices *= 2;
+    const int t_chunk = (kN + slices - 1) / slices;
+    dim3 grid(gx, gy, (unsigned)slices);
+    const size_t lds = (size_t)t_chunk * P.ks_l * sizeof(uint32_t);
+    if (slices > 1) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)count * ((size_t)P.n + 1) * sizeof(uint64_t), ctx->stream);
+        if (e != hipSuccess) return e;
+    }
 #define KS_CASE(LV)                                                                                                 \
     case LV: {                                                                                                      \
         static bool done = false;                                                                                   \
@@ -568,7 +583,7 @@ hipError_t launch_ks64(helm_si_ctx *ctx, const Ks64Job *jobs, int64_t count, con
             done = true;                                                                                            \
         }                                                                                                           \
         hipLaunchKernelGGL(k_keyswitch64<LV>, grid, dim3(256), lds, ctx->stream, jobs, big, ctx->ksk, out, P.n, kN, \
-                           P.ks_logB, (int)count);                                                                  \
+                           P.ks_logB, (int)count, t_chunk);                                                         \
         break;                                                                                                      \
     }
     switch (P.ks_l) {
@@ -675,6 +690,7 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
     if (!ctx) return fail(HELM_ERR_OOM, "ctx");
     ctx->device = device_id;
     ctx->P = P;
+    ctx->n_cus = prop.multiProcessorCount;
     while ((1 << ctx->logN) < P.N) ctx->logN++;
     ctx->delta = (1ull << 63) / (uint64_t)t;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
