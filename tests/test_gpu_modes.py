@@ -169,3 +169,34 @@ def test_division_u16(keys):
     enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U16(51234), "B": PtxtType.U16(321)})
     out = ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, "u16"), True)
     assert out["Q"] == PtxtType.U16(51234 // 321)
+
+
+def test_radix_operators_random_u8(keys):
+    """Every FheUint operator of arithmetic mode on random operands (one level, all gates batched)."""
+    client_key, server_key = keys
+    text = """input [7:0] A, B;
+output [7:0] S, D, P, Q, L, R, SA, SS, SM, SQ, SL, SR;
+add g0(A, B, S);
+sub g1(A, B, D);
+mult g2(A, B, P);
+div g3(A, B, Q);
+shl g4(A, B, L);
+shr g5(A, B, R);
+add g6(A, 77, SA);
+sub g7(A, 77, SS);
+mult g8(A, 77, SM);
+div g9(A, 11, SQ);
+shl g10(A, 5, SL);
+shr g11(A, 5, SR);
+"""
+    circuit, wire_set, _, _ = _circuit(text, is_arith=True, is_text=True)
+    ac = ArithCircuit(client_key, server_key, circuit)
+    rng = np.random.default_rng(2024)
+    for _ in range(3):
+        a, b = int(rng.integers(0, 256)), int(rng.integers(1, 256))
+        enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U8(a), "B": PtxtType.U8(b)})
+        out = {k: v.value for k, v in ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, "u8"), True).items()}
+        want = {"S": (a + b) % 256, "D": (a - b) % 256, "P": (a * b) % 256, "Q": a // b, "L": (a << (b % 8)) % 256,
+                "R": a >> (b % 8), "SA": (a + 77) % 256, "SS": (a - 77) % 256, "SM": (a * 77) % 256, "SQ": a // 11,
+                "SL": (a << 5) % 256, "SR": a >> 5}
+        assert out == want, (a, b)
