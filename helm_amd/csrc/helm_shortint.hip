@@ -45,6 +45,27 @@ namespace {
 using F0 = Fp<49>;
 using F1 = Fp49b;
 
+#ifdef HELM_WIDE_STAMPS
+__device__ unsigned long long g_stamps64[8 * 8];
+#define STAMP_DECL unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1;
+#define STAMP_BEGIN                        \
+    t0 = __builtin_amdgcn_s_memtime();     \
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#define STAMP(k)                           \
+    t1 = __builtin_amdgcn_s_memtime();     \
+    __builtin_amdgcn_s_waitcnt(0xC07F);    \
+    ph[k] += t1 - t0;                      \
+    t0 = t1;
+#define STAMP_END(wave)                    \
+    if (blockIdx.x == 0 && lane == 0)      \
+        for (int q = 0; q < 8; q++) g_stamps64[(wave) * 8 + q] = ph[q];
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN
+#define STAMP(k)
+#define STAMP_END(wave)
+#endif
+
 struct Pbs64Job {
     int32_t in_row;  // row of the small-LWE buffer (n+1 words)
     int32_t lut;     // row of the look-up-table buffer (N words)
@@ -119,9 +140,11 @@ __device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__
     const size_t bsk_step = (size_t)K1 * K1 * L * per_poly;
     const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * L * 2 + f) * (N / 2) + lane;
 
+    STAMP_DECL
     for (int i = 0; i < n; i++) {
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
         if (a == 0) continue; // uniform over the workgroup: every wave skips the same steps
+        STAMP_BEGIN
         const double2 *bp_i = bsk_w + (size_t)i * bsk_step;
 
         // ---- rotate / subtract, decomposition state (least significant level first; the
@@ -152,22 +175,21 @@ __device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__
                 state[e] = st + carry;
                 x[0][e] = (double)((int32_t)d - (int32_t)(carry << logB));
             }
-            // key words: the first column is fetched before the transform (which hides its
-            // latency), the second after it (hidden by the first column's products)
-            double2 kw[K1][E / 2];
+            // key words in chunks of E/4 (two per column), software-pipelined: the first chunk is
+            // fetched before the transform, each next one just before the products of the previous
+            // (at most two chunks = 64 registers in flight; whole columns spilled to AGPRs)
+            constexpr int CH = E / 4; // double2 per chunk
+            auto fetch = [&](int q, double2 (&dst)[CH]) { // chunk q of 4: column q / 2, half q % 2
+                const double2 *kp = bp_i + (size_t)((q >> 1) * L + lev) * per_poly + (size_t)(q & 1) * CH * 64;
 #pragma unroll
-            for (int e2 = 0; e2 < E / 2; e2++) kw[0][e2] = (bp_i + (size_t)(0 * L + lev) * per_poly)[e2 * 64];
-            __builtin_amdgcn_sched_barrier(0);
-            ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < CH; u++) dst[u] = kp[u * 64];
+            };
+            auto products = [&](int q, const double2 (&kq)[CH]) {
+                const int c = q >> 1, e20 = (q & 1) * CH;
 #pragma unroll
-            for (int e2 = 0; e2 < E / 2; e2++) kw[1][e2] = (bp_i + (size_t)(1 * L + lev) * per_poly)[e2 * 64];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < K1; c++) {
-#pragma unroll
-                for (int e2 = 0; e2 < E / 2; e2++) {
-                    const double t0 = mulmod<F>(x[0][2 * e2], kw[c][e2].x), t1 = mulmod<F>(x[0][2 * e2 + 1], kw[c][e2].y);
+                for (int u = 0; u < CH; u++) {
+                    const int e2 = e20 + u;
+                    const double t0 = mulmod<F>(x[0][2 * e2], kq[u].x), t1 = mulmod<F>(x[0][2 * e2 + 1], kq[u].y);
                     if (c == p) {
                         mine[2 * e2] = lev == L - 1 ? t0 : mine[2 * e2] + t0;
                         mine[2 * e2 + 1] = lev == L - 1 ? t1 : mine[2 * e2 + 1] + t1;
@@ -176,17 +198,40 @@ __device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__
                         other[2 * e2 + 1] = lev == L - 1 ? t1 : other[2 * e2 + 1] + t1;
                     }
                 }
-            }
+            };
+            double2 ka[CH], kb2[CH];
+            fetch(0, ka);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(0) // rotation, decomposition, first key chunk issued
+            ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+            STAMP(1) // forward transform
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(1, kb2);
+            __builtin_amdgcn_sched_barrier(0);
+            products(0, ka);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(2, ka);
+            __builtin_amdgcn_sched_barrier(0);
+            products(1, kb2);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(3, kb2);
+            __builtin_amdgcn_sched_barrier(0);
+            products(2, ka);
+            products(3, kb2);
         }
         // hand the other polynomial's partial sum over through the (now idle) scratch
 #pragma unroll
         for (int e = 0; e < E; e++) xb[e * 64 + lane] = reduce<F>(other[e]);
+        STAMP(2) // products, hand-over written
         lds_block_sync();
+        STAMP(3) // barrier 1
 #pragma unroll
         for (int e = 0; e < E; e++) mine[e] = reduce<F>(reduce<F>(mine[e]) + x_poly[e * 64 + lane]);
         lds_block_sync(); // hand-over slots read: scratch free again
+        STAMP(4) // sum + barrier 2
 
         ntt_inverse<F, LOGN>(mine, xb, twi, lane);
+        STAMP(5) // inverse transform
 
         // ---- CRT: field-f wave lifts slots [f*H, f*H+H); it needs the other field's
         //      residues for those and provides its own for the other half ----------------
@@ -203,7 +248,9 @@ __device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__
             acc_p[G::jA(lane, f * H + e)] += xv;
         }
         lds_block_sync(); // accumulator complete before the next step's rotated reads
+        STAMP(6) // CRT exchange, lift, accumulate, barriers 3 and 4
     }
+    STAMP_END(p * 2 + f)
 }
 
 template <typename C>
@@ -544,6 +591,17 @@ hipError_t launch_pbs64_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count,
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, small, luts, ctx->bsk,
                        ctx->tw[0], ctx->tw[1], out, ctx->P.n, ctx->P.pbs_logB, ctx->p0inv_mod_p1);
+#ifdef HELM_WIDE_STAMPS
+    {
+        unsigned long long v[8 * 8];
+        (void)hipStreamSynchronize(ctx->stream);
+        if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_stamps64), sizeof(v)) == hipSuccess)
+            for (int w = 0; w < C::NW; w++)
+                fprintf(stderr, "[stamps k_pbs64: prep | fwd | products | bar1 | sum+bar2 | inverse | crt+bars] wave %d: %llu %llu %llu %llu %llu %llu %llu cycles/step\n",
+                        w, v[w * 8] / ctx->P.n, v[w * 8 + 1] / ctx->P.n, v[w * 8 + 2] / ctx->P.n, v[w * 8 + 3] / ctx->P.n,
+                        v[w * 8 + 4] / ctx->P.n, v[w * 8 + 5] / ctx->P.n, v[w * 8 + 6] / ctx->P.n);
+    }
+#endif
     return hipGetLastError();
 }
 

@@ -396,8 +396,10 @@ __device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const TW &t
 #pragma unroll
     for (int sb = SB_LO; sb <= SB_HI; sb++) {
         const int eb = sb - SHIFT;
-        if (sb - SB_LO == 2 && SB_HI - SB_LO == 3) {
-            // 4-stage block: the pure-sum path has doubled twice; recentre.
+        if (!F::LAZY && sb - SB_LO == 2 && SB_HI - SB_LO == 3) {
+            // 4-stage block: the pure-sum path has doubled twice; recentre (51-bit field: 2^53 = 5.3 p.
+            // The lazy 49-bit fields hold four doublings from 0.5 p: sums <= 8 p, differences fed to
+            // the multiplications <= 8 p at the last stage, below 2^53 = 14.2 p).
 #pragma unroll
             for (int e = 0; e < E; e++) x[e] = reduce<F>(x[e]);
         }
