@@ -323,6 +323,254 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
 }
 
 // ------------------------------------------------------------------------------------
+// k_pbs64s<LOGN>: the same bootstrap with EIGHT waves per ciphertext (two per SIMD), L = 1:
+// wave w = (polynomial p, field f, half h).  A size-N negacyclic transform splits, after its
+// first butterfly stage (pairs j, j + N/2, twiddle psi^(N/2)), into two independent size-N/2
+// transforms whose twiddles are slices of the full table: half h, stage with m' groups, group i'
+// uses table[2m' + h m' + i'].  So wave (p, f, h) transforms half h with the LOGN-1 machinery of
+// ntt_fp64.h on a derived table; by the mirror identity the inverse of half h reads the table of
+// half 1-h mirrored.  The halves meet once per step, in the last inverse stage.
+// Per step: (1) each of the four waves of a polynomial decomposes a quarter of its coefficients
+// and publishes the digits (int32, LDS); (2) stage 1 + half transform + products with the key
+// words of its half of the spectrum; other-polynomial sum handed over; (3) half inverse, exchange
+// with the other half, last stage; (4) CRT with the other field on half of the wave's
+// coefficients, accumulate.  Seven workgroup barriers per step, no redundant work except the
+// 16 stage-1 products per lane.
+// ------------------------------------------------------------------------------------
+template <int LOGN_>
+struct Pbs64sCfg {
+    static constexpr int LOGN = LOGN_, L = 1, K = 1, K1 = 2, NW = 8;
+    using G = Geo<LOGN>;      // decomposition geometry: E coefficients per lane
+    using GS = Geo<LOGN - 1>; // half transforms
+    static constexpr int MAX_SMALL_N = 1024;
+    static constexpr int TW_IDX = GS::N >> GS::BC, TW_PART = TW_IDX + GS::TWC * 64; // per (field, half)
+    static constexpr size_t X_OFF = 0;                                              // double [NW][GS::XPAD]
+    static constexpr size_t TW_OFF = X_OFF + sizeof(double) * NW * GS::XPAD;        // double [2][2][TW_PART]
+    static constexpr size_t ACC_OFF = TW_OFF + sizeof(double) * 4 * TW_PART;        // u64 [K1][N]
+    static constexpr size_t DIG_OFF = ACC_OFF + sizeof(uint64_t) * K1 * G::N;       // i32 [K1][N]
+    static constexpr size_t MS_OFF = DIG_OFF + sizeof(int32_t) * K1 * G::N;         // u16 [n+1]
+    static constexpr size_t BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
+};
+
+template <typename C, typename F>
+__device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *__restrict__ bsk, int n, int logB,
+                                            double p0inv_mod_p1, double w1, int p, int f, int h, int lane)
+{
+    constexpr int LOGN = C::LOGN, K1 = C::K1;
+    using G = typename C::G;
+    using GS = typename C::GS;
+    constexpr int N = G::N, E = G::E, EH = GS::E, Q = E / 4, HC = EH / 2;
+    double *X = reinterpret_cast<double *>(smem + C::X_OFF);
+    uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
+    int32_t *DIG = reinterpret_cast<int32_t *>(smem + C::DIG_OFF);
+    const uint16_t *MS = reinterpret_cast<const uint16_t *>(smem + C::MS_OFF);
+    auto wave_of = [](int pp, int ff, int hh) { return (pp * 2 + ff) * 2 + hh; };
+    double *xb = X + (size_t)wave_of(p, f, h) * GS::XPAD;
+    const double *x_poly = X + (size_t)wave_of(1 - p, f, h) * GS::XPAD;  // same field and half, other polynomial
+    const double *x_half = X + (size_t)wave_of(p, f, 1 - h) * GS::XPAD;  // same polynomial and field, other half
+    const double *x_field = X + (size_t)wave_of(p, 1 - f, h) * GS::XPAD; // same polynomial and half, other field
+    uint64_t *acc_p = ACC + (size_t)p * N;
+    int32_t *dig_p = DIG + (size_t)p * N;
+    const double *twt = reinterpret_cast<const double *>(smem + C::TW_OFF);
+    const double *tw_own = twt + (size_t)(f * 2 + h) * C::TW_PART, *tw_oth = twt + (size_t)(f * 2 + (1 - h)) * C::TW_PART;
+    TwHybrid<LOGN - 1, false> twf{tw_own, tw_own + C::TW_IDX + lane};
+    TwHybrid<LOGN - 1, true> twi{tw_oth, tw_oth + C::TW_IDX + (63 - lane)};
+    const int quarter = f * 2 + h; // which E/4 slots of the polynomial this wave decomposes
+
+    // key words of this wave: [i][row p][c][f][h][e/2][lane] as double2 (L = 1)
+    const size_t part = (size_t)(GS::N / 2);
+    const size_t bsk_step = (size_t)K1 * K1 * 4 * part;
+    const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * 4 + f * 2 + h) * part + lane;
+    const uint32_t mask = (1u << logB) - 1u;
+
+    for (int i = 0; i < n; i++) {
+        const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
+        if (a == 0) continue; // uniform over the workgroup
+        const double2 *bp_i = bsk_w + (size_t)i * bsk_step;
+        // ---- (1) digits of this wave's quarter of polynomial p -------------------------------
+#pragma unroll
+        for (int u = 0; u < Q; u++) {
+            const int j = G::jA(lane, quarter * Q + u);
+            const int src = (j - a) & (2 * N - 1);
+            uint64_t v = acc_p[src & (N - 1)];
+            if (src >= N) v = 0ull - v;
+            v -= acc_p[j];
+            const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
+            const uint32_t d = st & mask; // L = 1: the carry decides between d and d - B
+            const int nc = __builtin_amdgcn_sbfe(((d - 1u) | (st >> logB)) & d, logB - 1, 1);
+            dig_p[j] = (int)d + (int)((uint32_t)nc << logB);
+        }
+        // first key column of this wave's half (E/4 double2 per column)
+        double2 kw[K1][HC];
+#pragma unroll
+        for (int u = 0; u < HC; u++) kw[0][u] = (bp_i + (size_t)0 * 4 * part)[u * 64];
+        lds_block_sync(); // digits published
+        // ---- (2) stage 1 of the full transform, half transform, products ---------------------
+        double x[1][EH];
+        {
+            const int32_t *dg = dig_p + lane;
+#pragma unroll
+            for (int e = 0; e < EH; e++) {
+                const double U = (double)dg[64 * e], V = mulmod<F>((double)dg[64 * (e + EH)], w1);
+                x[0][e] = h ? U - V : U + V;
+            }
+        }
+        ntt_forward<F, LOGN - 1, 1>(x, xb, twf, lane);
+#pragma unroll
+        for (int u = 0; u < HC; u++) kw[1][u] = (bp_i + (size_t)1 * 4 * part)[u * 64];
+        double mine[EH], other[EH];
+#pragma unroll
+        for (int c = 0; c < K1; c++)
+#pragma unroll
+            for (int u = 0; u < HC; u++) {
+                const double t0 = mulmod<F>(x[0][2 * u], kw[c][u].x), t1 = mulmod<F>(x[0][2 * u + 1], kw[c][u].y);
+                if (c == p) {
+                    mine[2 * u] = t0;
+                    mine[2 * u + 1] = t1;
+                } else {
+                    other[2 * u] = t0;
+                    other[2 * u + 1] = t1;
+                }
+            }
+#pragma unroll
+        for (int e = 0; e < EH; e++) xb[e * 64 + lane] = reduce<F>(other[e]);
+        lds_block_sync();
+#pragma unroll
+        for (int e = 0; e < EH; e++) mine[e] = reduce<F>(reduce<F>(mine[e]) + x_poly[e * 64 + lane]);
+        lds_block_sync(); // hand-over read: scratch free again
+        // ---- (3) half inverse, meet the other half, last stage -------------------------------
+        ntt_inverse<F, LOGN - 1>(mine, xb, twi, lane); // a_h[e * 64 + lane], centred
+#pragma unroll
+        for (int e = 0; e < EH; e++) xb[e * 64 + lane] = mine[e];
+        lds_block_sync();
+#pragma unroll
+        for (int e = 0; e < EH; e++) {
+            const double o = x_half[e * 64 + lane];
+            // y[j] = a0 + a1 ; y[j + N/2] = (a0 - a1) * psi^-(N/2) = (a1 - a0) * psi^(N/2)
+            mine[e] = h ? reduce<F>(mulmod<F>(mine[e] - o, w1)) : reduce<F>(mine[e] + o);
+        }
+        lds_block_sync(); // the other half has read: scratch free again
+        // ---- (4) CRT: field-f wave lifts slots [f*EH/2, (f+1)*EH/2) of its half ----------------
+        constexpr int HH = EH / 2;
+#pragma unroll
+        for (int e = 0; e < HH; e++) xb[e * 64 + lane] = mine[(1 - f) * HH + e];
+        lds_block_sync();
+#pragma unroll
+        for (int e = 0; e < HH; e++) {
+            const double own = mine[f * HH + e], oth = x_field[e * 64 + lane];
+            const double r0 = f == 0 ? own : oth, r1 = f == 0 ? oth : own;
+            const double t = mulmod<F1>(r1 - r0, p0inv_mod_p1);
+            const uint64_t xv = (uint64_t)to_int64(r0) + F0::P_U64 * (uint64_t)to_int64(t);
+            acc_p[h * (N / 2) + (f * HH + e) * 64 + lane] += xv;
+        }
+        lds_block_sync(); // accumulator complete
+    }
+}
+
+template <typename C>
+__global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64s(const Pbs64Job *__restrict__ jobs,
+                                                          const uint64_t *__restrict__ small,
+                                                          const uint64_t *__restrict__ luts,
+                                                          const double *__restrict__ bsk,    // split layout
+                                                          const double *__restrict__ tw_sub, // [2 fields][2 halves][N/2]
+                                                          const double *__restrict__ tw0, const double *__restrict__ tw1,
+                                                          uint64_t *__restrict__ out, int n, int logB,
+                                                          double p0inv_mod_p1)
+{
+    constexpr int LOGN = C::LOGN, K = C::K;
+    using G = typename C::G;
+    using GS = typename C::GS;
+    constexpr int N = G::N, E = G::E;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
+    uint16_t *MS = reinterpret_cast<uint16_t *>(smem + C::MS_OFF);
+    double *TW = reinterpret_cast<double *>(smem + C::TW_OFF);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = w >> 2, f = (w >> 1) & 1, h = w & 1;
+    const Pbs64Job job = jobs[blockIdx.x];
+    const uint64_t *lwe = small + (size_t)job.in_row * ((size_t)n + 1);
+    for (int i = tid; i <= n; i += 64 * C::NW) MS[i] = (uint16_t)modswitch64(lwe[i], LOGN + 1);
+    // derived tables: index part for blocks A, B and lane table for block C, per (field, half)
+    for (int q = 0; q < 4; q++) {
+        const double *src = tw_sub + (size_t)q * GS::N;
+        double *dst = TW + (size_t)q * C::TW_PART;
+        for (int i = tid; i < C::TW_IDX; i += 64 * C::NW) dst[i] = src[i];
+        for (int r = w; r < GS::TWC; r += C::NW) dst[C::TW_IDX + r * 64 + lane] = src[tw_lane_index<LOGN - 1>(GS::TWB + r, lane)];
+    }
+    __syncthreads();
+    {
+        const int bt = (int)MS[n];
+        const uint64_t *tv = luts + (size_t)job.lut * N;
+        for (int j = tid; j < (K + 1) * N; j += 64 * C::NW) {
+            uint64_t v = 0;
+            if (j >= K * N) {
+                const int idx = ((j - K * N) + bt) & (2 * N - 1);
+                v = tv[idx & (N - 1)];
+                if (idx >= N) v = 0ull - v;
+            }
+            ACC[j] = v;
+        }
+    }
+    __syncthreads();
+    // psi^(N/2): entry 1 of the full forward table of this wave's field
+    const double w1 = f == 0 ? tw0[1] : tw1[1];
+    if (f == 0) pbs64s_body<C, F0>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 0, h, lane);
+    else pbs64s_body<C, F1>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 1, h, lane);
+
+    uint64_t *ob = out + (size_t)job.out_row * ((size_t)K * N + 1);
+    const uint64_t *acc_p = ACC + (size_t)p * N;
+    const int quarter = f * 2 + h;
+    if (p < K) {
+#pragma unroll
+        for (int u = 0; u < E / 4; u++) {
+            const int j = G::jA(lane, quarter * (E / 4) + u);
+            const uint64_t v = acc_p[j];
+            if (j == 0) ob[p * N] = v;
+            else ob[p * N + (N - j)] = 0ull - v;
+        }
+    } else if (w == K * 4 && lane == 0) {
+        ob[K * N] = acc_p[0];
+    }
+}
+
+// key conversion for k_pbs64s: standard-domain u64 -> field F, stage 1 + half transform h, times N^-1:
+//   dst[i][r][c][f][h][e/2][lane][e&1]    (src is [i][lev = 0][r][c][N]); one wave per (polynomial, half)
+template <typename F, int LOGN>
+__global__ __launch_bounds__(64) void k_bsk_convert64s(const uint64_t *__restrict__ src, double *__restrict__ dst,
+                                                       const double *__restrict__ tw_full, const double *__restrict__ tw_sub_f,
+                                                       double n_inv, double two32, int K1, int f)
+{
+    using G = Geo<LOGN>;
+    using GS = Geo<LOGN - 1>;
+    constexpr int N = G::N, EH = GS::E;
+    __shared__ double xbuf[GS::XPAD];
+    const int lane = threadIdx.x;
+    const size_t poly = blockIdx.x >> 1;
+    const int h = blockIdx.x & 1;
+    const int c = poly % K1;
+    const int r = (poly / K1) % K1;
+    const size_t i = poly / ((size_t)K1 * K1);
+    const double w1 = tw_full[1];
+    auto load = [&](int j) {
+        const uint64_t v = src[poly * N + j];
+        const double hi = (double)(int32_t)(uint32_t)(v >> 32), lo = (double)(uint32_t)v;
+        return reduce<F>(mulmod<F>(hi, two32) + lo);
+    };
+    double x[1][EH];
+#pragma unroll
+    for (int e = 0; e < EH; e++) {
+        const double U = load(e * 64 + lane), V = mulmod<F>(load(e * 64 + lane + N / 2), w1);
+        x[0][e] = reduce<F>(h ? U - V : U + V);
+    }
+    ntt_forward<F, LOGN - 1, 1>(x, xbuf, TwMem{tw_sub_f + (size_t)h * GS::N}, lane);
+    const size_t dpoly = ((((i * K1 + r) * K1 + c) * 2 + f) * 2 + h);
+    double *d = dst + dpoly * GS::N;
+#pragma unroll
+    for (int e = 0; e < EH; e++) d[((e >> 1) * 64 + lane) * 2 + (e & 1)] = reduce<F>(mulmod<F>(x[0][e], n_inv));
+}
+
+// ------------------------------------------------------------------------------------
 // k_keyswitch64: as k_keyswitch of helm_hip.hip, 64-bit words.  Grid (ceil(jobs/4),
 // column chunks of 256); digits of four ciphertexts packed as 4 x int8 per LDS word.
 //   out[c] = (c == n ? body : 0) - sum_t sum_j digit(t,j) * KSK[t][j][c]
@@ -531,6 +779,9 @@ struct helm_si_ctx {
     double n_inv[2] = {0, 0}, two32[2] = {0, 0};
     double p0inv_mod_p1 = 0;
     double *bsk = nullptr;
+    double *bsk_split = nullptr; // layout of k_pbs64s (N >= 1024, pbs_l = 1)
+    double *tw_sub = nullptr;    // derived half-transform tables [2 fields][2 halves][N/2]
+    bool use_split = false;
     uint64_t *ksk = nullptr;
     bool have_bsk = false, have_ksk = false;
     uint64_t delta = 0;
@@ -605,10 +856,32 @@ hipError_t launch_pbs64_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count,
     return hipGetLastError();
 }
 
+template <typename C>
+hipError_t launch_pbs64s_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
+                           const uint64_t *luts, uint64_t *out)
+{
+    static bool attr_done[64] = {false};
+    auto kern = k_pbs64s<C>;
+    if (!attr_done[ctx->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
+        if (e != hipSuccess) return e;
+        attr_done[ctx->device & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, small, luts,
+                       ctx->bsk_split, ctx->tw_sub, ctx->tw[0], ctx->tw[1], out, ctx->P.n, ctx->P.pbs_logB,
+                       ctx->p0inv_mod_p1);
+    return hipGetLastError();
+}
+
 hipError_t launch_pbs64(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
                         const uint64_t *luts, uint64_t *out)
 {
     const helm_si_params &P = ctx->P;
+    if (ctx->use_split) {
+        if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10>>(ctx, jobs, count, small, luts, out);
+        if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11>>(ctx, jobs, count, small, luts, out);
+    }
 #define PBS64_CASE(LN, LV) \
     if (ctx->logN == LN && P.pbs_l == LV) return launch_pbs64_c<Pbs64Cfg<LN, LV>>(ctx, jobs, count, small, luts, out);
     PBS64_CASE(9, 1) PBS64_CASE(9, 2) PBS64_CASE(10, 1) PBS64_CASE(10, 2) PBS64_CASE(11, 1) PBS64_CASE(11, 2)
@@ -769,6 +1042,21 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
         HIP_TRY(hipMemcpy(ctx->tw[f], tf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
     }
     ctx->p0inv_mod_p1 = centred(powmod_u64(pm[0] % pm[1], pm[1] - 2, pm[1]), pm[1]);
+    // eight-wave kernel (split transforms) where it exists: N >= 1024, one level (HELM_SI_SPLIT=0: off)
+    ctx->use_split = P.pbs_l == 1 && N >= 1024;
+    if (const char *v = getenv("HELM_SI_SPLIT")) ctx->use_split = ctx->use_split && atoi(v) != 0;
+    if (ctx->use_split) {
+        // half h of field f, stage with m' groups, group i': full table entry 2m' + h m' + i'
+        std::vector<double> sub((size_t)4 * (N / 2), 0.0), full(N);
+        for (int f = 0; f < 2; f++) {
+            HIP_TRY(hipMemcpy(full.data(), ctx->tw[f], sizeof(double) * N, hipMemcpyDeviceToHost));
+            for (int h = 0; h < 2; h++)
+                for (int m = 1; m < N / 2; m <<= 1)
+                    for (int i = 0; i < m; i++) sub[(size_t)(f * 2 + h) * (N / 2) + m + i] = full[2 * m + h * m + i];
+        }
+        HIP_TRY(hipMalloc(&ctx->tw_sub, sub.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(ctx->tw_sub, sub.data(), sub.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     *out = ctx;
     return 0;
 }
@@ -791,6 +1079,8 @@ int helm_si_ctx_destroy(helm_si_ctx *ctx)
     (void)hipFree(ctx->tw[0]);
     (void)hipFree(ctx->tw[1]);
     (void)hipFree(ctx->bsk);
+    (void)hipFree(ctx->bsk_split);
+    (void)hipFree(ctx->tw_sub);
     (void)hipFree(ctx->ksk);
     ctx->d_pbs.release();
     ctx->d_ks.release();
@@ -854,6 +1144,19 @@ int helm_si_load_bootstrap_key(helm_si_ctx *ctx, const uint64_t *bsk_std, size_t
     }
     CONV(9) CONV(10) CONV(11)
 #undef CONV
+    if (ctx->use_split) {
+        if (!ctx->bsk_split) HIP_TRY(hipMalloc(&ctx->bsk_split, n_words * 2 * sizeof(double)));
+#define CONVS(LN)                                                                                                       \
+    if (ctx->logN == LN) {                                                                                              \
+        hipLaunchKernelGGL((k_bsk_convert64s<F0, LN>), dim3((unsigned)(polys * 2)), dim3(64), 0, ctx->stream, d_std,     \
+                           ctx->bsk_split, ctx->tw[0], ctx->tw_sub, ctx->n_inv[0], ctx->two32[0], (int)K1, 0);           \
+        hipLaunchKernelGGL((k_bsk_convert64s<F1, LN>), dim3((unsigned)(polys * 2)), dim3(64), 0, ctx->stream, d_std,     \
+                           ctx->bsk_split, ctx->tw[1], ctx->tw_sub + (size_t)2 * (P.N / 2), ctx->n_inv[1], ctx->two32[1], \
+                           (int)K1, 1);                                                                                  \
+    }
+        CONVS(10) CONVS(11)
+#undef CONVS
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(d_std));
