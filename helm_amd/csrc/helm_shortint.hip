@@ -383,9 +383,11 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
     const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * 4 + f * 2 + h) * part + lane;
     const uint32_t mask = (1u << logB) - 1u;
 
+    STAMP_DECL
     for (int i = 0; i < n; i++) {
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
         if (a == 0) continue; // uniform over the workgroup
+        STAMP_BEGIN
         const double2 *bp_i = bsk_w + (size_t)i * bsk_step;
         // ---- (1) digits of this wave's quarter of polynomial p -------------------------------
 #pragma unroll
@@ -404,7 +406,9 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         double2 kw[K1][HC];
 #pragma unroll
         for (int u = 0; u < HC; u++) kw[0][u] = (bp_i + (size_t)0 * 4 * part)[u * 64];
+        STAMP(0) // quarter decomposition
         lds_block_sync(); // digits published
+        STAMP(1) // barrier 1
         // ---- (2) stage 1 of the full transform, half transform, products ---------------------
         double x[1][EH];
         {
@@ -416,6 +420,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
             }
         }
         ntt_forward<F, LOGN - 1, 1>(x, xb, twf, lane);
+        STAMP(2) // digits read, stage 1, half transform
 #pragma unroll
         for (int u = 0; u < HC; u++) kw[1][u] = (bp_i + (size_t)1 * 4 * part)[u * 64];
         double mine[EH], other[EH];
@@ -434,12 +439,15 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
             }
 #pragma unroll
         for (int e = 0; e < EH; e++) xb[e * 64 + lane] = reduce<F>(other[e]);
+        STAMP(3) // products
         lds_block_sync();
 #pragma unroll
         for (int e = 0; e < EH; e++) mine[e] = reduce<F>(reduce<F>(mine[e]) + x_poly[e * 64 + lane]);
         lds_block_sync(); // hand-over read: scratch free again
+        STAMP(4) // barrier 2, sum, barrier 3
         // ---- (3) half inverse, meet the other half, last stage -------------------------------
         ntt_inverse<F, LOGN - 1>(mine, xb, twi, lane); // a_h[e * 64 + lane], centred
+        STAMP(5) // half inverse
 #pragma unroll
         for (int e = 0; e < EH; e++) xb[e * 64 + lane] = mine[e];
         lds_block_sync();
@@ -450,6 +458,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
             mine[e] = h ? reduce<F>(mulmod<F>(mine[e] - o, w1)) : reduce<F>(mine[e] + o);
         }
         lds_block_sync(); // the other half has read: scratch free again
+        STAMP(6) // half exchange, last stage, barriers 4 and 5
         // ---- (4) CRT: field-f wave lifts slots [f*EH/2, (f+1)*EH/2) of its half ----------------
         constexpr int HH = EH / 2;
 #pragma unroll
@@ -464,7 +473,9 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
             acc_p[h * (N / 2) + (f * HH + e) * 64 + lane] += xv;
         }
         lds_block_sync(); // accumulator complete
+        STAMP(7) // CRT, barriers 6 and 7
     }
+    STAMP_END((p * 2 + f) * 2 + h)
 }
 
 template <typename C>
@@ -871,6 +882,18 @@ hipError_t launch_pbs64s_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, small, luts,
                        ctx->bsk_split, ctx->tw_sub, ctx->tw[0], ctx->tw[1], out, ctx->P.n, ctx->P.pbs_logB,
                        ctx->p0inv_mod_p1);
+#ifdef HELM_WIDE_STAMPS
+    {
+        unsigned long long v[8 * 8];
+        (void)hipStreamSynchronize(ctx->stream);
+        if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_stamps64), sizeof(v)) == hipSuccess)
+            for (int w = 0; w < C::NW; w++) {
+                fprintf(stderr, "[stamps k_pbs64s: digits | bar1 | fwd | products | sum+bars | inverse | halves+bars | crt+bars] wave %d:", w);
+                for (int q = 0; q < 8; q++) fprintf(stderr, " %llu", v[w * 8 + q] / ctx->P.n);
+                fprintf(stderr, " cycles/step\n");
+            }
+    }
+#endif
     return hipGetLastError();
 }
 
