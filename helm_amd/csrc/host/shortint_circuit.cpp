@@ -793,8 +793,12 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops, i
             std::vector<uint64_t> z(zero_rows.size(), 0);
             si_ok(helm_si_wires_set_trivial(ctx_, w, zero_rows.data(), z.data(), (int64_t)zero_rows.size()), "set_trivial");
         }
+        // one batch: the keyswitch of every ciphertext of a call finishes before any bootstrap writes,
+        // so the lo look-ups may overwrite the packed rows the hi look-ups also read
+        in.insert(in.end(), in2.begin(), in2.end());
+        lut.insert(lut.end(), lut2.begin(), lut2.end());
+        out.insert(out.end(), out2.begin(), out2.end());
         apply(w, in, lut, out);
-        apply(w, in2, lut2, out2);
     }
 
     // ---- multiplications: reduce the terms (sums of <= 15 per block, then message + carry) ----
@@ -851,11 +855,9 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops, i
             std::vector<uint64_t> z(zero_rows.size(), 0);
             si_ok(helm_si_wires_set_trivial(ctx_, w, zero_rows.data(), z.data(), (int64_t)zero_rows.size()), "set_trivial");
         }
+        // carries and (in place) messages of every summed row in one batch (see above)
+        for (auto r : lo) { in.push_back(r); lut.push_back(lut_msg_); out.push_back(r); }
         apply(w, in, lut, out);
-        // message in place: every summed row
-        std::vector<int32_t> min_, mlut, mout;
-        for (auto r : lo) { min_.push_back(r); mlut.push_back(lut_msg_); mout.push_back(r); }
-        apply(w, min_, mlut, mout);
     }
     // ---- multiplications: last addition ---------------------------------------------------------
     {
