@@ -99,6 +99,9 @@ HIP_API = {
     "helm_hip_get_timing": (C.c_int, [vp, C.POINTER(Timing), C.c_int]),
 }
 
+# helm_si_exchange_fn: int (*)(void *user, int64_t rows_per_rank)
+SI_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int64)
+
 # every symbol include/helm_shortint.h declares
 SI_API = {
     "helm_si_ctx_create": (C.c_int, [C.c_int, C.POINTER(SiParams), C.POINTER(vp)]),
@@ -118,6 +121,8 @@ SI_API = {
     "helm_si_make_lut": (C.c_int, [vp, u64p, u64p]),
     "helm_si_apply_luts": (C.c_int, [vp, vp, i32p, i32p, i32p, C.c_int64, u64p, C.c_int64]),
     "helm_si_eval_lut_level": (C.c_int, [vp, vp, i32p, i32p, C.c_int32, u64p, i32p, C.c_int64]),
+    "helm_si_set_exchange": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_int64, SI_EXCHANGE_FN, vp]),
+    "helm_si_exchange_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "helm_si_keyswitch_batch": (C.c_int, [vp, u64p, u64p, C.c_int64]),
     "helm_si_pbs_batch": (C.c_int, [vp, u64p, u64p, C.c_int64, i32p, u64p, C.c_int64]),
     "helm_si_timing_enable": (C.c_int, [vp, C.c_int]),

@@ -807,6 +807,15 @@ struct helm_si_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pbs, ev_ks, ev_lin;
     helm_si_timing tacc{};
     std::vector<helm_si_wires *> child_wires; // released with the context (see helm_hip.hip)
+    // multi-GPU (helm_si_set_exchange): every bootstrap batch of at least x_min ciphertexts is split
+    // into x_world contiguous chunks, this rank bootstraps chunk x_rank into x_stage, the caller's
+    // collective fills x_gather with every rank's chunk and the rows are scattered into the table
+    int x_rank = 0, x_world = 1;
+    int64_t x_min = 0, x_cap = 0;
+    uint64_t *x_stage = nullptr, *x_gather = nullptr;
+    helm_si_exchange_fn x_fn = nullptr;
+    void *x_user = nullptr;
+    int64_t x_batches = 0, x_rows = 0;
 };
 
 namespace {
@@ -1000,6 +1009,42 @@ int apply_luts_device(helm_si_ctx *ctx, const uint64_t *src, uint64_t *dst, cons
     }
     ctx->tacc.pbs_launches++;
     ctx->tacc.pbs_count += count;
+    return 0;
+}
+
+// helm_si_apply_luts with the batch sharded over the ranks of helm_si_set_exchange(): identical
+// ciphertexts to the unsharded call (every bootstrap is independent and deterministic)
+int apply_luts_sharded(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, const int32_t *lut_idx,
+                       const int32_t *out_idx, int64_t count, const uint64_t *luts, int64_t n_luts)
+{
+    const int dim = ctx->P.k * ctx->P.N;
+    const int64_t world = ctx->x_world;
+    for (int64_t base = 0; base < count;) {
+        const int64_t per = std::min(count - base, ctx->x_cap * world);
+        const int64_t rows = (per + world - 1) / world;
+        const int64_t lo = std::min(base + per, base + ctx->x_rank * rows), hi = std::min(base + per, lo + rows);
+        std::vector<Ks64Job> ks((size_t)(hi - lo));
+        std::vector<Pbs64Job> pbs((size_t)(hi - lo));
+        for (int64_t g = lo; g < hi; g++) {
+            ks[(size_t)(g - lo)] = Ks64Job{in_idx[g], (int32_t)(g - lo)};
+            pbs[(size_t)(g - lo)] = Pbs64Job{(int32_t)(g - lo), lut_idx[g], (int32_t)(g - lo), 0};
+        }
+        if (int rc = apply_luts_device(ctx, w->d, ctx->x_stage, ks, pbs, luts, n_luts)) return rc;
+        // the collective is the caller's (RCCL all-gather on this context's stream): every rank calls it,
+        // also one whose chunk is empty
+        if (int rc = ctx->x_fn(ctx->x_user, rows))
+            return fail(HELM_ERR_STATE, "exchange callback failed with " + std::to_string(rc));
+        if (int rc = drain(ctx)) return rc;
+        if (int rc = upload(ctx, ctx->d_idx2, out_idx + base, (size_t)per)) return rc;
+        // gathered row q * rows + i is gate base + q * rows + i: the chunks are contiguous
+        hipLaunchKernelGGL(k_rows64, dim3((unsigned)per), dim3(256), 0, ctx->stream, ctx->x_gather,
+                           (const int32_t *)nullptr, w->d, ctx->d_idx2.p, dim);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->x_batches++;
+        ctx->x_rows += rows * world;
+        base += per;
+    }
     return 0;
 }
 
@@ -1384,8 +1429,43 @@ int helm_si_apply_luts(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx
         ks[(size_t)g] = Ks64Job{in_idx[g], (int32_t)g};
         pbs[(size_t)g] = Pbs64Job{(int32_t)g, lut_idx[g], out_idx[g], 0};
     }
+    if (ctx->x_world > 1 && count >= ctx->x_min)
+        return apply_luts_sharded(ctx, w, in_idx, lut_idx, out_idx, count, luts, n_luts);
     // every keyswitch finishes (kernel boundary) before any bootstrap writes its output row
     return apply_luts_device(ctx, w->d, w->d, ks, pbs, luts, n_luts);
+}
+
+int helm_si_set_exchange(helm_si_ctx *ctx, int32_t rank, int32_t world, int64_t min_batch, void *stage_dev,
+                         void *gather_dev, int64_t capacity_rows, helm_si_exchange_fn fn, void *user)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null context");
+    if (world <= 1) { // back to single-GPU evaluation
+        ctx->x_world = 1;
+        ctx->x_rank = 0;
+        ctx->x_fn = nullptr;
+        ctx->x_stage = ctx->x_gather = nullptr;
+        return 0;
+    }
+    if (rank < 0 || rank >= world || min_batch < 1 || capacity_rows < 1 || !stage_dev || !gather_dev || !fn)
+        return fail(HELM_ERR_INVALID, "helm_si_set_exchange: bad argument");
+    ctx->x_rank = rank;
+    ctx->x_world = world;
+    ctx->x_min = min_batch;
+    ctx->x_cap = capacity_rows;
+    ctx->x_stage = static_cast<uint64_t *>(stage_dev);
+    ctx->x_gather = static_cast<uint64_t *>(gather_dev);
+    ctx->x_fn = fn;
+    ctx->x_user = user;
+    ctx->x_batches = ctx->x_rows = 0;
+    return 0;
+}
+
+int helm_si_exchange_stats(const helm_si_ctx *ctx, int64_t *batches, int64_t *rows)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null context");
+    if (batches) *batches = ctx->x_batches;
+    if (rows) *rows = ctx->x_rows;
+    return 0;
 }
 
 int helm_si_eval_lut_level(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *arity, const int32_t *in_idx,

@@ -128,6 +128,44 @@ class SiServerKey:
     def set_stream(self, stream_ptr):
         hip_check(hip.helm_si_set_stream(self._h, nv.vp(stream_ptr)))
 
+    def set_exchange(self, dist, rank, world, min_batch=None, capacity_rows=4096):
+        """Shard every bootstrap batch of at least `min_batch` ciphertexts over the `world`
+        ranks of torch.distributed `dist` (backend nccl = RCCL; helm_si_set_exchange).  The
+        engine is put on torch's current stream so that the all-gather is ordered behind the
+        kernels that fill the staging rows.  world <= 1 switches sharding off."""
+        if world <= 1:
+            hip_check(hip.helm_si_set_exchange(self._h, 0, 1, 1, None, None, 1, nv.SI_EXCHANGE_FN(0), None))
+            self._exchange = None
+            return
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.set_stream(torch.cuda.current_stream().cuda_stream)
+        row = self.dim + 1
+        stage = torch.empty((capacity_rows, row), dtype=torch.int64, device=dev)
+        gather = torch.empty((capacity_rows * world, row), dtype=torch.int64, device=dev)
+
+        def exchange(_user, rows):
+            try:
+                dist.all_gather_into_tensor(gather[:rows * world], stage[:rows])
+                return 0
+            except Exception:  # an exception cannot cross the C frames
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        fn = nv.SI_EXCHANGE_FN(exchange)
+        if min_batch is None:
+            # a batch that fits one wave of workgroups (one bootstrap per CU) gains nothing from sharding
+            min_batch = torch.cuda.get_device_properties(dev).multi_processor_count + 1
+        hip_check(hip.helm_si_set_exchange(self._h, rank, world, int(min_batch), nv.vp(stage.data_ptr()),
+                                           nv.vp(gather.data_ptr()), capacity_rows, fn, None))
+        self._exchange = (fn, stage, gather)  # kept alive for the engine
+
+    def exchange_stats(self):
+        b, r = C.c_int64(0), C.c_int64(0)
+        hip_check(hip.helm_si_exchange_stats(self._h, C.byref(b), C.byref(r)))
+        return int(b.value), int(r.value)
+
     def wires(self, n_rows):
         return SiWires(self, n_rows)
 

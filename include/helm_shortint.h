@@ -108,6 +108,24 @@ int helm_si_apply_luts(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx
 int helm_si_eval_lut_level(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *arity, const int32_t *in_idx,
                            int32_t max_in, const uint64_t *table, const int32_t *out_idx, int64_t count);
 
+/* Multi-GPU (one process per GPU, keys and wire tables replicated): after this call every
+ * bootstrap batch of at least `min_batch` ciphertexts - helm_si_apply_luts() and everything
+ * built on it: helm_si_eval_lut_level(), the radix operators of the host library - is split
+ * into `world` contiguous chunks.  This rank keyswitches and bootstraps chunk `rank` into
+ * `stage_dev` (rows of k*N+1 words), calls fn(user, rows_per_rank), which must all-gather
+ * rows_per_rank rows of stage_dev from every rank into gather_dev in rank order ON THE
+ * CONTEXT'S STREAM (ncclAllGather over RCCL/xGMI; helm_si_set_stream) and return 0, and then
+ * scatters the gathered rows into the table.  Every rank must issue the same calls in the same
+ * order; the ciphertexts are identical to a single-GPU evaluation.  stage_dev holds
+ * capacity_rows rows, gather_dev capacity_rows * world (larger batches go in several rounds).
+ * world <= 1 switches sharding off.  The reference has no multi-GPU path; its unit of
+ * parallelism is the level (src/circuit.rs:1057 par_iter_mut over the gates of a level). */
+typedef int (*helm_si_exchange_fn)(void *user, int64_t rows_per_rank);
+int helm_si_set_exchange(helm_si_ctx *ctx, int32_t rank, int32_t world, int64_t min_batch, void *stage_dev,
+                         void *gather_dev, int64_t capacity_rows, helm_si_exchange_fn fn, void *user);
+/* batches sharded so far and rows moved through gather_dev (per rank) */
+int helm_si_exchange_stats(const helm_si_ctx *ctx, int64_t *batches, int64_t *rows);
+
 /* Primitive forms on host buffers (tests).  small: count x (n+1); big: count x (k*N+1). */
 int helm_si_keyswitch_batch(helm_si_ctx *ctx, const uint64_t *in_big, uint64_t *out_small, int64_t count);
 int helm_si_pbs_batch(helm_si_ctx *ctx, const uint64_t *in_small, const uint64_t *luts, int64_t n_luts,
