@@ -37,6 +37,11 @@ class Timing(C.Structure):
                 ("ks_launches", C.c_int64), ("ks_count", C.c_int64)]
 
 
+class HipTiming(C.Structure):  # helm_hip_timing
+    _fields_ = Timing._fields_ + [("pbs_main_ms", C.c_double), ("pbs_main_launches", C.c_int64),
+                                  ("pbs_main_count", C.c_int64)]
+
+
 class SiParams(C.Structure):
     _fields_ = [(f, C.c_int32) for f in ("n", "k", "N", "pbs_l", "pbs_logB", "ks_l", "ks_logB",
                                          "message_modulus", "carry_modulus")]
@@ -96,7 +101,7 @@ HIP_API = {
     "helm_hip_keyswitch_batch": (C.c_int, [vp, u32p, u32p, C.c_int64]),
     "helm_hip_ntt_roundtrip": (C.c_int, [vp, u32p, u32p, C.c_int64]),
     "helm_hip_timing_enable": (C.c_int, [vp, C.c_int]),
-    "helm_hip_get_timing": (C.c_int, [vp, C.POINTER(Timing), C.c_int]),
+    "helm_hip_get_timing": (C.c_int, [vp, C.POINTER(HipTiming), C.c_int]),
 }
 
 # helm_si_exchange_fn: int (*)(void *user, int64_t rows_per_rank)

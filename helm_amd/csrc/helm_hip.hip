@@ -160,10 +160,15 @@ __device__ unsigned long long g_wide_stamps[2 * 16 * 6];
 // ------------------------------------------------------------------------------------
 enum { TW_REG = 0, TW_LANE = 1 /* lane-major LDS table of forward twiddles, inverse reads it mirrored */ };
 
-template <typename F_, int LOGN_, int K_, int L_, int M_, int TW_, bool PREFETCH_, int MINW_>
+template <typename F_, int LOGN_, int K_, int L_, int M_, int TW_, bool PREFETCH_, int MINW_, int NB_ = 1>
 struct PbsCfg {
     using F = F_;
     static constexpr int LOGN = LOGN_, K = K_, L = L_, M = M_, TW = TW_, MINW = MINW_;
+    // bootstraps per workgroup.  NB = 4: wave w serves bootstrap w % 4 as polynomial w / 4; the
+    // hardware deals the waves of a workgroup round the four SIMDs (tools/ubench_placement.hip), so
+    // the k+1 waves of a bootstrap share one SIMD, every SIMD carries the same work, and the
+    // workgroup barriers couple waves that progress alike
+    static constexpr int NB = NB_;
     static constexpr bool PREFETCH = PREFETCH_;
     using G = Geo<LOGN>;
     static constexpr int K1 = K + 1;
@@ -184,11 +189,12 @@ struct PbsCfg {
     static constexpr size_t X_OFF = 0;                                                // double [K1][WAVE_STRIDE]
     static constexpr size_t TW_OFF = X_OFF + sizeof(double) * K1 * WAVE_STRIDE;       // double [TW_ROWS][64]
     static constexpr size_t MS_OFF = TW_OFF + sizeof(double) * TW_ROWS * 64;          // u16 [n+1]
-    static constexpr size_t BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
+    static constexpr size_t BOOT_BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
+    static constexpr size_t BYTES = BOOT_BYTES * NB;
 };
 
 template <typename C>
-__global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *__restrict__ jobs,
+__global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const PbsJob *__restrict__ jobs,
                                                                   const uint32_t *__restrict__ wires,  // rows of n+1
                                                                   const uint32_t *__restrict__ raw_in, // rows of n+1
                                                                   const uint32_t *__restrict__ tvs,    // rows of N
@@ -196,19 +202,25 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
                                                                   const double *__restrict__ tw_fwd,
                                                                   const double *__restrict__ tw_inv,
                                                                   uint32_t *__restrict__ out_big, // rows of K*N+1
-                                                                  int n, int logB, int probe)
+                                                                  int n, int logB, int probe, int count)
 {
-    constexpr int LOGN = C::LOGN, K = C::K, L = C::L, M = C::M;
+    constexpr int LOGN = C::LOGN, K = C::K, L = C::L, M = C::M, NB = C::NB;
     using F = typename C::F;
     using G = Geo<LOGN>;
     constexpr int N = G::N, E = G::E, K1 = K + 1;
-    extern __shared__ __align__(16) unsigned char smem[];
+    extern __shared__ __align__(16) unsigned char smem_wg[];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int p = wv / NB;                       // this wave's polynomial
+    const int tid = p * 64 + lane;               // thread index within the bootstrap's k+1 waves
+    const int jix = (int)blockIdx.x * NB + wv % NB; // this wave's bootstrap
+    // a wave without a bootstrap leaves; the hardware barrier counts the surviving waves only
+    if (NB > 1 && jix >= count) return;
+    unsigned char *smem = smem_wg + (size_t)(wv % NB) * C::BOOT_BYTES;
     double *X = reinterpret_cast<double *>(smem + C::X_OFF);
     uint16_t *MS = reinterpret_cast<uint16_t *>(smem + C::MS_OFF);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int p = __builtin_amdgcn_readfirstlane(tid >> 6); // this wave's polynomial
-    const PbsJob job = jobs[blockIdx.x];
+    const PbsJob job = jobs[jix];
     const size_t row = (size_t)n + 1;
 
     // ---- gate linear step + modulus switch (whole workgroup) ------------------------
@@ -296,7 +308,10 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
         }
     };
     auto next_nonzero = [&](int i) {
-        while (i < n && __builtin_amdgcn_readfirstlane((int)MS[i]) == 0) i++;
+        // a zero rotation contributes nothing; bootstraps that share a workgroup keep it (one step in
+        // 2N) so that they meet at the same barriers
+        if constexpr (NB == 1)
+            while (i < n && __builtin_amdgcn_readfirstlane((int)MS[i]) == 0) i++;
         return i;
     };
 
@@ -501,7 +516,7 @@ __global__ __launch_bounds__(64 * (C::K + 1), C::MINW) void k_pbs(const PbsJob *
         g_clock_probe[3] = __builtin_amdgcn_s_memrealtime();
     }
     // ---- sample extract (coefficient 0): wave p writes its own polynomial -------------
-    uint32_t *ob = out_big + (size_t)blockIdx.x * ((size_t)K * N + 1);
+    uint32_t *ob = out_big + (size_t)jix * ((size_t)K * N + 1);
     if (p < K) {
 #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -983,7 +998,7 @@ struct helm_hip_ctx {
     int n_cus = 256;
     int narrow_variant = 4;  // build for launches of at most one workgroup per CU: 4 wide, 1 latency (HELM_HIP_NARROW)
     int clock_probe = 0;     // HELM_HIP_CLOCK_PROBE: print the in-kernel clock of every k_pbs launch
-    int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput (HELM_HIP_PBS_VARIANT)
+    int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput, 4 wide, 5 lockstep (HELM_HIP_PBS_VARIANT)
     // per-call scratch
     DevBuf<PbsJob> d_pbs;
     DevBuf<KsJob> d_ks;
@@ -991,7 +1006,7 @@ struct helm_hip_ctx {
     DevBuf<uint32_t> d_big;
     // timing
     bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pbs, ev_ks, ev_lin;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pbs, ev_pbs_main, ev_ks, ev_lin;
     helm_hip_timing tacc{};
     // wire tables and programs created from this context: released with it, so that a handle
     // freed after its context (host-language destructors run in any order) is harmless
@@ -1073,6 +1088,27 @@ static int plan_level(const int32_t *op, const int32_t *in0, const int32_t *in1,
     return 0;
 }
 
+struct TimedScope {
+    helm_hip_ctx *ctx;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> *list;
+    hipEvent_t a = nullptr, b = nullptr;
+    TimedScope(helm_hip_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> *l) : ctx(c), list(l)
+    {
+        if (ctx->timing) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, ctx->stream);
+        }
+    }
+    ~TimedScope()
+    {
+        if (ctx->timing) {
+            (void)hipEventRecord(b, ctx->stream);
+            list->push_back({a, b});
+        }
+    }
+};
+
 template <typename C>
 static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
                                const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
@@ -1086,16 +1122,17 @@ static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
         attr_done[ctx->device & 63] = true;
         if (getenv("HELM_HIP_VERBOSE")) {
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 64 * (C::K + 1),
-                                                               C::BYTES);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern),
+                                                               64 * (C::K + 1) * C::NB, C::BYTES);
             hipFuncAttributes fa{};
             (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
-            fprintf(stderr, "[helm_hip] k_pbs M=%d TW=%d MINW=%d: LDS %zu B, regs %d, scratch %zu B, max %d workgroups/CU\n",
-                    C::M, C::TW, C::MINW, (size_t)C::BYTES, fa.numRegs, (size_t)fa.localSizeBytes, nb);
+            fprintf(stderr, "[helm_hip] k_pbs M=%d TW=%d MINW=%d NB=%d: LDS %zu B, regs %d, scratch %zu B, max %d workgroups/CU\n",
+                    C::M, C::TW, C::MINW, C::NB, (size_t)C::BYTES, fa.numRegs, (size_t)fa.localSizeBytes, nb);
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * (C::K + 1)), C::BYTES, ctx->stream, jobs, wires, raw, tvs,
-                       ctx->bsk, ctx->tw_fwd, ctx->tw_inv, out_big, ctx->P.n, ctx->P.pbs_logB, ctx->clock_probe);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((count + C::NB - 1) / C::NB)), dim3(64 * (C::K + 1) * C::NB), C::BYTES,
+                       ctx->stream, jobs, wires, raw, tvs, ctx->bsk, ctx->tw_fwd, ctx->tw_inv, out_big, ctx->P.n,
+                       ctx->P.pbs_logB, ctx->clock_probe, (int)count);
     hipError_t e = hipGetLastError();
     print_stamps(ctx, C::K + 1, "k_pbs: work | bar1 | sum | bar2 | inverse | publish");
     if (e == hipSuccess && (ctx->clock_probe & 1)) {
@@ -1152,15 +1189,18 @@ static hipError_t launch_pbs_wide(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t
     return hipGetLastError();
 }
 
-// Build choice.  Measured on MI355X, boolean_default (profiles/r01/microbench_nand_*): one
-// launch of B bootstraps takes, by the largest number j of workgroups a CU receives,
+// Build choice.  Measured on MI355X, boolean_default (profiles/r01/microbench_*): one launch of B
+// bootstraps takes
+//   wide       3.7 - 4.0 ms per round of <= 256 ((k+1) L = 9 waves per bootstrap: k_pbs_wide)
 //   latency    4.4 ms per round of 256 (one workgroup per CU)
-//   balanced   4.8 (j = 1), 7.6 (j = 2) ms
-//   throughput 4.9, 7.4, 9.9, 12.4 ms for j = 1..4 (12 waves per CU, three per SIMD), 12.0 ms
-//              per 1,024 in longer launches
-//   wide       3.7 - 3.9 ms per round of <= 256 ((k+1) L = 9 waves per bootstrap: k_pbs_wide)
-// so a launch that fits one workgroup per CU uses the wide kernel (HELM_HIP_NARROW=1: the latency
-// build) and every wider one the throughput build.  HELM_HIP_PBS_VARIANT=1|2|3|4 forces a build.
+//   balanced   4.8 (<= 256), 7.6 (<= 512) ms
+//   throughput 4.9, 7.4, 9.9, 12.4 ms for up to 1..4 workgroups per CU (12 waves per CU, three per
+//              SIMD), 10.6 ms per 1,024 in longer launches
+//   lockstep   9.0 - 9.2 ms per round of <= 1,024 (four bootstraps per workgroup, one per SIMD)
+// so a launch runs its full rounds of 4 bootstraps per CU in lockstep and the remainder by size:
+// up to one per CU wide (HELM_HIP_NARROW=1: latency), up to two per CU throughput, more another
+// lockstep round.  HELM_HIP_PBS_VARIANT=1|2|3|4|5 forces latency | balanced | throughput | wide |
+// lockstep for the whole launch.
 template <typename F, int LOGN, int K, int L>
 static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
                                const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
@@ -1169,11 +1209,31 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
         using Lat = PbsCfg<F, LOGN, K, L, L, TW_REG, true, 1>;
         using Bal = PbsCfg<F, LOGN, K, L, L, TW_LANE, true, 2>;
         using Thr = PbsCfg<F, LOGN, K, L, 1, TW_LANE, false, 3>;
+        using Lock = PbsCfg<F, LOGN, K, L, 1, TW_LANE, false, 1, 4>;
         int v = ctx->pbs_variant;
-        if (v == 0) v = count <= ctx->n_cus ? ctx->narrow_variant : 3;
+        if (v == 0) {
+            const int64_t round = 4 * (int64_t)ctx->n_cus;
+            int64_t full = count / round * round;
+            if (count - full > 2 * (int64_t)ctx->n_cus) full = count;
+            if (full) {
+                hipError_t e;
+                {
+                    TimedScope t(ctx, &ctx->ev_pbs_main);
+                    e = launch_pbs_v<Lock>(ctx, jobs, full, wires, raw, tvs, out_big);
+                }
+                ctx->tacc.pbs_main_launches++;
+                ctx->tacc.pbs_main_count += full;
+                if (e != hipSuccess || full == count) return e;
+                jobs += full;
+                out_big += (size_t)full * ((size_t)K * (1 << LOGN) + 1);
+                count -= full;
+            }
+            v = count <= ctx->n_cus ? ctx->narrow_variant : 3;
+        }
         if (v == 4) return launch_pbs_wide<WideCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (v == 1) return launch_pbs_v<Lat>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (v == 2) return launch_pbs_v<Bal>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if (v == 5) return launch_pbs_v<Lock>(ctx, jobs, count, wires, raw, tvs, out_big);
         return launch_pbs_v<Thr>(ctx, jobs, count, wires, raw, tvs, out_big);
     } else {
         // N = 1024 (k = 1): two waves per bootstrap, 422 registers: two workgroups per CU put one
@@ -1245,26 +1305,6 @@ static hipError_t launch_ks(helm_hip_ctx *ctx, const KsJob *jobs, int64_t count,
     return hipGetLastError();
 }
 
-struct TimedScope {
-    helm_hip_ctx *ctx;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> *list;
-    hipEvent_t a = nullptr, b = nullptr;
-    TimedScope(helm_hip_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> *l) : ctx(c), list(l)
-    {
-        if (ctx->timing) {
-            (void)hipEventCreate(&a);
-            (void)hipEventCreate(&b);
-            (void)hipEventRecord(a, ctx->stream);
-        }
-    }
-    ~TimedScope()
-    {
-        if (ctx->timing) {
-            (void)hipEventRecord(b, ctx->stream);
-            list->push_back({a, b});
-        }
-    }
-};
 
 // Run one planned level whose job arrays are already on the device.
 static int run_level_device(helm_hip_ctx *ctx, const PbsJob *d_pbs, int64_t n_pbs, const KsJob *d_ks, int64_t n_ks,
@@ -1386,7 +1426,7 @@ int helm_hip_ctx_destroy(helm_hip_ctx *ctx)
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto *l : {&ctx->ev_pbs, &ctx->ev_ks, &ctx->ev_lin})
+    for (auto *l : {&ctx->ev_pbs, &ctx->ev_pbs_main, &ctx->ev_ks, &ctx->ev_lin})
         for (auto &p : *l) {
             (void)hipEventDestroy(p.first);
             (void)hipEventDestroy(p.second);
@@ -1957,6 +1997,7 @@ int helm_hip_get_timing(helm_hip_ctx *ctx, helm_hip_timing *out, int reset)
         l.clear();
     };
     drain(ctx->ev_pbs, ctx->tacc.pbs_ms);
+    drain(ctx->ev_pbs_main, ctx->tacc.pbs_main_ms);
     drain(ctx->ev_ks, ctx->tacc.ks_ms);
     drain(ctx->ev_lin, ctx->tacc.linear_ms);
     *out = ctx->tacc;

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as nv
-from ._native import Params, Timing, hip, host, hip_check, client_check
+from ._native import Params, HipTiming as Timing, hip, host, hip_check, client_check
 
 
 def named_params(name):

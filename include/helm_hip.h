@@ -190,6 +190,10 @@ typedef struct {
     double linear_ms;   /* ... NOT/BUF/const kernel                           */
     int64_t pbs_launches, pbs_count; /* launches, bootstraps                   */
     int64_t ks_launches, ks_count;
+    /* the lockstep build of the blind-rotate kernel alone (the full rounds of every launch: the
+     * dominant kernel of wide levels); also contained in pbs_ms */
+    double pbs_main_ms;
+    int64_t pbs_main_launches, pbs_main_count;
 } helm_hip_timing;
 /* When enabled, HIP events on the context's stream bracket each kernel launch
  * (adds a sync per get_timing call, not per launch). */
