@@ -169,6 +169,9 @@ struct PbsCfg {
     // the k+1 waves of a bootstrap share one SIMD, every SIMD carries the same work, and the
     // workgroup barriers couple waves that progress alike
     static constexpr int NB = NB_;
+    // level-at-a-time path: key columns fetched before the level's transform (the rest after it)
+    // (2 of k+1 = 3: fetching the third one early as well measured the same in the lockstep build)
+    static constexpr int EARLY_COLS = 2;
     static constexpr bool PREFETCH = PREFETCH_;
     using G = Geo<LOGN>;
     static constexpr int K1 = K + 1;
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
                 // (the last column is fetched after the transform: during it the transform's own
                 // temporaries need the registers, and the first two products cover its latency)
                 double2 bwl[K1][E / 2];
-                constexpr int EARLY = K1 > 2 ? 2 : K1;
+                constexpr int EARLY = C::EARLY_COLS < K1 ? C::EARLY_COLS : K1;
 #pragma unroll
                 for (int d = 0; d < EARLY; d++)
 #pragma unroll

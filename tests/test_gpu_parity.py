@@ -196,3 +196,51 @@ def test_upload_rejects_duplicate_rows():
         sw.upload([0, 0], sck.encrypt([1, 2]))
     sk.close()
     ssk.close()
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+def test_every_build_of_k_pbs_bit_exact(variant, monkeypatch):
+    """HELM_HIP_PBS_VARIANT forces one build of the blind-rotate kernel for a whole launch (latency,
+    balanced, throughput, wide, lockstep); each must reproduce the oracle bit for bit.  Nine
+    ciphertexts: two full workgroups and one with a single bootstrap in the lockstep build (its
+    other waves leave before the first barrier); an all-zero mask keeps every rotation at zero."""
+    monkeypatch.setenv("HELM_HIP_PBS_VARIANT", str(variant))
+    ck = helm_amd.ClientKey.generate("toy_k2", seed=11)
+    sk = helm_amd.ServerKey(ck)  # the variant is read when the context is created
+    orc = oracle.Oracle(ck.params.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True)
+    p = ck.params
+    rng = np.random.default_rng(20 + variant)
+    lwe = rng.integers(0, 2**32, size=(9, p.n + 1), dtype=np.uint32)
+    lwe[0] = ck.encrypt(True)
+    lwe[3, :] = 0
+    tvs = rng.integers(0, 2**32, size=(2, p.N), dtype=np.uint32)
+    idx = rng.integers(0, 2, size=9).astype(np.int32)
+    got = sk.pbs_batch(lwe, tvs, idx)
+    for g in range(len(lwe)):
+        assert np.array_equal(got[g], orc.bootstrap_noks(lwe[g], tvs[idx[g]])), f"variant {variant}, ciphertext {g}"
+    sk.close()
+
+
+def test_launch_split_over_builds_bit_exact(monkeypatch):
+    """Default dispatch of a wide launch: the full rounds (4 bootstraps per CU) go to the lockstep
+    build, the remainder to the wide / throughput build.  Same ciphertexts as the throughput build
+    alone, and as the oracle on a sample."""
+    ck = helm_amd.ClientKey.generate("toy_k2", seed=12)
+    p = ck.params
+    rng = np.random.default_rng(5)
+    sk = helm_amd.ServerKey(ck)
+    import torch
+    n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+    count = 4 * n_cus + 7
+    lwe = rng.integers(0, 2**32, size=(count, p.n + 1), dtype=np.uint32)
+    tvs = rng.integers(0, 2**32, size=(3, p.N), dtype=np.uint32)
+    idx = rng.integers(0, 3, size=count).astype(np.int32)
+    got = sk.pbs_batch(lwe, tvs, idx)
+    sk.close()
+    monkeypatch.setenv("HELM_HIP_PBS_VARIANT", "3")
+    sk3 = helm_amd.ServerKey(ck)
+    assert np.array_equal(got, sk3.pbs_batch(lwe, tvs, idx))
+    sk3.close()
+    orc = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True)
+    for g in (0, 1, 4 * n_cus - 1, count - 7, count - 1):
+        assert np.array_equal(got[g], orc.bootstrap_noks(lwe[g], tvs[idx[g]])), g
