@@ -172,6 +172,10 @@ struct PbsCfg {
     // level-at-a-time path: key columns fetched before the level's transform (the rest after it)
     // (2 of k+1 = 3: fetching the third one early as well measured the same in the lockstep build)
     static constexpr int EARLY_COLS = 2;
+#ifndef HELM_PRIO_STAGES
+#define HELM_PRIO_STAGES 1 /* 0: plain oldest-first issue (109 k instead of 116 k gates/s) */
+#endif
+    static constexpr bool PRIO_STAGES = HELM_PRIO_STAGES != 0;
     static constexpr bool PREFETCH = PREFETCH_;
     using G = Geo<LOGN>;
     static constexpr int K1 = K + 1;
@@ -326,16 +330,17 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
     // ---- blind rotation: acc += BSK_i (x) (X^{a_i} acc - acc) -------------------------
     int i = next_nonzero(0);
     if (i < n) prefetch(i);
+    // Lockstep build: the waves of a bootstrap share a SIMD, which issues oldest-first, so the youngest
+    // would run the end of every step alone (and a lone wave cannot hide its own latencies).  Each wave
+    // lowers its priority as it advances through the step - 3 from the second barrier through the
+    // inverse transform and the first level, 2 for the second level, 1 for the last level's digits and
+    // transform, 0 for its products - so whoever is behind goes first and the three reach the first
+    // barrier within one short stage of each other (finer stages towards the end, where it matters).
+    constexpr bool PRIO = NB > 1 && C::PRIO_STAGES;
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(3);
     STAMP_DECL
     while (i < n) {
         STAMP_BEGIN
-        if (probe & 2) {
-            // experiment (HELM_HIP_PRIO_ROTATE): the CU arbitrates VALU issue oldest-first, so the four
-            // workgroups of a CU drift apart; rotate a raised priority through them instead
-            const int pr = ((i >> 4) + (int)(blockIdx.x >> 8)) & 3;
-            if (pr == 0) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
         const unsigned so_i = (unsigned)i * step_bytes + row_off;
 
@@ -437,6 +442,8 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
 #pragma unroll
                     for (int e2 = 0; e2 < E / 2; e2++) bwl[d][e2] = kb.load(so_i + (unsigned)(cd[d] * L + lev) * poly_bytes, e2 * 1024);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (PRIO)
+                    if (lev == 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                 for (int d = 0; d < K1; d++)
 #pragma unroll
@@ -460,6 +467,10 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
                             }
                         }
                     }
+                if constexpr (PRIO) {
+                    if (lev == L - 1) __builtin_amdgcn_s_setprio(2);
+                    else if (lev == 1) __builtin_amdgcn_s_setprio(1);
+                }
             }
             {
                 double *dst = xb + C::slot_off(0) + lane;
@@ -502,6 +513,7 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
         STAMP(2) // hand-over read and summed
         lds_block_sync(); // every hand-over slot has been read: the slots are free again
         STAMP(3) // barrier 2
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(3);
 
         ntt_inverse<F, LOGN>(mine, xb, twi, lane);
         STAMP(4) // inverse transform
@@ -1389,7 +1401,6 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
     if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) ctx->pbs_variant = atoi(v);
     if (const char *v = getenv("HELM_HIP_NARROW")) ctx->narrow_variant = atoi(v) == 4 ? 4 : 1;
     if (const char *v = getenv("HELM_HIP_CLOCK_PROBE")) ctx->clock_probe = atoi(v);
-    if (const char *v = getenv("HELM_HIP_PRIO_ROTATE")) ctx->clock_probe |= atoi(v) ? 2 : 0;
     while ((1 << ctx->logN) < P.N) ctx->logN++;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
