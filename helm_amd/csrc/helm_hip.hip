@@ -561,6 +561,10 @@ struct WideCfg {
     static constexpr int LOGN = LOGN_, K = K_, L = L_, K1 = K_ + 1, NW = (K_ + 1) * L_;
     using G = Geo<LOGN>;
     static constexpr int MAX_SMALL_N = 1024;
+#ifndef HELM_WIDE_PRIO
+#define HELM_WIDE_PRIO 1
+#endif
+    static constexpr bool PRIO = HELM_WIDE_PRIO != 0;
     static constexpr int ACC3 = (3 * G::N - 64 + 1) / 2 * 2; // u32 entries per polynomial (see PbsCfg)
     static constexpr int TW_ROWS = G::TWB + G::TWC;
     static constexpr size_t X_OFF = 0;                                              // double [NW][XPAD]
@@ -661,6 +665,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
     const int rep = logB * L;
 
     STAMP_DECL
+    if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
     for (int i = 0; i < n; i++) {
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
         if (a == 0) continue; // uniform over the workgroup
@@ -699,7 +704,10 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
             for (int e = 0; e < E; e++) x[0][e] = (double)dig[e];
         }
         STAMP(0) // loads issued, rotation, decomposition
-        ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+        // the SIMD that hosts three of the nine waves bounds this phase: stepping the issue priority down
+        // block by block keeps its waves abreast instead of letting the youngest finish alone
+        ntt_forward<F, LOGN, 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
         STAMP(1) // forward transform
 #pragma unroll
         for (int c = 0; c < K1; c++) {
@@ -731,6 +739,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
         STAMP(4) // inverse side (lev = 0) or nothing
         lds_block_sync(); // accumulator copies published, columns cleared
         STAMP(5) // barrier 2
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
     }
     STAMP_END(w)
 

@@ -343,6 +343,10 @@ struct Pbs64sCfg {
     using G = Geo<LOGN>;      // decomposition geometry: E coefficients per lane
     using GS = Geo<LOGN - 1>; // half transforms
     static constexpr int MAX_SMALL_N = 1024;
+#ifndef HELM_SI_PRIO
+#define HELM_SI_PRIO 1
+#endif
+    static constexpr bool PRIO = HELM_SI_PRIO != 0;
     static constexpr int TW_IDX = GS::N >> GS::BC, TW_PART = TW_IDX + GS::TWC * 64; // per (field, half)
     static constexpr size_t X_OFF = 0;                                              // double [NW][GS::XPAD]
     static constexpr size_t TW_OFF = X_OFF + sizeof(double) * NW * GS::XPAD;        // double [2][2][TW_PART]
@@ -410,6 +414,10 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         lds_block_sync(); // digits published
         STAMP(1) // barrier 1
         // ---- (2) stage 1 of the full transform, half transform, products ---------------------
+        // the two waves of a SIMD (polynomials 0 and 1 of one field and half) run every phase together;
+        // stepping the issue priority down block by block keeps them abreast, so that neither finishes
+        // the phase alone (a lone wave cannot hide its LDS latencies)
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
         double x[1][EH];
         {
             const int32_t *dg = dig_p + lane;
@@ -419,7 +427,8 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
                 x[0][e] = h ? U - V : U + V;
             }
         }
-        ntt_forward<F, LOGN - 1, 1>(x, xb, twf, lane);
+        ntt_forward<F, LOGN - 1, 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
         STAMP(2) // digits read, stage 1, half transform
 #pragma unroll
         for (int u = 0; u < HC; u++) kw[1][u] = (bp_i + (size_t)1 * 4 * part)[u * 64];
@@ -446,7 +455,9 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         lds_block_sync(); // hand-over read: scratch free again
         STAMP(4) // barrier 2, sum, barrier 3
         // ---- (3) half inverse, meet the other half, last stage -------------------------------
-        ntt_inverse<F, LOGN - 1>(mine, xb, twi, lane); // a_h[e * 64 + lane], centred
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
+        ntt_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0>(mine, xb, twi, lane); // a_h[e * 64 + lane], centred
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
         STAMP(5) // half inverse
 #pragma unroll
         for (int e = 0; e < EH; e++) xb[e * 64 + lane] = mine[e];

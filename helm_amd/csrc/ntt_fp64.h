@@ -423,11 +423,14 @@ __device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const TW &t
 // out: x[m][e] = transform word at position jC(lane,e) of the bit-reversed output,
 //      |x| <= ~3p (Fp51) / ~7.1p (Fp49, lazy); not recentred: the pointwise product absorbs it.
 // xbuf: wave-private LDS scratch of M * Geo::XPAD doubles.
-template <typename F, int LOGN, int M, typename TW>
+// PRIO > 0: the wave enters at issue priority PRIO and steps down by one after each of the first two
+// blocks (waves that share a SIMD and run the same phase then advance block by block, see k_pbs).
+template <typename F, int LOGN, int M, typename TW, int PRIO = 0>
 __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double *xbuf, const TW &tw, int lane)
 {
     using G = Geo<LOGN>;
     fwd_block<F, LOGN, M, 6, LOGN - 1, LOGN - G::BA, 0>(x, tw, G::jA(lane, 0));
+    if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);
     double *pA = xbuf + G::baseA(lane), *pB = xbuf + G::baseB(lane), *pC = xbuf + G::baseC(lane);
 #pragma unroll
     for (int m = 0; m < M; m++)
@@ -440,6 +443,7 @@ __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double
         for (int e = 0; e < G::E; e++) x[m][e] = pB[m * G::XPAD + G::offB1(e)];
     lds_wave_sync();
     fwd_block<F, LOGN, M, G::BC, G::BC + G::BB - 1, G::BC, G::TWA>(x, tw, G::jB(lane, 0));
+    if constexpr (PRIO > 1) __builtin_amdgcn_s_setprio(PRIO - 2);
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
@@ -456,11 +460,12 @@ __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double
 // Inverse (without the 1/N factor, which is folded into the bootstrapping key).
 // in : x[e] = transform word at jC(lane,e), |x| <= 0.5p.
 // out: x[e] = coefficient jA(lane,e), exactly centred (|x| <= p/2).
-template <typename F, int LOGN, typename TW>
+template <typename F, int LOGN, typename TW, int PRIO = 0>
 __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *xbuf, const TW &tw, int lane)
 {
     using G = Geo<LOGN>;
     inv_block<F, LOGN, 0, 0, G::BC - 1, 0>(x, tw, G::jC(lane, 0));
+    if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);
     double *pA = xbuf + G::baseA(lane), *pB = xbuf + G::baseB(lane), *pC = xbuf + G::baseC(lane);
 #pragma unroll
     for (int e = 0; e < G::E; e++) pC[e] = reduce<F>(x[e]);
@@ -469,6 +474,7 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *x
     for (int e = 0; e < G::E; e++) x[e] = pB[G::offB2(e)];
     lds_wave_sync();
     inv_block<F, LOGN, G::BC, G::BC, G::BC + G::BB - 1, G::TWC>(x, tw, G::jB(lane, 0));
+    if constexpr (PRIO > 1) __builtin_amdgcn_s_setprio(PRIO - 2);
 #pragma unroll
     for (int e = 0; e < G::E; e++) pB[G::offB1(e)] = reduce<F>(x[e]);
     lds_wave_sync();
