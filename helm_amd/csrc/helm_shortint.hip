@@ -356,9 +356,9 @@ struct Pbs64sCfg {
     static constexpr size_t BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
 };
 
-template <typename C, typename F>
+template <typename C, typename F, int h>
 __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *__restrict__ bsk, int n, int logB,
-                                            double p0inv_mod_p1, double w1, int p, int f, int h, int lane)
+                                            double p0inv_mod_p1, double w1, int p, int f, int lane)
 {
     constexpr int LOGN = C::LOGN, K1 = C::K1;
     using G = typename C::G;
@@ -446,12 +446,14 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
                     other[2 * u + 1] = t1;
                 }
             }
+        // a product is below 1.5 p (mulmod: (0.5 + 0.75 |a| 2^-52) p with |a| <= 9.6 p): two of them are summed
+        // as they are and recentred once
 #pragma unroll
-        for (int e = 0; e < EH; e++) xb[e * 64 + lane] = reduce<F>(other[e]);
+        for (int e = 0; e < EH; e++) xb[e * 64 + lane] = other[e];
         STAMP(3) // products
         lds_block_sync();
 #pragma unroll
-        for (int e = 0; e < EH; e++) mine[e] = reduce<F>(reduce<F>(mine[e]) + x_poly[e * 64 + lane]);
+        for (int e = 0; e < EH; e++) mine[e] = reduce<F>(mine[e] + x_poly[e * 64 + lane]);
         lds_block_sync(); // hand-over read: scratch free again
         STAMP(4) // barrier 2, sum, barrier 3
         // ---- (3) half inverse, meet the other half, last stage -------------------------------
@@ -537,8 +539,14 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64s(const Pbs64Job *__rest
     __syncthreads();
     // psi^(N/2): entry 1 of the full forward table of this wave's field
     const double w1 = f == 0 ? tw0[1] : tw1[1];
-    if (f == 0) pbs64s_body<C, F0>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 0, h, lane);
-    else pbs64s_body<C, F1>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 1, h, lane);
+    // one specialisation per (field, transform half): both are uniform over the wave
+    if (f == 0) {
+        if (h == 0) pbs64s_body<C, F0, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 0, lane);
+        else pbs64s_body<C, F0, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 0, lane);
+    } else {
+        if (h == 0) pbs64s_body<C, F1, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 1, lane);
+        else pbs64s_body<C, F1, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 1, lane);
+    }
 
     uint64_t *ob = out + (size_t)job.out_row * ((size_t)K * N + 1);
     const uint64_t *acc_p = ACC + (size_t)p * N;
