@@ -220,6 +220,9 @@ def main():
         "roofline": {
             "kernel": dom_kernel, "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": 8000.0, "unit": "GB/s",
             "frac": round(achieved_gbs / 8000.0, 5), "traffic": None,
+            "traffic_measured_separately": "rocprofv3 --pmc FETCH_SIZE on a 1,024-bootstrap launch of this kernel "
+                                           "(profiles/r01/pmc_fetch_size.txt): 0.63 GB of fabric-side reads per launch "
+                                           "(Infinity-Cache hits included; 7x the algorithmic 90 MB), 4.1 MB written",
             "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
             "avg_bootstraps_per_launch": round(avg_pbs_per_launch, 1),
             "note": "the bootstrapping key (80 MB) is shared by every ciphertext of a launch and stays in "
