@@ -91,24 +91,34 @@ __device__ __forceinline__ uint32_t modswitch(uint32_t x, int log2_2N)
     return (r >> 1) & ((1u << log2_2N) - 1u);
 }
 
-// Signed gadget decomposition, closest representable + balanced digits; dig[0] is
-// the most significant level.  L and logB are compile-time / uniform.
+// Signed gadget decomposition, closest representable + balanced digits (tfhe's SignedDecomposer:
+//   d = state & (B-1); state >>= logB; carry = (((d-1) | state) & d) >> (logB-1); state += carry;
+//   digit = d - carry*B), least significant level first.
+// The carry is set when d > B/2, or d == B/2 and bit logB-1 of the remaining state is set, i.e. when
+// d - 1 + sb >= B/2 with sb = bit 2 logB - 1 of the state before the shift; adding B/2 - 1 + sb to the
+// whole state carries into the upper part exactly then:
+//   next = (state + B/2 - 1 + sb) >> logB;  digit = state - next * B
+// - five instructions per digit with the conversion (bit-field extract, three-operand add, shift,
+// 24-bit multiply-add, convert) instead of eight.  Needs state + B/2 < 2^32 (logB * L <= 31) and
+// next < 2^23; both follow from the field-size bound checked in helm_hip_ctx_create.
+__device__ __forceinline__ int decompose_step(uint32_t &state, int logB, uint32_t half_m1, int neg_B)
+{
+    const uint32_t s = state;
+    const uint32_t next = (s + half_m1 + __builtin_amdgcn_ubfe(s, 2 * logB - 1, 1)) >> logB;
+    state = next;
+    return __mul24((int)next, neg_B) + (int)s;
+}
+
+// dig[0] is the most significant level.  L and logB are compile-time / uniform.
 template <int L>
 __device__ __forceinline__ void decompose(uint32_t x, int logB, int (&dig)[L])
 {
     const int rep = logB * L;
     uint32_t state = (x + (1u << (31 - rep))) >> (32 - rep);
-    const uint32_t mask = (1u << logB) - 1u;
+    const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+    const int neg_B = -(1 << logB);
 #pragma unroll
-    for (int lev = L - 1; lev >= 0; lev--) {
-        const uint32_t d = state & mask;
-        state >>= logB;
-        // -carry straight from the deciding bit (one signed bit-field extract), then
-        // state -= (-carry), digit = d + ((-carry) << logB) (one shift-add)
-        const int nc = __builtin_amdgcn_sbfe(((d - 1u) | state) & d, logB - 1, 1);
-        state -= (uint32_t)nc;
-        dig[lev] = (int)d + (int)((uint32_t)nc << logB);
-    }
+    for (int lev = L - 1; lev >= 0; lev--) dig[lev] = decompose_step(state, logB, half_m1, neg_B);
 }
 
 // Diagnostic clock stamps (HELM_HIP_CLOCK_PROBE=1): workgroup 0 records s_memtime (shader
@@ -410,7 +420,8 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
             // hand-over slot with ds_add_f64 (exact: integers below 2^53) - three partial
             // sums never live in registers together.
             double keep[E];
-            const uint32_t mask = (1u << logB) - 1u;
+            const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+            const int neg_B = -(1 << logB);
             int cd[K1]; // wave-uniform column of each distance
 #pragma unroll
             for (int d = 0; d < K1; d++) cd[d] = p + d >= K1 ? p + d - K1 : p + d;
@@ -418,13 +429,7 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
             for (int lev = L - 1; lev >= 0; lev--) {
                 double x[1][E];
 #pragma unroll
-                for (int e = 0; e < E; e++) {
-                    const uint32_t d = state[e] & mask;
-                    const uint32_t st = state[e] >> logB;
-                    const int nc = __builtin_amdgcn_sbfe(((d - 1u) | st) & d, logB - 1, 1); // -carry
-                    state[e] = st - (uint32_t)nc;
-                    x[0][e] = (double)((int)d + (int)((uint32_t)nc << logB));
-                }
+                for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(state[e], logB, half_m1, neg_B);
                 // this level's key words: issued before the transform that hides their latency
                 // (the last column is fetched after the transform: during it the transform's own
                 // temporaries need the registers, and the first two products cover its latency)
@@ -661,7 +666,8 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
     const unsigned wave_off = (unsigned)(r * K1 * L + lev) * poly_bytes; // + c * L * poly_bytes per column
     KeyBuf kb;
     kb.init(bsk, (size_t)n * step_bytes, lane);
-    const uint32_t mask = (1u << logB) - 1u;
+    const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+    const int neg_B = -(1 << logB);
     const int rep = logB * L;
 
     STAMP_DECL
@@ -691,13 +697,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
             for (int l = L - 1; l >= 0; l--) {
                 if (l >= lev) {
 #pragma unroll
-                    for (int e = 0; e < E; e++) {
-                        const uint32_t d = st[e] & mask;
-                        st[e] >>= logB;
-                        const int nc = __builtin_amdgcn_sbfe(((d - 1u) | st[e]) & d, logB - 1, 1);
-                        st[e] -= (uint32_t)nc;
-                        dig[e] = (int)d + (int)((uint32_t)nc << logB);
-                    }
+                    for (int e = 0; e < E; e++) dig[e] = decompose_step(st[e], logB, half_m1, neg_B);
                 }
             }
 #pragma unroll
@@ -1385,7 +1385,7 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         return fail(HELM_ERR_INVALID, "unsupported (N,k,pbs_l): built variants are (512,2,3) (512,1,3) (512,1,2) "
                                       "(1024,1,3) (1024,1,2)");
     if (P.n < 1 || P.n > 1024) return fail(HELM_ERR_INVALID, "n must be in [1,1024]");
-    if (P.pbs_logB < 1 || P.pbs_logB * P.pbs_l > 32) return fail(HELM_ERR_INVALID, "bad PBS decomposition");
+    if (P.pbs_logB < 1 || P.pbs_logB * P.pbs_l > 31) return fail(HELM_ERR_INVALID, "bad PBS decomposition");
     if (P.ks_logB < 1 || P.ks_logB > 7 || P.ks_logB * P.ks_l > 32 ||
         !(P.ks_l >= 1 && (P.ks_l <= 6 || P.ks_l == 8)))
         return fail(HELM_ERR_INVALID, "bad keyswitch decomposition (ks_logB <= 7, ks_l in {1..6,8})");

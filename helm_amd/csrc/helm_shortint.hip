@@ -163,17 +163,18 @@ __device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__
             }
         }
         double mine[E], other[E];
-        const uint32_t mask = (1u << logB) - 1u;
+        const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
 #pragma unroll
         for (int lev = L - 1; lev >= 0; lev--) {
             double x[1][E];
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                const uint32_t d = state[e] & mask;
-                const uint32_t st = state[e] >> logB;
-                const uint32_t carry = (((d - 1u) | st) & d) >> (logB - 1);
-                state[e] = st + carry;
-                x[0][e] = (double)((int32_t)d - (int32_t)(carry << logB));
+                // tfhe's carry rule as one addition (see decompose_step in helm_hip.hip): the digit is what
+                // the state loses when B/2 - 1 + (bit 2 logB - 1) is added and logB bits are shifted out
+                const uint32_t s = state[e];
+                const uint32_t next = (s + half_m1 + __builtin_amdgcn_ubfe(s, 2 * logB - 1, 1)) >> logB;
+                state[e] = next;
+                x[0][e] = (double)((int32_t)s - (int32_t)(next << logB));
             }
             // key words in chunks of E/4 (two per column), software-pipelined: the first chunk is
             // fetched before the transform, each next one just before the products of the previous
@@ -385,7 +386,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
     const size_t part = (size_t)(GS::N / 2);
     const size_t bsk_step = (size_t)K1 * K1 * 4 * part;
     const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * 4 + f * 2 + h) * part + lane;
-    const uint32_t mask = (1u << logB) - 1u;
+    const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
 
     STAMP_DECL
     for (int i = 0; i < n; i++) {
@@ -402,9 +403,8 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
             if (src >= N) v = 0ull - v;
             v -= acc_p[j];
             const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
-            const uint32_t d = st & mask; // L = 1: the carry decides between d and d - B
-            const int nc = __builtin_amdgcn_sbfe(((d - 1u) | (st >> logB)) & d, logB - 1, 1);
-            dig_p[j] = (int)d + (int)((uint32_t)nc << logB);
+            // L = 1: nothing is left above the digit, the carry decides between d and d - B (d > B/2)
+            dig_p[j] = (int)st - (int)(((st + half_m1) >> logB) << logB);
         }
         // first key column of this wave's half (E/4 double2 per column)
         double2 kw[K1][HC];
@@ -1079,8 +1079,8 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
     if (!si_supported(P))
         return fail(HELM_ERR_INVALID, "unsupported (k,N,pbs_l): built variants are k = 1, N in {512,1024,2048}, pbs_l in {1,2}");
     if (P.n < 1 || P.n > 1024) return fail(HELM_ERR_INVALID, "n must be in [1,1024]");
-    if (P.pbs_logB < 2 || P.pbs_logB > 30 || P.pbs_logB * P.pbs_l > 32)
-        return fail(HELM_ERR_INVALID, "bad PBS decomposition (pbs_logB * pbs_l <= 32: every tfhe shortint set)");
+    if (P.pbs_logB < 2 || P.pbs_logB > 30 || P.pbs_logB * P.pbs_l > 31)
+        return fail(HELM_ERR_INVALID, "bad PBS decomposition (pbs_logB * pbs_l <= 31: every tfhe shortint set)");
     if (P.ks_logB < 1 || P.ks_logB > 7 || P.ks_l < 1 || P.ks_l > 8 || P.ks_logB * P.ks_l > 63)
         return fail(HELM_ERR_INVALID, "bad keyswitch decomposition (ks_logB <= 7, ks_l <= 8)");
     const int t = P.message_modulus * P.carry_modulus;
