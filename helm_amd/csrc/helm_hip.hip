@@ -164,9 +164,13 @@ __device__ unsigned long long g_wide_stamps[2 * 16 * 6];
 //   throughput M = 1: one level at a time (digits produced in the order the signed
 //              decomposition generates them), that level's key words fetched around its
 //              transform, only two partial sums in registers (the third accumulates in LDS),
-//              twiddles from the LDS lane table; 168 registers and 35 KB LDS -> four
-//              workgroups per CU = three waves on every SIMD, which hide each other's LDS
-//              and key latencies.  Wide launches.
+//              twiddles from the LDS lane table; 168 registers and 35 KB LDS -> up to four
+//              workgroups per CU.  Remainders of wide launches.
+//   lockstep   the throughput structure with NB = 4 bootstraps per workgroup of 12 waves, one
+//              bootstrap per SIMD (see NB below) and issue priorities that fall as a wave
+//              advances through the step; 132 registers, 138 KB LDS -> one workgroup per CU,
+//              three waves on every SIMD doing the same work at the same time.  The full rounds
+//              of every wide launch: the dominant kernel of the benchmark.
 // ------------------------------------------------------------------------------------
 enum { TW_REG = 0, TW_LANE = 1 /* lane-major LDS table of forward twiddles, inverse reads it mirrored */ };
 
