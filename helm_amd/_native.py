@@ -44,7 +44,7 @@ class HipTiming(C.Structure):  # helm_hip_timing
 
 class SiParams(C.Structure):
     _fields_ = [(f, C.c_int32) for f in ("n", "k", "N", "pbs_l", "pbs_logB", "ks_l", "ks_logB",
-                                         "message_modulus", "carry_modulus")]
+                                         "message_modulus", "carry_modulus", "grouping_factor")]
 
     def as_tuple(self):
         return tuple(getattr(self, f) for f, _ in self._fields_)

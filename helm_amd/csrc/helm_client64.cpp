@@ -90,6 +90,24 @@ int helm_si_client_named_params(const char *name, helm_si_params *p, double *lwe
         p->n = 742; p->N = 2048; p->pbs_l = 1; p->pbs_logB = 23; p->ks_l = 5; p->ks_logB = 3;
         *lwe_std = 0.000007069849454709433;
         *glwe_std = 0.00000000000000029403601535432533;
+    } else if (s == "shortint_m2c2_multibit3") {
+        // PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS, the set of reference src/bin/helm.rs:83
+        // [dimensions recalled; noise: the LWE value extrapolated along tfhe's
+        // security line through the n = 684 and n = 742 sets, the GLWE value of the N = 2048 sets]
+        p->n = 888; p->N = 2048; p->pbs_l = 1; p->pbs_logB = 21; p->ks_l = 3; p->ks_logB = 4;
+        p->grouping_factor = 3;
+        *lwe_std = 0.00000049;
+        *glwe_std = 0.00000000000000029403601535432533;
+    } else if (s == "si_toy_2048_mb3") {
+        p->n = 12; p->N = 2048; p->pbs_l = 1; p->pbs_logB = 21; p->ks_l = 3; p->ks_logB = 4;
+        p->grouping_factor = 3;
+        *lwe_std = 1e-9;
+        *glwe_std = 1e-16;
+    } else if (s == "si_toy_1024_mb2") {
+        p->n = 8; p->N = 1024; p->pbs_l = 1; p->pbs_logB = 22; p->ks_l = 5; p->ks_logB = 3;
+        p->grouping_factor = 2;
+        *lwe_std = 1e-9;
+        *glwe_std = 1e-15;
     } else if (s == "si_toy_512") {
         p->n = 12; p->N = 512; p->pbs_l = 2; p->pbs_logB = 15; p->ks_l = 4; p->ks_logB = 4;
         *lwe_std = 1e-9;
@@ -121,6 +139,8 @@ int helm_si_client_keygen(const helm_si_params *params, double lwe_std, double g
     if (P.n < 1 || P.k < 1 || P.N < 2 || (P.N & (P.N - 1)) || P.pbs_l < 1 || P.ks_l < 1 || P.pbs_logB < 1 ||
         P.ks_logB < 1 || P.pbs_logB * P.pbs_l > 64 || P.ks_logB * P.ks_l > 64 || t < 2 || (t & (t - 1)))
         return fail64(HELM_ERR_INVALID, "bad parameter set");
+    const int g = P.grouping_factor > 1 ? P.grouping_factor : 1;
+    if (g > 4 || P.n % g) return fail64(HELM_ERR_INVALID, "grouping_factor must be at most 4 and divide n");
     helm_si_client_key *K = new (std::nothrow) helm_si_client_key();
     if (!K) return fail64(HELM_ERR_OOM, "key");
     K->P = P;
@@ -135,11 +155,22 @@ int helm_si_client_keygen(const helm_si_params *params, double lwe_std, double g
     for (auto &b : K->glwe_sk) b = r0.next() >> 63;
     K->enc_rng = Rng64(seed, 0xE1C64);
 
-    // ---- bootstrapping key: GGSW(s_i), [n][l][k+1 rows][k+1 polys][N] -----------------
+    // ---- bootstrapping key, [n_ggsw][l][k+1 rows][k+1 polys][N] ---------------------------
+    //      classical: GGSW(s_i) for every mask word; multi-bit: per group of g words the 2^g
+    //      GGSWs of the subset indicators (bit i of the subset index = member i of the group)
     const size_t poly_per_i = (size_t)P.pbs_l * k1 * k1;
-    K->bsk.assign((size_t)n * poly_per_i * N, 0);
+    const int subsets = g > 1 ? 1 << g : 1;
+    const int n_ggsw = g > 1 ? (n / g) * subsets : n;
+    K->bsk.assign((size_t)n_ggsw * poly_per_i * N, 0);
     #pragma omp parallel for schedule(dynamic, 4)
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n_ggsw; i++) {
+        uint64_t message = 0;
+        if (g > 1) {
+            const int grp = i / subsets, S = i % subsets;
+            message = 1;
+            for (int q = 0; q < g; q++) message &= ((S >> q) & 1) ? K->lwe_sk[grp * g + q] : 1 - K->lwe_sk[grp * g + q];
+        } else
+            message = K->lwe_sk[i];
         Rng64 r(seed, 0x6400000 + (uint64_t)i);
         std::vector<uint64_t> body(N);
         for (int j = 0; j < P.pbs_l; j++)
@@ -157,7 +188,7 @@ int helm_si_client_keygen(const helm_si_params *params, double lwe_std, double g
                     }
                 }
                 std::memcpy(glwe + (size_t)k * N, body.data(), sizeof(uint64_t) * N);
-                if (K->lwe_sk[i]) glwe[(size_t)row * N] += (uint64_t)1 << (64 - P.pbs_logB * (j + 1));
+                if (message) glwe[(size_t)row * N] += (uint64_t)1 << (64 - P.pbs_logB * (j + 1));
             }
     }
     // ---- keyswitching key: [k*N][ks_l][n+1] ---------------------------------------------

@@ -491,7 +491,148 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
     STAMP_END((p * 2 + f) * 2 + h)
 }
 
-template <typename C>
+// Multi-bit blind rotation (tfhe MultiBitPBS, grouping factor g <= 3; reference src/bin/helm.rs:83 installs
+// the g = 3 set for arithmetic mode): per group of g mask words ONE external product
+//     acc <- ( sum_S X^(e_S) * GGSW_S ) (x) acc,      e_S = sum_{i in S} a~_i,
+// evaluated as  sum_S ( NTT(digits(acc)) .* M(e_S) ) .* K_S  in the transform domain: multiplying by the monomial
+// X^e is a pointwise product with M(e)[j] = psi^(expo[j] * e), expo[j] the (odd) exponent of the evaluation
+// point of spectrum position j (probed once per context through the key-conversion kernel) and psi_pow the 2N
+// powers of psi.  Same wave roles, transforms, hand-over and CRT as pbs64s_body; n/g steps instead of n, the
+// accumulator is replaced instead of added to.
+template <typename C, typename F, int h>
+__device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double *__restrict__ bsk, int n, int logB,
+                                               double p0inv_mod_p1, double w1, int p, int f, int lane, int g,
+                                               const uint16_t *__restrict__ expo, const double *__restrict__ psi_pow)
+{
+    constexpr int LOGN = C::LOGN, K1 = C::K1;
+    using G = typename C::G;
+    using GS = typename C::GS;
+    constexpr int N = G::N, E = G::E, EH = GS::E, Q = E / 4, HC = EH / 2;
+    double *X = reinterpret_cast<double *>(smem + C::X_OFF);
+    uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
+    int32_t *DIG = reinterpret_cast<int32_t *>(smem + C::DIG_OFF);
+    const uint16_t *MS = reinterpret_cast<const uint16_t *>(smem + C::MS_OFF);
+    auto wave_of = [](int pp, int ff, int hh) { return (pp * 2 + ff) * 2 + hh; };
+    double *xb = X + (size_t)wave_of(p, f, h) * GS::XPAD;
+    const double *x_poly = X + (size_t)wave_of(1 - p, f, h) * GS::XPAD;
+    const double *x_half = X + (size_t)wave_of(p, f, 1 - h) * GS::XPAD;
+    const double *x_field = X + (size_t)wave_of(p, 1 - f, h) * GS::XPAD;
+    uint64_t *acc_p = ACC + (size_t)p * N;
+    int32_t *dig_p = DIG + (size_t)p * N;
+    const double *twt = reinterpret_cast<const double *>(smem + C::TW_OFF);
+    const double *tw_own = twt + (size_t)(f * 2 + h) * C::TW_PART, *tw_oth = twt + (size_t)(f * 2 + (1 - h)) * C::TW_PART;
+    TwHybrid<LOGN - 1, false> twf{tw_own, tw_own + C::TW_IDX + lane};
+    TwHybrid<LOGN - 1, true> twi{tw_oth, tw_oth + C::TW_IDX + (63 - lane)};
+    const int quarter = f * 2 + h;
+    const size_t part = (size_t)(GS::N / 2);
+    const size_t bsk_step = (size_t)K1 * K1 * 4 * part; // one GGSW
+    const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * 4 + f * 2 + h) * part + lane;
+    const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+    const int subsets = 1 << g;
+    // exponents of this wave's spectrum positions, in the order of the key words
+    int ex[EH];
+#pragma unroll
+    for (int u = 0; u < HC; u++) {
+        const ushort2 v = reinterpret_cast<const ushort2 *>(expo)[((size_t)h * HC + u) * 64 + lane];
+        ex[2 * u] = v.x;
+        ex[2 * u + 1] = v.y;
+    }
+    for (int t = 0; t < n / g; t++) {
+        int am[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) am[q] = q < g ? __builtin_amdgcn_readfirstlane((int)MS[t * g + q]) : 0;
+        // ---- (1) digits of this wave's quarter of polynomial p ----------------------------------
+#pragma unroll
+        for (int u = 0; u < Q; u++) {
+            const int j = G::jA(lane, quarter * Q + u);
+            const uint64_t v = acc_p[j];
+            const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
+            dig_p[j] = (int)st - (int)(((st + half_m1) >> logB) << logB);
+        }
+        lds_block_sync(); // digits published
+        // ---- (2) stage 1 of the full transform, half transform ----------------------------------
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
+        double x[1][EH];
+        {
+            const int32_t *dg = dig_p + lane;
+#pragma unroll
+            for (int e = 0; e < EH; e++) {
+                const double U = (double)dg[64 * e], V = mulmod<F>((double)dg[64 * (e + EH)], w1);
+                x[0][e] = h ? U - V : U + V;
+            }
+        }
+        ntt_forward<F, LOGN - 1, 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
+        // ---- products with the 2^g keys of the group: col[c] = sum_S (x .* M(e_S)) .* K_S[p][c] -----
+        // (the first product is below 1.5 p, the others - operands below 1.5 p - below 0.6 p: <= 5.7 p per sum)
+        double col[K1][EH];
+        for (int S = 0; S < subsets; S++) {
+            int e_s = 0;
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                if ((S >> q) & 1) e_s += am[q];
+            e_s &= 2 * N - 1;
+            const double2 *kp = bsk_w + ((size_t)t * subsets + S) * bsk_step;
+            double2 kw[K1][HC];
+#pragma unroll
+            for (int c = 0; c < K1; c++)
+#pragma unroll
+                for (int u = 0; u < HC; u++) kw[c][u] = (kp + (size_t)c * 4 * part)[u * 64];
+#pragma unroll
+            for (int u = 0; u < HC; u++) {
+                double xs0 = x[0][2 * u], xs1 = x[0][2 * u + 1];
+                if (S != 0) {
+                    xs0 = mulmod<F>(xs0, psi_pow[(ex[2 * u] * e_s) & (2 * N - 1)]);
+                    xs1 = mulmod<F>(xs1, psi_pow[(ex[2 * u + 1] * e_s) & (2 * N - 1)]);
+                }
+#pragma unroll
+                for (int c = 0; c < K1; c++) {
+                    const double t0 = mulmod<F>(xs0, kw[c][u].x), t1 = mulmod<F>(xs1, kw[c][u].y);
+                    col[c][2 * u] = S == 0 ? t0 : col[c][2 * u] + t0;
+                    col[c][2 * u + 1] = S == 0 ? t1 : col[c][2 * u + 1] + t1;
+                }
+            }
+        }
+        double mine[EH];
+#pragma unroll
+        for (int e = 0; e < EH; e++) {
+            xb[e * 64 + lane] = p == 0 ? col[1][e] : col[0][e];
+            mine[e] = p == 0 ? col[0][e] : col[1][e];
+        }
+        lds_block_sync();
+#pragma unroll
+        for (int e = 0; e < EH; e++) mine[e] = reduce<F>(mine[e] + x_poly[e * 64 + lane]); // <= 11.4 p before
+        lds_block_sync(); // hand-over read: scratch free again
+        // ---- (3) half inverse, meet the other half, last stage -----------------------------------
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
+        ntt_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0>(mine, xb, twi, lane);
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int e = 0; e < EH; e++) xb[e * 64 + lane] = mine[e];
+        lds_block_sync();
+#pragma unroll
+        for (int e = 0; e < EH; e++) {
+            const double o = x_half[e * 64 + lane];
+            mine[e] = h ? reduce<F>(mulmod<F>(mine[e] - o, w1)) : reduce<F>(mine[e] + o);
+        }
+        lds_block_sync();
+        // ---- (4) CRT: the lifted value REPLACES the accumulator ----------------------------------
+        constexpr int HH = EH / 2;
+#pragma unroll
+        for (int e = 0; e < HH; e++) xb[e * 64 + lane] = mine[(1 - f) * HH + e];
+        lds_block_sync();
+#pragma unroll
+        for (int e = 0; e < HH; e++) {
+            const double own = mine[f * HH + e], oth = x_field[e * 64 + lane];
+            const double r0 = f == 0 ? own : oth, r1 = f == 0 ? oth : own;
+            const double tt = mulmod<F1>(r1 - r0, p0inv_mod_p1);
+            acc_p[h * (N / 2) + (f * HH + e) * 64 + lane] = (uint64_t)to_int64(r0) + F0::P_U64 * (uint64_t)to_int64(tt);
+        }
+        lds_block_sync(); // accumulator complete
+    }
+}
+
+template <typename C, bool MB>
 __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64s(const Pbs64Job *__restrict__ jobs,
                                                           const uint64_t *__restrict__ small,
                                                           const uint64_t *__restrict__ luts,
@@ -499,7 +640,9 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64s(const Pbs64Job *__rest
                                                           const double *__restrict__ tw_sub, // [2 fields][2 halves][N/2]
                                                           const double *__restrict__ tw0, const double *__restrict__ tw1,
                                                           uint64_t *__restrict__ out, int n, int logB,
-                                                          double p0inv_mod_p1)
+                                                          double p0inv_mod_p1, int g,
+                                                          const uint16_t *__restrict__ expo, // multi-bit: [2 halves][N/2]
+                                                          const double *__restrict__ psi_pow) // multi-bit: [2 fields][2N]
 {
     constexpr int LOGN = C::LOGN, K = C::K;
     using G = typename C::G;
@@ -540,7 +683,15 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64s(const Pbs64Job *__rest
     // psi^(N/2): entry 1 of the full forward table of this wave's field
     const double w1 = f == 0 ? tw0[1] : tw1[1];
     // one specialisation per (field, transform half): both are uniform over the wave
-    if (f == 0) {
+    if constexpr (MB) {
+        if (f == 0) {
+            if (h == 0) pbs64s_mb_body<C, F0, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 0, lane, g, expo, psi_pow);
+            else pbs64s_mb_body<C, F0, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 0, lane, g, expo, psi_pow);
+        } else {
+            if (h == 0) pbs64s_mb_body<C, F1, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 1, lane, g, expo, psi_pow + 2 * N);
+            else pbs64s_mb_body<C, F1, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 1, lane, g, expo, psi_pow + 2 * N);
+        }
+    } else if (f == 0) {
         if (h == 0) pbs64s_body<C, F0, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 0, lane);
         else pbs64s_body<C, F0, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 0, lane);
     } else {
@@ -811,6 +962,9 @@ struct helm_si_ctx {
     double *bsk = nullptr;
     double *bsk_split = nullptr; // layout of k_pbs64s (N >= 1024, pbs_l = 1)
     double *tw_sub = nullptr;    // derived half-transform tables [2 fields][2 halves][N/2]
+    int group = 1;               // multi-bit grouping factor (1: classical blind rotation)
+    uint16_t *expo = nullptr;    // multi-bit: exponent of the evaluation point per spectrum position [2 halves][N/2]
+    double *psi_pow = nullptr;   // multi-bit: psi^t, t < 2N, per field
     bool use_split = false;
     uint64_t *ksk = nullptr;
     bool have_bsk = false, have_ksk = false;
@@ -895,12 +1049,12 @@ hipError_t launch_pbs64_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count,
     return hipGetLastError();
 }
 
-template <typename C>
+template <typename C, bool MB>
 hipError_t launch_pbs64s_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
                            const uint64_t *luts, uint64_t *out)
 {
     static bool attr_done[64] = {false};
-    auto kern = k_pbs64s<C>;
+    auto kern = k_pbs64s<C, MB>;
     if (!attr_done[ctx->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
@@ -909,7 +1063,7 @@ hipError_t launch_pbs64s_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, small, luts,
                        ctx->bsk_split, ctx->tw_sub, ctx->tw[0], ctx->tw[1], out, ctx->P.n, ctx->P.pbs_logB,
-                       ctx->p0inv_mod_p1);
+                       ctx->p0inv_mod_p1, ctx->group, ctx->expo, ctx->psi_pow);
 #ifdef HELM_WIDE_STAMPS
     {
         unsigned long long v[8 * 8];
@@ -930,8 +1084,12 @@ hipError_t launch_pbs64(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, c
 {
     const helm_si_params &P = ctx->P;
     if (ctx->use_split) {
-        if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10>>(ctx, jobs, count, small, luts, out);
-        if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11>>(ctx, jobs, count, small, luts, out);
+        if (ctx->group > 1) {
+            if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10>, true>(ctx, jobs, count, small, luts, out);
+            if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11>, true>(ctx, jobs, count, small, luts, out);
+        }
+        if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10>, false>(ctx, jobs, count, small, luts, out);
+        if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11>, false>(ctx, jobs, count, small, luts, out);
     }
 #define PBS64_CASE(LN, LV) \
     if (ctx->logN == LN && P.pbs_l == LV) return launch_pbs64_c<Pbs64Cfg<LN, LV>>(ctx, jobs, count, small, luts, out);
@@ -1031,6 +1189,53 @@ int apply_luts_device(helm_si_ctx *ctx, const uint64_t *src, uint64_t *dst, cons
     return 0;
 }
 
+// Multi-bit: which power of psi is the evaluation point of each spectrum position, in the order the key
+// words (and the transform outputs of k_pbs64s) are held?  Transform the polynomial X through the key
+// conversion kernel (one "key" of one polynomial) and look the values up among the powers of psi.
+int probe_spectrum_positions(helm_si_ctx *ctx)
+{
+    const int N = ctx->P.N, H = N / 2;
+    std::vector<uint64_t> xpoly((size_t)N, 0);
+    xpoly[1] = 1;
+    uint64_t *d_x = nullptr;
+    double *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_x, sizeof(uint64_t) * N));
+    HIP_TRY(hipMalloc(&d_out, sizeof(double) * 4 * H));
+    HIP_TRY(hipMemcpy(d_x, xpoly.data(), sizeof(uint64_t) * N, hipMemcpyHostToDevice));
+    // one polynomial, K1 = 1: blocks (poly 0, half h) write d_out[(f * 2 + h) * N/2 ...] scaled by 1 (n_inv = 1)
+#define PROBE(LN)                                                                                                        \
+    if (ctx->logN == LN) {                                                                                              \
+        hipLaunchKernelGGL((k_bsk_convert64s<F0, LN>), dim3(2), dim3(64), 0, ctx->stream, d_x, d_out, ctx->tw[0],        \
+                           ctx->tw_sub, 1.0, ctx->two32[0], 1, 0);                                                       \
+        hipLaunchKernelGGL((k_bsk_convert64s<F1, LN>), dim3(2), dim3(64), 0, ctx->stream, d_x, d_out, ctx->tw[1],        \
+                           ctx->tw_sub + (size_t)2 * H, 1.0, ctx->two32[1], 1, 1);                                       \
+    }
+    PROBE(10) PROBE(11)
+#undef PROBE
+    HIP_TRY(hipGetLastError());
+    std::vector<double> val((size_t)4 * H), pw((size_t)4 * N);
+    HIP_TRY(hipMemcpyAsync(val.data(), d_out, sizeof(double) * 4 * H, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(pw.data(), ctx->psi_pow, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_x);
+    (void)hipFree(d_out);
+    std::vector<uint16_t> expo((size_t)2 * H);
+    for (int f = 0; f < 2; f++) {
+        std::map<int64_t, int> where;
+        for (int t = 0; t < 2 * N; t++) where[(int64_t)pw[(size_t)f * 2 * N + t]] = t;
+        for (int q = 0; q < 2 * H; q++) {
+            auto it = where.find((int64_t)val[(size_t)f * 2 * H + q]);
+            if (it == where.end() || !(it->second & 1)) return fail(HELM_ERR_HIP, "multi-bit: spectrum position probe failed");
+            if (f == 0) expo[(size_t)q] = (uint16_t)it->second;
+            else if (expo[(size_t)q] != (uint16_t)it->second)
+                return fail(HELM_ERR_HIP, "multi-bit: the two fields disagree on a spectrum position");
+        }
+    }
+    HIP_TRY(hipMalloc(&ctx->expo, expo.size() * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(ctx->expo, expo.data(), expo.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
 // helm_si_apply_luts with the batch sharded over the ranks of helm_si_set_exchange(): identical
 // ciphertexts to the unsharded call (every bootstrap is independent and deterministic)
 int apply_luts_sharded(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, const int32_t *lut_idx,
@@ -1086,6 +1291,11 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
     const int t = P.message_modulus * P.carry_modulus;
     if (P.message_modulus < 2 || P.carry_modulus < 1 || (t & (t - 1)) || t > P.N / 2)
         return fail(HELM_ERR_INVALID, "message_modulus * carry_modulus must be a power of two <= N/2");
+    const int group = P.grouping_factor > 1 ? P.grouping_factor : 1;
+    if (P.grouping_factor < 0 || group > 3 || P.n % group)
+        return fail(HELM_ERR_INVALID, "grouping_factor must be 0..3 and divide n");
+    if (group > 1 && !(P.pbs_l == 1 && P.N >= 1024))
+        return fail(HELM_ERR_INVALID, "multi-bit blind rotation is built for pbs_l = 1, N >= 1024 (every tfhe multi-bit set)");
     // exactness: |sum| <= (k+1) * l * N * (B/2) * 2^63 must stay below p0 * p1 / 2
     {
         const long double bound = (long double)(P.k + 1) * P.pbs_l * P.N * (long double)(1ull << (P.pbs_logB - 1)) *
@@ -1129,9 +1339,23 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
         HIP_TRY(hipMemcpy(ctx->tw[f], tf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
     }
     ctx->p0inv_mod_p1 = centred(powmod_u64(pm[0] % pm[1], pm[1] - 2, pm[1]), pm[1]);
+    ctx->group = group;
+    if (group > 1) { // the 2N powers of psi per field: monomial products in the transform domain
+        std::vector<double> pw((size_t)4 * N);
+        for (int f = 0; f < 2; f++) {
+            const uint64_t psi = powmod_u64(gen[f], (pm[f] - 1) / (2 * (uint64_t)N), pm[f]);
+            uint64_t a = 1;
+            for (int i = 0; i < 2 * N; i++) {
+                pw[(size_t)f * 2 * N + i] = centred(a, pm[f]);
+                a = mulmod_u64(a, psi, pm[f]);
+            }
+        }
+        HIP_TRY(hipMalloc(&ctx->psi_pow, pw.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(ctx->psi_pow, pw.data(), pw.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     // eight-wave kernel (split transforms) where it exists: N >= 1024, one level (HELM_SI_SPLIT=0: off)
     ctx->use_split = P.pbs_l == 1 && N >= 1024;
-    if (const char *v = getenv("HELM_SI_SPLIT")) ctx->use_split = ctx->use_split && atoi(v) != 0;
+    if (const char *v = getenv("HELM_SI_SPLIT")) ctx->use_split = (ctx->use_split && atoi(v) != 0) || group > 1;
     if (ctx->use_split) {
         // half h of field f, stage with m' groups, group i': full table entry 2m' + h m' + i'
         std::vector<double> sub((size_t)4 * (N / 2), 0.0), full(N);
@@ -1168,6 +1392,8 @@ int helm_si_ctx_destroy(helm_si_ctx *ctx)
     (void)hipFree(ctx->bsk);
     (void)hipFree(ctx->bsk_split);
     (void)hipFree(ctx->tw_sub);
+    (void)hipFree(ctx->expo);
+    (void)hipFree(ctx->psi_pow);
     (void)hipFree(ctx->ksk);
     ctx->d_pbs.release();
     ctx->d_ks.release();
@@ -1213,17 +1439,18 @@ int helm_si_load_bootstrap_key(helm_si_ctx *ctx, const uint64_t *bsk_std, size_t
     if (!ctx || !bsk_std) return fail(HELM_ERR_INVALID, "null argument");
     const helm_si_params &P = ctx->P;
     const size_t K1 = P.k + 1;
-    const size_t polys = (size_t)P.n * P.pbs_l * K1 * K1;
+    const size_t n_ggsw = ctx->group > 1 ? (size_t)(P.n / ctx->group) << ctx->group : (size_t)P.n;
+    const size_t polys = n_ggsw * P.pbs_l * K1 * K1;
     if (n_words != polys * P.N)
         return fail(HELM_ERR_INVALID, "bootstrapping key: expected " + std::to_string(polys * P.N) + " words, got " +
                                           std::to_string(n_words));
     HIP_TRY(hipSetDevice(ctx->device));
     uint64_t *d_std = nullptr;
     HIP_TRY(hipMalloc(&d_std, n_words * sizeof(uint64_t)));
-    if (!ctx->bsk) HIP_TRY(hipMalloc(&ctx->bsk, n_words * 2 * sizeof(double)));
+    if (!ctx->bsk && ctx->group == 1) HIP_TRY(hipMalloc(&ctx->bsk, n_words * 2 * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(d_std, bsk_std, n_words * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
 #define CONV(LN)                                                                                                     \
-    if (ctx->logN == LN) {                                                                                           \
+    if (ctx->logN == LN && ctx->group == 1) {                                                                                           \
         hipLaunchKernelGGL((k_bsk_convert64<F0, LN>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk, \
                            ctx->tw[0], ctx->n_inv[0], ctx->two32[0], (int)K1, P.pbs_l, 0);                           \
         hipLaunchKernelGGL((k_bsk_convert64<F1, LN>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk, \
@@ -1247,6 +1474,9 @@ int helm_si_load_bootstrap_key(helm_si_ctx *ctx, const uint64_t *bsk_std, size_t
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(d_std));
+    if (ctx->group > 1 && !ctx->expo) {
+        if (int rc = probe_spectrum_positions(ctx)) return rc;
+    }
     ctx->have_bsk = true;
     return 0;
 }

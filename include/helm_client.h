@@ -66,7 +66,9 @@ int helm_client_phase(const helm_client_key *key, const uint32_t *lwe, int64_t c
  * Ciphertexts are encrypted under the BIG key (k*N words + body). */
 typedef struct helm_si_client_key helm_si_client_key;
 /* "shortint_m2c2": PARAM_MESSAGE_2_CARRY_2_KS_PBS [recalled; the 3-bit-capable
- * class tests/circuit_test.rs:287 needs]; "si_toy_*": small sets for exact oracle comparisons. */
+ * class tests/circuit_test.rs:287 needs]; "shortint_m2c2_multibit3":
+ * PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS, the arithmetic-mode set of src/bin/helm.rs:83
+ * [dimensions recalled]; "si_toy_*": small sets for exact oracle comparisons. */
 int helm_si_client_named_params(const char *name, helm_si_params *params, double *lwe_noise_std,
                                 double *glwe_noise_std);
 int helm_si_client_keygen(const helm_si_params *params, double lwe_noise_std, double glwe_noise_std,
@@ -75,7 +77,7 @@ void helm_si_client_key_free(helm_si_client_key *key);
 int helm_si_client_params(const helm_si_client_key *key, helm_si_params *out);
 size_t helm_si_client_bsk_words(const helm_si_client_key *key);
 size_t helm_si_client_ksk_words(const helm_si_client_key *key);
-const uint64_t *helm_si_client_bsk(const helm_si_client_key *key); /* [n][pbs_l][k+1][k+1][N] */
+const uint64_t *helm_si_client_bsk(const helm_si_client_key *key); /* [n][pbs_l][k+1][k+1][N]; multi-bit: [n/g][2^g][...] */
 const uint64_t *helm_si_client_ksk(const helm_si_client_key *key); /* [k*N][ks_l][n+1]       */
 const uint64_t *helm_si_client_lwe_secret(const helm_si_client_key *key);  /* n   words of 0/1 */
 const uint64_t *helm_si_client_glwe_secret(const helm_si_client_key *key); /* k*N words of 0/1 */

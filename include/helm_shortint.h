@@ -28,7 +28,8 @@
  *
  * Layouts (all words uint64_t, arithmetic mod 2^64)
  *   big LWE / wire row   k*N mask words + body
- *   bootstrapping key    [n][pbs_l][k+1][k+1][N]      (as helm_hip.h, 64-bit)
+ *   bootstrapping key    [n][pbs_l][k+1][k+1][N]      (as helm_hip.h, 64-bit); multi-bit sets
+ *                        (grouping_factor g > 1): [n/g][2^g][pbs_l][k+1][k+1][N]
  *   keyswitching key     [k*N][ks_l][n+1]
  *   encoding             value v in [0, message_modulus*carry_modulus) -> v * delta,
  *                        delta = 2^63 / (message_modulus * carry_modulus)
@@ -50,13 +51,21 @@ extern "C" {
 typedef struct helm_si_ctx helm_si_ctx;
 typedef struct helm_si_wires helm_si_wires;
 
-/* tfhe::shortint::ClassicPBSParameters as HELM picks them (src/bin/helm.rs:301,
- * tests/circuit_test.rs:287), runtime values. */
+/* tfhe::shortint::{ClassicPBSParameters, MultiBitPBSParameters} as HELM picks them
+ * (src/bin/helm.rs:301, tests/circuit_test.rs:287; src/bin/helm.rs:83 for arithmetic mode),
+ * runtime values.
+ * grouping_factor g: 0 or 1 = classical blind rotation (n CMUX steps, key = GGSW(s_i));
+ * g = 2 or 3 = multi-bit blind rotation (tfhe's MultiBitPBS, reference helm.rs:83 uses g = 3):
+ * n/g group steps; the key holds, per group, 2^g GGSWs of the indicators
+ * prod_{i in S} s_i * prod_{i not in S} (1 - s_i), S a subset of the group (bit i of the subset
+ * index = member i), and a step is acc <- (sum_S X^(sum_{i in S} a~_i) * GGSW_S) (x) acc.
+ * n must be a multiple of g. */
 typedef struct {
     int32_t n, k, N;
     int32_t pbs_l, pbs_logB;
     int32_t ks_l, ks_logB;
     int32_t message_modulus, carry_modulus;
+    int32_t grouping_factor;
 } helm_si_params;
 
 /* Replaces shortint ServerKey construction (helm.rs:301: gen_keys(PARAM_...)). */

@@ -144,7 +144,7 @@ def max_threads():
 # ---------------------------------------------------------------------------------------
 class Params64(C.Structure):
     _fields_ = [(f, C.c_int32) for f in ("n", "k", "N", "pbs_l", "pbs_logB", "ks_l", "ks_logB",
-                                         "message_modulus", "carry_modulus")]
+                                         "message_modulus", "carry_modulus", "grouping_factor")]
 
 
 _LIB64 = None

@@ -37,6 +37,7 @@ typedef struct {
     int32_t pbs_l, pbs_logB;
     int32_t ks_l, ks_logB;
     int32_t message_modulus, carry_modulus;
+    int32_t grouping_factor; /* 0 / 1: classical blind rotation; 2, 3: multi-bit (helm_shortint.h) */
 } orc64_params;
 
 u64 orc64_delta(const orc64_params *P) { return ((u64)1 << 63) / (u64)(P->message_modulus * P->carry_modulus); }
@@ -119,6 +120,32 @@ void orc64_bootstrap(const orc64_params *P, const u64 *bsk, const u64 *lwe, cons
     int bt = (int)orc64_modswitch(lwe[n], log2_2N);
     for (int j = 0; j < N; j++) acc[(size_t)P->k * N + j] = rot_coeff64(tv, N, j, (2 * N - bt) & (2 * N - 1));
     size_t stride = (size_t)l * k1 * k1 * N;
+    int g = P->grouping_factor;
+    if (g > 1) {
+        /* Multi-bit blind rotation (tfhe MultiBitPBS, the parameter set of reference
+         * src/bin/helm.rs:83; algorithm as published): per group of g mask words
+         *   G = sum_{S subset of group} X^(sum_{i in S} a~_i) * GGSW_S,   acc <- G (x) acc
+         * where GGSW_S encrypts the indicator that exactly the key bits of S are set, so G is a GGSW
+         * of X^(sum_i a~_i s_i).  bsk layout [n/g][2^g][level][row][col][N]. */
+        int subsets = 1 << g;
+        u64 *G = (u64 *)malloc(sizeof(u64) * stride);
+        for (int t = 0; t < n / g; t++) {
+            memset(G, 0, sizeof(u64) * stride);
+            for (int S = 0; S < subsets; S++) {
+                int e = 0;
+                for (int i = 0; i < g; i++)
+                    if ((S >> i) & 1) e += (int)orc64_modswitch(lwe[t * g + i], log2_2N);
+                e &= 2 * N - 1;
+                const u64 *src = bsk + ((size_t)t * subsets + S) * stride;
+                for (size_t q = 0; q < stride / N; q++)
+                    for (int j = 0; j < N; j++) G[q * N + j] += rot_coeff64(src + q * N, N, j, e);
+            }
+            memcpy(diff, acc, sizeof(u64) * (size_t)k1 * N);
+            memset(acc, 0, sizeof(u64) * (size_t)k1 * N);
+            extprod_add64(P, G, diff, acc);
+        }
+        free(G);
+    } else
     for (int i = 0; i < n; i++) {
         int a = (int)orc64_modswitch(lwe[i], log2_2N);
         if (a == 0) continue;

@@ -73,10 +73,13 @@ def test_parameter_validation_needs_no_device():
 
 def test_shortint_parameter_validation_needs_no_device():
     p, _, _ = helm_amd.si_named_params("shortint_m2c2")
-    assert p.as_tuple() == (742, 1, 2048, 1, 23, 5, 3, 4, 4)
+    assert p.as_tuple() == (742, 1, 2048, 1, 23, 5, 3, 4, 4, 0)
+    mb, _, _ = helm_amd.si_named_params("shortint_m2c2_multibit3")  # the arithmetic-mode set of helm.rs:83
+    assert mb.as_tuple() == (888, 1, 2048, 1, 21, 3, 4, 4, 4, 3)
     h = nv.vp()
     for field, value, msg in (("k", 2, b"unsupported"), ("N", 4096, b"unsupported"), ("pbs_logB", 31, b"decomposition"),
-                              ("message_modulus", 3, b"power of two"), ("ks_logB", 9, b"keyswitch")):
+                              ("message_modulus", 3, b"power of two"), ("ks_logB", 9, b"keyswitch"),
+                              ("grouping_factor", 4, b"grouping_factor"), ("grouping_factor", 3, b"grouping_factor")):
         bad = helm_amd.SiParams.from_buffer_copy(p)
         setattr(bad, field, value)
         assert nv.hip.helm_si_ctx_create(0, C.byref(bad), C.byref(h)) == -1, field
@@ -97,6 +100,9 @@ def test_shortint_client_roundtrip():
         assert np.array_equal(ck.decrypt(ct), vals % ck.params.message_modulus)
         assert ck.bsk.size == ck.params.n * ck.params.pbs_l * 4 * ck.params.N
         assert ck.ksk.size == ck.dim * ck.params.ks_l * (ck.params.n + 1)
+    # multi-bit key: 2^g GGSWs per group of g mask words (include/helm_shortint.h)
+    ck = helm_amd.SiClientKey.generate("si_toy_2048_mb3", seed=4)
+    assert ck.bsk.size == (ck.params.n // 3) * 8 * ck.params.pbs_l * 4 * ck.params.N
 
 
 def test_no_cpu_fallback(have_gpu):

@@ -10,7 +10,7 @@ import oracle
 
 pytestmark = pytest.mark.gpu
 
-TOYS = ["si_toy_512", "si_toy_1024", "si_toy_2048", "si_toy_2048_l2"]
+TOYS = ["si_toy_512", "si_toy_1024", "si_toy_2048", "si_toy_2048_l2", "si_toy_1024_mb2", "si_toy_2048_mb3"]
 
 
 @pytest.fixture(scope="module", params=TOYS)

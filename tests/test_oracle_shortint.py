@@ -195,3 +195,60 @@ def test_golden_vectors_two_independent_routes():
         want = ((tb >> sum(b << (ar - 1 - q) for q, b in enumerate(x))) & 1) if ar >= 2 else \
             (x[0] if (ar == 0 or tb == 0) else (-x[0]) % t)
         assert orc.decrypt(g["glwe_sk"], g["expected"][gi]) == want, gi
+
+
+# ---------------------------------------------------------------------------------------
+# multi-bit blind rotation (grouping factor g; the arithmetic-mode set of reference src/bin/helm.rs:83)
+# ---------------------------------------------------------------------------------------
+def _np_multibit_bootstrap(P, bsk, small, tv):
+    """numpy restatement of the multi-bit programmable bootstrap: per group of g mask words
+    G = sum_S X^(sum_{i in S} a_i) * GGSW_S, acc <- G (x) acc."""
+    n, k, N, l, logB = P[:5]
+    g = P[9]
+    ms = lambda x: ((int(x) >> (64 - (N.bit_length()) - 1)) + 1 >> 1) & (2 * N - 1)
+    rot = lambda poly, a: np.array([poly[(j - a) % (2 * N)] if (j - a) % (2 * N) < N else
+                                    np.uint64(0) - poly[(j - a) % (2 * N) - N] for j in range(N)], dtype=np.uint64)
+    acc = np.zeros((k + 1, N), dtype=np.uint64)
+    acc[k] = rot(tv, (2 * N - ms(small[n])) % (2 * N))
+    bsk = bsk.reshape(n // g, 1 << g, l, k + 1, k + 1, N)
+    for t in range(n // g):
+        a = [ms(small[t * g + q]) for q in range(g)]
+        G = np.zeros((l, k + 1, k + 1, N), dtype=np.uint64)
+        for S in range(1 << g):
+            e = sum(a[q] for q in range(g) if (S >> q) & 1) % (2 * N)
+            for j in range(l):
+                for r in range(k + 1):
+                    for c in range(k + 1):
+                        G[j, r, c] += rot(bsk[t, S, j, r, c], e)
+        new = np.zeros_like(acc)
+        for r in range(k + 1):
+            digs = _np_decompose(acc[r], logB, l)
+            for j in range(l):
+                for c in range(k + 1):
+                    new[c] += _np_negacyclic(digs[j], G[j, r, c])
+        acc = new
+    out = np.zeros(k * N + 1, dtype=np.uint64)
+    for r in range(k):
+        out[r * N] = acc[r][0]
+        out[r * N + 1:(r + 1) * N] = np.uint64(0) - acc[r][:0:-1]
+    out[k * N] = acc[k][0]
+    return out
+
+
+@pytest.mark.parametrize("g,n", [(2, 4), (3, 6)])
+def test_multibit_bootstrap_two_routes_and_every_value(g, n):
+    p = helm_amd.SiParams(n=n, k=1, N=256, pbs_l=2, pbs_logB=12, ks_l=4, ks_logB=4, message_modulus=4,
+                          carry_modulus=4, grouping_factor=g)
+    ck = helm_amd.SiClientKey(p, 1e-9, 1e-15, seed=7)
+    assert ck.bsk.size == (n // g) * (1 << g) * p.pbs_l * 4 * p.N  # 2^g GGSWs per group
+    orc = oracle.Oracle64(p.as_tuple(), ck.bsk, ck.ksk)
+    f = lambda v: (7 * v + 2) % ck.t
+    lut = orc.make_lut(f)
+    cts = ck.encrypt(np.arange(ck.t, dtype=np.uint64))
+    with np.errstate(over="ignore"):
+        for v in range(ck.t):
+            small = orc.keyswitch(cts[v])
+            out = orc.bootstrap(small, lut)
+            assert ck.decrypt_message_and_carry(out) == f(v)
+            if v in (0, 5, 15):  # the numpy route, bit for bit
+                assert np.array_equal(out, _np_multibit_bootstrap(list(p.as_tuple()), ck.bsk, small, lut)), v
