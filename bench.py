@@ -296,9 +296,18 @@ def main():
 
 
 def other_modes(device):
+    """LUT mode under PARAM_MESSAGE_2_CARRY_2 (classical blind rotation) and arithmetic mode under both that set
+    and the reference's own PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3 (helm.rs:83, multi-bit blind rotation)."""
+    res = _other_modes_set(device, "shortint_m2c2", "PARAM_MESSAGE_2_CARRY_2_KS_PBS")
+    mb = _other_modes_set(device, "shortint_m2c2_multibit3", "PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS")
+    res["lut_mode_multibit3"], res["arith_mode_multibit3"] = mb["lut_mode"], mb["arith_mode"]
+    return res
+
+
+def _other_modes_set(device, set_name, tfhe_name):
     import helm_amd
     from helm_amd import ArithCircuit, Circuit, PtxtType, verilog_parser
-    ck, sk = helm_amd.gen_keys_shortint("shortint_m2c2", seed=1, device=device)
+    ck, sk = helm_amd.gen_keys_shortint(set_name, seed=1, device=device)
     B = 1024
     bits = np.random.default_rng(0).integers(0, 2, size=3 * B).astype(np.uint64)
     w = sk.wires(4 * B)
@@ -312,8 +321,8 @@ def other_modes(device):
     sk.sync()
     dt = time.perf_counter() - t0
     ok = bool(np.array_equal(ck.decrypt(w.download(out)), (bits[:B] + bits[B:2 * B] + bits[2 * B:]) >= 2))
-    res = {"lut_mode": {"workload": f"{B} independent 3-input LUT gates (keyswitch + programmable bootstrap), "
-                                    "PARAM_MESSAGE_2_CARRY_2", "luts_per_s": round(B / dt, 1), "decrypt_ok": ok}}
+    res = {"lut_mode": {"workload": f"{B} independent 3-input LUT gates (keyswitch + programmable bootstrap), " + tfhe_name,
+                        "luts_per_s": round(B / dt, 1), "decrypt_ok": ok}}
     g, ws, i, o, d, _, _ = verilog_parser.read_verilog_file(os.path.join(ROOT, "tests", "netlists", "chi_squared_arith.v"), True)
     c = Circuit(g, i, o, d)
     c.sort_circuit()
@@ -325,7 +334,7 @@ def other_modes(device):
     outm = ac.evaluate_encrypted(enc, 1, "u32")
     dt = time.perf_counter() - t0
     dec = {k: int(v.value) for k, v in ac.decrypt_outputs(outm, True).items()}
-    res["arith_mode"] = {"workload": "chi_squared_arith.v, u32 (16 radix blocks per integer)", "wall_s": round(dt, 4),
+    res["arith_mode"] = {"workload": "chi_squared_arith.v, u32 (16 radix blocks per integer), " + tfhe_name, "wall_s": round(dt, 4),
                          "bootstraps": ac.pbs_per_cycle(), "batched_rounds": ac.pbs_rounds_per_cycle(),
                          "decrypt_ok": dec == {"alpha": 529, "beta1": 242, "beta2": 275, "beta3": 1250}}
     sk.close()

@@ -491,6 +491,13 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
     STAMP_END((p * 2 + f) * 2 + h)
 }
 
+__host__ __device__ constexpr int bitrev_c(int v, int bits)
+{
+    int r = 0;
+    for (int b = 0; b < bits; b++) r |= ((v >> b) & 1) << (bits - 1 - b);
+    return r;
+}
+
 // Multi-bit blind rotation (tfhe MultiBitPBS, grouping factor g <= 3; reference src/bin/helm.rs:83 installs
 // the g = 3 set for arithmetic mode): per group of g mask words ONE external product
 //     acc <- ( sum_S X^(e_S) * GGSW_S ) (x) acc,      e_S = sum_{i in S} a~_i,
@@ -529,18 +536,19 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
     const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * 4 + f * 2 + h) * part + lane;
     const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
     const int subsets = 1 << g;
-    // exponents of this wave's spectrum positions, in the order of the key words
-    int ex[EH];
-#pragma unroll
-    for (int u = 0; u < HC; u++) {
-        const ushort2 v = reinterpret_cast<const ushort2 *>(expo)[((size_t)h * HC + u) * 64 + lane];
-        ex[2 * u] = v.x;
-        ex[2 * u + 1] = v.y;
-    }
+    // exponent of this lane's first spectrum position (slot e = 0 of the key-word order)
+    const int c_lane = (int)expo[((size_t)h * HC * 64 + lane) * 2];
+    // omega^k, k < EH (omega = psi^(2N/EH)), held by lane k: read with v_readlane by a uniform index
+    const double om_tab = psi_pow[(lane & (EH - 1)) * (2 * N / EH)];
+    const int om_lo = __double2loint(om_tab), om_hi = __double2hiint(om_tab);
     for (int t = 0; t < n / g; t++) {
         int am[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) am[q] = q < g ? __builtin_amdgcn_readfirstlane((int)MS[t * g + q]) : 0;
+        // psi^(c_lane a_q) of the group's members: in flight during the decomposition and the transform
+        double bq[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) bq[q] = psi_pow[(c_lane * am[q]) & (2 * N - 1)];
         // ---- (1) digits of this wave's quarter of polynomial p ----------------------------------
 #pragma unroll
         for (int u = 0; u < Q; u++) {
@@ -563,36 +571,73 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
         }
         ntt_forward<F, LOGN - 1, 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
-        // ---- products with the 2^g keys of the group: col[c] = sum_S (x .* M(e_S)) .* K_S[p][c] -----
-        // (the first product is below 1.5 p, the others - operands below 1.5 p - below 0.6 p: <= 5.7 p per sum)
-        double col[K1][EH];
+        // ---- the group's key in the transform domain: G[c] = sum_S M(e_S) .* K_S[p][c], then the products
+        //      x .* G[c].  The spectrum positions of a lane are expo(lane, e) = c_lane + (2N/EH) rev(e)
+        //      (verified when the table is probed), so M(e_S)[e] = psi^(c_lane e_S) * omega^(e_S rev(e)) with
+        //      omega = psi^(2N/EH) of order EH: one gathered power per lane and subset, EH wave-uniform ones.
+        // The transformed digits wait in the wave's scratch meanwhile (their registers carry the key
+        // pipeline: the two key polynomials of a subset are fetched one half-step ahead of their use).
+        static_assert(K1 == 2, "two key columns, pipelined alternately");
+#pragma unroll
+        for (int e = 0; e < EH; e++) xb[e * 64 + lane] = x[0][e];
+        double gcol[K1][EH];
+        double2 ka[HC], kb[HC];
+        {
+            const double2 *kp = bsk_w + ((size_t)t * subsets) * bsk_step;
+#pragma unroll
+            for (int u = 0; u < HC; u++) ka[u] = kp[u * 64];
+#pragma unroll
+            for (int u = 0; u < HC; u++) kb[u] = (kp + (size_t)4 * part)[u * 64];
+        }
         for (int S = 0; S < subsets; S++) {
             int e_s = 0;
 #pragma unroll
             for (int q = 0; q < 3; q++)
                 if ((S >> q) & 1) e_s += am[q];
             e_s &= 2 * N - 1;
-            const double2 *kp = bsk_w + ((size_t)t * subsets + S) * bsk_step;
-            double2 kw[K1][HC];
+            // the next subset's keys (the last iteration refetches its own: harmless, keeps the loop uniform)
+            const double2 *kn = bsk_w + ((size_t)t * subsets + (S + 1 < subsets ? S + 1 : S)) * bsk_step;
+            double mf[EH];
+            if (S != 0) {
+                // psi^(c_lane e_S) as the product of the members' powers (fetched at the top of the step);
+                // omega^(e_S rev(e)) out of the lane-held table by wave-uniform index: no memory access here
+                double bs = (S & 1) ? bq[0] : ((S & 2) ? bq[1] : bq[2]);
+                if ((S & 1) && (S & 2)) bs = reduce<F>(mulmod<F>(bs, bq[1]));
+                if ((S & 3) && (S & 4)) bs = reduce<F>(mulmod<F>(bs, bq[2]));
+                // |m| <= 0.51 p, every term <= 0.51 p: G <= 4.1 p before the recentring below
 #pragma unroll
-            for (int c = 0; c < K1; c++)
-#pragma unroll
-                for (int u = 0; u < HC; u++) kw[c][u] = (kp + (size_t)c * 4 * part)[u * 64];
-#pragma unroll
-            for (int u = 0; u < HC; u++) {
-                double xs0 = x[0][2 * u], xs1 = x[0][2 * u + 1];
-                if (S != 0) {
-                    xs0 = mulmod<F>(xs0, psi_pow[(ex[2 * u] * e_s) & (2 * N - 1)]);
-                    xs1 = mulmod<F>(xs1, psi_pow[(ex[2 * u + 1] * e_s) & (2 * N - 1)]);
-                }
-#pragma unroll
-                for (int c = 0; c < K1; c++) {
-                    const double t0 = mulmod<F>(xs0, kw[c][u].x), t1 = mulmod<F>(xs1, kw[c][u].y);
-                    col[c][2 * u] = S == 0 ? t0 : col[c][2 * u] + t0;
-                    col[c][2 * u + 1] = S == 0 ? t1 : col[c][2 * u + 1] + t1;
+                for (int e = 0; e < EH; e++) {
+                    const int k = (e_s * bitrev_c(e, GS::LOGE)) & (EH - 1);
+                    const double om = __hiloint2double(__builtin_amdgcn_readlane(om_hi, k), __builtin_amdgcn_readlane(om_lo, k));
+                    mf[e] = mulmod<F>(bs, om);
                 }
             }
+#pragma unroll
+            for (int u = 0; u < HC; u++) {
+                gcol[0][2 * u] = S == 0 ? ka[u].x : gcol[0][2 * u] + mulmod<F>(ka[u].x, mf[2 * u]);
+                gcol[0][2 * u + 1] = S == 0 ? ka[u].y : gcol[0][2 * u + 1] + mulmod<F>(ka[u].y, mf[2 * u + 1]);
+            }
+#pragma unroll
+            for (int u = 0; u < HC; u++) ka[u] = kn[u * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < HC; u++) {
+                gcol[1][2 * u] = S == 0 ? kb[u].x : gcol[1][2 * u] + mulmod<F>(kb[u].x, mf[2 * u]);
+                gcol[1][2 * u + 1] = S == 0 ? kb[u].y : gcol[1][2 * u + 1] + mulmod<F>(kb[u].y, mf[2 * u + 1]);
+            }
+#pragma unroll
+            for (int u = 0; u < HC; u++) kb[u] = (kn + (size_t)4 * part)[u * 64];
+            __builtin_amdgcn_sched_barrier(0);
         }
+        lds_wave_sync();
+#pragma unroll
+        for (int e = 0; e < EH; e++) x[0][e] = xb[e * 64 + lane];
+        lds_wave_sync();
+        double col[K1][EH];
+#pragma unroll
+        for (int c = 0; c < K1; c++)
+#pragma unroll
+            for (int e = 0; e < EH; e++) col[c][e] = mulmod<F>(x[0][e], reduce<F>(gcol[c][e])); // <= 1.5 p
         double mine[EH];
 #pragma unroll
         for (int e = 0; e < EH; e++) {
@@ -1229,6 +1274,25 @@ int probe_spectrum_positions(helm_si_ctx *ctx)
             if (f == 0) expo[(size_t)q] = (uint16_t)it->second;
             else if (expo[(size_t)q] != (uint16_t)it->second)
                 return fail(HELM_ERR_HIP, "multi-bit: the two fields disagree on a spectrum position");
+        }
+    }
+    { // the structure pbs64s_mb_body relies on: expo(h, lane, e) = expo(h, lane, 0) + (2N/EH) rev(e)  (mod 2N)
+        const int EH = H / 64;
+        int loge = 0;
+        while ((1 << loge) < EH) loge++;
+        for (int hh = 0; hh < 2; hh++)
+            for (int e = 0; e < EH; e++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int v = expo[(size_t)hh * H + ((size_t)(e >> 1) * 64 + lane) * 2 + (e & 1)];
+                    const int v0 = expo[(size_t)hh * H + (size_t)lane * 2];
+                    if (v != ((v0 + (2 * N / EH) * bitrev_c(e, loge)) & (2 * N - 1)))
+                        return fail(HELM_ERR_HIP, "multi-bit: unexpected order of the spectrum positions");
+                }
+    }
+    if (const char *path = getenv("HELM_SI_DUMP_EXPO")) { // diagnostic: the probed table, [2 halves][N/2] u16
+        if (FILE *fp = fopen(path, "wb")) {
+            fwrite(expo.data(), sizeof(uint16_t), expo.size(), fp);
+            fclose(fp);
         }
     }
     HIP_TRY(hipMalloc(&ctx->expo, expo.size() * sizeof(uint16_t)));

@@ -200,3 +200,26 @@ shr g11(A, 5, SR);
                 "R": a >> (b % 8), "SA": (a + 77) % 256, "SS": (a - 77) % 256, "SM": (a * 77) % 256, "SQ": a // 11,
                 "SL": (a << 5) % 256, "SR": a >> 5}
         assert out == want, (a, b)
+
+
+def test_arithmetic_mode_under_the_multibit_set():
+    """The reference installs PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS for arithmetic mode
+    (src/bin/helm.rs:83): same circuits, multi-bit blind rotation (296 group steps).  chi-squared on u32
+    (circuit_test.rs:313-370) and an FheUint16 known answer (gates_test.rs:127-310)."""
+    client_key, server_key = helm_amd.gen_keys_shortint("shortint_m2c2_multibit3", seed=1)
+    assert client_key.params.grouping_factor == 3 and client_key.params.n == 888
+    try:
+        circuit, wire_set, input_wires, output_wires = _circuit(f"{NET}/chi_squared_arith.v", is_arith=True)
+        inputs = verilog_parser.read_input_wires(os.path.join(HERE, "golden", "chi_squared_arith_1.inputs.csv"), "u32")
+        ac = ArithCircuit(client_key, server_key, circuit)
+        enc = EvalCircuit.evaluate_encrypted(ac, EvalCircuit.encrypt_inputs(ac, wire_set, inputs), 1, "u32")
+        out = {k: v.value for k, v in EvalCircuit.decrypt_outputs(ac, enc, True).items()}
+        assert out == {"alpha": 529, "beta1": 242, "beta2": 275, "beta3": 1250}
+        text = "input [15:0] A, B;\noutput [15:0] S, D, P;\nadd g0(A, B, S);\nsub g1(B, A, D);\nmult g2(A, B, P);\n"
+        circuit, wire_set, input_wires, output_wires = _circuit(text, is_arith=True, is_text=True)
+        ac = ArithCircuit(client_key, server_key, circuit)
+        enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U16(30), "B": PtxtType.U16(40)})
+        out = {k: v.value for k, v in ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, "u16"), True).items()}
+        assert out == {"S": 70, "D": 10, "P": 1200}
+    finally:
+        server_key.close()
