@@ -1,7 +1,8 @@
 """Generates tests/golden/shortint_toy.npz: a tiny 64-bit-torus parameter set (n=3, N=512, k=1,
 message = carry = 4), its keys, four input ciphertexts and the expected output ciphertext of one
 LUT gate of every kind gates::lut() distinguishes (reference src/gates.rs:754-785), produced by
-the CPU oracle (oracle/shortint_oracle.c: schoolbook products in wrapping u64 arithmetic).
+the CPU oracle (oracle/shortint_oracle.c: schoolbook products in wrapping u64 arithmetic); and
+tests/golden/shortint_mb_toy.npz: the same gates under a multi-bit set (grouping factor 2, N=1024).
 
 tests/test_oracle_shortint.py re-derives the same ciphertexts with an independent numpy
 restatement; the GPU tests compare the HIP path with them.  The reference (Rust + un-vendored tfhe
@@ -42,4 +43,21 @@ np.savez_compressed(os.path.join(ROOT, "tests", "golden", "shortint_toy.npz"),
                     glwe_sk=ck.glwe_secret.copy(), bsk=ck.bsk.copy(), ksk=ck.ksk.copy(), bits=bits, inputs=inputs,
                     arity=arity, in_idx=in_idx, table=table, expected=wires[n_in:])
 print("wrote shortint_toy.npz:", len(gates), "gates; decrypted:",
+      [orc.decrypt(ck.glwe_secret, wires[n_in + g]) for g in range(len(gates))])
+
+# ---- multi-bit blind rotation (grouping factor 2: one group of two mask words, four GGSWs), N = 1024 so that
+#      the GPU build exists; same gate list -> tests/golden/shortint_mb_toy.npz ---------------------------------
+p = helm_amd.SiParams(n=2, k=1, N=1024, pbs_l=1, pbs_logB=22, ks_l=3, ks_logB=5, message_modulus=4, carry_modulus=4,
+                      grouping_factor=2)
+ck = helm_amd.SiClientKey(p, 1e-9, 1e-16, seed=2026)
+orc = oracle.Oracle64(p.as_tuple(), ck.bsk, ck.ksk)
+wires = np.zeros((n_in + len(gates), ck.dim + 1), dtype=np.uint64)
+wires[:n_in] = ck.encrypt(bits)
+inputs = wires[:n_in].copy()
+orc.eval_lut_level(wires, arity, in_idx, table, out_idx)
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "shortint_mb_toy.npz"),
+                    params=np.array(p.as_tuple(), dtype=np.int32), lwe_sk=ck.lwe_secret.copy(),
+                    glwe_sk=ck.glwe_secret.copy(), bsk=ck.bsk.copy(), ksk=ck.ksk.copy(), bits=bits, inputs=inputs,
+                    arity=arity, in_idx=in_idx, table=table, expected=wires[n_in:])
+print("wrote shortint_mb_toy.npz:", len(gates), "gates; decrypted:",
       [orc.decrypt(ck.glwe_secret, wires[n_in + g]) for g in range(len(gates))])

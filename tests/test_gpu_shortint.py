@@ -142,9 +142,10 @@ def test_full_parameter_set_m2c2():
     sk.close()
 
 
-def test_golden_vectors_on_gpu():
+@pytest.mark.parametrize("fixture", ["shortint_toy.npz", "shortint_mb_toy.npz"])  # classical / multi-bit blind rotation
+def test_golden_vectors_on_gpu(fixture):
     import os
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shortint_toy.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
     p = helm_amd.SiParams(*[int(x) for x in g["params"]])
     sk = helm_amd.SiServerKey(params=p, bsk=g["bsk"], ksk=g["ksk"])
     n_in = len(g["inputs"])

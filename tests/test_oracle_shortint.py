@@ -252,3 +252,33 @@ def test_multibit_bootstrap_two_routes_and_every_value(g, n):
             assert ck.decrypt_message_and_carry(out) == f(v)
             if v in (0, 5, 15):  # the numpy route, bit for bit
                 assert np.array_equal(out, _np_multibit_bootstrap(list(p.as_tuple()), ck.bsk, small, lut)), v
+
+
+def test_multibit_golden_vectors_two_routes():
+    """tests/golden/shortint_mb_toy.npz (grouping factor 2, N = 1024): the C oracle reproduces the committed
+    ciphertexts; the numpy route re-derives the first 3-input gate from the packed operand."""
+    g = np.load(os.path.join(HERE, "golden", "shortint_mb_toy.npz"))
+    P = [int(x) for x in g["params"]]
+    assert P[9] == 2
+    orc = oracle.Oracle64(P, g["bsk"], g["ksk"])
+    n_in = len(g["inputs"])
+    wires = np.zeros((n_in + len(g["arity"]), P[1] * P[2] + 1), dtype=np.uint64)
+    wires[:n_in] = g["inputs"]
+    orc.eval_lut_level(wires, g["arity"], g["in_idx"], g["table"], np.arange(n_in, len(wires), dtype=np.int32))
+    assert np.array_equal(wires[n_in:], g["expected"])
+    t = P[7] * P[8]
+    with np.errstate(over="ignore"):
+        ar, ins, tb = int(g["arity"][0]), g["in_idx"][0], int(g["table"][0])
+        packed = np.zeros_like(wires[0])
+        for q in range(ar):
+            packed += np.uint64(1 << (ar - 1 - q)) * g["inputs"][ins[q]]
+        tv = orc.make_lut([(tb >> (v & ((1 << ar) - 1))) & 1 for v in range(t)])
+        small = orc.keyswitch(packed)
+        assert np.array_equal(_np_multibit_bootstrap(P, g["bsk"], small, tv), g["expected"][0])
+    bits = [int(b) for b in g["bits"]]
+    for gi in range(len(g["arity"])):
+        ar, ins, tb = int(g["arity"][gi]), g["in_idx"][gi], int(g["table"][gi])
+        x = [bits[i] for i in ins[:max(ar, 1)]]
+        want = ((tb >> sum(b << (ar - 1 - q) for q, b in enumerate(x))) & 1) if ar >= 2 else \
+            (x[0] if (ar == 0 or tb == 0) else (-x[0]) % t)
+        assert orc.decrypt(g["glwe_sk"], g["expected"][gi]) == want, gi
