@@ -1268,6 +1268,27 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
         // wave on every SIMD (82.6 k gates/s on helm_cuda; a one-level-at-a-time build with 256
         // registers spilled and measured 73 k)
         using Big = PbsCfg<F, LOGN, K, L, L, TW_LANE, true, 1>;
+        // lockstep build (level at a time, four bootstraps per workgroup, the two waves of a bootstrap on
+        // one SIMD): the full rounds of wide launches (HELM_HIP_PBS_VARIANT=1 keeps the build above)
+        using Lock = PbsCfg<F, LOGN, K, L, 1, TW_LANE, false, 1, 4>;
+        if (ctx->pbs_variant != 1) {
+            const int64_t round = 4 * (int64_t)ctx->n_cus;
+            int64_t full = ctx->pbs_variant == 5 ? count : count / round * round;
+            if (ctx->pbs_variant != 5 && count - full > 2 * (int64_t)ctx->n_cus) full = count;
+            if (full) {
+                hipError_t e;
+                {
+                    TimedScope t(ctx, &ctx->ev_pbs_main);
+                    e = launch_pbs_v<Lock>(ctx, jobs, full, wires, raw, tvs, out_big);
+                }
+                ctx->tacc.pbs_main_launches++;
+                ctx->tacc.pbs_main_count += full;
+                if (e != hipSuccess || full == count) return e;
+                jobs += full;
+                out_big += (size_t)full * ((size_t)K * (1 << LOGN) + 1);
+                count -= full;
+            }
+        }
         return launch_pbs_v<Big>(ctx, jobs, count, wires, raw, tvs, out_big);
     }
 }

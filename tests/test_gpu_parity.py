@@ -244,3 +244,24 @@ def test_launch_split_over_builds_bit_exact(monkeypatch):
     orc = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True)
     for g in (0, 1, 4 * n_cus - 1, count - 7, count - 1):
         assert np.array_equal(got[g], orc.bootstrap_noks(lwe[g], tvs[idx[g]])), g
+
+
+def test_lockstep_build_n1024_bit_exact(monkeypatch):
+    """N = 1024 sets (the reference's CUDA parameters, helm.rs:141-146): the lockstep build (two waves per
+    bootstrap on one SIMD, four bootstraps per workgroup) against the oracle; 9 ciphertexts = two full
+    workgroups and one with a single bootstrap."""
+    monkeypatch.setenv("HELM_HIP_PBS_VARIANT", "5")
+    ck = helm_amd.ClientKey.generate("toy_1024", seed=13)
+    sk = helm_amd.ServerKey(ck)
+    orc = oracle.Oracle(ck.params.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True)
+    p = ck.params
+    rng = np.random.default_rng(31)
+    lwe = rng.integers(0, 2**32, size=(9, p.n + 1), dtype=np.uint32)
+    lwe[0] = ck.encrypt(True)
+    lwe[3, :] = 0
+    tvs = rng.integers(0, 2**32, size=(2, p.N), dtype=np.uint32)
+    idx = rng.integers(0, 2, size=9).astype(np.int32)
+    got = sk.pbs_batch(lwe, tvs, idx)
+    for g in range(len(lwe)):
+        assert np.array_equal(got[g], orc.bootstrap_noks(lwe[g], tvs[idx[g]])), g
+    sk.close()
