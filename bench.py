@@ -213,6 +213,7 @@ def main():
             "exchanged_MB_per_step": round(runner.exchanged_bytes_per_pass() / 1e6, 2),
         },
         "wall_s_per_step": round(elapsed / args.steps, 4),
+        "netlist_gates_per_s": round(float(widths.sum()) * args.steps / elapsed, 1),  # every gate, NOT / BUF included
         "decrypt_check": "all blocks == software AES (FIPS-197 C.1 vector in block 0)",
         "kernel_ms_per_step": {"k_pbs": round(tm.pbs_ms / args.steps, 3),
                                "k_pbs_lockstep_build": round(tm.pbs_main_ms / args.steps, 3), "k_keyswitch": round(tm.ks_ms / args.steps, 3),
