@@ -47,13 +47,13 @@ def _both_ways(circ, sk, wire_set, inputs, ptxt_type, blocks, rank, world):
     return sharded, single, batches, out
 
 
-def _worker(rank, world, port, result_dir):
+def _worker(rank, world, port, result_dir, set_name):
     import helm_amd
     from helm_amd import ArithCircuit, LutCircuit, PtxtType, verilog_parser
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    ck, sk = helm_amd.gen_keys_shortint("shortint_m2c2", seed=1)  # same seed: same keys and encryptions on every rank
+    ck, sk = helm_amd.gen_keys_shortint(set_name, seed=1)  # same seed: same keys and encryptions on every rank
     res = []
 
     # LUT mode: the 8-bit adder of 3-input LUTs (BASELINE config 3)
@@ -83,12 +83,13 @@ def _worker(rank, world, port, result_dir):
     sk.close()
 
 
-def test_lut_and_arith_modes_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("set_name", ["shortint_m2c2", "shortint_m2c2_multibit3"])  # classical / multi-bit rotation
+def test_lut_and_arith_modes_two_ranks_on_one_gpu(tmp_path, set_name):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), set_name), nprocs=2, join=True)
     for r in range(2):
         lut_same, lut_batches, lut_ok, ar_same, ar_batches, ar_ok = np.load(tmp_path / f"rank{r}.npy")
         assert lut_same == 1, f"rank {r}: sharded LUT evaluation differs from the single-GPU one"
