@@ -223,3 +223,22 @@ def test_arithmetic_mode_under_the_multibit_set():
         assert out == {"S": 70, "D": 10, "P": 1200}
     finally:
         server_key.close()
+
+
+@pytest.mark.parametrize("width,kind", [(64, "u64"), (128, "u128")])
+def test_wide_integers_add_sub_mul(keys, width, kind):
+    """FheUint64 / FheUint128 (32 / 64 radix blocks): the width match of gates.rs:306-702 beyond u32."""
+    client_key, server_key = keys
+    text = "input A, B;\noutput S, D, P, M;\nadd g0(A, B, S);\nsub g1(A, B, D);\nmult g2(A, B, P);\nmult g3(A, 1000003, M);\n"
+    circuit, wire_set, input_wires, output_wires = _circuit(text, is_arith=True, is_text=True)
+    ac = ArithCircuit(client_key, server_key, circuit)
+    rng = np.random.default_rng(width)
+    a = int.from_bytes(rng.bytes(width // 8), "little")
+    b = int.from_bytes(rng.bytes(width // 8), "little")
+    mk = PtxtType.U64 if width == 64 else PtxtType.U128
+    enc = ac.encrypt_inputs(wire_set, {"A": mk(a), "B": mk(b)})
+    out = ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, kind), True)
+    M = 1 << width
+    assert out["S"].value == (a + b) % M and out["D"].value == (a - b) % M
+    assert out["P"].value == (a * b) % M and out["M"].value == (a * 1000003) % M
+    assert all(v.kind == kind.upper() for v in out.values())
