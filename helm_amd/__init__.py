@@ -14,13 +14,13 @@ from .circuit import (Circuit, GateCircuit, EvalCircuit, EncWireMap, LutCircuit,
 from .gates import PtxtType, GateType, Gate  # noqa: F401,E402
 
 
-def gen_keys(name="boolean_default", seed=1, device=0):
+def gen_keys(name="boolean_default", seed=None, device=0):
     """tfhe::boolean::gen_keys() (reference src/bin/helm.rs:241) -> (client_key, server_key)."""
     ck = ClientKey.generate(name, seed)
     return ck, ServerKey(ck, device=device)
 
 
-def gen_keys_shortint(name="shortint_m2c2", seed=1, device=0):
+def gen_keys_shortint(name="shortint_m2c2", seed=None, device=0):
     """tfhe::shortint::gen_keys(PARAM_...) (reference src/bin/helm.rs:301) -> (client_key, server_key)."""
     ck = SiClientKey.generate(name, seed)
     return ck, SiServerKey(ck, device=device)

@@ -153,6 +153,7 @@ SI_CLIENT_API = {
 CLIENT_API = {
     "helm_client_named_params": (C.c_int, [C.c_char_p, C.POINTER(Params), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "helm_client_last_error": (C.c_char_p, []),
+    "helm_client_rng_selftest": (C.c_int, []),
     "helm_client_keygen": (C.c_int, [C.POINTER(Params), C.c_double, C.c_double, C.c_uint64, C.POINTER(vp)]),
     "helm_client_key_free": (None, [vp]),
     "helm_client_params": (C.c_int, [vp, C.POINTER(Params)]),

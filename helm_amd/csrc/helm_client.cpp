@@ -2,9 +2,11 @@
 // Client-side counterpart of tfhe::boolean::{gen_keys, ClientKey} as HELM uses them
 // (reference src/bin/helm.rs:241, src/circuit.rs:463-476,558).
 #include "../../include/helm_client.h"
+#include "rng.hpp"
 
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -18,51 +20,7 @@ int fail(int code, const std::string &m)
     return code;
 }
 
-struct Rng {
-    uint64_t s[4];
-    static uint64_t splitmix(uint64_t &x)
-    {
-        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        return z ^ (z >> 31);
-    }
-    explicit Rng(uint64_t seed, uint64_t stream = 0)
-    {
-        uint64_t x = seed ^ (stream * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull);
-        for (auto &v : s) v = splitmix(x);
-    }
-    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-    uint64_t next()
-    {
-        const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
-        s[2] ^= s[0];
-        s[3] ^= s[1];
-        s[1] ^= s[2];
-        s[0] ^= s[3];
-        s[2] ^= t;
-        s[3] = rotl(s[3], 45);
-        return r;
-    }
-    uint32_t u32() { return (uint32_t)(next() >> 32); }
-    double unit() { return ((next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); } // (0,1)
-    bool have_spare = false;
-    double spare = 0;
-    double gauss()
-    {
-        if (have_spare) {
-            have_spare = false;
-            return spare;
-        }
-        const double u = unit(), v = unit();
-        const double r = std::sqrt(-2.0 * std::log(u)), a = 6.283185307179586476925 * v;
-        spare = r * std::sin(a);
-        have_spare = true;
-        return r * std::cos(a);
-    }
-    // torus noise: round(gauss * std * 2^32) mod 2^32
-    uint32_t noise32(double std_dev) { return (uint32_t)(int64_t)std::llround(gauss() * std_dev * 4294967296.0); }
-};
+using helm_rng::Rng;
 
 } // namespace
 
@@ -72,7 +30,7 @@ struct helm_client_key {
     std::vector<uint32_t> lwe_sk;  // n bits
     std::vector<uint32_t> glwe_sk; // k*N bits
     std::vector<uint32_t> bsk, ksk;
-    Rng enc_rng{0};
+    Rng enc_rng;
 };
 
 extern "C" {
@@ -127,23 +85,32 @@ int helm_client_keygen(const helm_hip_params *params, double lwe_std, double glw
         return fail(HELM_ERR_INVALID, "bad parameter set");
     helm_client_key *K = new (std::nothrow) helm_client_key();
     if (!K) return fail(HELM_ERR_OOM, "key");
+    // seed 0: ChaCha20 streams under an OS-drawn key; otherwise the deterministic test generator (rng.hpp)
+    std::unique_ptr<helm_rng::Source> src_p;
+    try {
+        src_p.reset(new helm_rng::Source(seed));
+        K->enc_rng = src_p->encryption(0xE1C);
+    } catch (const std::exception &e) {
+        delete K;
+        return fail(HELM_ERR_STATE, e.what());
+    }
+    const helm_rng::Source &src = *src_p;
     K->P = P;
     K->lwe_std = lwe_std;
     K->glwe_std = glwe_std;
     const int n = P.n, k = P.k, N = P.N, k1 = k + 1, kN = k * N;
-    Rng r0(seed, 0);
+    Rng r0 = src.stream(0);
     K->lwe_sk.resize(n);
     for (auto &b : K->lwe_sk) b = (uint32_t)(r0.next() >> 63);
     K->glwe_sk.resize(kN);
     for (auto &b : K->glwe_sk) b = (uint32_t)(r0.next() >> 63);
-    K->enc_rng = Rng(seed, 0xE1C);
 
     // ---- bootstrapping key: GGSW(s_i), [n][l][k+1 rows][k+1 polys][N] -----------------
     const size_t poly_per_i = (size_t)P.pbs_l * k1 * k1;
     K->bsk.assign((size_t)n * poly_per_i * N, 0);
     #pragma omp parallel for schedule(dynamic, 4)
     for (int i = 0; i < n; i++) {
-        Rng r(seed, 0x1000 + (uint64_t)i);
+        Rng r = src.stream(0x1000 + (uint64_t)i);
         std::vector<uint32_t> body(N);
         for (int j = 0; j < P.pbs_l; j++)
             for (int row = 0; row < k1; row++) {
@@ -170,7 +137,7 @@ int helm_client_keygen(const helm_hip_params *params, double lwe_std, double glw
     K->ksk.assign((size_t)kN * P.ks_l * (n + 1), 0);
     #pragma omp parallel for schedule(dynamic, 16)
     for (int t = 0; t < kN; t++) {
-        Rng r(seed, 0x100000 + (uint64_t)t);
+        Rng r = src.stream(0x100000 + (uint64_t)t);
         for (int j = 0; j < P.ks_l; j++) {
             uint32_t *ct = K->ksk.data() + ((size_t)t * P.ks_l + j) * (n + 1);
             uint32_t b = r.noise32(lwe_std);
@@ -187,6 +154,11 @@ int helm_client_keygen(const helm_hip_params *params, double lwe_std, double glw
 }
 
 void helm_client_key_free(helm_client_key *key) { delete key; }
+
+int helm_client_rng_selftest(void)
+{
+    return helm_rng::Rng::selftest() ? 0 : fail(HELM_ERR_STATE, "ChaCha20 block function does not reproduce RFC 8439 2.3.2");
+}
 
 int helm_client_params(const helm_client_key *key, helm_hip_params *out)
 {

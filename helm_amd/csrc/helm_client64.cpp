@@ -3,9 +3,11 @@
 // (include/helm_client.h).  Client-side counterpart of tfhe::shortint::{gen_keys,
 // ClientKey} as HELM uses them (reference src/bin/helm.rs:301, src/circuit.rs:982-996,1092).
 #include "../../include/helm_client.h"
+#include "rng.hpp"
 
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -19,51 +21,7 @@ int fail64(int code, const std::string &m)
     return code;
 }
 
-// same generator as helm_client.cpp (xoshiro256**, seeded streams)
-struct Rng64 {
-    uint64_t s[4];
-    static uint64_t splitmix(uint64_t &x)
-    {
-        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        return z ^ (z >> 31);
-    }
-    explicit Rng64(uint64_t seed, uint64_t stream = 0)
-    {
-        uint64_t x = seed ^ (stream * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull);
-        for (auto &v : s) v = splitmix(x);
-    }
-    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-    uint64_t next()
-    {
-        const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
-        s[2] ^= s[0];
-        s[3] ^= s[1];
-        s[1] ^= s[2];
-        s[0] ^= s[3];
-        s[2] ^= t;
-        s[3] = rotl(s[3], 45);
-        return r;
-    }
-    double unit() { return ((next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
-    bool have_spare = false;
-    double spare = 0;
-    double gauss()
-    {
-        if (have_spare) {
-            have_spare = false;
-            return spare;
-        }
-        const double u = unit(), v = unit();
-        const double r = std::sqrt(-2.0 * std::log(u)), a = 6.283185307179586476925 * v;
-        spare = r * std::sin(a);
-        have_spare = true;
-        return r * std::cos(a);
-    }
-    // torus noise: round(gauss * std * 2^64) mod 2^64
-    uint64_t noise64(double std_dev) { return (uint64_t)(int64_t)std::llround(gauss() * std_dev * 18446744073709551616.0); }
-};
+using Rng64 = helm_rng::Rng;
 
 } // namespace
 
@@ -72,7 +30,7 @@ struct helm_si_client_key {
     double lwe_std, glwe_std;
     std::vector<uint64_t> lwe_sk, glwe_sk, bsk, ksk;
     uint64_t delta;
-    Rng64 enc_rng{0};
+    Rng64 enc_rng;
 };
 
 extern "C" {
@@ -143,17 +101,26 @@ int helm_si_client_keygen(const helm_si_params *params, double lwe_std, double g
     if (g > 4 || P.n % g) return fail64(HELM_ERR_INVALID, "grouping_factor must be at most 4 and divide n");
     helm_si_client_key *K = new (std::nothrow) helm_si_client_key();
     if (!K) return fail64(HELM_ERR_OOM, "key");
+    // seed 0: ChaCha20 streams under an OS-drawn key; otherwise the deterministic test generator (rng.hpp)
+    std::unique_ptr<helm_rng::Source> src_p;
+    try {
+        src_p.reset(new helm_rng::Source(seed));
+        K->enc_rng = src_p->encryption(0xE1C64);
+    } catch (const std::exception &e) {
+        delete K;
+        return fail64(HELM_ERR_STATE, e.what());
+    }
+    const helm_rng::Source &src = *src_p;
     K->P = P;
     K->lwe_std = lwe_std;
     K->glwe_std = glwe_std;
     K->delta = (1ull << 63) / (uint64_t)t;
     const int n = P.n, k = P.k, N = P.N, k1 = k + 1, kN = k * N;
-    Rng64 r0(seed, 0x51);
+    Rng64 r0 = src.stream(0x51);
     K->lwe_sk.resize(n);
     for (auto &b : K->lwe_sk) b = r0.next() >> 63;
     K->glwe_sk.resize(kN);
     for (auto &b : K->glwe_sk) b = r0.next() >> 63;
-    K->enc_rng = Rng64(seed, 0xE1C64);
 
     // ---- bootstrapping key, [n_ggsw][l][k+1 rows][k+1 polys][N] ---------------------------
     //      classical: GGSW(s_i) for every mask word; multi-bit: per group of g words the 2^g
@@ -171,7 +138,7 @@ int helm_si_client_keygen(const helm_si_params *params, double lwe_std, double g
             for (int q = 0; q < g; q++) message &= ((S >> q) & 1) ? K->lwe_sk[grp * g + q] : 1 - K->lwe_sk[grp * g + q];
         } else
             message = K->lwe_sk[i];
-        Rng64 r(seed, 0x6400000 + (uint64_t)i);
+        Rng64 r = src.stream(0x6400000 + (uint64_t)i);
         std::vector<uint64_t> body(N);
         for (int j = 0; j < P.pbs_l; j++)
             for (int row = 0; row < k1; row++) {
@@ -195,7 +162,7 @@ int helm_si_client_keygen(const helm_si_params *params, double lwe_std, double g
     K->ksk.assign((size_t)kN * P.ks_l * (n + 1), 0);
     #pragma omp parallel for schedule(dynamic, 16)
     for (int u = 0; u < kN; u++) {
-        Rng64 r(seed, 0x6500000 + (uint64_t)u);
+        Rng64 r = src.stream(0x6500000 + (uint64_t)u);
         for (int j = 0; j < P.ks_l; j++) {
             uint64_t *ct = K->ksk.data() + ((size_t)u * P.ks_l + j) * (n + 1);
             uint64_t b = r.noise64(lwe_std);

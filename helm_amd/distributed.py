@@ -24,6 +24,12 @@ class GpuLevelExecutor:
         self.row_words = program.sk.params.n + 1
         self.device = torch.device("cuda", program.sk.device)
 
+    def bind_stream(self):
+        """Put the engine on torch's current stream of this device: the collective is issued there, and the
+        shard kernels (before it) and the scatter (after it) are ordered with it only if they share it."""
+        with self.torch.cuda.device(self.device):
+            self.program.sk.set_stream(self.torch.cuda.current_stream(self.device).cuda_stream)
+
     def level_count(self, level):
         off = self.program.level_offsets
         return int(off[level + 1] - off[level])
@@ -56,6 +62,8 @@ class ShardedRunner:
         self.sharded_levels = []
         self._staging, self._gathered = {}, {}
         if world > 1:
+            if hasattr(executor, "bind_stream"):
+                executor.bind_stream()  # not left to the caller: an unordered all-gather silently corrupts wires
             for l in range(executor.n_levels):
                 if executor.level_pbs(l) > replicate_below:
                     self.sharded_levels.append(l)

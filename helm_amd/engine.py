@@ -21,17 +21,28 @@ def named_params(name):
     return p, a.value, b.value
 
 
+def _seed_arg(seed):
+    """None -> 0 = OS entropy (ChaCha20 under a getrandom key; the default, like tfhe's gen_keys()).
+    An integer selects the DETERMINISTIC, INSECURE test generator (helm_amd/csrc/rng.hpp)."""
+    if seed is None:
+        return 0
+    seed = int(seed)
+    if seed == 0:
+        raise ValueError("seed=0 is reserved for OS entropy: pass seed=None, or a non-zero test seed")
+    return seed
+
+
 class ClientKey:
     """Secret keys + the exported server key material (CPU)."""
 
-    def __init__(self, params, lwe_std, glwe_std, seed=1):
+    def __init__(self, params, lwe_std, glwe_std, seed=None):
         self.params = params
         h = nv.vp()
-        client_check(host.helm_client_keygen(C.byref(params), lwe_std, glwe_std, seed, C.byref(h)))
+        client_check(host.helm_client_keygen(C.byref(params), lwe_std, glwe_std, _seed_arg(seed), C.byref(h)))
         self._h = h
 
     @classmethod
-    def generate(cls, name="boolean_default", seed=1):
+    def generate(cls, name="boolean_default", seed=None):
         p, a, b = named_params(name)
         return cls(p, a, b, seed)
 

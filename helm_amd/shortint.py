@@ -23,11 +23,22 @@ def si_named_params(name):
     return p, a.value, b.value
 
 
+def _seed_arg(seed):
+    """None -> 0 = OS entropy (ChaCha20 under a getrandom key; the default, like tfhe's gen_keys()).
+    An integer selects the DETERMINISTIC, INSECURE test generator (helm_amd/csrc/rng.hpp)."""
+    if seed is None:
+        return 0
+    seed = int(seed)
+    if seed == 0:
+        raise ValueError("seed=0 is reserved for OS entropy: pass seed=None, or a non-zero test seed")
+    return seed
+
+
 class SiClientKey:
-    def __init__(self, params, lwe_std, glwe_std, seed=1):
+    def __init__(self, params, lwe_std, glwe_std, seed=None):
         self.params = params
         h = nv.vp()
-        rc = host.helm_si_client_keygen(C.byref(params), lwe_std, glwe_std, seed, C.byref(h))
+        rc = host.helm_si_client_keygen(C.byref(params), lwe_std, glwe_std, _seed_arg(seed), C.byref(h))
         if rc != 0:
             raise nv.HelmError(f"helm_si_client_keygen failed ({rc})")
         self._h = h
@@ -36,7 +47,7 @@ class SiClientKey:
         self.delta = (1 << 63) // self.t
 
     @classmethod
-    def generate(cls, name="shortint_m2c2", seed=1):
+    def generate(cls, name="shortint_m2c2", seed=None):
         p, a, b = si_named_params(name)
         return cls(p, a, b, seed)
 

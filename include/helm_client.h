@@ -10,9 +10,13 @@
  *
  * The "server key" is exported in the standard (coefficient) domain in the
  * layouts include/helm_hip.h documents, ready for helm_hip_load_*_key().
- * All randomness comes from one seeded xoshiro256** generator so that runs are
- * reproducible (the reference seeds from the OS; tests/circuit_test.rs:119 uses
- * a fixed seed for the same reason).
+ * Randomness (helm_amd/csrc/rng.hpp): `seed` = HELM_SEED_OS_ENTROPY (0) draws a 256-bit key
+ * from the operating system (getrandom) and runs ChaCha20 streams under it for the secret
+ * keys, the key material's masks and noise; the client key's encryption generator gets its
+ * own, independent OS key - as tfhe's gen_keys() seeds from the OS (helm.rs:241,301).
+ * Any other seed selects a DETERMINISTIC, INSECURE xoshiro256** generator: for tests,
+ * golden vectors and reproducible benchmarks only (tests/circuit_test.rs:119 fixes its
+ * seed for the same reason).
  */
 #ifndef HELM_CLIENT_H
 #define HELM_CLIENT_H
@@ -27,6 +31,11 @@ extern "C" {
 #endif
 
 typedef struct helm_client_key helm_client_key;
+
+#define HELM_SEED_OS_ENTROPY 0ull
+
+/* 0 when the ChaCha20 block function reproduces the RFC 8439 section 2.3.2 vector. */
+int helm_client_rng_selftest(void);
 
 /* Named parameter sets.  "boolean_default": tfhe 0.4.1 boolean::DEFAULT_PARAMETERS
  * (what gen_keys() uses, helm.rs:241) as recalled in SURVEY.md App. B;

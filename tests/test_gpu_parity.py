@@ -266,3 +266,65 @@ def test_lockstep_build_n1024_bit_exact(monkeypatch):
     for g in range(len(lwe)):
         assert np.array_equal(got[g], orc.bootstrap_noks(lwe[g], tvs[idx[g]])), g
     sk.close()
+
+
+@pytest.mark.parametrize("name", ["boolean_default", "helm_cuda"])
+def test_full_size_lockstep_rounds_bit_exact(name):
+    """The benchmark's dominant kernel at the benchmark's parameter set (tfhe boolean DEFAULT, helm.rs:241)
+    and at the reference's cited CUDA set (helm.rs:141-146), through one eval_gate_level per dispatch shape:
+      4 CU + 7        one full lockstep round + a remainder that goes to the wide (N = 512) / all-levels
+                      (N = 1024) build
+      5 CU + 5        lockstep round + a remainder of more than one bootstrap per CU (throughput build)
+      6 CU + CU/2 + 2 more than two per CU left over: the whole launch in lockstep, last workgroup partial
+    Rows of the first and last lockstep workgroup, of the partial workgroup and of the remainder build are
+    compared bit for bit with the oracle (same gate formulas as tests/gates_test.rs:82-107 decrypts); every
+    output is checked after decryption."""
+    import torch
+    cu = torch.cuda.get_device_properties(0).multi_processor_count
+    ck = helm_amd.ClientKey.generate(name, seed=7)
+    p = ck.params
+    sk = helm_amd.ServerKey(ck)
+    orc = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True)
+    rng = np.random.default_rng(0xB007)
+    n_in = 24
+    bits = rng.integers(0, 2, n_in)
+    ct = ck.encrypt(bits.astype(bool))
+    two_in = [oracle.AND, oracle.OR, oracle.NAND, oracle.NOR, oracle.XOR, oracle.XNOR]
+    for count in (4 * cu + 7, 5 * cu + 5, 6 * cu + cu // 2 + 2):
+        ops = rng.choice(two_in, size=count).astype(np.int32)
+        i0 = rng.integers(0, n_in, count).astype(np.int32)
+        i1 = rng.integers(0, n_in, count).astype(np.int32)
+        i2 = np.full(count, -1, np.int32)
+        outs = np.arange(n_in, n_in + count, dtype=np.int32)
+        w = sk.wires(n_in + count)
+        w.upload(np.arange(n_in), ct)
+        w.eval_gate_level(ops, i0, i1, i2, outs)
+        got = w.download()
+        w.free()
+        want_bits = [GATES2[int(o)](int(bits[a]), int(bits[b])) for o, a, b in zip(ops, i0, i1)]
+        assert list(ck.decrypt(got[n_in:]).astype(int)) == want_bits, f"{name}: launch of {count} decrypts wrong"
+        full = count // (4 * cu) * (4 * cu)
+        if count - full > 2 * cu:
+            full = count
+        sample = sorted({0, 1, 2, 3, 5, 4 * cu // 2 + 1, full - 4, full - 3, full - 2, full - 1,  # lockstep part
+                         min(full, count - 1), count - 3, count - 2, count - 1,                    # remainder build
+                         (count - 1) // 4 * 4, count // 2})                                        # last (partial) workgroup
+        ref = np.zeros_like(got)
+        ref[:n_in] = ct
+        orc.eval_level(ref, ops[sample], i0[sample], i1[sample], i2[sample], outs[sample])
+        for g in sample:
+            assert np.array_equal(got[n_in + g], ref[n_in + g]), f"{name}: launch of {count}, gate {g} differs from the oracle"
+    # MUX at full size: two bootstraps + recombination fused into the keyswitch
+    ops = np.full(8, oracle.MUX, np.int32)
+    i0, i1, i2 = (rng.integers(0, n_in, 8).astype(np.int32) for _ in range(3))
+    outs = np.arange(n_in, n_in + 8, dtype=np.int32)
+    w = sk.wires(n_in + 8)
+    w.upload(np.arange(n_in), ct)
+    w.eval_gate_level(ops, i0, i1, i2, outs)
+    got = w.download()
+    ref = np.zeros_like(got)
+    ref[:n_in] = ct
+    orc.eval_level(ref, ops, i0, i1, i2, outs)
+    assert np.array_equal(got, ref)
+    assert list(ck.decrypt(got[n_in:]).astype(int)) == [int(bits[a] if bits[s] else bits[b]) for a, b, s in zip(i0, i1, i2)]
+    sk.close()

@@ -142,6 +142,32 @@ def test_full_parameter_set_m2c2():
     sk.close()
 
 
+def test_full_parameter_set_multibit3():
+    """The reference's arithmetic-mode set (helm.rs:83, PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS: n = 888,
+    g = 3, 296 group steps, 310 MB key) at full size: apply_lookup_table rows (keyswitch + multi-bit blind rotation
+    + sample extract) bit for bit against the integer oracle, one from a batch of one and two from a batch that
+    fills workgroups differently; every plaintext value through a LUT after decryption."""
+    ck = helm_amd.SiClientKey.generate("shortint_m2c2_multibit3", seed=1)
+    assert ck.params.grouping_factor == 3 and ck.params.n == 888
+    sk = helm_amd.SiServerKey(ck)
+    orc = oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk)
+    vals = np.arange(ck.t, dtype=np.uint64)
+    cts = ck.encrypt(vals)
+    w = sk.wires(3 * ck.t)
+    w.upload(np.arange(ck.t), cts)
+    lut = sk.make_lut(lambda x: (3 * x + 1) % ck.t)
+    assert np.array_equal(lut, orc.make_lut(lambda x: (3 * x + 1) % ck.t))
+    w.apply_luts(np.arange(ck.t), lut, np.arange(ck.t) + ck.t)
+    got = w.download(np.arange(ck.t) + ck.t)
+    assert list(ck.decrypt_message_and_carry(got)) == [(3 * v + 1) % ck.t for v in range(ck.t)]
+    for g in (0, 11):
+        assert np.array_equal(got[g], orc.apply_lut(cts[g], lut)), f"row {g} of the batch differs from the oracle"
+    w.apply_luts([6], lut, [2 * ck.t])  # a batch of one
+    assert np.array_equal(w.download([2 * ck.t])[0], orc.apply_lut(cts[6], lut))
+    assert np.array_equal(w.download([2 * ck.t])[0], got[6])  # and the same ciphertext as inside the batch of 16
+    sk.close()
+
+
 @pytest.mark.parametrize("fixture", ["shortint_toy.npz", "shortint_mb_toy.npz"])  # classical / multi-bit blind rotation
 def test_golden_vectors_on_gpu(fixture):
     import os

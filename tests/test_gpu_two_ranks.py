@@ -26,7 +26,8 @@ def _worker(rank, world, port, blocks, result_dir):
     torch.cuda.set_device(0)
     ck = helm_amd.ClientKey.generate("toy_k2", seed=5)
     sk = helm_amd.ServerKey(ck, device=0)
-    sk.set_stream(torch.cuda.current_stream().cuda_stream)
+    # no sk.set_stream() here: ShardedRunner binds the engine to torch's current stream itself (an engine
+    # left on its own stream would run the all-gather unordered with the shard kernels)
     # the AES netlist: 207 levels, several hundred gates wide with `blocks` copies - launches long enough
     # that a collective not ordered behind the engine's kernels reads stale staging rows (this test
     # caught exactly that: helm_hip_set_stream(NULL) used to mean "the context's own stream")
