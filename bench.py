@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — encrypted gate-bootstraps/sec on the AES-128 gates-mode netlist.
 
-A step = one full level-by-level evaluation of the (generated, stand-in) AES-128 netlist
-over a batch of `--blocks` independent input blocks per GPU, inputs already encrypted
-and resident in HBM.  With N > 1 ranks the batch is N x blocks and every level wider
-than one GPU wave is sharded across the ranks, the level's output ciphertexts
-all-gathered over RCCL (helm_amd/distributed.py); keys and wire table are replicated.
+A step = one full evaluation of the (generated, stand-in) AES-128 netlist over a batch of independent input
+blocks, inputs already encrypted and resident in HBM.  The level schedule of the batch is launch-packed
+(helm_amd/csrc/host/level_pack.cpp): the blocks share no wires, so launches hold whole lockstep rounds and only
+the drain at the end of a pass is partial.
+
+  --scaling weak   (default)  every GPU evaluates its own `--blocks` blocks: the partition the workload offers
+                   (independent blocks), no data-path collective; N GPUs = N x blocks.
+  --scaling strong            `--blocks` blocks in total, every launch sharded across the N GPUs, keys and wire
+                   table replicated, the launch's output ciphertexts all-gathered over RCCL
+                   (helm_amd/distributed.py) - the north star's per-level shard, the mode that shortens ONE job.
+With N > 1 the weak run also times a short strong-scaling pass (outside the timed region) and reports it under
+"strong_scaling", so one driver invocation exercises RCCL.
 
 Contract: python bench.py --gpus N --steps K --warmup W   (N>1 under torch.distributed.run)
 prints ONE JSON line on rank 0.
@@ -20,6 +27,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+PEAK_CLOCK_GHZ = 2.4          # MI355X engine clock the nominal peaks are quoted at
+HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")  # tools/pmc_traffic.sh, separate --pmc passes
 
 
 def build_program_arrays(circuit, wire_names, blocks):
@@ -37,20 +48,51 @@ def build_program_arrays(circuit, wire_names, blocks):
     return cat(opsT), cat(T(i0)), cat(T(i1)), cat(T(i2)), cat(T(out)), new_off, index
 
 
+def make_program(sk, circuit, wire_names, blocks, quantum, pack=True):
+    """-> (Program, launches, levels): the batch's level schedule, launch-packed to `quantum` bootstraps."""
+    import helm_amd
+    from helm_amd.distributed import pack_levels
+    ops, i0, i1, i2, out, off, _ = build_program_arrays(circuit, wire_names, blocks)
+    levels = len(off) - 1
+    if pack:
+        ops, i0, i1, i2, out, off, _ = pack_levels(ops, i0, i1, i2, out, off, quantum)
+    return helm_amd.Program(sk, ops, i0, i1, i2, out, off), len(off) - 1, levels
+
+
+def upload_inputs(ck, wires, index, nw, keys_pt, first_block=0):
+    in_rows, in_bits = [], []
+    for b, (key, pt) in enumerate(keys_pt):
+        kv, pv = int.from_bytes(key, "big"), int.from_bytes(pt, "big")
+        for i in range(128):
+            in_rows += [(first_block + b) * nw + index[f"key[{i}]"], (first_block + b) * nw + index[f"pt[{i}]"]]
+            in_bits += [(kv >> i) & 1, (pv >> i) & 1]
+    wires.upload(np.array(in_rows, np.int32), ck.encrypt(np.array(in_bits, dtype=bool)))
+
+
+def check_outputs(ck, wires, index, nw, keys_pt, what):
+    from helm_amd.netlists import aes128_reference_encrypt
+    out_rows = np.array([b * nw + index[f"ct[{i}]"] for b in range(len(keys_pt)) for i in range(128)], np.int32)
+    dec = ck.decrypt(wires.download(out_rows)).reshape(len(keys_pt), 128)
+    for b, (key, pt) in enumerate(keys_pt):
+        got = sum(int(dec[b, i]) << i for i in range(128)).to_bytes(16, "big")
+        if got != aes128_reference_encrypt(key, pt):
+            raise SystemExit(f"{what}: decrypted AES output of block {b} is WRONG")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=32, help="AES blocks per GPU evaluated together")
+    ap.add_argument("--blocks", type=int, default=32, help="AES blocks per GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--params", default="boolean_default")
+    ap.add_argument("--no-pack", action="store_true", help="level-synchronous launches (the round-1 schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the LUT-mode / arithmetic-mode side measurements")
-    ap.add_argument("--cpu-levels", type=int, default=8, help="at most this many netlist levels (1 block) on the CPU oracle")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="stop the CPU sample after this much time")
-    ap.add_argument("--cpu-threads", type=int, default=32,
-                    help="OpenMP threads of the CPU sample (0 = every logical CPU); measured on the 1-GPU box, whose CPU "
-                         "share is 16 cores: 16 -> 192, 32 -> 212, 64 -> 213, 128 -> 160, 256 -> 123 gates/s")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N > 1, weak: skip the short strong-scaling pass")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline: stop after the level that passes this time")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = the cores this process may use)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,7 +108,7 @@ def main():
     import helm_amd
     from helm_amd import Circuit, verilog_parser
     from helm_amd.distributed import GpuLevelExecutor, ShardedRunner
-    from helm_amd.netlists import aes128, aes128_reference_encrypt
+    from helm_amd.netlists import aes128
 
     # rehearsal of the N > 1 path on a one-GPU box: HELM_BENCH_REHEARSE=1 puts every rank on cuda:0 and
     # carries the collectives over gloo (RCCL needs one GPU per rank); never used for reported numbers
@@ -80,43 +122,41 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    # ---- keys (identical on every rank: same seed) and engine --------------------------
+    # ---- keys (identical on every rank: same deterministic benchmark seed) and engine ---
     t0 = time.time()
     ck = helm_amd.ClientKey.generate(args.params, seed=1)
     sk = helm_amd.ServerKey(ck, device=local_rank)
     sk.set_stream(torch.cuda.current_stream().cuda_stream)
     p = ck.params
     t_keys = time.time() - t0
+    quantum = sk.launch_quantum()
 
-    # ---- netlist -> level schedule over the whole batch --------------------------------
+    # ---- netlist -> launch schedule over this rank's batch -----------------------------
     gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_text(aes128(), False)
     circuit = Circuit(gates, inputs, outputs, dffs)
     circuit.sort_circuit()
     circuit.compute_levels()
     wire_names = list(inputs) + sorted(wire_set)
-    total_blocks = args.blocks * world
-    ops, i0, i1, i2, out, off, index = build_program_arrays(circuit, wire_names, total_blocks)
     nw = len(wire_names)
-    prog = helm_amd.Program(sk, ops, i0, i1, i2, out, off)
-    pbs_per_step = prog.total_pbs()
-    widths = np.diff(off)
+    index = {w: i for i, w in enumerate(wire_names)}
+    strong = args.scaling == "strong" and world > 1
+    my_blocks = args.blocks                         # blocks in this rank's wire table
+    total_blocks = args.blocks if (strong or world == 1) else args.blocks * world
+    prog, launches, levels = make_program(sk, circuit, wire_names, my_blocks, quantum * (world if strong else 1),
+                                          pack=not args.no_pack)
+    pbs_per_pass = prog.total_pbs()                 # of this rank's table (strong: the whole job)
 
     # ---- synthetic inputs: seeded random key / plaintext per block, encrypted on the host,
     #      uploaded once: resident in HBM before the timed region ------------------------
-    rng = np.random.default_rng(0x48454C4D)
+    rng = np.random.default_rng(0x48454C4D + (0 if strong else rank))
     keys_pt = [(bytes(rng.integers(0, 256, 16, dtype=np.uint8)), bytes(rng.integers(0, 256, 16, dtype=np.uint8)))
-               for _ in range(total_blocks)]
-    keys_pt[0] = (bytes(range(16)), bytes.fromhex("00112233445566778899aabbccddeeff"))  # FIPS-197 C.1
-    wires = sk.wires(nw * total_blocks)
-    in_rows, in_bits = [], []
-    for b, (key, pt) in enumerate(keys_pt):
-        kv, pv = int.from_bytes(key, "big"), int.from_bytes(pt, "big")
-        for i in range(128):
-            in_rows += [b * nw + index[f"key[{i}]"], b * nw + index[f"pt[{i}]"]]
-            in_bits += [(kv >> i) & 1, (pv >> i) & 1]
-    wires.upload(np.array(in_rows, np.int32), ck.encrypt(np.array(in_bits, dtype=bool)))
+               for _ in range(my_blocks)]
+    if rank == 0 or strong:
+        keys_pt[0] = (bytes(range(16)), bytes.fromhex("00112233445566778899aabbccddeeff"))  # FIPS-197 C.1
+    wires = sk.wires(nw * my_blocks)
+    upload_inputs(ck, wires, index, nw, keys_pt)
 
-    runner = ShardedRunner(GpuLevelExecutor(prog, wires), rank, world, dist if world > 1 else None)
+    runner = ShardedRunner(GpuLevelExecutor(prog, wires), rank, world if strong else 1, dist if strong else None)
 
     def sync_all():
         if world > 1:
@@ -135,20 +175,19 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = sk.timing(reset=True)
     sk.timing_enable(False)
+    clock_ghz = sk.kernel_clock_ghz()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- correctness of what was timed: every block decrypts to AES(key, pt) ------------
-    ok = True
-    out_rows = np.array([b * nw + index[f"ct[{i}]"] for b in range(total_blocks) for i in range(128)], np.int32)
-    dec = ck.decrypt(wires.download(out_rows)).reshape(total_blocks, 128)
-    for b, (key, pt) in enumerate(keys_pt):
-        got = sum(int(dec[b, i]) << i for i in range(128)).to_bytes(16, "big")
-        ok &= got == aes128_reference_encrypt(key, pt)
-    if not ok:
-        raise SystemExit(f"rank {rank}: decrypted AES outputs are WRONG")
+    check_outputs(ck, wires, index, nw, keys_pt, f"rank {rank}")
+
+    # ---- N > 1, weak: a short strong-scaling pass on a fixed job (outside the timed region) ----
+    strong_leg = None
+    if world > 1 and not strong and not args.no_strong_leg:
+        strong_leg = strong_scaling_leg(sk, ck, circuit, wire_names, index, nw, args.blocks, quantum, rank, world, dist, torch)
 
     if rank != 0:
         if world > 1:
@@ -156,37 +195,38 @@ def main():
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = pbs_per_step * args.steps / elapsed
+    job_pbs = pbs_per_pass if (strong or world == 1) else pbs_per_pass * world
+    value = job_pbs * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel (k_pbs), from HIP events on its own stream -----
+    # ---- roofline of the dominant kernel (lockstep build of k_pbs), HIP events on its own stream ----
     K1 = p.k + 1
-    bsk_bytes = p.n * p.pbs_l * K1 * K1 * p.N * 8
-    io_bytes = 2 * (p.n + 1) * 4 + (p.k * p.N + 1) * 4
-    # the dominant kernel is the lockstep build of k_pbs, which takes the full rounds (4 bootstraps per
-    # CU) of every level; a level's remainder goes to the throughput / wide builds (part of pbs_ms)
-    if tm.pbs_main_launches > 0:
-        dom_kernel, launches = "k_pbs<PbsCfg<..., NB = 4>> (lockstep build)", tm.pbs_main_launches
-        avg_pbs_per_launch = tm.pbs_main_count / launches
-        avg_launch_s = tm.pbs_main_ms / launches * 1e-3
-    else:
-        dom_kernel, launches = "k_pbs (all builds)", max(1, tm.pbs_launches)
-        avg_pbs_per_launch = tm.pbs_count / launches
-        avg_launch_s = tm.pbs_ms / launches * 1e-3
-    algo_bytes = bsk_bytes + avg_pbs_per_launch * io_bytes
-    achieved_gbs = algo_bytes / avg_launch_s / 1e9
-    # fp64 lane-operations of one bootstrap (DESIGN.md "k_pbs"): per CMUX step and wave, forward
-    # transforms (8 per butterfly), pointwise multiply-accumulate (6 + 1 per word), inverse
-    # transform (8 per butterfly + 4 recentrings of 3) and the hand-over sums; the 49-bit field
-    # needs no recentring inside forward transforms and products
     logN = int(np.log2(p.N))
-    E = p.N // 64
-    bfly = E // 2 * logN
-    lazy = p.N == 512  # field chosen by helm_hip_ctx_create for boolean_default
-    dp_fwd = p.pbs_l * (bfly * 8 + (0 if lazy else 2 * E * 3))
-    dp_mac = K1 * E * (p.pbs_l * 7 - 1) + (0 if lazy else K1 * E * 3)
-    dp_inv = bfly * 8 + 4 * E * 3 + E * p.k
-    dp_ops_per_pbs = p.n * K1 * 64 * (dp_fwd + dp_mac + dp_inv)
-    fp64_tops = dp_ops_per_pbs * tm.pbs_count / (tm.pbs_ms * 1e-3) / 1e12
+    bsk_bytes = p.n * p.pbs_l * K1 * K1 * p.N * 8
+    io_bytes = 2 * (p.n + 1) * 4 + (p.k * p.N + 1) * 4      # two input LWEs read, one big LWE written
+    if tm.pbs_main_launches > 0:
+        dom_kernel, n_launch = "k_pbs<PbsCfg<..., NB = 4>> (lockstep build)", tm.pbs_main_launches
+        avg_pbs_per_launch, avg_launch_s = tm.pbs_main_count / n_launch, tm.pbs_main_ms / n_launch * 1e-3
+    else:
+        dom_kernel, n_launch = "k_pbs (all builds)", max(1, tm.pbs_launches)
+        avg_pbs_per_launch, avg_launch_s = tm.pbs_count / n_launch, tm.pbs_ms / n_launch * 1e-3
+    algo_bytes = bsk_bytes + avg_pbs_per_launch * io_bytes
+    # ALGORITHMIC arithmetic of one bootstrap, SURVEY.md 8(d): n steps x [((k+1) l + (k+1)) transforms of
+    # N/2 log2 N butterflies + (k+1)^2 l N multiply-accumulates]; priced at 8 fp64 lane-operations per butterfly
+    # (6-operation exact modular multiplication + add + sub) and 7 per multiply-accumulate (FMA = 1 operation)
+    bfly = p.n * (K1 * p.pbs_l + K1) * (p.N // 2) * logN
+    macs = p.n * K1 * K1 * p.pbs_l * p.N
+    algo_ops = bfly * 8 + macs * 7
+    n_cus = quantum // 4
+    peak_tops = n_cus * 64 * PEAK_CLOCK_GHZ * 1e9 / 1e12
+    achieved_tops = algo_ops * avg_pbs_per_launch / avg_launch_s / 1e12
+    traffic = None
+    if os.path.exists(PMC_TRAFFIC):
+        with open(PMC_TRAFFIC) as f:
+            traffic = json.load(f)
+    traffic_bytes = None
+    if traffic:
+        # bytes per bootstrap measured at the launch size of the committed profile, scaled to this run's average launch
+        traffic_bytes = int(traffic["bytes_per_launch"] * avg_pbs_per_launch / traffic["bootstraps_per_launch"])
 
     result = {
         "metric": "encrypted gate-bootstraps/sec on AES-128 gates-mode netlist",
@@ -197,49 +237,58 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "u32 torus (exact NTT in f64 FMA over a 49-bit prime)",
         "data": "synthetic: generated AES-128 netlist (stand-in for HELM's), seeded random keys/plaintexts, "
                 "fresh encryptions resident in HBM" + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearse else ""),
         "config": {
-            "workload": f"AES-128 gates-mode netlist, {args.blocks} block(s) per GPU evaluated level-synchronously",
+            "workload": f"AES-128 gates-mode netlist, {my_blocks} block(s) " + ("in total, every launch sharded" if strong else "per GPU")
+                        + (", launch-packed" if not args.no_pack else ", level-synchronous"),
             "params": args.params, "n": p.n, "k": p.k, "N": p.N, "pbs_l": p.pbs_l, "pbs_logB": p.pbs_logB,
             "ks_l": p.ks_l, "ks_logB": p.ks_logB,
-            "netlist_gates_per_block": int(widths.sum() // total_blocks), "levels": int(len(widths)),
-            "bootstraps_per_step": int(pbs_per_step), "blocks_total": total_blocks,
-            "parallelism": f"level-shard x{world} + all-gather of level outputs" if world > 1 else "single GPU",
-            "sharded_levels": len(runner.sharded_levels),
+            "levels": levels, "launches_per_step": launches, "bootstraps_per_step": int(job_pbs), "blocks_total": total_blocks,
+            "parallelism": ("single GPU" if world == 1 else
+                            f"launch-shard x{world} + all-gather of launch outputs (RCCL)" if strong else
+                            f"block-parallel x{world}: independent blocks per GPU, keys replicated, no data-path collective"),
+            "sharded_launches": len(runner.sharded_levels),
             "exchanged_MB_per_step": round(runner.exchanged_bytes_per_pass() / 1e6, 2),
         },
         "wall_s_per_step": round(elapsed / args.steps, 4),
-        "netlist_gates_per_s": round(float(widths.sum()) * args.steps / elapsed, 1),  # every gate, NOT / BUF included
         "decrypt_check": "all blocks == software AES (FIPS-197 C.1 vector in block 0)",
         "kernel_ms_per_step": {"k_pbs": round(tm.pbs_ms / args.steps, 3),
-                               "k_pbs_lockstep_build": round(tm.pbs_main_ms / args.steps, 3), "k_keyswitch": round(tm.ks_ms / args.steps, 3),
+                               "k_pbs_lockstep_build": round(tm.pbs_main_ms / args.steps, 3),
+                               "k_pbs_other_builds_share": round(1.0 - tm.pbs_main_ms / max(tm.pbs_ms, 1e-9), 4),
+                               "k_keyswitch": round(tm.ks_ms / args.steps, 3),
                                "k_linear": round(tm.linear_ms / args.steps, 3)},
         "roofline": {
-            "kernel": dom_kernel, "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(achieved_gbs / 8000.0, 5), "traffic": None,
-            "traffic_measured_separately": "rocprofv3 --pmc FETCH_SIZE on a 1,024-bootstrap launch of this kernel "
-                                           "(profiles/r01/pmc_fetch_size.txt): 0.63 GB of fabric-side reads per launch "
-                                           "(Infinity-Cache hits included; 7x the algorithmic 90 MB), 4.1 MB written",
-            "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
-            "avg_bootstraps_per_launch": round(avg_pbs_per_launch, 1),
-            "note": "the bootstrapping key (80 MB) is shared by every ciphertext of a launch and stays in "
-                    "L2/Infinity Cache, so HBM is not the binding resource; the kernel is bound by fp64 VALU "
-                    "issue (see fp64_valu)",
+            "kernel": dom_kernel,
+            # the binding resource: fp64 vector issue - the key is served by L2 / Infinity Cache
+            "bound": "fp64_valu",
+            "achieved": round(achieved_tops, 2), "peak": round(peak_tops, 2), "unit": "T fp64 lane-op/s (FMA = 1)",
+            "frac": round(achieved_tops / peak_tops, 4),
+            "peak_assumes": f"{n_cus} CUs x 64 lanes x {PEAK_CLOCK_GHZ} GHz, one fp64 operation per lane and cycle",
+            "held_clock_ghz": round(clock_ghz, 3) if clock_ghz else None,
+            "frac_at_held_clock": round(achieved_tops / (peak_tops * clock_ghz / PEAK_CLOCK_GHZ), 4) if clock_ghz else None,
+            "algorithmic_lane_ops_per_bootstrap": int(algo_ops),
+            "avg_launch_ms": round(avg_launch_s * 1e3, 4), "avg_bootstraps_per_launch": round(avg_pbs_per_launch, 1),
+            "traffic": traffic_bytes,
+            "traffic_over_algorithmic": round(traffic_bytes / algo_bytes, 2) if traffic_bytes else None,
+            "traffic_source": (traffic or {}).get("source"),
+            "hbm": {"achieved": round(algo_bytes / avg_launch_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(algo_bytes / avg_launch_s / 1e9 / HBM_PEAK_GBS, 5),
+                    "algorithmic_bytes_per_launch": int(algo_bytes),
+                    "note": "BSK (shared by every ciphertext of a launch) + per-bootstrap LWE rows; not the binding resource"},
         },
-        "fp64_valu": {"achieved": round(fp64_tops, 2), "peak": 39.3, "unit": "T lane-op/s (FMA = 1)",
-                      "frac": round(fp64_tops / 39.3, 4), "dp_lane_ops_per_bootstrap": int(dp_ops_per_pbs)},
         "setup_s": {"keygen_upload": round(t_keys, 2)},
     }
+    if strong_leg:
+        result["strong_scaling"] = strong_leg
 
     # ---- wall-clock of ONE AES-128 evaluation (latency; levels are 80-256 gates wide, so the
     #      GPU is far from full: this is the n-step blind-rotation chain, 207 levels deep) ------
     if world == 1:
-        o1 = build_program_arrays(circuit, wire_names, 1)
-        prog1 = helm_amd.Program(sk, *o1[:6])
+        prog1, _, _ = make_program(sk, circuit, wire_names, 1, quantum)
         prog1.run(wires)
         sync_all()
         t0 = time.perf_counter()
@@ -252,38 +301,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port, not tfhe-rs) on this box's host cores --------
     if world == 1 and not args.no_cpu_baseline:
-        import oracle
-        orc = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk)
-        one = build_program_arrays(circuit, wire_names, 1)
-        o_ops, o_i0, o_i1, o_i2, o_out, o_off, _ = one
-        host = np.zeros((nw, p.n + 1), dtype=np.uint32)
-        key, pt = keys_pt[0]
-        kv, pv = int.from_bytes(key, "big"), int.from_bytes(pt, "big")
-        bits = np.array([(kv >> i) & 1 for i in range(128)] + [(pv >> i) & 1 for i in range(128)], dtype=bool)
-        rows = [index[f"key[{i}]"] for i in range(128)] + [index[f"pt[{i}]"] for i in range(128)]
-        del bits  # the oracle must see the very ciphertexts the GPU evaluated
-        host[rows] = wires.download(np.array(rows, np.int32))
-        ncpu = os.cpu_count() or 1
-        threads = max(1, min(args.cpu_threads or ncpu, ncpu))
-        n_pbs, L = 0, 0
-        t0 = time.perf_counter()
-        while L < min(args.cpu_levels, len(o_off) - 1) and (L < 1 or time.perf_counter() - t0 < args.cpu_seconds):
-            s = slice(o_off[L], o_off[L + 1])
-            orc.eval_level(host, o_ops[s], o_i0[s], o_i1[s], o_i2[s], o_out[s], nthreads=threads)
-            n_pbs += int(np.sum(o_ops[s] != oracle.NOT))
-            L += 1
-        cpu_s = time.perf_counter() - t0
-        gpu_rows = wires.download(o_out[:o_off[L]])
-        same = bool(np.array_equal(gpu_rows, host[o_out[:o_off[L]]]))
-        result["cpu_baseline"] = {
-            "value": round(n_pbs / cpu_s, 2), "unit": "gate-bootstraps/s", "cores": threads, "kind": "port",
-            "sample": f"first {L} level(s) of the same AES-128 netlist, 1 block ({n_pbs} gate-bootstraps, "
-                      f"{cpu_s:.1f} s); scalar C restatement with a Goldilocks NTT, OpenMP over gates; NOT tfhe-rs",
-            "gpu_ciphertexts_bit_identical_on_sample": same,
-            "host": f"{os.cpu_count()} logical CPUs",
-        }
-        if not same:
-            raise SystemExit("GPU ciphertexts differ from the CPU oracle on the sampled levels")
+        result["cpu_baseline"] = cpu_baseline(args, ck, circuit, wire_names, index, nw, wires, keys_pt)
     # ---- the other two modes of the reference, same GPU, outside the timed region: 3-input LUT
     #      gates (BASELINE config 3's primitive) and the chi-squared u32 netlist (config 5) ------
     if world == 1 and not args.no_other_modes:
@@ -296,11 +314,82 @@ def main():
         dist.destroy_process_group()
 
 
+def strong_scaling_leg(sk, ck, circuit, wire_names, index, nw, blocks, quantum, rank, world, dist, torch, steps=2):
+    """A fixed job of `blocks` AES blocks, every packed launch sharded across the ranks (helm_amd/distributed.py):
+    the regime launch-sharding exists for.  Same inputs on every rank (replicated wire table)."""
+    from helm_amd.distributed import GpuLevelExecutor, ShardedRunner
+    prog, launches, _ = make_program(sk, circuit, wire_names, blocks, quantum * world)
+    rng = np.random.default_rng(0x57A0)
+    keys_pt = [(bytes(rng.integers(0, 256, 16, dtype=np.uint8)), bytes(rng.integers(0, 256, 16, dtype=np.uint8)))
+               for _ in range(blocks)]
+    wires = sk.wires(nw * blocks)
+    upload_inputs(ck, wires, index, nw, keys_pt)
+    runner = ShardedRunner(GpuLevelExecutor(prog, wires), rank, world, dist, time_collective=True)
+    runner.run()
+    dist.barrier()
+    torch.cuda.synchronize()
+    runner.collective_ms(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.run()
+    dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    check_outputs(ck, wires, index, nw, keys_pt, f"strong-scaling leg, rank {rank}")
+    res = {"workload": f"{blocks} AES-128 blocks in total, every launch sharded over {world} GPUs", "steps": steps,
+           "ms_per_step": round(el / steps * 1e3, 3), "value": round(prog.total_pbs() * steps / el, 1),
+           "unit": "gate-bootstraps/s", "launches_per_step": launches, "sharded_launches": len(runner.sharded_levels),
+           "exchanged_MB_per_step": round(runner.exchanged_bytes_per_pass() / 1e6, 2),
+           "collective_ms_per_step": round(runner.collective_ms(reset=True) / steps, 3),
+           "decrypt_check": "all blocks == software AES on every rank"}
+    prog.destroy()
+    wires.free()
+    return res
+
+
+def cpu_baseline(args, ck, circuit, wire_names, index, nw, wires, keys_pt):
+    """The oracle on the first levels of the same netlist (one block) on the cores this process may use; the GPU's
+    ciphertexts of those levels must be bit-identical (the oracle is the checker here, never the product)."""
+    import oracle
+    p = ck.params
+    orc = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk)
+    o_ops, o_i0, o_i1, o_i2, o_out, o_off, _ = build_program_arrays(circuit, wire_names, 1)
+    host = np.zeros((nw, p.n + 1), dtype=np.uint32)
+    rows = [index[f"key[{i}]"] for i in range(128)] + [index[f"pt[{i}]"] for i in range(128)]
+    host[rows] = wires.download(np.array(rows, np.int32))  # the very ciphertexts the GPU evaluated (block 0)
+    granted = len(os.sched_getaffinity(0))
+    threads = max(1, args.cpu_threads or granted)
+    n_pbs, L = 0, 0
+    t0 = time.perf_counter()
+    while L < len(o_off) - 1 and (L < 1 or time.perf_counter() - t0 < args.cpu_seconds):
+        s = slice(o_off[L], o_off[L + 1])
+        orc.eval_level(host, o_ops[s], o_i0[s], o_i1[s], o_i2[s], o_out[s], nthreads=threads)
+        n_pbs += int(np.sum(o_ops[s] != oracle.NOT))
+        L += 1
+    cpu_s = time.perf_counter() - t0
+    same = bool(np.array_equal(wires.download(o_out[:o_off[L]]), host[o_out[:o_off[L]]]))
+    if not same:
+        raise SystemExit("GPU ciphertexts differ from the CPU oracle on the sampled levels")
+    return {
+        "value": round(n_pbs / cpu_s, 2), "unit": "gate-bootstraps/s", "cores": threads, "kind": "port",
+        "per_core": round(n_pbs / cpu_s / threads, 2), "ms_per_gate_per_thread": round(cpu_s * threads / n_pbs * 1e3, 2),
+        "sample": f"first {L} level(s) of the same AES-128 netlist, 1 block ({n_pbs} gate-bootstraps, {cpu_s:.1f} s); "
+                  f"{oracle.ntt_route_name()}, OpenMP over the gates of a level; NOT tfhe-rs",
+        "gpu_ciphertexts_bit_identical_on_sample": same,
+        "host": f"{os.cpu_count()} logical CPUs, {granted} granted to this process (sched_getaffinity)",
+    }
+
+
 def other_modes(device):
     """LUT mode under PARAM_MESSAGE_2_CARRY_2 (classical blind rotation) and arithmetic mode under both that set
     and the reference's own PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3 (helm.rs:83, multi-bit blind rotation)."""
-    res = _other_modes_set(device, "shortint_m2c2", "PARAM_MESSAGE_2_CARRY_2_KS_PBS")
-    mb = _other_modes_set(device, "shortint_m2c2_multibit3", "PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS")
+    res = _other_modes_set(device, "shortint_m2c2", "PARAM_MESSAGE_2_CARRY_2_KS_PBS [dimensions recalled; the reference binary's "
+                           "LUT mode names PARAM_MESSAGE_1_CARRY_1 (helm.rs:301), which cannot hold 3-input LUT indices]")
+    mb = _other_modes_set(device, "shortint_m2c2_multibit3", "dimensions of PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS "
+                          "(helm.rs:83) [recalled; LWE noise extrapolated, not tfhe's value: approximate set]")
     res["lut_mode_multibit3"], res["arith_mode_multibit3"] = mb["lut_mode"], mb["arith_mode"]
     return res
 

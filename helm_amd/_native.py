@@ -81,6 +81,7 @@ HIP_API = {
     "helm_hip_get_params": (C.c_int, [vp, C.POINTER(Params)]),
     "helm_hip_set_stream": (C.c_int, [vp, vp]),
     "helm_hip_sync": (C.c_int, [vp]),
+    "helm_hip_launch_quantum": (C.c_int64, [vp]),
     "helm_hip_load_bootstrap_key": (C.c_int, [vp, u32p, C.c_size_t]),
     "helm_hip_load_keyswitch_key": (C.c_int, [vp, u32p, C.c_size_t]),
     "helm_hip_wires_alloc": (C.c_int, [vp, C.c_int64, C.POINTER(vp)]),
@@ -94,6 +95,7 @@ HIP_API = {
     "helm_hip_program_destroy": (C.c_int, [vp, vp]),
     "helm_hip_program_run": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64]),
     "helm_hip_program_chunk_rows": (C.c_int64, [vp, C.c_int64, C.c_int]),
+    "helm_hip_program_shard_prepare": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "helm_hip_program_run_level_shard": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "helm_hip_program_scatter_level": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
     "helm_hip_program_level_pbs": (C.c_int64, [vp, C.c_int64]),
@@ -102,6 +104,7 @@ HIP_API = {
     "helm_hip_ntt_roundtrip": (C.c_int, [vp, u32p, u32p, C.c_int64]),
     "helm_hip_timing_enable": (C.c_int, [vp, C.c_int]),
     "helm_hip_get_timing": (C.c_int, [vp, C.POINTER(HipTiming), C.c_int]),
+    "helm_hip_get_clock": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 # helm_si_exchange_fn: int (*)(void *user, int64_t rows_per_rank)

@@ -336,7 +336,8 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
         return i;
     };
 
-    const bool stamp = (probe & 1) && blockIdx.x == 0 && tid == 0;
+    (void)probe;
+    const bool stamp = blockIdx.x == 0 && tid == 0; // four scalar clock reads per launch: always on (helm_hip_get_clock)
     if (stamp) {
         g_clock_probe[0] = __builtin_amdgcn_s_memtime();
         g_clock_probe[1] = __builtin_amdgcn_s_memrealtime();
@@ -1054,11 +1055,14 @@ struct helm_hip_program {
     LinJob *d_lin = nullptr;
     std::vector<int64_t> pbs_off, ks_off, lin_off;
     std::vector<LevelPlan> plans; // host copies (used for sharding)
-    // shard scratch
+    // shard tables of (sh_rank, sh_world), built once (shard_prepare): per level the job lists of this rank's
+    // chunk (destination rows = rows of the staging chunk) and the scatter rows of the gathered level
+    int sh_rank = -1, sh_world = 0;
     DevBuf<PbsJob> s_pbs;
     DevBuf<KsJob> s_ks;
     DevBuf<LinJob> s_lin;
     DevBuf<int32_t> s_rows;
+    std::vector<int64_t> sh_pbs_off, sh_ks_off, sh_lin_off, sh_rows_off;
 };
 
 static bool needs_pbs(int op)
@@ -1536,6 +1540,12 @@ int helm_hip_sync(helm_hip_ctx *ctx)
     return 0;
 }
 
+int64_t helm_hip_launch_quantum(const helm_hip_ctx *ctx)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");
+    return 4 * (int64_t)ctx->n_cus; // PbsCfg::NB bootstraps per workgroup, one workgroup per CU
+}
+
 int helm_hip_load_bootstrap_key(helm_hip_ctx *ctx, const uint32_t *bsk_std, size_t n_words)
 {
     if (!ctx || !bsk_std) return fail(HELM_ERR_INVALID, "null argument");
@@ -1870,14 +1880,72 @@ int64_t helm_hip_program_level_pbs(helm_hip_program *prog, int64_t level)
     return prog->pbs_off[level + 1] - prog->pbs_off[level];
 }
 
+// Per-(rank, world) shard tables: every level's chunk planned and uploaded ONCE, so that the per-level
+// calls below only launch kernels (no host planning, no host-device copies, no stream synchronisation
+// inside the level loop - the exchange is latency-bound).
+static int shard_prepare(helm_hip_ctx *ctx, helm_hip_program *prog, int rank, int world)
+{
+    if (prog->sh_rank == rank && prog->sh_world == world) return 0;
+    std::vector<PbsJob> all_pbs;
+    std::vector<KsJob> all_ks;
+    std::vector<LinJob> all_lin;
+    std::vector<int32_t> all_rows;
+    std::vector<int64_t> po{0}, ko{0}, lo{0}, ro{0};
+    LevelPlan pl;
+    for (int64_t level = 0; level < prog->n_levels; level++) {
+        const int64_t b = prog->off[level], cnt = prog->off[level + 1] - b;
+        const int64_t chunk = (cnt + world - 1) / world;
+        const int64_t g0 = std::min(cnt, chunk * rank), g1 = std::min(cnt, g0 + chunk);
+        if (g1 > g0) {
+            if (int rc = plan_level(prog->op.data() + b + g0, prog->in0.data() + b + g0, prog->in1.data() + b + g0,
+                                    prog->in2.data() + b + g0, g1 - g0, [&](int64_t g) { return (int32_t)g; }, pl))
+                return rc;
+            all_pbs.insert(all_pbs.end(), pl.pbs.begin(), pl.pbs.end());
+            all_ks.insert(all_ks.end(), pl.ks.begin(), pl.ks.end());
+            all_lin.insert(all_lin.end(), pl.lin.begin(), pl.lin.end());
+        }
+        // chunks are contiguous: gathered row g = gate g of the level; padding rows are skipped
+        for (int64_t g = 0; g < chunk * world; g++) all_rows.push_back(g < cnt ? prog->out[(size_t)(b + g)] : -1);
+        po.push_back((int64_t)all_pbs.size());
+        ko.push_back((int64_t)all_ks.size());
+        lo.push_back((int64_t)all_lin.size());
+        ro.push_back((int64_t)all_rows.size());
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // an earlier (rank, world) table may still be in use
+    if (prog->s_pbs.ensure(all_pbs.size()) || prog->s_ks.ensure(all_ks.size()) || prog->s_lin.ensure(all_lin.size()) ||
+        prog->s_rows.ensure(all_rows.size()))
+        return fail(HELM_ERR_OOM, "shard tables");
+    if (!all_pbs.empty()) HIP_TRY(hipMemcpy(prog->s_pbs.p, all_pbs.data(), all_pbs.size() * sizeof(PbsJob), hipMemcpyHostToDevice));
+    if (!all_ks.empty()) HIP_TRY(hipMemcpy(prog->s_ks.p, all_ks.data(), all_ks.size() * sizeof(KsJob), hipMemcpyHostToDevice));
+    if (!all_lin.empty()) HIP_TRY(hipMemcpy(prog->s_lin.p, all_lin.data(), all_lin.size() * sizeof(LinJob), hipMemcpyHostToDevice));
+    if (!all_rows.empty()) HIP_TRY(hipMemcpy(prog->s_rows.p, all_rows.data(), all_rows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    prog->sh_pbs_off.swap(po);
+    prog->sh_ks_off.swap(ko);
+    prog->sh_lin_off.swap(lo);
+    prog->sh_rows_off.swap(ro);
+    prog->sh_rank = rank;
+    prog->sh_world = world;
+    return 0;
+}
+
+int helm_hip_program_shard_prepare(helm_hip_ctx *ctx, helm_hip_program *prog, int rank, int world)
+{
+    if (!ctx || !prog) return fail(HELM_ERR_INVALID, "null argument");
+    if (prog->owner != ctx) return fail(HELM_ERR_STATE, "program belongs to another context");
+    if (world <= 0 || rank < 0 || rank >= world) return fail(HELM_ERR_INVALID, "bad shard arguments");
+    return shard_prepare(ctx, prog, rank, world);
+}
+
 int helm_hip_program_run_level_shard(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, int64_t level,
                                      int rank, int world, void *staging_dev)
 {
     if (int rc = check_program(ctx, prog, w)) return rc;
     if (level < 0 || level >= prog->n_levels || world <= 0 || rank < 0 || rank >= world || !staging_dev)
         return fail(HELM_ERR_INVALID, "bad shard arguments");
+    if (int rc = shard_prepare(ctx, prog, rank, world)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    const int64_t b = prog->off[level], cnt = prog->off[level + 1] - b;
+    const int64_t cnt = prog->off[level + 1] - prog->off[level];
     const int64_t chunk = (cnt + world - 1) / world;
     const int64_t g0 = std::min(cnt, chunk * rank), g1 = std::min(cnt, g0 + chunk);
     const size_t row = (size_t)ctx->P.n + 1;
@@ -1886,22 +1954,10 @@ int helm_hip_program_run_level_shard(helm_hip_ctx *ctx, helm_hip_program *prog, 
         HIP_TRY(hipMemsetAsync(static_cast<uint32_t *>(staging_dev) + row * (size_t)(g1 - g0), 0,
                                row * (size_t)(chunk - (g1 - g0)) * sizeof(uint32_t), ctx->stream));
     if (g1 == g0) return 0;
-    LevelPlan pl;
-    if (int rc = plan_level(prog->op.data() + b + g0, prog->in0.data() + b + g0, prog->in1.data() + b + g0,
-                            prog->in2.data() + b + g0, g1 - g0, [&](int64_t g) { return (int32_t)g; }, pl))
-        return rc;
-    if (prog->s_pbs.ensure(pl.pbs.size()) || prog->s_ks.ensure(pl.ks.size()) || prog->s_lin.ensure(pl.lin.size()))
-        return fail(HELM_ERR_OOM, "shard job buffers");
-    HIP_TRY(hipStreamSynchronize(ctx->stream)); // the previous level's shard may still read these buffers (see eval_gate_level)
-    if (!pl.pbs.empty())
-        HIP_TRY(hipMemcpyAsync(prog->s_pbs.p, pl.pbs.data(), pl.pbs.size() * sizeof(PbsJob), hipMemcpyHostToDevice, ctx->stream));
-    if (!pl.ks.empty())
-        HIP_TRY(hipMemcpyAsync(prog->s_ks.p, pl.ks.data(), pl.ks.size() * sizeof(KsJob), hipMemcpyHostToDevice, ctx->stream));
-    if (!pl.lin.empty())
-        HIP_TRY(hipMemcpyAsync(prog->s_lin.p, pl.lin.data(), pl.lin.size() * sizeof(LinJob), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return run_level_device(ctx, prog->s_pbs.p, (int64_t)pl.pbs.size(), prog->s_ks.p, (int64_t)pl.ks.size(),
-                            prog->s_lin.p, (int64_t)pl.lin.size(), w->d, static_cast<uint32_t *>(staging_dev));
+    const int64_t pb = prog->sh_pbs_off[level], kb = prog->sh_ks_off[level], lb = prog->sh_lin_off[level];
+    return run_level_device(ctx, prog->s_pbs.p + pb, prog->sh_pbs_off[level + 1] - pb, prog->s_ks.p + kb,
+                            prog->sh_ks_off[level + 1] - kb, prog->s_lin.p + lb, prog->sh_lin_off[level + 1] - lb, w->d,
+                            static_cast<uint32_t *>(staging_dev));
 }
 
 int helm_hip_program_scatter_level(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, int64_t level,
@@ -1910,18 +1966,13 @@ int helm_hip_program_scatter_level(helm_hip_ctx *ctx, helm_hip_program *prog, he
     if (int rc = check_program(ctx, prog, w)) return rc;
     if (level < 0 || level >= prog->n_levels || world <= 0 || !gathered_dev)
         return fail(HELM_ERR_INVALID, "bad scatter arguments");
+    if (prog->sh_world != world)
+        return fail(HELM_ERR_STATE, "scatter_level: run_level_shard / shard_prepare with this world size first");
     HIP_TRY(hipSetDevice(ctx->device));
-    const int64_t b = prog->off[level], cnt = prog->off[level + 1] - b;
-    if (cnt == 0) return 0;
-    const int64_t chunk = (cnt + world - 1) / world;
-    std::vector<int32_t> rows((size_t)(chunk * world), -1);
-    for (int64_t g = 0; g < cnt; g++) rows[(size_t)g] = prog->out[(size_t)(b + g)]; // chunks are contiguous: row g = gate g
-    if (prog->s_rows.ensure(rows.size())) return fail(HELM_ERR_OOM, "scatter rows");
-    HIP_TRY(hipStreamSynchronize(ctx->stream)); // previous scatter may still read s_rows
-    HIP_TRY(hipMemcpyAsync(prog->s_rows.p, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)rows.size()), dim3(256), 0, ctx->stream,
-                       static_cast<const uint32_t *>(gathered_dev), prog->s_rows.p, w->d, ctx->P.n);
+    const int64_t rb = prog->sh_rows_off[level], rows = prog->sh_rows_off[level + 1] - rb;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)rows), dim3(256), 0, ctx->stream,
+                       static_cast<const uint32_t *>(gathered_dev), prog->s_rows.p + rb, w->d, ctx->P.n);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2020,6 +2071,19 @@ int helm_hip_ntt_roundtrip(helm_hip_ctx *ctx, const uint32_t *poly_in, uint32_t 
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(d_in));
     HIP_TRY(hipFree(d_out));
+    return 0;
+}
+
+int helm_hip_get_clock(helm_hip_ctx *ctx, double *shader_ghz, double *blind_rotation_ms)
+{
+    if (!ctx || !shader_ghz) return fail(HELM_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long v[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_clock_probe), sizeof(v)));
+    if (v[3] <= v[1] || v[2] <= v[0]) return fail(HELM_ERR_STATE, "no k_pbs launch has run on this device yet");
+    *shader_ghz = (double)(v[2] - v[0]) / (double)(v[3] - v[1]) * 0.1; // s_memrealtime ticks at 100 MHz
+    if (blind_rotation_ms) *blind_rotation_ms = (double)(v[3] - v[1]) * 1e-5;
     return 0;
 }
 

@@ -196,6 +196,27 @@ int helm_host_circuit_evaluate(helm_circuit *c, const char *wire_map, char **out
     return guard([&] { *out_map = dup(map_text(c->c.evaluate(parse_map(wire_map)))); });
 }
 
+int helm_host_pack_levels(const int32_t *opcode, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                          const int32_t *out, const int64_t *level_offsets, int64_t n_levels, int64_t quantum,
+                          int64_t *order, int64_t *new_offsets, int64_t *n_launches)
+{
+    if (!opcode || !in0 || !in1 || !in2 || !out || !level_offsets || !order || !new_offsets || !n_launches || n_levels < 0) {
+        g_err = "null argument";
+        return -1;
+    }
+    try {
+        std::vector<int64_t> ord, off;
+        const int rc = pack_levels(opcode, in0, in1, in2, out, level_offsets, n_levels, quantum, ord, off);
+        std::copy(ord.begin(), ord.end(), order);
+        std::copy(off.begin(), off.end(), new_offsets);
+        *n_launches = (int64_t)off.size() - 1;
+        return rc;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 int helm_host_enc_map_new(helm_hip_ctx *server_key, helm_enc_map **out)
 {
     return guard([&] {

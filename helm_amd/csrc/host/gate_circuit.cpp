@@ -271,6 +271,26 @@ std::unique_ptr<EncWireMap> GateCircuit::evaluate_encrypted(const EncWireMap &en
             }
             off.push_back((int64_t)op.size());
         }
+        // launch packing (level_pack.cpp): wide levels are re-timed into whole lockstep rounds; a netlist
+        // whose levels are narrower than one round keeps its level schedule unchanged
+        {
+            const int64_t quantum = helm_hip_launch_quantum(server_key_);
+            std::vector<int64_t> order, poff;
+            if (quantum > 0 &&
+                pack_levels(op.data(), i0.data(), i1.data(), i2.data(), out.data(), off.data(), (int64_t)off.size() - 1,
+                            quantum, order, poff) == 0 &&
+                poff != off) {
+                auto permute = [&](std::vector<int32_t> &v) {
+                    std::vector<int32_t> t(v.size());
+                    for (size_t q = 0; q < order.size(); q++) t[q] = v[(size_t)order[q]];
+                    v.swap(t);
+                };
+                permute(op); permute(i0); permute(i1); permute(i2); permute(out);
+                off = poff;
+                packed_ = true;
+            } else
+                packed_ = false;
+        }
         if (int rc = helm_hip_program_create(server_key_, op.data(), i0.data(), i1.data(), i2.data(), out.data(),
                                              off.data(), (int64_t)off.size() - 1, &prog_)) {
             (void)rc;
@@ -280,16 +300,22 @@ std::unique_ptr<EncWireMap> GateCircuit::evaluate_encrypted(const EncWireMap &en
         prog_keys_ = keys;
         prog_rows_.clear();
         for (auto &k : keys) prog_rows_.push_back(eval_values->row(k));
+        prog_launches_ = (int64_t)off.size() - 1;
         pbs_count_ = 0;
-        for (int64_t l = 0; l + 1 < (int64_t)off.size(); l++) pbs_count_ += helm_hip_program_level_pbs(prog_, l);
+        for (int64_t l = 0; l < prog_launches_; l++) pbs_count_ += helm_hip_program_level_pbs(prog_, l);
     }
     const int64_t total_levels = (int64_t)circuit_.level_map().size();
-    int64_t l = 0;
     std::ostringstream os;
-    for (auto &kv : circuit_.level_map()) {
-        hip_ok(helm_hip_program_run(server_key_, prog_, eval_values->table(), l, l + 1), "program_run");
-        os << "  Evaluated gates in level [" << kv.first << "/" << total_levels << "]\n";
-        l++;
+    if (!packed_) {
+        int64_t l = 0;
+        for (auto &kv : circuit_.level_map()) {
+            hip_ok(helm_hip_program_run(server_key_, prog_, eval_values->table(), l, l + 1), "program_run");
+            os << "  Evaluated gates in level [" << kv.first << "/" << total_levels << "]\n";
+            l++;
+        }
+    } else {
+        hip_ok(helm_hip_program_run(server_key_, prog_, eval_values->table(), 0, prog_launches_), "program_run");
+        os << "  Evaluated gates of " << total_levels << " levels in " << prog_launches_ << " packed launches\n";
     }
     hip_ok(helm_hip_sync(server_key_), "sync");
     log_ += os.str();

@@ -141,6 +141,13 @@ class Circuit {
     std::map<size_t, std::vector<Gate>> level_map_;
 };
 
+// Launch packing (level_pack.cpp): the level map of circuit.rs:174-239 as index arrays -> `order`
+// (new position -> gate) and `new_off` (launch boundaries) such that every launch but the last few
+// holds a whole number of `quantum` bootstraps.  Returns 0, or 1 when the schedule was kept as it is.
+int pack_levels(const int32_t *op, const int32_t *in0, const int32_t *in1, const int32_t *in2, const int32_t *out,
+                const int64_t *off, int64_t n_levels, int64_t quantum, std::vector<int64_t> &order,
+                std::vector<int64_t> &new_off);
+
 // Device-resident replacement of HashMap<String, Ciphertext> (circuit.rs:517-520):
 // wire name -> row of an HBM wire table owned by the engine context.
 class EncWireMap {
@@ -211,6 +218,8 @@ class GateCircuit : public EvalCircuit<EncWireMap> {
     std::vector<std::string> prog_keys_;
     std::vector<int> prog_rows_;
     int64_t pbs_count_ = 0;
+    int64_t prog_launches_ = 0;
+    bool packed_ = false; // the program's launches are packed rounds, not the circuit's levels
     std::string log_;
 };
 

@@ -43,6 +43,13 @@ class GpuLevelExecutor:
     def run_level(self, level):
         self.program.run(self.wires, level, level + 1)
 
+    def shard_prepare(self, rank, world):
+        """Plan and upload this rank's chunk of every launch once: the per-launch calls then only launch kernels."""
+        self.program.shard_prepare(rank, world)
+
+    def new_events(self):
+        return self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+
     def run_level_shard(self, level, rank, world, staging):
         self.program.run_level_shard(self.wires, level, rank, world, staging.data_ptr())
 
@@ -56,9 +63,11 @@ class ShardedRunner:
     `dist` is torch.distributed (backend "nccl" = RCCL on GPUs; "gloo" in the CPU
     tests); with world == 1 nothing is imported and nothing is exchanged."""
 
-    def __init__(self, executor, rank=0, world=1, dist=None, replicate_below=256):
+    def __init__(self, executor, rank=0, world=1, dist=None, replicate_below=256, time_collective=False):
         self.ex, self.rank, self.world, self.dist = executor, rank, world, dist
         self.replicate_below = replicate_below
+        self.time_collective = time_collective and world > 1 and hasattr(executor, "new_events")
+        self._events = []
         self.sharded_levels = []
         self._staging, self._gathered = {}, {}
         if world > 1:
@@ -67,6 +76,8 @@ class ShardedRunner:
             for l in range(executor.n_levels):
                 if executor.level_pbs(l) > replicate_below:
                     self.sharded_levels.append(l)
+            if hasattr(executor, "shard_prepare"):
+                executor.shard_prepare(rank, world)
             rows = max([-(-executor.level_count(l) // world) for l in self.sharded_levels], default=0)
             if rows:
                 self._stage = executor.new_buffer(rows)
@@ -83,8 +94,25 @@ class ShardedRunner:
             stage = self._stage[:rows]
             gathered = self._gather[:rows * self.world]
             ex.run_level_shard(l, self.rank, self.world, stage)
-            self.dist.all_gather_into_tensor(gathered, stage)
+            if self.time_collective:  # events on the stream the engine and the collective share
+                a, b = ex.new_events()
+                a.record()
+                self.dist.all_gather_into_tensor(gathered, stage)
+                b.record()
+                self._events.append((a, b))
+            else:
+                self.dist.all_gather_into_tensor(gathered, stage)
             ex.scatter_level(l, self.world, gathered)
+
+    def collective_ms(self, reset=False):
+        """GPU time between the records around every all-gather since the last reset (time_collective=True);
+        includes the wait for the slowest rank's chunk, which is what the exchange costs a launch."""
+        if self._events:
+            self._events[-1][1].synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._events)
+        if reset:
+            self._events = []
+        return ms
 
     def exchanged_bytes_per_pass(self):
         ex = self.ex
@@ -105,3 +133,23 @@ def level_arrays(circuit, index):
         off.append(len(ops))
     return (np.array(ops, np.int32), np.array(i0, np.int32), np.array(i1, np.int32), np.array(i2, np.int32),
             np.array(out, np.int32), np.array(off, np.int64))
+
+
+def pack_levels(opcode, in0, in1, in2, out, level_offsets, quantum):
+    """Launch packing (helm_host_pack_levels, helm_amd/csrc/host/level_pack.cpp): the level schedule re-timed so
+    that a launch holds a whole number of `quantum` bootstraps while that many gates are ready; dependency order
+    kept, outputs bit-identical.  -> (opcode, in0, in1, in2, out, launch_offsets, packed: bool)"""
+    import ctypes as C
+    from . import _host as H
+    arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (opcode, in0, in1, in2, out)]
+    off = np.ascontiguousarray(level_offsets, dtype=np.int64)
+    total = len(arrs[0])
+    order = np.zeros(total, dtype=np.int64)
+    new_off = np.zeros(total + 1, dtype=np.int64)
+    n = C.c_int64()
+    i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    rc = H.host.helm_host_pack_levels(*[a.ctypes.data_as(i32p) for a in arrs], off.ctypes.data_as(i64p), len(off) - 1,
+                                      int(quantum), order.ctypes.data_as(i64p), new_off.ctypes.data_as(i64p), C.byref(n))
+    if rc < 0:
+        raise H.Panic(H.host.helm_host_last_error().decode())
+    return tuple(a[order] for a in arrs) + (new_off[:n.value + 1].copy(), rc == 0)

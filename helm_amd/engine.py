@@ -129,6 +129,13 @@ class ServerKey:
     def sync(self):
         hip_check(hip.helm_hip_sync(self._h))
 
+    def launch_quantum(self):
+        """Bootstraps of one full round of the lockstep build (4 per compute unit)."""
+        q = int(hip.helm_hip_launch_quantum(self._h))
+        if q <= 0:
+            hip_check(q or -1)
+        return q
+
     def wires(self, n_wires):
         return DeviceWires(self, n_wires)
 
@@ -157,6 +164,13 @@ class ServerKey:
         out = np.zeros_like(polys)
         hip_check(hip.helm_hip_ntt_roundtrip(self._h, nv.as_u32p(polys), nv.as_u32p(out), len(polys)))
         return out
+
+    def kernel_clock_ghz(self):
+        """Shader clock held during the most recent k_pbs launch (None before the first one)."""
+        g, ms = C.c_double(), C.c_double()
+        if hip.helm_hip_get_clock(self._h, C.byref(g), C.byref(ms)) != 0:
+            return None
+        return g.value
 
     def timing_enable(self, on=True):
         hip_check(hip.helm_hip_timing_enable(self._h, int(on)))
@@ -249,6 +263,9 @@ class Program:
 
     def chunk_rows(self, level, world):
         return int(hip.helm_hip_program_chunk_rows(self._h, level, world))
+
+    def shard_prepare(self, rank, world):
+        hip_check(hip.helm_hip_program_shard_prepare(self.sk._h, self._h, rank, world))
 
     def run_level_shard(self, wires, level, rank, world, staging_ptr):
         hip_check(hip.helm_hip_program_run_level_shard(self.sk._h, self._h, wires._h, level, rank, world,

@@ -108,6 +108,10 @@ int helm_hip_get_params(const helm_hip_ctx *ctx, helm_hip_params *out);
  * context runs on a non-blocking stream of its own. */
 int helm_hip_set_stream(helm_hip_ctx *ctx, void *hip_stream);
 int helm_hip_sync(helm_hip_ctx *ctx);
+/* Bootstraps of one full round of the dominant (lockstep) build on this device: 4 per compute unit.
+ * A launch of a whole number of rounds leaves no partial round behind; the host's launch packing
+ * (helm_host_pack_levels) sizes launches with it.  Negative on error. */
+int64_t helm_hip_launch_quantum(const helm_hip_ctx *ctx);
 
 /* -- keys ------------------------------------------------------------------ */
 /* Replaces convert_lwe_bootstrap_key / convert_lwe_keyswitch_key (reference
@@ -161,7 +165,11 @@ int helm_hip_program_run(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wir
  * (device memory, chunk_rows(level, world) rows of n+1 words, zero padded).
  * After an all-gather of the staging buffers (RCCL, driven by the caller),
  * helm_hip_program_scatter_level() writes all `world` chunks into the wire
- * table.  Keys and the wire table are replicated on every rank. */
+ * table.  Keys and the wire table are replicated on every rank.
+ * The chunk job lists and scatter tables of a (rank, world) pair are planned and
+ * uploaded once - by helm_hip_program_shard_prepare(), or by the first
+ * run_level_shard() - so that the per-level calls only launch kernels. */
+int helm_hip_program_shard_prepare(helm_hip_ctx *ctx, helm_hip_program *prog, int rank, int world);
 int64_t helm_hip_program_chunk_rows(helm_hip_program *prog, int64_t level, int world);
 int helm_hip_program_run_level_shard(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w,
                                      int64_t level, int rank, int world, void *staging_dev);
@@ -199,6 +207,11 @@ typedef struct {
  * (adds a sync per get_timing call, not per launch). */
 int helm_hip_timing_enable(helm_hip_ctx *ctx, int enable);
 int helm_hip_get_timing(helm_hip_ctx *ctx, helm_hip_timing *out, int reset);
+/* Shader clock the chip held during the blind rotation of the most recent k_pbs launch on this
+ * device (workgroup 0: s_memtime ticks per 100 MHz s_memrealtime tick), and that rotation's
+ * duration.  The roofline of bench.py quotes its peak at the nominal clock and reports this one
+ * beside it.  Synchronises the stream. */
+int helm_hip_get_clock(helm_hip_ctx *ctx, double *shader_ghz, double *blind_rotation_ms);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,15 @@ int helm_host_circuit_initialize_wire_map(const helm_circuit *c, const char *wir
                                           const char *ptxt_type, char **out_map);
 int helm_host_circuit_evaluate(helm_circuit *c, const char *wire_map, char **out_map);
 
+/* Launch packing of a level schedule (the level loop of circuit.rs:524-543 made GPU-shaped): gates in level
+ * order as index arrays (helm_hip_program_create's arguments) -> `order[total]` (new position -> gate index)
+ * and `new_offsets` (room for total + 1 entries; *n_launches + 1 are written): dependency order is kept, a
+ * launch holds a whole number of `quantum` bootstraps (helm_hip_launch_quantum()) while that many gates are
+ * ready.  Returns 0 packed, 1 schedule kept unchanged (state-writing gates feed later gates), -1 error. */
+int helm_host_pack_levels(const int32_t *opcode, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                          const int32_t *out, const int64_t *level_offsets, int64_t n_levels, int64_t quantum,
+                          int64_t *order, int64_t *new_offsets, int64_t *n_launches);
+
 /* encrypted wire maps */
 int helm_host_enc_map_new(helm_hip_ctx *server_key, helm_enc_map **out);
 void helm_host_enc_map_free(helm_enc_map *m);

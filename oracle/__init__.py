@@ -135,6 +135,15 @@ def decompose(x, logB, l):
     return d
 
 
+def ntt_route_name():
+    """What the timed NTT route of liborc.so is (bench.py's cpu_baseline quotes it)."""
+    L = lib()
+    if hasattr(L, "orc_ntt_route"):
+        L.orc_ntt_route.restype = C.c_char_p
+        return L.orc_ntt_route().decode()
+    return "scalar C restatement with a Goldilocks NTT"
+
+
 def max_threads():
     return int(lib().orc_max_threads())
 

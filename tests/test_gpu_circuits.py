@@ -236,3 +236,73 @@ def test_aes128_fips197_encrypted(keys):  # K-8 / config 4 on one GPU, one block
     out = gc.decrypt_outputs(enc, False)
     ct = sum(out[f"ct[{i}]"].value << i for i in range(128)).to_bytes(16, "big")
     assert ct == bytes.fromhex("69c4e0d86a7b0430d8cdb78070b4c55a") == aes128_reference_encrypt(key, pt)
+
+
+def test_packed_launches_equal_level_schedule_bit_exact():
+    """Launch packing (helm_host_pack_levels): 6 AES blocks under a toy set, quantum forced small so that the
+    packing really re-times the batch - every wire of every block must hold the SAME ciphertext bits as under the
+    level schedule of circuit.rs:524-543, and the outputs decrypt to a software AES."""
+    from helm_amd.distributed import pack_levels
+    ck = helm_amd.ClientKey.generate("toy_k2", seed=21)
+    sk = helm_amd.ServerKey(ck)
+    circuit, wire_set, input_wires, output_wires = _circuit(aes128(), is_text=True)
+    names = list(input_wires) + sorted(wire_set)
+    index = {w: i for i, w in enumerate(names)}
+    ops, i0, i1, i2, out, off = level_arrays(circuit, index)
+    blocks, nw, nl = 6, len(names), len(off) - 1
+    t = lambda a: np.concatenate([np.concatenate([np.where(a[off[l]:off[l + 1]] >= 0, a[off[l]:off[l + 1]] + b * nw, -1)
+                                                  for b in range(blocks)]) for l in range(nl)]).astype(np.int32)
+    opsT = np.concatenate([np.tile(ops[off[l]:off[l + 1]], blocks) for l in range(nl)]).astype(np.int32)
+    arrs = (opsT, t(i0), t(i1), t(i2), t(out), (off * blocks).astype(np.int64))
+    packed = pack_levels(*arrs, 128)
+    assert packed[6] and len(packed[5]) != len(arrs[5])
+    rng = np.random.default_rng(4)
+    keys_pt = [(bytes(rng.integers(0, 256, 16, dtype=np.uint8)), bytes(rng.integers(0, 256, 16, dtype=np.uint8)))
+               for _ in range(blocks)]
+    rows, bits = [], []
+    for b, (key, pt) in enumerate(keys_pt):
+        kv, pv = int.from_bytes(key, "big"), int.from_bytes(pt, "big")
+        for i in range(128):
+            rows += [b * nw + index[f"key[{i}]"], b * nw + index[f"pt[{i}]"]]
+            bits += [(kv >> i) & 1, (pv >> i) & 1]
+    cts = ck.encrypt(np.array(bits, dtype=bool))
+    tables = []
+    for a in (arrs, packed[:6]):
+        prog = helm_amd.Program(sk, *a)
+        w = sk.wires(nw * blocks)
+        w.upload(np.array(rows, np.int32), cts)
+        prog.run(w)
+        tables.append(w.download())
+        prog.destroy()
+        w.free()
+    assert np.array_equal(tables[0], tables[1])
+    for b, (key, pt) in enumerate(keys_pt):
+        dec = ck.decrypt(tables[1][[b * nw + index[f"ct[{i}]"] for i in range(128)]])
+        assert sum(int(dec[i]) << i for i in range(128)).to_bytes(16, "big") == aes128_reference_encrypt(key, pt)
+    sk.close()
+
+
+def test_gate_circuit_packs_wide_levels():
+    """GateCircuit::evaluate_encrypted on a netlist whose levels exceed one lockstep round: the host front end
+    packs the launches itself (gate_circuit.cpp) and every wire still decrypts to the plaintext evaluation."""
+    import torch
+    cu = torch.cuda.get_device_properties(0).multi_processor_count
+    width = 4 * cu + 40  # one round and a bit per level
+    lines = ["input [%d:0] a;" % (width - 1), "input [%d:0] b;" % (width - 1), "output [%d:0] y;" % (width - 1)]
+    for i in range(width):
+        lines.append(f"xor g0_{i}(a[{i}], b[{i}], t{i});")
+        lines.append(f"and g1_{i}(t{i}, a[{(i + 1) % width}], u{i});")
+        lines.append(f"or g2_{i}(u{i}, b[{(i + 3) % width}], y[{i}]);")
+    client_key = helm_amd.ClientKey.generate("toy_k2", seed=9)
+    server_key = helm_amd.ServerKey(client_key)
+    circuit, wire_set, input_wires, output_wires = _circuit("\n".join(lines) + "\n", is_text=True)
+    rng = np.random.default_rng(6)
+    inputs = {w: PtxtType.Bool(bool(rng.integers(0, 2))) for w in input_wires}
+    ptxt = circuit.evaluate(circuit.initialize_wire_map(wire_set, inputs, "bool"))
+    gc = GateCircuit(client_key, server_key, circuit)
+    enc = gc.evaluate_encrypted(gc.encrypt_inputs(wire_set, inputs), 1, "bool")
+    assert "packed launches" in gc.log()
+    assert gc.pbs_per_cycle() == 3 * width
+    for wire, want in ptxt.items():
+        assert client_key.decrypt(enc[wire]) == bool(want), wire
+    server_key.close()

@@ -242,3 +242,36 @@ def test_wide_integers_add_sub_mul(keys, width, kind):
     assert out["S"].value == (a + b) % M and out["D"].value == (a - b) % M
     assert out["P"].value == (a * b) % M and out["M"].value == (a * 1000003) % M
     assert all(v.kind == kind.upper() for v in out.values())
+
+
+@pytest.mark.parametrize("width,kind", [(32, "u32"), (64, "u64")])
+def test_division_and_shifts_wide(keys, width, kind):
+    """div / shl / shr with encrypted and plain right-hand sides at FheUint32 and FheUint64 (the width match of
+    gates.rs:386-452, 488-600; circuit.rs:1363-1435): one level, all six operators batched."""
+    client_key, server_key = keys
+    text = ("input A, B;\noutput Q, QS, L, R, LS, RS;\ndiv g0(A, B, Q);\ndiv g1(A, 1000003, QS);\nshl g2(A, B, L);\n"
+            "shr g3(A, B, R);\nshl g4(A, 13, LS);\nshr g5(A, 21, RS);\n")
+    circuit, wire_set, _, _ = _circuit(text, is_arith=True, is_text=True)
+    ac = ArithCircuit(client_key, server_key, circuit)
+    rng = np.random.default_rng(width)
+    a = int.from_bytes(rng.bytes(width // 8), "little")
+    b = int.from_bytes(rng.bytes(width // 16), "little") | 1  # half-width divisor: a multi-digit quotient
+    mk = {32: PtxtType.U32, 64: PtxtType.U64}[width]
+    enc = ac.encrypt_inputs(wire_set, {"A": mk(a), "B": mk(b)})
+    out = {k: v.value for k, v in ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, kind), True).items()}
+    M = 1 << width
+    assert out == {"Q": a // b, "QS": a // 1000003, "L": (a << (b % width)) % M, "R": a >> (b % width),
+                   "LS": (a << 13) % M, "RS": a >> 21}, (a, b)
+
+
+def test_division_u128(keys):
+    """FheUint128 / FheUint128 (64 radix blocks, 128 restoring steps), and x / 0 = all ones as tfhe's."""
+    client_key, server_key = keys
+    circuit, wire_set, _, _ = _circuit("input A, B, Z;\noutput Q, QZ;\ndiv g0(A, B, Q);\ndiv g1(A, Z, QZ);\n",
+                                       is_arith=True, is_text=True)
+    ac = ArithCircuit(client_key, server_key, circuit)
+    a = 0xFEDCBA9876543210_0123456789ABCDEF
+    b = 0x1_0000_0001_F00D
+    enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U128(a), "B": PtxtType.U128(b), "Z": PtxtType.U128(0)})
+    out = ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, "u128"), True)
+    assert out["Q"].value == a // b and out["QZ"].value == (1 << 128) - 1
