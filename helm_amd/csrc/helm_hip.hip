@@ -336,8 +336,10 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
         return i;
     };
 
-    (void)probe;
-    const bool stamp = blockIdx.x == 0 && tid == 0; // four scalar clock reads per launch: always on (helm_hip_get_clock)
+    // four scalar clock reads per launch that fills the chip (probe bit 1, set by the host), taken by the LAST
+    // workgroup - it runs in the launch's last round, when the chip has been under this load for the whole launch
+    // (helm_hip_get_clock); HELM_HIP_CLOCK_PROBE=1 (bit 0) stamps every launch
+    const bool stamp = (probe & 3) && blockIdx.x == gridDim.x - 1 && tid == 0;
     if (stamp) {
         g_clock_probe[0] = __builtin_amdgcn_s_memtime();
         g_clock_probe[1] = __builtin_amdgcn_s_memrealtime();
@@ -1164,7 +1166,7 @@ static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((count + C::NB - 1) / C::NB)), dim3(64 * (C::K + 1) * C::NB), C::BYTES,
                        ctx->stream, jobs, wires, raw, tvs, ctx->bsk, ctx->tw_fwd, ctx->tw_inv, out_big, ctx->P.n,
-                       ctx->P.pbs_logB, ctx->clock_probe, (int)count);
+                       ctx->P.pbs_logB, ctx->clock_probe | (count >= (int64_t)C::NB * ctx->n_cus ? 2 : 0), (int)count);
     hipError_t e = hipGetLastError();
     print_stamps(ctx, C::K + 1, "k_pbs: work | bar1 | sum | bar2 | inverse | publish");
     if (e == hipSuccess && (ctx->clock_probe & 1)) {
