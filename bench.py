@@ -350,23 +350,40 @@ def strong_scaling_leg(sk, ck, circuit, wire_names, index, nw, blocks, quantum, 
     return res
 
 
-def cpu_baseline(args, ck, circuit, wire_names, index, nw, wires, keys_pt):
-    """The oracle on the first levels of the same netlist (one block) on the cores this process may use; the GPU's
-    ciphertexts of those levels must be bit-identical (the oracle is the checker here, never the product)."""
+def granted_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (the 1-GPU box shows
+    every logical CPU in the mask but grants a share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(args, ck, circuit, wire_names, index, nw, wires, keys_pt, cpu_blocks=8):
+    """The oracle's SIMD route (oracle/fp_route.inc: exact fp64-FMA NTT, one gate per SIMD lane, OpenMP over
+    groups of gates like rayon over a level) on the first levels of the same netlist, `cpu_blocks` blocks of the
+    GPU's batch, on the cores this process is granted; the GPU's ciphertexts of those levels must be bit-identical
+    (the oracle is the checker here, never the product)."""
     import oracle
     p = ck.params
-    orc = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk)
-    o_ops, o_i0, o_i1, o_i2, o_out, o_off, _ = build_program_arrays(circuit, wire_names, 1)
-    host = np.zeros((nw, p.n + 1), dtype=np.uint32)
-    rows = [index[f"key[{i}]"] for i in range(128)] + [index[f"pt[{i}]"] for i in range(128)]
-    host[rows] = wires.download(np.array(rows, np.int32))  # the very ciphertexts the GPU evaluated (block 0)
-    granted = len(os.sched_getaffinity(0))
+    cpu_blocks = min(cpu_blocks, len(keys_pt))
+    orc = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk, use_ntt=False, use_fp=True)
+    o_ops, o_i0, o_i1, o_i2, o_out, o_off, _ = build_program_arrays(circuit, wire_names, cpu_blocks)
+    host = np.zeros((nw * cpu_blocks, p.n + 1), dtype=np.uint32)
+    rows = np.array([b * nw + index[f"{w}[{i}]"] for b in range(cpu_blocks) for w in ("key", "pt") for i in range(128)], np.int32)
+    host[rows] = wires.download(rows)  # the very ciphertexts the GPU evaluated (blocks 0..cpu_blocks-1)
+    granted = granted_cores()
     threads = max(1, args.cpu_threads or granted)
     n_pbs, L = 0, 0
     t0 = time.perf_counter()
     while L < len(o_off) - 1 and (L < 1 or time.perf_counter() - t0 < args.cpu_seconds):
         s = slice(o_off[L], o_off[L + 1])
-        orc.eval_level(host, o_ops[s], o_i0[s], o_i1[s], o_i2[s], o_out[s], nthreads=threads)
+        orc.eval_level_fp(host, o_ops[s], o_i0[s], o_i1[s], o_i2[s], o_out[s], nthreads=threads)
         n_pbs += int(np.sum(o_ops[s] != oracle.NOT))
         L += 1
     cpu_s = time.perf_counter() - t0
@@ -376,10 +393,10 @@ def cpu_baseline(args, ck, circuit, wire_names, index, nw, wires, keys_pt):
     return {
         "value": round(n_pbs / cpu_s, 2), "unit": "gate-bootstraps/s", "cores": threads, "kind": "port",
         "per_core": round(n_pbs / cpu_s / threads, 2), "ms_per_gate_per_thread": round(cpu_s * threads / n_pbs * 1e3, 2),
-        "sample": f"first {L} level(s) of the same AES-128 netlist, 1 block ({n_pbs} gate-bootstraps, {cpu_s:.1f} s); "
-                  f"{oracle.ntt_route_name()}, OpenMP over the gates of a level; NOT tfhe-rs",
+        "sample": f"first {L} level(s) of the same AES-128 netlist, {cpu_blocks} block(s) of the GPU's batch ({n_pbs} gate-bootstraps, "
+                  f"{cpu_s:.1f} s); {oracle.ntt_route_name()}; prime {orc.fp_prime():#x}; OpenMP over groups of gates of a level; NOT tfhe-rs",
         "gpu_ciphertexts_bit_identical_on_sample": same,
-        "host": f"{os.cpu_count()} logical CPUs, {granted} granted to this process (sched_getaffinity)",
+        "host": f"{os.cpu_count()} logical CPUs, {granted} granted to this process (affinity mask capped by the cgroup quota)",
     }
 
 

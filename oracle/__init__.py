@@ -50,6 +50,17 @@ def lib():
         L.orc_modswitch.argtypes = [C.c_uint32, C.c_int]
         L.orc_decompose.argtypes = [C.c_uint32, C.c_int, C.c_int, i32p]
         L.orc_max_threads.restype = C.c_int
+        pp = C.POINTER(u32p)
+        L.orc_bsk_fp_new.restype = C.c_void_p
+        L.orc_bsk_fp_new.argtypes = [C.POINTER(Params), u32p]
+        L.orc_bsk_fp_free.argtypes = [C.c_void_p]
+        L.orc_bsk_fp_prime.restype = C.c_double
+        L.orc_bsk_fp_prime.argtypes = [C.c_void_p]
+        L.orc_bootstrap_noks_fp.argtypes = [C.c_void_p, pp, u32p, pp, C.c_int]
+        L.orc_eval_level_fp.argtypes = [C.POINTER(Params), C.c_void_p, u32p, u32p, i32p, i32p, i32p, i32p, i32p,
+                                        C.c_int, C.c_int]
+        L.orc_fp_lanes.restype = C.c_int
+        L.orc_ntt_route.restype = C.c_char_p
         _LIB = L
     return _LIB
 
@@ -70,16 +81,45 @@ class Oracle:
     """Server-side evaluation with a given (bsk, ksk), both in the standard
     domain layouts documented in include/helm_hip.h."""
 
-    def __init__(self, params, bsk_std, ksk, use_ntt=True):
+    def __init__(self, params, bsk_std, ksk, use_ntt=True, use_fp=False):
+        """Routes: schoolbook (use_ntt=False), Goldilocks NTT (default), and with use_fp=True additionally the
+        SIMD fp64 route (eval_level_fp / bootstrap_noks_fp: the timed CPU baseline)."""
         self.p = Params(*[int(x) for x in params])
         self.bsk = np.ascontiguousarray(bsk_std, dtype=np.uint32)
         self.ksk = np.ascontiguousarray(ksk, dtype=np.uint32)
         self._ntt = lib().orc_bsk_ntt_new(C.byref(self.p), _u32(self.bsk)) if use_ntt else None
+        self._fp = lib().orc_bsk_fp_new(C.byref(self.p), _u32(self.bsk)) if use_fp else None
+        if use_fp and not self._fp:
+            raise RuntimeError("fp64 route unavailable: no AVX2 + FMA, or the set's exact products exceed the 51-bit prime")
 
     def __del__(self):
         if getattr(self, "_ntt", None):
             lib().orc_bsk_ntt_free(self._ntt)
             self._ntt = None
+        if getattr(self, "_fp", None):
+            lib().orc_bsk_fp_free(self._fp)
+            self._fp = None
+
+    def fp_prime(self):
+        return int(lib().orc_bsk_fp_prime(self._fp))
+
+    def bootstrap_noks_fp(self, lwes, tv):
+        """[count, n+1] -> [count, k*N+1] by the SIMD fp64 route (one test vector for all)."""
+        lwes = np.ascontiguousarray(lwes, dtype=np.uint32).reshape(-1, self.p.n + 1)
+        tv = np.ascontiguousarray(tv, dtype=np.uint32)
+        out = np.zeros((len(lwes), self.p.k * self.p.N + 1), dtype=np.uint32)
+        u32p = C.POINTER(C.c_uint32)
+        ins = (u32p * len(lwes))(*[_u32(lwes[g]) for g in range(len(lwes))])
+        outs = (u32p * len(lwes))(*[_u32(out[g]) for g in range(len(lwes))])
+        lib().orc_bootstrap_noks_fp(self._fp, ins, _u32(tv), outs, len(lwes))
+        return out
+
+    def eval_level_fp(self, wires, opcode, in0, in1, in2, outw, nthreads=0):
+        """eval_level by the SIMD fp64 route; in place on `wires`."""
+        assert wires.dtype == np.uint32 and wires.flags["C_CONTIGUOUS"]
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (opcode, in0, in1, in2, outw)]
+        lib().orc_eval_level_fp(C.byref(self.p), self._fp, _u32(self.ksk), _u32(wires), *[_i32(a) for a in arrs],
+                                len(arrs[0]), int(nthreads))
 
     def gate(self, op, in0, in1=None, in2=None):
         out = np.zeros(self.p.n + 1, dtype=np.uint32)
@@ -137,11 +177,11 @@ def decompose(x, logB, l):
 
 def ntt_route_name():
     """What the timed NTT route of liborc.so is (bench.py's cpu_baseline quotes it)."""
-    L = lib()
-    if hasattr(L, "orc_ntt_route"):
-        L.orc_ntt_route.restype = C.c_char_p
-        return L.orc_ntt_route().decode()
-    return "scalar C restatement with a Goldilocks NTT"
+    return lib().orc_ntt_route().decode()
+
+
+def fp_lanes():
+    return int(lib().orc_fp_lanes())
 
 
 def max_threads():

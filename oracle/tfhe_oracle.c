@@ -29,14 +29,17 @@
  * and reduced mod 2^32.  Two independent routes are provided and cross-checked
  * in the tests: (1) schoolbook negacyclic convolution in wrapping u32
  * arithmetic (obviously correct, O(N^2)); (2) a negacyclic NTT over the
- * Goldilocks prime 2^64-2^32+1 with centred lifting (fast; used for the timed
- * CPU baseline).  Because both are exact, the HIP path (which uses a different
- * prime and fp64 arithmetic) must agree with them bit for bit.
+ * Goldilocks prime 2^64-2^32+1 with centred lifting (scalar); (3) an fp64-FMA
+ * NTT over a 49/51-bit prime, one gate per SIMD lane (AVX2 / AVX-512, picked at
+ * run time: fp_route.inc) - the timed CPU baseline of bench.py.  All three are
+ * exact, so they and the HIP path must agree bit for bit; route 3 runs boolean
+ * parameter sets in a different prime field from the GPU's.
  */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <immintrin.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -368,6 +371,194 @@ void orc_bootstrap_noks(const orc_params *P, const u32 *bsk_std, const orc_bsk_n
     free(acc); free(diff); free(scratch);
 }
 
+/* ------------------------------------------------------------------------- */
+/* Route 3: fp64-FMA NTT, one gate per SIMD lane (fp_route.inc).               */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int N, logN;
+    double p, pinv, lim;          /* lim: largest |value| / p kept unreduced (0.95 * 2^53 / p) */
+    double *psi_rev, *psi_inv_rev; /* bit-reversed powers of the 2N-th root, centred           */
+    double n_inv;
+} orc_fp_tables;
+
+typedef struct {
+    orc_params P;
+    orc_fp_tables *T;
+    double *data; /* [n][l][k+1][k+1][N], transform domain, centred, 1/N folded in */
+} orc_bsk_fp;
+
+/* |mulmod(a, w)| <= fp_mo(b) p for |a| <= b p, |w| <= p/2 (quotient estimate off by <= 1.5 b p / 2^53) */
+static inline double fp_mo(const orc_fp_tables *T, double b) { return 0.5 + 1.5 * b * T->p / 9007199254740992.0 + 1e-9; }
+
+static u64 mulmod_u64(u64 a, u64 b, u64 p) { return (u64)((u128)a * b % p); }
+static u64 powmod_u64(u64 a, u64 e, u64 p) { u64 r = 1; while (e) { if (e & 1) r = mulmod_u64(r, a, p); a = mulmod_u64(a, a, p); e >>= 1; } return r; }
+static double centred_d(u64 v, u64 p) { return v > p / 2 ? -(double)(p - v) : (double)v; }
+
+static orc_fp_tables *fp_tables_new(int N, u64 p)
+{
+    orc_fp_tables *T = (orc_fp_tables *)malloc(sizeof(*T));
+    int logN = 0; while ((1 << logN) < N) logN++;
+    T->N = N; T->logN = logN; T->p = (double)p; T->pinv = 1.0 / (double)p;
+    T->lim = 0.95 * 9007199254740992.0 / (double)p;
+    u64 psi = 0;
+    for (u64 g = 2; g < 64 && !psi; g++) { /* an element of order exactly 2N */
+        u64 c = powmod_u64(g, (p - 1) / (2 * (u64)N), p);
+        if (powmod_u64(c, (u64)N, p) == p - 1) psi = c;
+    }
+    u64 psi_inv = powmod_u64(psi, p - 2, p), a = 1, b = 1;
+    T->psi_rev = (double *)malloc(sizeof(double) * N);
+    T->psi_inv_rev = (double *)malloc(sizeof(double) * N);
+    for (int i = 0; i < N; i++) {
+        T->psi_rev[bitrev(i, logN)] = centred_d(a, p); T->psi_inv_rev[bitrev(i, logN)] = centred_d(b, p);
+        a = mulmod_u64(a, psi, p); b = mulmod_u64(b, psi_inv, p);
+    }
+    T->n_inv = centred_d(powmod_u64((u64)N, p - 2, p), p);
+    return T;
+}
+
+#define VI_ADD(a, b) ((a) + (b))
+#define VI_SUB(a, b) ((a) - (b))
+#define VI_AND(a, b) ((a) & (b))
+#define VI_OR(a, b) ((a) | (b))
+#define VI_SRL(a, c) ((a) >> (c))   /* unsigned lanes: logical */
+#define VI_SLL(a, c) ((a) << (c))
+
+/* ---- AVX2 + FMA, 4 gates per call ---- */
+#pragma GCC push_options
+#pragma GCC target("avx2,fma")
+#define VL 4
+#define FN(x) fp4_##x
+typedef __m256d fp4_V;
+typedef u32 fp4_VI __attribute__((vector_size(16)));
+typedef int32_t fp4_VS __attribute__((vector_size(16)));
+#define V fp4_V
+#define VI fp4_VI
+#define VSET1(c) _mm256_set1_pd(c)
+#define VMUL(a, b) _mm256_mul_pd(a, b)
+#define VADD(a, b) _mm256_add_pd(a, b)
+#define VSUB(a, b) _mm256_sub_pd(a, b)
+#define VFMSUB(a, b, c) _mm256_fmsub_pd(a, b, c)
+#define VFNMADD(a, b, c) _mm256_fnmadd_pd(a, b, c)
+#define VRND(a) _mm256_round_pd(a, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC)
+#define VI_SET1(c) ((fp4_VI){(u32)(c), (u32)(c), (u32)(c), (u32)(c)})
+#define VI_TO_V(x) _mm256_cvtepi32_pd((__m128i)(x))
+#define V_LOW32(x) ((fp4_VI)_mm256_castsi256_si128(_mm256_permutevar8x32_epi32(_mm256_castpd_si256(x), _mm256_setr_epi32(0, 2, 4, 6, 0, 2, 4, 6))))
+#include "fp_route.inc"
+#undef VL
+#undef FN
+#undef V
+#undef VI
+#undef VSET1
+#undef VMUL
+#undef VADD
+#undef VSUB
+#undef VFMSUB
+#undef VFNMADD
+#undef VRND
+#undef VI_SET1
+#undef VI_TO_V
+#undef V_LOW32
+#pragma GCC pop_options
+
+/* ---- AVX-512F/DQ, 8 gates per call ---- */
+#pragma GCC push_options
+#pragma GCC target("avx512f,avx512dq,avx512vl,avx2,fma")
+#define VL 8
+#define FN(x) fp8_##x
+typedef __m512d fp8_V;
+typedef u32 fp8_VI __attribute__((vector_size(32)));
+#define V fp8_V
+#define VI fp8_VI
+#define VSET1(c) _mm512_set1_pd(c)
+#define VMUL(a, b) _mm512_mul_pd(a, b)
+#define VADD(a, b) _mm512_add_pd(a, b)
+#define VSUB(a, b) _mm512_sub_pd(a, b)
+#define VFMSUB(a, b, c) _mm512_fmsub_pd(a, b, c)
+#define VFNMADD(a, b, c) _mm512_fnmadd_pd(a, b, c)
+#define VRND(a) _mm512_roundscale_pd(a, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC)
+#define VI_SET1(c) ((fp8_VI){(u32)(c), (u32)(c), (u32)(c), (u32)(c), (u32)(c), (u32)(c), (u32)(c), (u32)(c)})
+#define VI_TO_V(x) _mm512_cvtepi32_pd((__m256i)(x))
+#define V_LOW32(x) ((fp8_VI)_mm512_cvtepi64_epi32(_mm512_castpd_si512(x)))
+#include "fp_route.inc"
+#undef VL
+#undef FN
+#undef V
+#undef VI
+#undef VSET1
+#undef VMUL
+#undef VADD
+#undef VSUB
+#undef VFMSUB
+#undef VFNMADD
+#undef VRND
+#undef VI_SET1
+#undef VI_TO_V
+#undef V_LOW32
+#pragma GCC pop_options
+
+static int fp_lanes(void)
+{
+    static int lanes = 0;
+    if (!lanes) {
+        const char *force = getenv("ORC_FP_LANES"); /* 4 forces the AVX2 build on an AVX-512 machine (tests) */
+        __builtin_cpu_init();
+        lanes = (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && !(force && atoi(force) == 4)) ? 8 : 4;
+        if (!__builtin_cpu_supports("avx2") || !__builtin_cpu_supports("fma")) lanes = -1;
+    }
+    return lanes;
+}
+const char *orc_ntt_route(void)
+{
+    return fp_lanes() == 8 ? "C restatement, exact fp64-FMA NTT over a 49/51-bit prime, AVX-512: 8 gates per call in SIMD lanes"
+         : fp_lanes() == 4 ? "C restatement, exact fp64-FMA NTT over a 49/51-bit prime, AVX2: 4 gates per call in SIMD lanes"
+                           : "scalar C restatement with a Goldilocks NTT";
+}
+int orc_fp_lanes(void) { return fp_lanes(); }
+
+/* Bootstrapping key for route 3.  The prime: 0x24007A8500001 (49 bits; NOT the GPU's field for boolean sets)
+ * when the exact products of the set stay below its half, else 0x6060002B00001 (51 bits); NULL when neither
+ * holds them or the CPU lacks AVX2 + FMA. */
+void orc_bsk_fp_free(orc_bsk_fp *B);
+orc_bsk_fp *orc_bsk_fp_new(const orc_params *P, const u32 *bsk_std)
+{
+    if (fp_lanes() < 0) return NULL;
+    const int N = P->N, k1 = P->k + 1, l = P->pbs_l;
+    /* |exact coefficient| <= (k+1) l N (B/2) 2^31 */
+    const u128 bound = (u128)k1 * l * N * ((u64)1 << (P->pbs_logB - 1)) * ((u64)1 << 31);
+    const u64 p49 = 0x24007A8500001ull, p51 = 0x6060002B00001ull;
+    const u64 p = bound < p49 / 2 ? p49 : bound < p51 / 2 ? p51 : 0;
+    if (!p) return NULL;
+    orc_bsk_fp *B = (orc_bsk_fp *)malloc(sizeof(*B));
+    B->P = *P; B->T = fp_tables_new(N, p);
+    const size_t polys = (size_t)P->n * l * k1 * k1;
+    B->data = (double *)aligned_alloc(64, sizeof(double) * polys * N);
+    const int lanes = fp_lanes();
+    #pragma omp parallel for schedule(static)
+    for (long q0 = 0; q0 < (long)polys; q0 += lanes) {
+        const int cnt = (int)((long)polys - q0 < lanes ? (long)polys - q0 : lanes);
+        if (lanes == 8) fp8_bsk_convert(B, bsk_std, (size_t)q0, cnt);
+        else fp4_bsk_convert(B, bsk_std, (size_t)q0, cnt);
+    }
+    return B;
+}
+void orc_bsk_fp_free(orc_bsk_fp *B)
+{
+    if (!B) return;
+    free(B->T->psi_rev); free(B->T->psi_inv_rev); free(B->T); free(B->data); free(B);
+}
+double orc_bsk_fp_prime(const orc_bsk_fp *B) { return B ? B->T->p : 0.0; }
+
+/* `count` bootstraps (no keyswitch) by route 3; lwe / out: arrays of row pointers. */
+void orc_bootstrap_noks_fp(const orc_bsk_fp *B, const u32 *const *lwe, const u32 *tv, u32 *const *out, int count)
+{
+    const int lanes = fp_lanes();
+    for (int g = 0; g < count; g += lanes) {
+        const int c = count - g < lanes ? count - g : lanes;
+        if (lanes == 8) fp8_bootstrap(B, lwe + g, tv, out + g, c);
+        else fp4_bootstrap(B, lwe + g, tv, out + g, c);
+    }
+}
+
 /* Keyswitch big (k*N) -> small (n). ksk layout [k*N][ks_l][n+1]. */
 void orc_keyswitch(const orc_params *P, const u32 *ksk, const u32 *in_big, u32 *out)
 {
@@ -434,6 +625,65 @@ void orc_eval_level(const orc_params *P, const u32 *bsk_std, const orc_bsk_ntt *
     }
     for (int g = 0; g < count; g++) memcpy(wires + row * (size_t)outw[g], tmp + row * (size_t)g, sizeof(u32) * row);
     free(tmp);
+}
+
+/* The same level by route 3: the bootstraps of the level (a MUX is two) in groups of one SIMD vector of
+ * gates, OpenMP over the groups; then the keyswitch per gate.  Bit-identical to orc_eval_level. */
+void orc_eval_level_fp(const orc_params *P, const orc_bsk_fp *B, const u32 *ksk, u32 *wires, const int32_t *opcode,
+                       const int32_t *in0, const int32_t *in1, const int32_t *in2, const int32_t *outw, int count,
+                       int nthreads)
+{
+    const size_t row = (size_t)P->n + 1, brow = (size_t)P->k * P->N + 1;
+    const int lanes = fp_lanes();
+    int n_boot = 0;
+    for (int g = 0; g < count; g++)
+        n_boot += opcode[g] == ORC_MUX ? 2 : (opcode[g] == ORC_NOT || opcode[g] == ORC_BUF || opcode[g] == ORC_DFF ||
+                                              opcode[g] == ORC_CONST_ONE || opcode[g] == ORC_CONST_ZERO) ? 0 : 1;
+    u32 *tmp = (u32 *)malloc(sizeof(u32) * row * (size_t)count);
+    u32 *lin = (u32 *)malloc(sizeof(u32) * row * (size_t)(n_boot + 1));
+    u32 *big = (u32 *)malloc(sizeof(u32) * brow * (size_t)(n_boot + 1));
+    const u32 **lp = (const u32 **)malloc(sizeof(u32 *) * (size_t)(n_boot + 1));
+    u32 **bp = (u32 **)malloc(sizeof(u32 *) * (size_t)(n_boot + 1));
+    int *first = (int *)malloc(sizeof(int) * (size_t)(count + 1));
+    u32 *tv = (u32 *)malloc(sizeof(u32) * (size_t)P->N);
+    for (int j = 0; j < P->N; j++) tv[j] = PT_TRUE;
+    int nb = 0;
+    for (int g = 0; g < count; g++) {
+        const u32 *a = in0[g] >= 0 ? wires + row * (size_t)in0[g] : NULL;
+        const u32 *b = in1[g] >= 0 ? wires + row * (size_t)in1[g] : NULL;
+        const u32 *c = in2[g] >= 0 ? wires + row * (size_t)in2[g] : NULL;
+        first[g] = nb;
+        const int op = opcode[g];
+        if (op == ORC_NOT || op == ORC_BUF || op == ORC_DFF || op == ORC_CONST_ONE || op == ORC_CONST_ZERO) {
+            orc_gate_linear_only(P->n, op, a, tmp + row * (size_t)g);
+            continue;
+        }
+        for (int which = 0; which < (op == ORC_MUX ? 2 : 1); which++, nb++) {
+            orc_gate_lincomb(P->n, op, which, a, b, c, lin + row * (size_t)nb);
+            lp[nb] = lin + row * (size_t)nb;
+            bp[nb] = big + brow * (size_t)nb;
+        }
+    }
+    first[count] = nb;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int g = 0; g < nb; g += lanes)
+        orc_bootstrap_noks_fp(B, lp + g, tv, bp + g, nb - g < lanes ? nb - g : lanes);
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int g = 0; g < count; g++) {
+        if (first[g + 1] == first[g]) continue;
+        u32 *bg = big + brow * (size_t)first[g];
+        if (opcode[g] == ORC_MUX) {
+            const u32 *b2 = bg + brow;
+            for (size_t t = 0; t < brow; t++) bg[t] += b2[t];
+            bg[brow - 1] += PT_TRUE;
+        }
+        orc_keyswitch(P, ksk, bg, tmp + row * (size_t)g);
+    }
+    for (int g = 0; g < count; g++) memcpy(wires + row * (size_t)outw[g], tmp + row * (size_t)g, sizeof(u32) * row);
+    free(tmp); free(lin); free(big); free(lp); free(bp); free(first); free(tv);
 }
 
 /* phase = b - <a, s>; decrypt: phase < 2^31 => true (reference src/circuit.rs:948) */

@@ -172,3 +172,87 @@ def test_encrypted_two_bit_adder_oracle():  # K-1/K-2: circuit_test.rs:47-94 wit
             orc.eval_level(wires, ops[s], i0[s], i1[s], i2[s], out[s])
         for w in names:  # every wire, not only outputs
             assert ck.decrypt(wires[index[w]]) == bool(ptxt[w].value), w
+
+
+# ---- route 3: the SIMD fp64 route that bench.py times as the CPU baseline (oracle/fp_route.inc) ----------------
+_FP_CHECK = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import helm_amd, oracle
+assert oracle.fp_lanes() == %d, oracle.fp_lanes()
+for name in ("toy", "toy_k2", "toy_1024"):
+    ck = helm_amd.ClientKey.generate(name, seed=7)
+    p = ck.params
+    o_sb = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk, use_ntt=False)
+    o = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True, use_fp=True)
+    rng = np.random.default_rng(5)
+    lwe = rng.integers(0, 2**32, size=(13, p.n + 1), dtype=np.uint32)  # 13: a full vector of lanes and a partial one
+    lwe[0] = ck.encrypt(True)
+    lwe[4, :] = 0                                                     # every rotation zero
+    lwe[5, :p.n] = 0                                                  # zero mask, non-zero body
+    tv = rng.integers(0, 2**32, size=p.N, dtype=np.uint32)
+    got = o.bootstrap_noks_fp(lwe, tv)
+    for g in range(len(lwe)):
+        assert np.array_equal(got[g], o.bootstrap_noks(lwe[g], tv)), (name, g, "fp vs Goldilocks")
+    assert np.array_equal(got[1], o_sb.bootstrap_noks(lwe[1], tv)), (name, "fp vs schoolbook")
+    # a whole level with every gate type, MUX included (two bootstraps, one keyswitch)
+    bits = rng.integers(0, 2, 6).astype(bool)
+    n_g = 21
+    ops = np.array([oracle.AND, oracle.OR, oracle.NAND, oracle.NOR, oracle.XOR, oracle.XNOR, oracle.MUX, oracle.NOT,
+                    oracle.BUF, oracle.CONST_ONE, oracle.CONST_ZERO] * 2, np.int32)[:n_g]
+    i0, i1, i2 = (rng.integers(0, 6, n_g).astype(np.int32) for _ in range(3))
+    out = np.arange(6, 6 + n_g, dtype=np.int32)
+    w1 = np.zeros((6 + n_g, p.n + 1), np.uint32)
+    w1[:6] = ck.encrypt(bits)
+    w2 = w1.copy()
+    o.eval_level_fp(w1, ops, i0, i1, i2, out, nthreads=2)
+    o.eval_level(w2, ops, i0, i1, i2, out, nthreads=2)
+    assert np.array_equal(w1, w2), (name, "level")
+print("ok", hex(o.fp_prime()))
+"""
+
+
+@pytest.mark.parametrize("lanes", [4, 8])
+def test_simd_fp64_route_equals_the_integer_routes(lanes):
+    """Route 3 (exact fp64-FMA NTT over a 49/51-bit prime, one gate per SIMD lane) against route 2 (Goldilocks) and
+    route 1 (schoolbook) bit for bit: single bootstraps incl. partial lane groups and all-zero rotations, and a level
+    with every gate type.  Both builds: AVX-512 (8 lanes) where the CPU has it, AVX2 (4 lanes, forced)."""
+    import subprocess
+    import sys
+    if oracle.fp_lanes() < 0:
+        pytest.skip("no AVX2 + FMA on this CPU")
+    if lanes == 8 and oracle.fp_lanes() != 8:
+        pytest.skip("no AVX-512 on this CPU: the 8-lane build cannot run here")
+    env = dict(os.environ, ORC_FP_LANES=str(lanes), OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-c", _FP_CHECK % (os.path.dirname(HERE), lanes)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+
+
+def test_simd_fp64_route_full_size_sets():
+    """boolean_default runs in the 49-bit prime 0x24007A8500001 (a different field from the GPU's), helm_cuda
+    (helm.rs:141-146: N = 1024, base 2^7) needs the 51-bit one; both equal the Goldilocks route on a mixed level."""
+    if oracle.fp_lanes() < 0:
+        pytest.skip("no AVX2 + FMA on this CPU")
+    for name, prime in (("boolean_default", 0x24007A8500001), ("helm_cuda", 0x6060002B00001)):
+        ck = helm_amd.ClientKey.generate(name, seed=5)
+        p = ck.params
+        o = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True, use_fp=True)
+        assert o.fp_prime() == prime
+        rng = np.random.default_rng(3)
+        bits = rng.integers(0, 2, 8).astype(bool)
+        n_g = 10
+        ops = rng.choice([oracle.AND, oracle.XOR, oracle.NOR, oracle.MUX], n_g).astype(np.int32)
+        i0, i1, i2 = (rng.integers(0, 8, n_g).astype(np.int32) for _ in range(3))
+        out = np.arange(8, 8 + n_g, dtype=np.int32)
+        w1 = np.zeros((8 + n_g, p.n + 1), np.uint32)
+        w1[:8] = ck.encrypt(bits)
+        w2 = w1.copy()
+        o.eval_level_fp(w1, ops, i0, i1, i2, out, nthreads=4)
+        o.eval_level(w2, ops, i0, i1, i2, out, nthreads=4)
+        assert np.array_equal(w1, w2), name
+        dec = ck.decrypt(w1[8:])
+        for g in range(n_g):
+            a, b, c = bits[i0[g]], bits[i1[g]], bits[i2[g]]
+            want = {oracle.AND: a & b, oracle.XOR: a ^ b, oracle.NOR: not (a | b), oracle.MUX: a if c else b}[int(ops[g])]
+            assert bool(dec[g]) == bool(want), (name, g)
