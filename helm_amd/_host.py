@@ -26,6 +26,7 @@ HOST_API = {
     "helm_host_circuit_level_map": (vp, [vp]),
     "helm_host_circuit_initialize_wire_map": (C.c_int, [vp, cp, cp, cp, C.POINTER(vp)]),
     "helm_host_circuit_evaluate": (C.c_int, [vp, cp, C.POINTER(vp)]),
+    "helm_host_preprocess": (C.c_int, [cp, C.c_int, C.POINTER(vp)]),
     "helm_host_pack_levels": (C.c_int, [C.POINTER(C.c_int32)] * 5 + [C.POINTER(C.c_int64), C.c_int64, C.c_int64] +
                               [C.POINTER(C.c_int64)] * 3),
     "helm_host_enc_map_new": (C.c_int, [vp, C.POINTER(vp)]),

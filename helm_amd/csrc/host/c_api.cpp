@@ -196,6 +196,21 @@ int helm_host_circuit_evaluate(helm_circuit *c, const char *wire_map, char **out
     return guard([&] { *out_map = dup(map_text(c->c.evaluate(parse_map(wire_map)))); });
 }
 
+int helm_host_preprocess(const char *text, int arithmetic, char **out)
+{
+    if (!text || !out) {
+        g_err = "null argument";
+        return -1;
+    }
+    try {
+        *out = dup(preprocess(text, arithmetic != 0));
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 int helm_host_pack_levels(const int32_t *opcode, const int32_t *in0, const int32_t *in1, const int32_t *in2,
                           const int32_t *out, const int64_t *level_offsets, int64_t n_levels, int64_t quantum,
                           int64_t *order, int64_t *new_offsets, int64_t *n_launches)

@@ -141,6 +141,10 @@ class Circuit {
     std::map<size_t, std::vector<Gate>> level_map_;
 };
 
+// Raw synthesis output (Yosys structural Verilog; with `arithmetic`, behavioural assign statements) -> the
+// netlist dialect read_verilog_file accepts (preprocessor.cpp; reference README.md:116-120,133-137).
+std::string preprocess(const std::string &text, bool arithmetic);
+
 // Launch packing (level_pack.cpp): the level map of circuit.rs:174-239 as index arrays -> `order`
 // (new position -> gate) and `new_off` (launch boundaries) such that every launch but the last few
 // holds a whole number of `quantum` bootstraps.  Returns 0, or 1 when the schedule was kept as it is.

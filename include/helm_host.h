@@ -60,6 +60,11 @@ int helm_host_circuit_initialize_wire_map(const helm_circuit *c, const char *wir
                                           const char *ptxt_type, char **out_map);
 int helm_host_circuit_evaluate(helm_circuit *c, const char *wire_map, char **out_map);
 
+/* The benchmark suite's `preprocessor` binary (reference README.md:116-120,133-137; its source lives in an
+ * un-vendored submodule): raw Yosys structural Verilog - or, with `arithmetic`, behavioural assign statements
+ * over + - * / << >> - to the dialect helm_host_read_verilog_* reads.  *out is malloc'd text. */
+int helm_host_preprocess(const char *text, int arithmetic, char **out);
+
 /* Launch packing of a level schedule (the level loop of circuit.rs:524-543 made GPU-shaped): gates in level
  * order as index arrays (helm_hip_program_create's arguments) -> `order[total]` (new position -> gate index)
  * and `new_offsets` (room for total + 1 entries; *n_launches + 1 are written): dependency order is kept, a

@@ -275,3 +275,28 @@ def test_division_u128(keys):
     enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U128(a), "B": PtxtType.U128(b), "Z": PtxtType.U128(0)})
     out = ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, "u128"), True)
     assert out["Q"].value == a // b and out["QZ"].value == (1 << 128) - 1
+
+
+def test_preprocessed_behavioural_chi_squared_u32(keys):
+    """README.md:116-120 end to end: behavioural arithmetic Verilog -> preprocessor --arithmetic -> arithmetic mode
+    (BASELINE config 5), decrypting to the chi-squared known answer (2, 7, 9) -> (529, 242, 275, 1250)."""
+    from helm_amd.preprocessor import preprocess
+    client_key, server_key = keys
+    raw = """module chi_squared(N0, N1, N2, alpha, beta1, beta2, beta3);
+  input [31:0] N0, N1, N2;
+  output [31:0] alpha, beta1, beta2, beta3;
+  wire [31:0] t, u, v;
+  assign t = 4 * N0 * N2 - N1 * N1;
+  assign alpha = t * t;
+  assign u = 2 * N0 + N1;
+  assign v = 2 * N2 + N1;
+  assign beta1 = 2 * (u * u);
+  assign beta2 = u * v;
+  assign beta3 = (v * v) << 1;
+endmodule
+"""
+    circuit, wire_set, _, _ = _circuit(preprocess(raw, arithmetic=True), is_arith=True, is_text=True)
+    ac = ArithCircuit(client_key, server_key, circuit)
+    enc = ac.encrypt_inputs(wire_set, {"N0": PtxtType.U32(2), "N1": PtxtType.U32(7), "N2": PtxtType.U32(9)})
+    out = {k: v.value for k, v in ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, "u32"), True).items()}
+    assert out == {"alpha": 529, "beta1": 242, "beta2": 275, "beta3": 1250}
