@@ -171,7 +171,19 @@ CLIENT_API = {
     "helm_client_phase": (C.c_int, [vp, u32p, C.c_int64, C.c_int, u32p]),
 }
 
-for _lib, _api in ((hip, HIP_API), (host, CLIENT_API), (hip, SI_API), (host, SI_CLIENT_API)):
+KEYS_API = {
+    "helm_keys_last_error": (C.c_char_p, []),
+    "helm_keys_bsk32_from_tfhe": (C.c_int, [C.POINTER(Params), u32p, u32p, C.c_size_t]),
+    "helm_keys_bsk32_to_tfhe": (C.c_int, [C.POINTER(Params), u32p, u32p, C.c_size_t]),
+    "helm_keys_ksk32_from_tfhe": (C.c_int, [C.POINTER(Params), u32p, u32p, C.c_size_t]),
+    "helm_keys_ksk32_to_tfhe": (C.c_int, [C.POINTER(Params), u32p, u32p, C.c_size_t]),
+    "helm_keys_bsk64_from_tfhe": (C.c_int, [C.POINTER(SiParams), u64p, u64p, C.c_size_t]),
+    "helm_keys_bsk64_to_tfhe": (C.c_int, [C.POINTER(SiParams), u64p, u64p, C.c_size_t]),
+    "helm_keys_ksk64_from_tfhe": (C.c_int, [C.POINTER(SiParams), u64p, u64p, C.c_size_t]),
+    "helm_keys_ksk64_to_tfhe": (C.c_int, [C.POINTER(SiParams), u64p, u64p, C.c_size_t]),
+}
+
+for _lib, _api in ((hip, HIP_API), (host, CLIENT_API), (hip, SI_API), (host, SI_CLIENT_API), (host, KEYS_API)):
     for _name, (_res, _args) in _api.items():
         _fn = getattr(_lib, _name)  # AttributeError here = header/library mismatch
         _fn.restype = _res

@@ -97,6 +97,23 @@ int helm_si_client_encrypt(helm_si_client_key *key, const uint64_t *values, int6
 int helm_si_client_decrypt(const helm_si_client_key *key, const uint64_t *lwe, int64_t count, uint64_t *values_out);
 int helm_si_client_phase(const helm_si_client_key *key, const uint64_t *lwe, int64_t count, int small, uint64_t *phase_out);
 
+/* ---- key import: tfhe-rs 0.4 containers <-> this ABI (helm_amd/csrc/host/key_import.cpp) ----------
+ * What the Rust shim (rust/helm-hip) calls between tfhe's `LweBootstrapKey` / `LweKeyswitchKey`
+ * containers (as_ref() words of the standard-domain keys generated from HELM's ClientKey,
+ * reference src/bin/helm.rs:241,301) and helm_hip_load_*_key / helm_si_load_*_key.
+ * [RECALLED] orders, stated in key_import.cpp and INTEGRATION.md: the BSK is the same order (copied);
+ * the KSK stores each block's levels last-to-first, this ABI first-to-last (levels reversed).
+ * n_words must be the key's size for the parameter set; 0 or HELM_ERR_INVALID (helm_keys_last_error()). */
+const char *helm_keys_last_error(void);
+int helm_keys_bsk32_from_tfhe(const helm_hip_params *p, const uint32_t *tfhe, uint32_t *abi, size_t n_words);
+int helm_keys_bsk32_to_tfhe(const helm_hip_params *p, const uint32_t *abi, uint32_t *tfhe, size_t n_words);
+int helm_keys_ksk32_from_tfhe(const helm_hip_params *p, const uint32_t *tfhe, uint32_t *abi, size_t n_words);
+int helm_keys_ksk32_to_tfhe(const helm_hip_params *p, const uint32_t *abi, uint32_t *tfhe, size_t n_words);
+int helm_keys_bsk64_from_tfhe(const helm_si_params *p, const uint64_t *tfhe, uint64_t *abi, size_t n_words);
+int helm_keys_bsk64_to_tfhe(const helm_si_params *p, const uint64_t *abi, uint64_t *tfhe, size_t n_words);
+int helm_keys_ksk64_from_tfhe(const helm_si_params *p, const uint64_t *tfhe, uint64_t *abi, size_t n_words);
+int helm_keys_ksk64_to_tfhe(const helm_si_params *p, const uint64_t *abi, uint64_t *tfhe, size_t n_words);
+
 #ifdef __cplusplus
 }
 #endif

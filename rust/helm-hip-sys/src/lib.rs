@@ -1,0 +1,97 @@
+//! `extern "C"` view of include/helm_hip.h, include/helm_shortint.h and the key-import helpers of
+//! include/helm_client.h.  One declaration per exported symbol the shim uses; field order and widths
+//! follow the headers (checked there by tests/test_abi.py against the built libraries).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct helm_hip_params {
+    pub torus_bits: i32,
+    pub n: i32,
+    pub k: i32,
+    pub N: i32,
+    pub pbs_l: i32,
+    pub pbs_logB: i32,
+    pub ks_l: i32,
+    pub ks_logB: i32,
+    pub pbs_order: i32,       // 0 = bootstrap then keyswitch (tfhe boolean)
+    pub grouping_factor: i32, // 1
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct helm_si_params {
+    pub n: i32,
+    pub k: i32,
+    pub N: i32,
+    pub pbs_l: i32,
+    pub pbs_logB: i32,
+    pub ks_l: i32,
+    pub ks_logB: i32,
+    pub message_modulus: i32,
+    pub carry_modulus: i32,
+    pub grouping_factor: i32, // 0 | 1 classical, 2 | 3 multi-bit
+}
+
+#[repr(C)] pub struct helm_hip_ctx { _p: [u8; 0] }
+#[repr(C)] pub struct helm_hip_wires { _p: [u8; 0] }
+#[repr(C)] pub struct helm_hip_program { _p: [u8; 0] }
+#[repr(C)] pub struct helm_si_ctx { _p: [u8; 0] }
+#[repr(C)] pub struct helm_si_wires { _p: [u8; 0] }
+
+pub const HELM_GATE_AND: i32 = 0;  // = GateType discriminants, reference src/gates.rs:23-45
+pub const HELM_GATE_DFF: i32 = 1;
+pub const HELM_GATE_MUX: i32 = 3;
+pub const HELM_GATE_NOT: i32 = 6;
+
+extern "C" {
+    // ---- include/helm_hip.h ---------------------------------------------------------------
+    pub fn helm_hip_last_error() -> *const c_char;
+    pub fn helm_hip_device_count() -> c_int;
+    pub fn helm_hip_ctx_create(device_id: c_int, params: *const helm_hip_params, out: *mut *mut helm_hip_ctx) -> c_int;
+    pub fn helm_hip_ctx_destroy(ctx: *mut helm_hip_ctx) -> c_int;
+    pub fn helm_hip_set_stream(ctx: *mut helm_hip_ctx, hip_stream: *mut c_void) -> c_int;
+    pub fn helm_hip_sync(ctx: *mut helm_hip_ctx) -> c_int;
+    pub fn helm_hip_launch_quantum(ctx: *const helm_hip_ctx) -> i64;
+    pub fn helm_hip_load_bootstrap_key(ctx: *mut helm_hip_ctx, bsk_std: *const u32, n_words: usize) -> c_int;
+    pub fn helm_hip_load_keyswitch_key(ctx: *mut helm_hip_ctx, ksk: *const u32, n_words: usize) -> c_int;
+    pub fn helm_hip_wires_alloc(ctx: *mut helm_hip_ctx, n_wires: i64, out: *mut *mut helm_hip_wires) -> c_int;
+    pub fn helm_hip_wires_free(ctx: *mut helm_hip_ctx, w: *mut helm_hip_wires) -> c_int;
+    pub fn helm_hip_wires_upload(ctx: *mut helm_hip_ctx, w: *mut helm_hip_wires, idx: *const i32, lwe_host: *const u32, count: i64) -> c_int;
+    pub fn helm_hip_wires_download(ctx: *mut helm_hip_ctx, w: *mut helm_hip_wires, idx: *const i32, lwe_host: *mut u32, count: i64) -> c_int;
+    pub fn helm_hip_wires_set_trivial(ctx: *mut helm_hip_ctx, w: *mut helm_hip_wires, idx: *const i32, value: *const u8, count: i64) -> c_int;
+    pub fn helm_hip_eval_gate_level(ctx: *mut helm_hip_ctx, w: *mut helm_hip_wires, opcode: *const i32, in0: *const i32,
+                                    in1: *const i32, in2: *const i32, out: *const i32, count: i64) -> c_int;
+    pub fn helm_hip_program_create(ctx: *mut helm_hip_ctx, opcode: *const i32, in0: *const i32, in1: *const i32, in2: *const i32,
+                                   out: *const i32, level_offsets: *const i64, n_levels: i64, prog: *mut *mut helm_hip_program) -> c_int;
+    pub fn helm_hip_program_run(ctx: *mut helm_hip_ctx, prog: *mut helm_hip_program, w: *mut helm_hip_wires, level_begin: i64, level_end: i64) -> c_int;
+    pub fn helm_hip_program_destroy(ctx: *mut helm_hip_ctx, prog: *mut helm_hip_program) -> c_int;
+    pub fn helm_hip_program_level_pbs(prog: *mut helm_hip_program, level: i64) -> i64;
+
+    // ---- include/helm_host.h: launch packing of the level map -------------------------------
+    pub fn helm_host_pack_levels(opcode: *const i32, in0: *const i32, in1: *const i32, in2: *const i32, out: *const i32,
+                                 level_offsets: *const i64, n_levels: i64, quantum: i64, order: *mut i64,
+                                 new_offsets: *mut i64, n_launches: *mut i64) -> c_int;
+
+    // ---- include/helm_client.h: key import ---------------------------------------------------
+    pub fn helm_keys_last_error() -> *const c_char;
+    pub fn helm_keys_bsk32_from_tfhe(p: *const helm_hip_params, tfhe: *const u32, abi: *mut u32, n_words: usize) -> c_int;
+    pub fn helm_keys_ksk32_from_tfhe(p: *const helm_hip_params, tfhe: *const u32, abi: *mut u32, n_words: usize) -> c_int;
+    pub fn helm_keys_bsk64_from_tfhe(p: *const helm_si_params, tfhe: *const u64, abi: *mut u64, n_words: usize) -> c_int;
+    pub fn helm_keys_ksk64_from_tfhe(p: *const helm_si_params, tfhe: *const u64, abi: *mut u64, n_words: usize) -> c_int;
+
+    // ---- include/helm_shortint.h (LUT / arithmetic modes) -------------------------------------
+    pub fn helm_si_ctx_create(device_id: c_int, params: *const helm_si_params, out: *mut *mut helm_si_ctx) -> c_int;
+    pub fn helm_si_ctx_destroy(ctx: *mut helm_si_ctx) -> c_int;
+    pub fn helm_si_load_bootstrap_key(ctx: *mut helm_si_ctx, bsk_std: *const u64, n_words: usize) -> c_int;
+    pub fn helm_si_load_keyswitch_key(ctx: *mut helm_si_ctx, ksk: *const u64, n_words: usize) -> c_int;
+    pub fn helm_si_wires_alloc(ctx: *mut helm_si_ctx, n_rows: i64, out: *mut *mut helm_si_wires) -> c_int;
+    pub fn helm_si_wires_free(ctx: *mut helm_si_ctx, w: *mut helm_si_wires) -> c_int;
+    pub fn helm_si_wires_upload(ctx: *mut helm_si_ctx, w: *mut helm_si_wires, idx: *const i32, lwe: *const u64, count: i64) -> c_int;
+    pub fn helm_si_wires_download(ctx: *mut helm_si_ctx, w: *mut helm_si_wires, idx: *const i32, lwe: *mut u64, count: i64) -> c_int;
+    pub fn helm_si_wires_set_trivial(ctx: *mut helm_si_ctx, w: *mut helm_si_wires, idx: *const i32, value: *const u64, count: i64) -> c_int;
+    pub fn helm_si_eval_lut_level(ctx: *mut helm_si_ctx, w: *mut helm_si_wires, arity: *const i32, in_idx: *const i32, max_in: c_int,
+                                  table: *const u64, out_idx: *const i32, count: i64) -> c_int;
+    pub fn helm_si_sync(ctx: *mut helm_si_ctx) -> c_int;
+}

@@ -1,0 +1,36 @@
+"""The C stand-in for the Rust shim (rust/helm-hip cannot be compiled here: no rustc): tests/c/shim_sequence.c
+makes the shim's calls in the shim's order against the two shared libraries.  CPU: it compiles and links against
+include/*.h with nothing but the C ABI, and without a GPU it fails loudly at helm_hip_ctx_create (no fallback).
+GPU: it runs the 2-bit adder known answer of reference tests/circuit_test.rs:17-45 at the full parameter set."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "helm_amd", "csrc")
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "shim_sequence")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "shim_sequence.c"), "-o", exe, "-L", CSRC, "-lhelm_host", "-lhelm_hip",
+                           f"-Wl,-rpath,{CSRC}"])
+    return exe
+
+
+def test_shim_sequence_builds_against_the_c_abi_and_refuses_to_run_without_a_gpu(tmp_path):
+    from helm_amd import _native
+    exe = _build(tmp_path)
+    if _native.hip.helm_hip_device_count() > 0:
+        pytest.skip("a GPU is present: the run is covered by the gpu test")
+    r = subprocess.run([exe, "toy"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "helm_hip_ctx_create failed" in r.stderr and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("params", ["boolean_default", "helm_cuda"])
+def test_shim_sequence_on_the_gpu(tmp_path, params):
+    exe = _build(tmp_path)
+    r = subprocess.run([exe, params], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
