@@ -17,15 +17,19 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, blocks, result_dir):
+def _worker(rank, world, port, blocks, result_dir, backend="gloo"):
     import helm_amd
     from helm_amd import Circuit, verilog_parser
     from helm_amd.distributed import GpuLevelExecutor, ShardedRunner, level_arrays
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    dev = rank if backend == "nccl" else 0  # RCCL needs one GPU per rank; gloo shares cuda:0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     ck = helm_amd.ClientKey.generate("toy_k2", seed=5)
-    sk = helm_amd.ServerKey(ck, device=0)
+    sk = helm_amd.ServerKey(ck, device=dev)
     # no sk.set_stream() here: ShardedRunner binds the engine to torch's current stream itself (an engine
     # left on its own stream would run the all-gather unordered with the shard kernels)
     # the AES netlist: 207 levels, several hundred gates wide with `blocks` copies - launches long enough
@@ -74,4 +78,20 @@ def test_two_ranks_on_one_gpu(tmp_path):
     for r in range(2):
         same, sharded, nl = np.load(tmp_path / f"rank{r}.npy")
         assert same == 1, f"rank {r}: sharded evaluation differs from the single-process one"
+        assert 0 < sharded <= nl
+
+
+def test_two_ranks_over_rccl(tmp_path):
+    """The same run over the real `nccl` backend (RCCL over xGMI), one GPU per rank.  Needs two GPUs: on a one-GPU
+    box this is reported as an expected failure - RCCL NOT exercised - rather than passing silently."""
+    if torch.cuda.device_count() < 2:
+        pytest.xfail("RCCL not exercised: this box has one GPU (the all-gather ran over gloo only)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, 4, str(tmp_path), "nccl"), nprocs=2, join=True)
+    for r in range(2):
+        same, sharded, nl = np.load(tmp_path / f"rank{r}.npy")
+        assert same == 1, f"rank {r}: evaluation sharded over RCCL differs from the single-process one"
         assert 0 < sharded <= nl
