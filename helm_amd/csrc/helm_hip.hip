@@ -839,6 +839,126 @@ __global__ __launch_bounds__(256) void k_keyswitch(const KsJob *__restrict__ job
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Keyswitch on the matrix cores (ks_l in {1, 2, 4, 8}): the keyswitch of a level is a GEMM
+//   out[g][c] = body_g [c == n] - sum_r D[g][r] * K[r][c]     (mod 2^32),  r = t * ks_l + level
+// with D the signed digits (|d| <= 2^(logB-1) <= 64: int8) of the big LWE's mask words and K the key.
+// K is split into its four bytes, each recentred to a signed byte K_b - 128 (v_mfma_i32_16x16x64_i8 is
+// signed x signed):   sum_r d K = sum_b 2^(8b) sum_r d (K_b - 128)  +  0x80808080 * sum_r d
+// - four int8 GEMMs with exact int32 accumulators (|sum| <= 4096 * 64 * 128 < 2^25) and a per-gate
+// correction.  k_ks_digits decomposes once per gate (MUX recombination folded in) and writes D in
+// A-fragment order; k_ks_mfma: one wave = 64 gates x 32 key columns, the four gate tiles of a wave reuse
+// every B fragment (1 KiB, coalesced) four times.  Integer arithmetic: bit-identical to k_keyswitch.
+// ------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// fragment (tile, kc): 64 lanes x 16 bytes; lane = (k-quarter << 4 | row or column), byte j: k = 64 kc + 16 kq + j
+template <int KSL>
+__global__ __launch_bounds__(256) void k_ks_digits(const KsJob *__restrict__ jobs, const uint32_t *__restrict__ big,
+                                                   int8_t *__restrict__ dig, int32_t *__restrict__ dsum,
+                                                   uint32_t *__restrict__ body, int kN, int logB, int count, int kchunks)
+{
+    const int g = blockIdx.x; // padded gate index; g >= count: an all-zero row
+    __shared__ int red[256];
+    int local = 0;
+    const size_t brow = (size_t)kN + 1;
+    const bool live = g < count;
+    KsJob job{};
+    if (live) job = jobs[g];
+    int8_t *tile = dig + (size_t)(g >> 4) * kchunks * 1024;
+    for (int t = threadIdx.x; t < kN; t += 256) {
+        int d[KSL];
+        if (live) {
+            uint32_t v = big[brow * (size_t)job.big0 + t];
+            if (job.big1 >= 0) v += big[brow * (size_t)job.big1 + t];
+            decompose<KSL>(v, logB, d);
+        } else {
+#pragma unroll
+            for (int j = 0; j < KSL; j++) d[j] = 0;
+        }
+        const int r0 = t * KSL, kc = r0 >> 6, kq = (r0 & 63) >> 4, j0 = r0 & 15;
+        int8_t *dst = tile + ((size_t)kc * 64 + (kq << 4 | (g & 15))) * 16 + j0;
+#pragma unroll
+        for (int j = 0; j < KSL; j++) {
+            dst[j] = (int8_t)d[j];
+            local += d[j];
+        }
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        dsum[g] = red[0];
+        uint32_t b = 0;
+        if (live) {
+            b = big[brow * (size_t)job.big0 + kN] + job.add_body;
+            if (job.big1 >= 0) b += big[brow * (size_t)job.big1 + kN];
+        }
+        body[g] = b;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_ks_mfma(const KsJob *__restrict__ jobs, const int8_t *__restrict__ dig,
+                                                const int32_t *__restrict__ dsum, const uint32_t *__restrict__ body,
+                                                const int8_t *__restrict__ kplanes, uint32_t *__restrict__ out, int n,
+                                                int count, int kchunks, int ctiles)
+{
+    constexpr int GT = 4, CT = 2; // gate tiles (16 gates each) and column tiles (16 columns each) per wave
+    const int lane = threadIdx.x;
+    const int gt0 = blockIdx.x * GT, ct0 = blockIdx.y * CT;
+    const v4i *A = reinterpret_cast<const v4i *>(dig) + (size_t)gt0 * kchunks * 64 + lane;
+    const v4i *B = reinterpret_cast<const v4i *>(kplanes) + lane;
+    const size_t plane = (size_t)ctiles * kchunks * 64; // fragments of one byte plane, in v4i units
+    v4i acc[GT][CT][4];
+#pragma unroll
+    for (int a = 0; a < GT; a++)
+#pragma unroll
+        for (int c = 0; c < CT; c++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc[a][c][b] = v4i{0, 0, 0, 0};
+    for (int kc = 0; kc < kchunks; kc++) {
+        v4i fa[GT], fb[CT][4];
+#pragma unroll
+        for (int a = 0; a < GT; a++) fa[a] = A[((size_t)a * kchunks + kc) * 64];
+#pragma unroll
+        for (int c = 0; c < CT; c++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int ct = ct0 + c < ctiles ? ct0 + c : ctiles - 1; // a wave past the last tile repeats it (discarded)
+                fb[c][b] = B[(size_t)b * plane + ((size_t)ct * kchunks + kc) * 64];
+            }
+#pragma unroll
+        for (int a = 0; a < GT; a++)
+#pragma unroll
+            for (int c = 0; c < CT; c++)
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    acc[a][c][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[c][b], acc[a][c][b], 0, 0, 0);
+    }
+    // C/D map: column = lane & 15, row = (lane >> 4) * 4 + reg
+    const size_t krow = (size_t)n + 1;
+#pragma unroll
+    for (int a = 0; a < GT; a++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int g = (gt0 + a) * 16 + (lane >> 4) * 4 + reg;
+            if (g >= count) continue;
+            const uint32_t corr = 0x80808080u * (uint32_t)dsum[g];
+            uint32_t *dst = out + krow * (size_t)jobs[g].out;
+#pragma unroll
+            for (int c = 0; c < CT; c++) {
+                const int col = (ct0 + c) * 16 + (lane & 15);
+                if (ct0 + c >= ctiles || col > n) continue;
+                const uint32_t s = (uint32_t)acc[a][c][0][reg] + ((uint32_t)acc[a][c][1][reg] << 8) +
+                                   ((uint32_t)acc[a][c][2][reg] << 16) + ((uint32_t)acc[a][c][3][reg] << 24) + corr;
+                dst[col] = (col == n ? body[g] : 0u) - s;
+            }
+        }
+}
+
 // rows named by the keyswitch jobs <- 0 (before a row-split keyswitch accumulates into them)
 __global__ __launch_bounds__(256) void k_ks_zero(const KsJob *__restrict__ jobs, uint32_t *__restrict__ out, int n)
 {
@@ -1023,6 +1143,12 @@ struct helm_hip_ctx {
     double n_inv = 0;
     double *bsk = nullptr;
     uint32_t *ksk = nullptr;
+    int8_t *ksk_planes = nullptr; // matrix-core keyswitch: the key's four byte planes as signed bytes, B-fragment order
+    int ks_kchunks = 0, ks_ctiles = 0;
+    int ks_mfma = 1;             // HELM_HIP_KS_MFMA=0: the vector-ALU keyswitch for every launch
+    DevBuf<int8_t> d_dig;
+    DevBuf<int32_t> d_dsum;
+    DevBuf<uint32_t> d_body;
     uint32_t *tv_bool = nullptr; // one row: all +1/8
     bool have_bsk = false, have_ksk = false;
     int field = 51; // Fp<51> or Fp<49> (lazy), chosen from the parameter set
@@ -1335,6 +1461,28 @@ static hipError_t launch_ks(helm_hip_ctx *ctx, const KsJob *jobs, int64_t count,
 {
     const helm_hip_params &P = ctx->P;
     const int kN = P.k * P.N;
+    if (ctx->ksk_planes && ctx->ks_mfma) {
+        // matrix-core path: digits once per gate, then the int8 GEMM over the key's byte planes
+        const int64_t padded = (count + 63) / 64 * 64;
+        if (ctx->d_dig.ensure((size_t)padded * kN * P.ks_l) || ctx->d_dsum.ensure((size_t)padded) || ctx->d_body.ensure((size_t)padded))
+            return hipErrorOutOfMemory;
+#define KSD_CASE(LV)                                                                                              \
+    case LV:                                                                                                      \
+        hipLaunchKernelGGL(k_ks_digits<LV>, dim3((unsigned)padded), dim3(256), 0, ctx->stream, jobs, big, ctx->d_dig.p, \
+                           ctx->d_dsum.p, ctx->d_body.p, kN, P.ks_logB, (int)count, ctx->ks_kchunks);            \
+        break;
+        switch (P.ks_l) {
+            KSD_CASE(1) KSD_CASE(2) KSD_CASE(4) KSD_CASE(8)
+        default: return hipErrorInvalidValue;
+        }
+#undef KSD_CASE
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_ks_mfma, dim3((unsigned)(padded / 64), (unsigned)((ctx->ks_ctiles + 1) / 2)), dim3(64), 0, ctx->stream,
+                           jobs, ctx->d_dig.p, ctx->d_dsum.p, ctx->d_body.p, ctx->ksk_planes, out, P.n, (int)count,
+                           ctx->ks_kchunks, ctx->ks_ctiles);
+        return hipGetLastError();
+    }
     const unsigned gx = (unsigned)((count + 3) / 4), gy = (unsigned)((P.n + 1 + 255) / 256);
     // narrow launches: split the key rows until ~2 workgroups per CU exist (at most 16 slices)
     int slices = 1;
@@ -1441,6 +1589,7 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
     if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) ctx->pbs_variant = atoi(v);
     if (const char *v = getenv("HELM_HIP_NARROW")) ctx->narrow_variant = atoi(v) == 4 ? 4 : 1;
     if (const char *v = getenv("HELM_HIP_CLOCK_PROBE")) ctx->clock_probe = atoi(v);
+    if (const char *v = getenv("HELM_HIP_KS_MFMA")) ctx->ks_mfma = atoi(v);
     while ((1 << ctx->logN) < P.N) ctx->logN++;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
@@ -1507,6 +1656,10 @@ int helm_hip_ctx_destroy(helm_hip_ctx *ctx)
     (void)hipFree(ctx->tw_inv);
     (void)hipFree(ctx->bsk);
     (void)hipFree(ctx->ksk);
+    (void)hipFree(ctx->ksk_planes);
+    ctx->d_dig.release();
+    ctx->d_dsum.release();
+    ctx->d_body.release();
     (void)hipFree(ctx->tv_bool);
     ctx->d_pbs.release();
     ctx->d_ks.release();
@@ -1590,6 +1743,31 @@ int helm_hip_load_keyswitch_key(helm_hip_ctx *ctx, const uint32_t *ksk, size_t n
     if (!ctx->ksk) HIP_TRY(hipMalloc(&ctx->ksk, want * sizeof(uint32_t)));
     HIP_TRY(hipMemcpyAsync(ctx->ksk, ksk, want * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // byte planes for the matrix-core keyswitch: ks_l must divide 16 (a lane's 16 fragment bytes hold whole words'
+    // digits), the rows must fill 64-row chunks, digits must fit a signed byte (ks_logB <= 7: checked at ctx_create)
+    const int R = P.k * P.N * P.ks_l;
+    if ((P.ks_l == 1 || P.ks_l == 2 || P.ks_l == 4 || P.ks_l == 8) && R % 64 == 0) {
+        const int kchunks = R / 64, ctiles = (P.n + 1 + 15) / 16;
+        const size_t frag_per_plane = (size_t)ctiles * kchunks * 64;
+        std::vector<int8_t> planes(4 * frag_per_plane * 16);
+        const size_t krow = (size_t)P.n + 1;
+        for (int ct = 0; ct < ctiles; ct++)
+            for (int kc = 0; kc < kchunks; kc++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int c = ct * 16 + (lane & 15);
+                    for (int j = 0; j < 16; j++) {
+                        const int r = kc * 64 + 16 * (lane >> 4) + j;
+                        const uint32_t w = c <= P.n ? ksk[(size_t)r * krow + c] : 0u;
+                        for (int b = 0; b < 4; b++)
+                            planes[((size_t)b * frag_per_plane + ((size_t)ct * kchunks + kc) * 64 + lane) * 16 + j] =
+                                (int8_t)((int)((w >> (8 * b)) & 255u) - 128);
+                    }
+                }
+        if (!ctx->ksk_planes) HIP_TRY(hipMalloc(&ctx->ksk_planes, planes.size()));
+        HIP_TRY(hipMemcpy(ctx->ksk_planes, planes.data(), planes.size(), hipMemcpyHostToDevice));
+        ctx->ks_kchunks = kchunks;
+        ctx->ks_ctiles = ctiles;
+    }
     ctx->have_ksk = true;
     return 0;
 }
