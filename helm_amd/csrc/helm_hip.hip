@@ -1120,6 +1120,19 @@ template <typename T> struct DevBuf {
     }
 };
 
+// device temporary of one call: freed on every return path
+template <typename T> struct Scratch {
+    T *p = nullptr;
+    Scratch() = default;
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    ~Scratch()
+    {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)); }
+};
+
 struct LevelPlan {
     std::vector<PbsJob> pbs;
     std::vector<KsJob> ks;
@@ -1583,43 +1596,52 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
 
     helm_hip_ctx *ctx = new (std::nothrow) helm_hip_ctx();
     if (!ctx) return fail(HELM_ERR_OOM, "ctx");
-    ctx->device = device_id;
-    ctx->P = P;
-    ctx->n_cus = prop.multiProcessorCount;
-    if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) ctx->pbs_variant = atoi(v);
-    if (const char *v = getenv("HELM_HIP_NARROW")) ctx->narrow_variant = atoi(v) == 4 ? 4 : 1;
-    if (const char *v = getenv("HELM_HIP_CLOCK_PROBE")) ctx->clock_probe = atoi(v);
-    if (const char *v = getenv("HELM_HIP_KS_MFMA")) ctx->ks_mfma = atoi(v);
-    while ((1 << ctx->logN) < P.N) ctx->logN++;
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
-    ctx->stream = ctx->own_stream;
+    // everything below may fail half-way: the partially built context is destroyed on every error path
+    const int rc = [&]() -> int {
+        ctx->device = device_id;
+        ctx->P = P;
+        ctx->n_cus = prop.multiProcessorCount;
+        if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) ctx->pbs_variant = atoi(v);
+        if (const char *v = getenv("HELM_HIP_NARROW")) ctx->narrow_variant = atoi(v) == 4 ? 4 : 1;
+        if (const char *v = getenv("HELM_HIP_CLOCK_PROBE")) ctx->clock_probe = atoi(v);
+        if (const char *v = getenv("HELM_HIP_KS_MFMA")) ctx->ks_mfma = atoi(v);
+        while ((1 << ctx->logN) < P.N) ctx->logN++;
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+        ctx->stream = ctx->own_stream;
 
-    // twiddle tables: bit-reversed powers of psi (primitive 2N-th root) and of psi^-1
-    const int N = P.N, logN = ctx->logN;
-    // the 49-bit prime (no recentring inside transforms) when the set's exact products fit
-    // below its half and a lazy build exists (N = 512); HELM_HIP_FIELD=51 forces the other
-    ctx->field = (N == 512 && bound * 1.002 < Fp<49>::P / 2) ? 49 : 51;
-    if (const char *v = getenv("HELM_HIP_FIELD")) if (atoi(v) == 51) ctx->field = 51;
-    const uint64_t pm = ctx->field == 49 ? Fp<49>::P_U64 : Fp<51>::P_U64;
-    const uint64_t gen = ctx->field == 49 ? Fp<49>::GEN : Fp<51>::GEN;
-    const uint64_t psi = powmod_u64(gen, (pm - 1) / (2 * (uint64_t)N), pm);
-    const uint64_t psi_inv = powmod_u64(psi, pm - 2, pm);
-    std::vector<double> tf(N), ti(N);
-    uint64_t a = 1, b = 1;
-    for (int i = 0; i < N; i++) {
-        tf[bitrev(i, logN)] = centred(a, pm);
-        ti[bitrev(i, logN)] = centred(b, pm);
-        a = mulmod_u64(a, psi, pm);
-        b = mulmod_u64(b, psi_inv, pm);
+        // twiddle tables: bit-reversed powers of psi (primitive 2N-th root) and of psi^-1
+        const int N = P.N, logN = ctx->logN;
+        // the 49-bit prime (no recentring inside transforms) when the set's exact products fit
+        // below its half and a lazy build exists (N = 512); HELM_HIP_FIELD=51 forces the other
+        ctx->field = (N == 512 && bound * 1.002 < Fp<49>::P / 2) ? 49 : 51;
+        if (const char *v = getenv("HELM_HIP_FIELD")) if (atoi(v) == 51) ctx->field = 51;
+        const uint64_t pm = ctx->field == 49 ? Fp<49>::P_U64 : Fp<51>::P_U64;
+        const uint64_t gen = ctx->field == 49 ? Fp<49>::GEN : Fp<51>::GEN;
+        const uint64_t psi = powmod_u64(gen, (pm - 1) / (2 * (uint64_t)N), pm);
+        const uint64_t psi_inv = powmod_u64(psi, pm - 2, pm);
+        std::vector<double> tf(N), ti(N);
+        uint64_t a = 1, b = 1;
+        for (int i = 0; i < N; i++) {
+            tf[bitrev(i, logN)] = centred(a, pm);
+            ti[bitrev(i, logN)] = centred(b, pm);
+            a = mulmod_u64(a, psi, pm);
+            b = mulmod_u64(b, psi_inv, pm);
+        }
+        ctx->n_inv = centred(powmod_u64((uint64_t)N, pm - 2, pm), pm);
+        HIP_TRY(hipMalloc(&ctx->tw_fwd, sizeof(double) * N));
+        HIP_TRY(hipMalloc(&ctx->tw_inv, sizeof(double) * N));
+        HIP_TRY(hipMemcpy(ctx->tw_fwd, tf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->tw_inv, ti.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+        std::vector<uint32_t> tv(N, PT_TRUE);
+        HIP_TRY(hipMalloc(&ctx->tv_bool, sizeof(uint32_t) * N));
+        HIP_TRY(hipMemcpy(ctx->tv_bool, tv.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+        return 0;
+    }();
+    if (rc) {
+        const std::string msg = g_err;
+        (void)helm_hip_ctx_destroy(ctx);
+        return fail(rc, msg);
     }
-    ctx->n_inv = centred(powmod_u64((uint64_t)N, pm - 2, pm), pm);
-    HIP_TRY(hipMalloc(&ctx->tw_fwd, sizeof(double) * N));
-    HIP_TRY(hipMalloc(&ctx->tw_inv, sizeof(double) * N));
-    HIP_TRY(hipMemcpy(ctx->tw_fwd, tf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->tw_inv, ti.data(), sizeof(double) * N, hipMemcpyHostToDevice));
-    std::vector<uint32_t> tv(N, PT_TRUE);
-    HIP_TRY(hipMalloc(&ctx->tv_bool, sizeof(uint32_t) * N));
-    HIP_TRY(hipMemcpy(ctx->tv_bool, tv.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
     *out = ctx;
     return 0;
 }
@@ -1628,7 +1650,7 @@ int helm_hip_ctx_destroy(helm_hip_ctx *ctx)
 {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream || !ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto *l : {&ctx->ev_pbs, &ctx->ev_pbs_main, &ctx->ev_ks, &ctx->ev_lin})
         for (auto &p : *l) {
             (void)hipEventDestroy(p.first);
@@ -1665,7 +1687,7 @@ int helm_hip_ctx_destroy(helm_hip_ctx *ctx)
     ctx->d_ks.release();
     ctx->d_lin.release();
     ctx->d_big.release();
-    (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return 0;
 }
@@ -1711,22 +1733,21 @@ int helm_hip_load_bootstrap_key(helm_hip_ctx *ctx, const uint32_t *bsk_std, size
         return fail(HELM_ERR_INVALID, "bootstrapping key: expected " + std::to_string(polys * P.N) + " words, got " +
                                           std::to_string(n_words));
     HIP_TRY(hipSetDevice(ctx->device));
-    uint32_t *d_std = nullptr;
-    HIP_TRY(hipMalloc(&d_std, n_words * sizeof(uint32_t)));
+    Scratch<uint32_t> d_std;
+    HIP_TRY(d_std.alloc(n_words));
     if (!ctx->bsk) HIP_TRY(hipMalloc(&ctx->bsk, n_words * sizeof(double)));
-    HIP_TRY(hipMemcpyAsync(d_std, bsk_std, n_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_std.p, bsk_std, n_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     if (P.N == 512 && ctx->field == 49)
-        hipLaunchKernelGGL((k_bsk_convert<Fp<49>, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk,
+        hipLaunchKernelGGL((k_bsk_convert<Fp<49>, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
                            ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
     else if (P.N == 512)
-        hipLaunchKernelGGL((k_bsk_convert<Fp<51>, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk,
+        hipLaunchKernelGGL((k_bsk_convert<Fp<51>, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
                            ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
     else
-        hipLaunchKernelGGL((k_bsk_convert<Fp<51>, 10>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk,
+        hipLaunchKernelGGL((k_bsk_convert<Fp<51>, 10>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
                            ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_std));
     ctx->have_bsk = true;
     return 0;
 }
@@ -1831,17 +1852,15 @@ int helm_hip_wires_upload(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t *i
     }
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t row = (size_t)ctx->P.n + 1;
-    uint32_t *d_rows = nullptr;
-    int32_t *d_idx = nullptr;
-    HIP_TRY(hipMalloc(&d_rows, (size_t)count * row * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&d_idx, (size_t)count * sizeof(int32_t)));
-    HIP_TRY(hipMemcpyAsync(d_rows, lwe_host, (size_t)count * row * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_idx, idx, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_rows, d_idx, w->d, ctx->P.n);
+    Scratch<uint32_t> d_rows;
+    Scratch<int32_t> d_idx;
+    HIP_TRY(d_rows.alloc((size_t)count * row));
+    HIP_TRY(d_idx.alloc((size_t)count));
+    HIP_TRY(hipMemcpyAsync(d_rows.p, lwe_host, (size_t)count * row * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_idx.p, idx, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_rows.p, d_idx.p, w->d, ctx->P.n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_rows));
-    HIP_TRY(hipFree(d_idx));
     return 0;
 }
 
@@ -1853,17 +1872,15 @@ int helm_hip_wires_download(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t 
     if (int rc = check_idx(w, idx, count, false)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t row = (size_t)ctx->P.n + 1;
-    uint32_t *d_rows = nullptr;
-    int32_t *d_idx = nullptr;
-    HIP_TRY(hipMalloc(&d_rows, (size_t)count * row * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&d_idx, (size_t)count * sizeof(int32_t)));
-    HIP_TRY(hipMemcpyAsync(d_idx, idx, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)count), dim3(256), 0, ctx->stream, w->d, d_idx, d_rows, ctx->P.n);
+    Scratch<uint32_t> d_rows;
+    Scratch<int32_t> d_idx;
+    HIP_TRY(d_rows.alloc((size_t)count * row));
+    HIP_TRY(d_idx.alloc((size_t)count));
+    HIP_TRY(hipMemcpyAsync(d_idx.p, idx, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)count), dim3(256), 0, ctx->stream, w->d, d_idx.p, d_rows.p, ctx->P.n);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(lwe_host, d_rows, (size_t)count * row * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(lwe_host, d_rows.p, (size_t)count * row * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_rows));
-    HIP_TRY(hipFree(d_idx));
     return 0;
 }
 
@@ -1875,17 +1892,15 @@ int helm_hip_wires_set_trivial(helm_hip_ctx *ctx, helm_hip_wires *w, const int32
     if (count == 0) return 0;
     if (int rc = check_idx(w, idx, count, false)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    int32_t *d_idx = nullptr;
-    uint8_t *d_val = nullptr;
-    HIP_TRY(hipMalloc(&d_idx, (size_t)count * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&d_val, (size_t)count));
-    HIP_TRY(hipMemcpyAsync(d_idx, idx, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_val, value, (size_t)count, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_set_trivial, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_idx, d_val, w->d, ctx->P.n);
+    Scratch<int32_t> d_idx;
+    Scratch<uint8_t> d_val;
+    HIP_TRY(d_idx.alloc((size_t)count));
+    HIP_TRY(d_val.alloc((size_t)count));
+    HIP_TRY(hipMemcpyAsync(d_idx.p, idx, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_val.p, value, (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_set_trivial, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_idx.p, d_val.p, w->d, ctx->P.n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_idx));
-    HIP_TRY(hipFree(d_val));
     return 0;
 }
 
@@ -1982,16 +1997,26 @@ int helm_hip_program_create(helm_hip_ctx *ctx, const int32_t *opcode, const int3
         pr->ks_off.push_back((int64_t)all_ks.size());
         pr->lin_off.push_back((int64_t)all_lin.size());
     }
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (!all_pbs.empty()) {
-        HIP_TRY(hipMalloc(&pr->d_pbs, all_pbs.size() * sizeof(PbsJob)));
-        HIP_TRY(hipMemcpy(pr->d_pbs, all_pbs.data(), all_pbs.size() * sizeof(PbsJob), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc(&pr->d_ks, all_ks.size() * sizeof(KsJob)));
-        HIP_TRY(hipMemcpy(pr->d_ks, all_ks.data(), all_ks.size() * sizeof(KsJob), hipMemcpyHostToDevice));
-    }
-    if (!all_lin.empty()) {
-        HIP_TRY(hipMalloc(&pr->d_lin, all_lin.size() * sizeof(LinJob)));
-        HIP_TRY(hipMemcpy(pr->d_lin, all_lin.data(), all_lin.size() * sizeof(LinJob), hipMemcpyHostToDevice));
+    const int up = [&]() -> int {
+        HIP_TRY(hipSetDevice(ctx->device));
+        if (!all_pbs.empty()) {
+            HIP_TRY(hipMalloc(&pr->d_pbs, all_pbs.size() * sizeof(PbsJob)));
+            HIP_TRY(hipMemcpy(pr->d_pbs, all_pbs.data(), all_pbs.size() * sizeof(PbsJob), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc(&pr->d_ks, all_ks.size() * sizeof(KsJob)));
+            HIP_TRY(hipMemcpy(pr->d_ks, all_ks.data(), all_ks.size() * sizeof(KsJob), hipMemcpyHostToDevice));
+        }
+        if (!all_lin.empty()) {
+            HIP_TRY(hipMalloc(&pr->d_lin, all_lin.size() * sizeof(LinJob)));
+            HIP_TRY(hipMemcpy(pr->d_lin, all_lin.data(), all_lin.size() * sizeof(LinJob), hipMemcpyHostToDevice));
+        }
+        return 0;
+    }();
+    if (up) { // a half-uploaded program: release what was allocated
+        (void)hipFree(pr->d_pbs);
+        (void)hipFree(pr->d_ks);
+        (void)hipFree(pr->d_lin);
+        delete pr;
+        return up;
     }
     ctx->child_progs.push_back(pr);
     *prog = pr;
@@ -2172,27 +2197,23 @@ int helm_hip_pbs_batch(helm_hip_ctx *ctx, const uint32_t *lwe_in, const uint32_t
         if (tv_index[g] < 0 || tv_index[g] >= n_tv) return fail(HELM_ERR_INVALID, "tv_index out of range");
         jobs[(size_t)g] = PbsJob{-1, 0, (int32_t)g, -1, -1, tv_index[g]};
     }
-    uint32_t *d_in = nullptr, *d_tv = nullptr, *d_out = nullptr;
-    PbsJob *d_jobs = nullptr;
-    HIP_TRY(hipMalloc(&d_in, (size_t)count * row * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&d_tv, (size_t)n_tv * P.N * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&d_out, (size_t)count * brow * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&d_jobs, (size_t)count * sizeof(PbsJob)));
-    HIP_TRY(hipMemcpyAsync(d_in, lwe_in, (size_t)count * row * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_tv, test_vectors, (size_t)n_tv * P.N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), (size_t)count * sizeof(PbsJob), hipMemcpyHostToDevice, ctx->stream));
+    Scratch<uint32_t> d_in, d_tv, d_out;
+    Scratch<PbsJob> d_jobs;
+    HIP_TRY(d_in.alloc((size_t)count * row));
+    HIP_TRY(d_tv.alloc((size_t)n_tv * P.N));
+    HIP_TRY(d_out.alloc((size_t)count * brow));
+    HIP_TRY(d_jobs.alloc((size_t)count));
+    HIP_TRY(hipMemcpyAsync(d_in.p, lwe_in, (size_t)count * row * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_tv.p, test_vectors, (size_t)n_tv * P.N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), (size_t)count * sizeof(PbsJob), hipMemcpyHostToDevice, ctx->stream));
     {
         TimedScope t(ctx, &ctx->ev_pbs);
-        HIP_TRY(launch_pbs(ctx, d_jobs, count, nullptr, d_in, d_tv, d_out));
+        HIP_TRY(launch_pbs(ctx, d_jobs.p, count, nullptr, d_in.p, d_tv.p, d_out.p));
     }
     ctx->tacc.pbs_launches++;
     ctx->tacc.pbs_count += count;
-    HIP_TRY(hipMemcpyAsync(out_big, d_out, (size_t)count * brow * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_big, d_out.p, (size_t)count * brow * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_in));
-    HIP_TRY(hipFree(d_tv));
-    HIP_TRY(hipFree(d_out));
-    HIP_TRY(hipFree(d_jobs));
     return 0;
 }
 
@@ -2206,24 +2227,21 @@ int helm_hip_keyswitch_batch(helm_hip_ctx *ctx, const uint32_t *in_big, uint32_t
     const size_t row = (size_t)P.n + 1, brow = (size_t)P.k * P.N + 1;
     std::vector<KsJob> jobs((size_t)count);
     for (int64_t g = 0; g < count; g++) jobs[(size_t)g] = KsJob{(int32_t)g, -1, (int32_t)g, 0u};
-    uint32_t *d_in = nullptr, *d_out = nullptr;
-    KsJob *d_jobs = nullptr;
-    HIP_TRY(hipMalloc(&d_in, (size_t)count * brow * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&d_out, (size_t)count * row * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&d_jobs, (size_t)count * sizeof(KsJob)));
-    HIP_TRY(hipMemcpyAsync(d_in, in_big, (size_t)count * brow * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), (size_t)count * sizeof(KsJob), hipMemcpyHostToDevice, ctx->stream));
+    Scratch<uint32_t> d_in, d_out;
+    Scratch<KsJob> d_jobs;
+    HIP_TRY(d_in.alloc((size_t)count * brow));
+    HIP_TRY(d_out.alloc((size_t)count * row));
+    HIP_TRY(d_jobs.alloc((size_t)count));
+    HIP_TRY(hipMemcpyAsync(d_in.p, in_big, (size_t)count * brow * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), (size_t)count * sizeof(KsJob), hipMemcpyHostToDevice, ctx->stream));
     {
         TimedScope t(ctx, &ctx->ev_ks);
-        HIP_TRY(launch_ks(ctx, d_jobs, count, d_in, d_out));
+        HIP_TRY(launch_ks(ctx, d_jobs.p, count, d_in.p, d_out.p));
     }
     ctx->tacc.ks_launches++;
     ctx->tacc.ks_count += count;
-    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)count * row * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)count * row * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_in));
-    HIP_TRY(hipFree(d_out));
-    HIP_TRY(hipFree(d_jobs));
     return 0;
 }
 
@@ -2233,24 +2251,22 @@ int helm_hip_ntt_roundtrip(helm_hip_ctx *ctx, const uint32_t *poly_in, uint32_t 
     if (count == 0) return 0;
     const int N = ctx->P.N;
     HIP_TRY(hipSetDevice(ctx->device));
-    uint32_t *d_in = nullptr, *d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_in, (size_t)count * N * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&d_out, (size_t)count * N * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpyAsync(d_in, poly_in, (size_t)count * N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    Scratch<uint32_t> d_in, d_out;
+    HIP_TRY(d_in.alloc((size_t)count * N));
+    HIP_TRY(d_out.alloc((size_t)count * N));
+    HIP_TRY(hipMemcpyAsync(d_in.p, poly_in, (size_t)count * N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     if (N == 512 && ctx->field == 49)
-        hipLaunchKernelGGL((k_ntt_roundtrip<Fp<49>, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in, d_out,
+        hipLaunchKernelGGL((k_ntt_roundtrip<Fp<49>, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,
                            ctx->tw_fwd, ctx->tw_inv, ctx->n_inv);
     else if (N == 512)
-        hipLaunchKernelGGL((k_ntt_roundtrip<Fp<51>, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in, d_out,
+        hipLaunchKernelGGL((k_ntt_roundtrip<Fp<51>, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,
                            ctx->tw_fwd, ctx->tw_inv, ctx->n_inv);
     else
-        hipLaunchKernelGGL((k_ntt_roundtrip<Fp<51>, 10>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in, d_out,
+        hipLaunchKernelGGL((k_ntt_roundtrip<Fp<51>, 10>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,
                            ctx->tw_fwd, ctx->tw_inv, ctx->n_inv);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(poly_out, d_out, (size_t)count * N * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(poly_out, d_out.p, (size_t)count * N * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_in));
-    HIP_TRY(hipFree(d_out));
     return 0;
 }
 

@@ -1242,10 +1242,15 @@ int probe_spectrum_positions(helm_si_ctx *ctx)
     const int N = ctx->P.N, H = N / 2;
     std::vector<uint64_t> xpoly((size_t)N, 0);
     xpoly[1] = 1;
-    uint64_t *d_x = nullptr;
-    double *d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_x, sizeof(uint64_t) * N));
-    HIP_TRY(hipMalloc(&d_out, sizeof(double) * 4 * H));
+    // freed on every return path
+    struct Tmp {
+        void *p = nullptr;
+        ~Tmp() { if (p) (void)hipFree(p); }
+    } t_x, t_out;
+    HIP_TRY(hipMalloc(&t_x.p, sizeof(uint64_t) * N));
+    HIP_TRY(hipMalloc(&t_out.p, sizeof(double) * 4 * H));
+    uint64_t *d_x = static_cast<uint64_t *>(t_x.p);
+    double *d_out = static_cast<double *>(t_out.p);
     HIP_TRY(hipMemcpy(d_x, xpoly.data(), sizeof(uint64_t) * N, hipMemcpyHostToDevice));
     // one polynomial, K1 = 1: blocks (poly 0, half h) write d_out[(f * 2 + h) * N/2 ...] scaled by 1 (n_inv = 1)
 #define PROBE(LN)                                                                                                        \
@@ -1262,8 +1267,6 @@ int probe_spectrum_positions(helm_si_ctx *ctx)
     HIP_TRY(hipMemcpyAsync(val.data(), d_out, sizeof(double) * 4 * H, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(pw.data(), ctx->psi_pow, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d_x);
-    (void)hipFree(d_out);
     std::vector<uint16_t> expo((size_t)2 * H);
     for (int f = 0; f < 2; f++) {
         std::map<int64_t, int> where;
@@ -1509,8 +1512,12 @@ int helm_si_load_bootstrap_key(helm_si_ctx *ctx, const uint64_t *bsk_std, size_t
         return fail(HELM_ERR_INVALID, "bootstrapping key: expected " + std::to_string(polys * P.N) + " words, got " +
                                           std::to_string(n_words));
     HIP_TRY(hipSetDevice(ctx->device));
-    uint64_t *d_std = nullptr;
-    HIP_TRY(hipMalloc(&d_std, n_words * sizeof(uint64_t)));
+    struct Tmp {
+        void *p = nullptr;
+        ~Tmp() { if (p) (void)hipFree(p); }
+    } t_std; // freed on every return path
+    HIP_TRY(hipMalloc(&t_std.p, n_words * sizeof(uint64_t)));
+    uint64_t *d_std = static_cast<uint64_t *>(t_std.p);
     if (!ctx->bsk && ctx->group == 1) HIP_TRY(hipMalloc(&ctx->bsk, n_words * 2 * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(d_std, bsk_std, n_words * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
 #define CONV(LN)                                                                                                     \
@@ -1537,7 +1544,6 @@ int helm_si_load_bootstrap_key(helm_si_ctx *ctx, const uint64_t *bsk_std, size_t
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(d_std));
     if (ctx->group > 1 && !ctx->expo) {
         if (int rc = probe_spectrum_positions(ctx)) return rc;
     }

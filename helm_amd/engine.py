@@ -192,8 +192,10 @@ class DeviceWires:
         self._h = h
 
     def free(self):
-        if getattr(self, "_h", None) and getattr(self.sk, "_h", None):
-            hip.helm_hip_wires_free(self.sk._h, self._h)
+        if getattr(self, "_h", None):
+            # the owner may be gone already (destructor order is arbitrary): the C side then only deletes the
+            # host struct - the context released the device memory
+            hip.helm_hip_wires_free(getattr(self.sk, "_h", None), self._h)
         self._h = None
 
     def __del__(self):
@@ -243,8 +245,8 @@ class Program:
         self._h = h
 
     def destroy(self):
-        if getattr(self, "_h", None) and getattr(self.sk, "_h", None):
-            hip.helm_hip_program_destroy(self.sk._h, self._h)
+        if getattr(self, "_h", None):
+            hip.helm_hip_program_destroy(getattr(self.sk, "_h", None), self._h)  # NULL owner: host struct only
         self._h = None
 
     def __del__(self):

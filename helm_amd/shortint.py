@@ -228,8 +228,8 @@ class SiWires:
         self._h = h
 
     def free(self):
-        if getattr(self, "_h", None) and getattr(self.sk, "_h", None):
-            hip.helm_si_wires_free(self.sk._h, self._h)
+        if getattr(self, "_h", None):
+            hip.helm_si_wires_free(getattr(self.sk, "_h", None), self._h)  # NULL owner: host struct only
         self._h = None
 
     def __del__(self):
