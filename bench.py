@@ -187,7 +187,9 @@ def main():
     # ---- N > 1, weak: a short strong-scaling pass on a fixed job (outside the timed region) ----
     strong_leg = None
     if world > 1 and not strong and not args.no_strong_leg:
-        strong_leg = strong_scaling_leg(sk, ck, circuit, wire_names, index, nw, args.blocks, quantum, rank, world, dist, torch)
+        # a fixed job of 2 x --blocks blocks: its launches hold >= 8 x 1,024 ready bootstraps, so that up to 8 ranks
+        # each get whole lockstep rounds (a 32-block job leaves 640 per rank per launch at N = 8)
+        strong_leg = strong_scaling_leg(sk, ck, circuit, wire_names, index, nw, 2 * args.blocks, quantum, rank, world, dist, torch)
 
     if rank != 0:
         if world > 1:
