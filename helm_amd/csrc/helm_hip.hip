@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
                                                             const uint32_t *__restrict__ tvs,
                                                             const double *__restrict__ bsk,
                                                             const double *__restrict__ tw_fwd,
-                                                            uint32_t *__restrict__ out_big, int n, int logB)
+                                                            uint32_t *__restrict__ out_big, int n, int logB, int wave_map)
 {
     constexpr int LOGN = C::LOGN, K = C::K, L = C::L, K1 = C::K1, NW = C::NW;
     using F = typename C::F;
@@ -609,7 +609,19 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = w / L, lev = w - r * L; // polynomial (GGSW row) and decomposition level of this wave
+    // polynomial (GGSW row) and decomposition level of this wave.  The hardware deals the waves of a workgroup
+    // round the four SIMDs (wave w -> SIMD w % 4, tools/ubench_placement.hip), so with nine waves SIMD 0 hosts
+    // three of them and bounds the forward phase.  A unit's cost grows with the depth of its digit (the carry
+    // chain runs from the last level down to the wave's own): the three cheapest units - the last level of each
+    // polynomial - go to SIMD 0, and the three level-0 waves, which also run the inverse transforms, to three
+    // different SIMDs (wave_map = 0 keeps the plain (polynomial, level) order: 3.6 - 4.6 % slower, same-process
+    // A/B in tools/ab_wide.py).
+    int r = w / L, lev = w - r * L;
+    if (K1 == 3 && L == 3 && wave_map) {
+        constexpr int RR[9] = {0, 0, 1, 2, 1, 0, 1, 2, 2}, LL[9] = {2, 0, 0, 0, 2, 1, 1, 1, 2};
+        r = RR[w];
+        lev = LL[w];
+    }
     const PbsJob job = jobs[blockIdx.x];
     const size_t row = (size_t)n + 1;
     {
@@ -1158,6 +1170,7 @@ struct helm_hip_ctx {
     uint32_t *ksk = nullptr;
     int8_t *ksk_planes = nullptr; // matrix-core keyswitch: the key's four byte planes as signed bytes, B-fragment order
     int ks_kchunks = 0, ks_ctiles = 0;
+    int wide_map = 1;            // HELM_HIP_WIDE_MAP=0: k_pbs_wide with waves in (polynomial, level) order
     int ks_mfma = 1;             // HELM_HIP_KS_MFMA=0: the vector-ALU keyswitch for every launch
     DevBuf<int8_t> d_dig;
     DevBuf<int32_t> d_dsum;
@@ -1357,7 +1370,7 @@ static hipError_t launch_pbs_wide(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, wires, raw, tvs, ctx->bsk,
-                       ctx->tw_fwd, out_big, ctx->P.n, ctx->P.pbs_logB);
+                       ctx->tw_fwd, out_big, ctx->P.n, ctx->P.pbs_logB, ctx->wide_map);
     print_stamps(ctx, C::NW, "wide: prep | fwd | products | bar1 | inverse | bar2");
     return hipGetLastError();
 }
@@ -1605,6 +1618,7 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         if (const char *v = getenv("HELM_HIP_NARROW")) ctx->narrow_variant = atoi(v) == 4 ? 4 : 1;
         if (const char *v = getenv("HELM_HIP_CLOCK_PROBE")) ctx->clock_probe = atoi(v);
         if (const char *v = getenv("HELM_HIP_KS_MFMA")) ctx->ks_mfma = atoi(v);
+        if (const char *v = getenv("HELM_HIP_WIDE_MAP")) ctx->wide_map = atoi(v);
         while ((1 << ctx->logN) < P.N) ctx->logN++;
         HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
         ctx->stream = ctx->own_stream;
