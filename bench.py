@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the LUT-mode / arithmetic-mode side measurements")
     ap.add_argument("--no-strong-leg", action="store_true", help="N > 1, weak: skip the short strong-scaling pass")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline: stop after the level that passes this time")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="CPU baseline: stop after the level that passes this time")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = the cores this process may use)")
     args = ap.parse_args()
 
