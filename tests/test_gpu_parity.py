@@ -328,3 +328,26 @@ def test_full_size_lockstep_rounds_bit_exact(name):
     assert np.array_equal(got, ref)
     assert list(ck.decrypt(got[n_in:]).astype(int)) == [int(bits[a] if bits[s] else bits[b]) for a, b, s in zip(i0, i1, i2)]
     sk.close()
+
+
+@pytest.mark.parametrize("name", ["toy_k2", "toy_1024"])
+def test_vector_alu_keyswitch_fallback_bit_exact(name, monkeypatch):
+    """The matrix-core keyswitch serves ks_l in {1, 2, 4, 8}; other level counts (and HELM_HIP_KS_MFMA=0) run the
+    vector-ALU kernel, with its key rows split over workgroup slices on narrow launches.  Both paths must give the
+    oracle's words: a narrow batch (sliced, atomic adds) and a batch wide enough for plain stores."""
+    monkeypatch.setenv("HELM_HIP_KS_MFMA", "0")
+    ck = helm_amd.ClientKey.generate(name, seed=17)
+    sk = helm_amd.ServerKey(ck)
+    monkeypatch.delenv("HELM_HIP_KS_MFMA")
+    sk_mfma = helm_amd.ServerKey(ck)
+    orc = oracle.Oracle(ck.params.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True)
+    p = ck.params
+    rng = np.random.default_rng(8)
+    for count in (5, 2100):
+        big = rng.integers(0, 2**32, size=(count, p.k * p.N + 1), dtype=np.uint32)
+        got = sk.keyswitch_batch(big)
+        assert np.array_equal(got, sk_mfma.keyswitch_batch(big))  # the two kernels agree on every word
+        for g in (0, 1, count // 2, count - 1):
+            assert np.array_equal(got[g], orc.keyswitch(big[g])), (name, count, g)
+    sk.close()
+    sk_mfma.close()
