@@ -165,3 +165,39 @@ def test_bad_arguments():
     a = np.array([AND], np.int32)
     with pytest.raises(Panic):
         pack_levels(a, a * 0, a * 0, a * 0 - 1, a * 0 + 1, np.array([0, 1], np.int64), 0)
+
+
+def test_random_levelised_dags_property():
+    """Random levelised netlists (random widths, fan-in from any earlier level, a sprinkling of MUX and NOT gates):
+    for every quantum the packed schedule is a permutation, respects every dependency
+    and evaluates to the level schedule's values on every wire."""
+    rng = np.random.default_rng(2026)
+    for trial in range(25):
+        n_in = int(rng.integers(2, 9))
+        n_levels = int(rng.integers(1, 9))
+        ops, i0, i1, i2, out, off = [], [], [], [], [], [0]
+        avail = list(range(n_in))          # wires of earlier levels
+        nxt = n_in
+        for _ in range(n_levels):
+            width = int(rng.integers(1, 40))
+            new = []
+            prev_level = avail[-max(1, min(len(avail), 30)):]
+            for _ in range(width):
+                kind = rng.choice([AND, OR, XOR, NAND, NOR, XNOR, MUX, NOT], p=[.18, .12, .2, .1, .1, .1, .12, .08])
+                a = int(rng.choice(prev_level))   # at least one input from recent wires keeps the levels honest enough;
+                b, c = int(rng.choice(avail)), int(rng.choice(avail))  # level offsets only need producers to be earlier
+                ops.append(int(kind)); i0.append(a)
+                i1.append(b if kind != NOT else -1); i2.append(c if kind == MUX else -1)
+                out.append(nxt); new.append(nxt); nxt += 1
+            avail += new
+            off.append(len(ops))
+        arrs = [np.array(x, np.int32) for x in (ops, i0, i1, i2, out)] + [np.array(off, np.int64)]
+        vals = np.zeros(nxt, dtype=np.uint8)
+        vals[:n_in] = rng.integers(0, 2, n_in)
+        want = _plain_run(*arrs, vals)
+        for quantum in (1, 3, 8, 64, 10**6):
+            packed = pack_levels(*arrs, quantum)
+            per_launch = _check_schedule(tuple(arrs), packed, quantum)
+            assert np.array_equal(_plain_run(*packed[:6], vals), want), (trial, quantum)
+            # no more launches than levels plus one per quantum of work plus the drain
+            assert len(packed[5]) - 1 <= len(off) - 1 + int(per_launch.sum()) // max(1, quantum) + 2
