@@ -17,7 +17,8 @@
 #include "helm_host.hpp"
 
 #include <algorithm>
-#include <unordered_map>
+#include <functional>
+#include <queue>
 
 namespace helm {
 
@@ -94,37 +95,49 @@ int pack_levels(const int32_t *op, const int32_t *in0, const int32_t *in1, const
     for (int64_t g = 0; g < total; g++)
         if (tail[(size_t)g] && head[(size_t)g + 1] != head[(size_t)g]) return keep(); // state writer that also feeds later gates
 
-    // list scheduling; the gate index is the priority (levels ascend with it)
+    // list scheduling; the gate index is the priority (levels ascend with it).  Ready bootstrapped gates wait in
+    // a min-heap, ready linear gates (no bootstrap: they cost nothing and unlock their consumers) all go at once:
+    // O(total log total) whatever the quantum
     order.reserve((size_t)total);
-    std::vector<int64_t> ready, fresh, left;
+    std::priority_queue<int64_t, std::vector<int64_t>, std::greater<int64_t>> heap;
+    std::vector<int64_t> linear, skipped, launch;
+    int64_t ready_pbs = 0;
+    auto make_ready = [&](int64_t g) {
+        const int c = pbs_cost(op[g]);
+        if (c == 0) linear.push_back(g);
+        else {
+            heap.push(g);
+            ready_pbs += c;
+        }
+    };
     for (int64_t g = 0; g < total; g++)
-        if (!tail[(size_t)g] && indeg[(size_t)g] == 0) ready.push_back(g);
-    while (!ready.empty()) {
-        int64_t ready_pbs = 0;
-        for (int64_t g : ready) ready_pbs += pbs_cost(op[g]);
+        if (!tail[(size_t)g] && indeg[(size_t)g] == 0) make_ready(g);
+    while (!heap.empty() || !linear.empty()) {
         const int64_t target = ready_pbs >= quantum ? ready_pbs / quantum * quantum : ready_pbs;
         int64_t taken = 0;
-        left.clear();
-        fresh.clear();
-        const size_t begin = order.size();
-        for (int64_t g : ready) {
+        launch.clear();
+        skipped.clear();
+        while (taken < target && !heap.empty() && skipped.size() < 64) { // (a bounded look-ahead past MUXes that do not fit)
+            const int64_t g = heap.top();
+            heap.pop();
             const int c = pbs_cost(op[g]);
             if (taken + c <= target) {
                 taken += c;
-                order.push_back(g);
+                launch.push_back(g);
             } else
-                left.push_back(g);
+                skipped.push_back(g); // a two-bootstrap MUX that would overshoot: the next one-bootstrap gate fills the round
         }
-        if (order.size() == begin) throw Panic("pack_levels: no progress"); // cannot happen: target >= one gate's cost
+        for (int64_t g : skipped) heap.push(g);
+        ready_pbs -= taken;
+        launch.insert(launch.end(), linear.begin(), linear.end());
+        linear.clear();
+        if (launch.empty()) throw Panic("pack_levels: no progress"); // cannot happen: target >= one ready gate's cost
+        std::sort(launch.begin(), launch.end());
+        order.insert(order.end(), launch.begin(), launch.end());
         new_off.push_back((int64_t)order.size());
-        for (size_t q = begin; q < order.size(); q++) {
-            const int64_t g = order[q];
+        for (int64_t g : launch)
             for (int64_t e = head[(size_t)g]; e < head[(size_t)g + 1]; e++)
-                if (--indeg[(size_t)succ[(size_t)e]] == 0 && !tail[(size_t)succ[(size_t)e]]) fresh.push_back(succ[(size_t)e]);
-        }
-        std::sort(fresh.begin(), fresh.end());
-        ready.resize(left.size() + fresh.size());
-        std::merge(left.begin(), left.end(), fresh.begin(), fresh.end(), ready.begin());
+                if (--indeg[(size_t)succ[(size_t)e]] == 0 && !tail[(size_t)succ[(size_t)e]]) make_ready(succ[(size_t)e]);
     }
     // state writers, in their original level grouping
     for (int64_t l = 0; l < n_levels; l++) {
