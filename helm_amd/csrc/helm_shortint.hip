@@ -868,6 +868,109 @@ __global__ __launch_bounds__(256) void k_keyswitch64(const Ks64Job *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Keyswitch on the matrix cores (as k_ks_digits / k_ks_mfma of helm_hip.hip, 64-bit words): the key's EIGHT
+// byte planes as signed bytes (K_b - 128), the level count padded to LP in {1, 2, 4, 8} (a lane's 16 fragment
+// bytes hold whole words' digits; padded levels carry zero digits), int32 accumulators per plane, exact:
+//   sum_r d K = sum_b 2^(8b) sum_r d (K_b - 128) + 0x8080808080808080 * sum_r d      (mod 2^64)
+// One wave = 64 ciphertexts x 16 key columns x 8 planes (128 accumulator registers).
+// ------------------------------------------------------------------------------------
+typedef int v4i64k __attribute__((ext_vector_type(4)));
+
+template <int KSL>
+__global__ __launch_bounds__(256) void k_ks64_digits(const Ks64Job *__restrict__ jobs, const uint64_t *__restrict__ big,
+                                                     int8_t *__restrict__ dig, int32_t *__restrict__ dsum,
+                                                     uint64_t *__restrict__ body, int kN, int logB, int count, int kchunks)
+{
+    constexpr int LP = KSL <= 1 ? 1 : KSL <= 2 ? 2 : KSL <= 4 ? 4 : 8;
+    const int g = blockIdx.x; // padded index; g >= count: an all-zero row
+    __shared__ int red[256];
+    int local = 0;
+    const size_t brow = (size_t)kN + 1;
+    const bool live = g < count;
+    Ks64Job job{};
+    if (live) job = jobs[g];
+    int8_t *tile = dig + (size_t)(g >> 4) * kchunks * 1024;
+    const int rep = logB * KSL;
+    const uint64_t mask = (1ull << logB) - 1ull;
+    for (int t = threadIdx.x; t < kN; t += 256) {
+        int d[LP];
+#pragma unroll
+        for (int j = 0; j < LP; j++) d[j] = 0;
+        if (live) {
+            const uint64_t v = big[brow * (size_t)job.in_row + t];
+            uint64_t state = (v + (1ull << (63 - rep))) >> (64 - rep);
+#pragma unroll
+            for (int lev = KSL - 1; lev >= 0; lev--) {
+                const uint64_t dd = state & mask;
+                state >>= logB;
+                const uint64_t carry = (((dd - 1ull) | state) & dd) >> (logB - 1);
+                state += carry;
+                d[lev] = (int)(uint32_t)dd - (int)((uint32_t)carry << logB);
+            }
+        }
+        const int r0 = t * LP, kc = r0 >> 6, kq = (r0 & 63) >> 4, j0 = r0 & 15;
+        int8_t *dst = tile + ((size_t)kc * 64 + (kq << 4 | (g & 15))) * 16 + j0;
+#pragma unroll
+        for (int j = 0; j < LP; j++) {
+            dst[j] = (int8_t)d[j];
+            local += d[j];
+        }
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        dsum[g] = red[0];
+        body[g] = live ? big[brow * (size_t)job.in_row + kN] : 0ull;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_ks64_mfma(const Ks64Job *__restrict__ jobs, const int8_t *__restrict__ dig,
+                                                  const int32_t *__restrict__ dsum, const uint64_t *__restrict__ body,
+                                                  const int8_t *__restrict__ kplanes, uint64_t *__restrict__ out, int n,
+                                                  int count, int kchunks, int ctiles)
+{
+    constexpr int GT = 4; // gate tiles of 16 per wave; one column tile of 16; eight byte planes
+    const int lane = threadIdx.x;
+    const int gt0 = blockIdx.x * GT, ct = blockIdx.y;
+    const v4i64k *A = reinterpret_cast<const v4i64k *>(dig) + (size_t)gt0 * kchunks * 64 + lane;
+    const v4i64k *B = reinterpret_cast<const v4i64k *>(kplanes) + (size_t)ct * kchunks * 64 + lane;
+    const size_t plane = (size_t)ctiles * kchunks * 64;
+    v4i64k acc[GT][8];
+#pragma unroll
+    for (int a = 0; a < GT; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) acc[a][b] = v4i64k{0, 0, 0, 0};
+    for (int kc = 0; kc < kchunks; kc++) {
+        v4i64k fa[GT], fb[8];
+#pragma unroll
+        for (int a = 0; a < GT; a++) fa[a] = A[((size_t)a * kchunks + kc) * 64];
+#pragma unroll
+        for (int b = 0; b < 8; b++) fb[b] = B[(size_t)b * plane + (size_t)kc * 64];
+#pragma unroll
+        for (int a = 0; a < GT; a++)
+#pragma unroll
+            for (int b = 0; b < 8; b++) acc[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    const size_t krow = (size_t)n + 1;
+    const int col = ct * 16 + (lane & 15);
+#pragma unroll
+    for (int a = 0; a < GT; a++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int g = (gt0 + a) * 16 + (lane >> 4) * 4 + reg; // C/D map: column = lane & 15, row = (lane >> 4) * 4 + reg
+            if (g >= count || col > n) continue;
+            uint64_t s = 0x8080808080808080ull * (uint64_t)(int64_t)dsum[g];
+#pragma unroll
+            for (int b = 0; b < 8; b++) s += (uint64_t)(int64_t)acc[a][b][reg] << (8 * b);
+            out[krow * (size_t)jobs[g].out_row + col] = (col == n ? body[g] : 0ull) - s;
+        }
+}
+
 // out row = sum coef * in rows + const (body only).  One workgroup per output row.
 __global__ __launch_bounds__(256) void k_lincomb64(const int32_t *__restrict__ in_idx, const int64_t *__restrict__ coef,
                                                    const uint64_t *__restrict__ body_add,
@@ -1012,6 +1115,11 @@ struct helm_si_ctx {
     double *psi_pow = nullptr;   // multi-bit: psi^t, t < 2N, per field
     bool use_split = false;
     uint64_t *ksk = nullptr;
+    int8_t *ksk_planes = nullptr; // matrix-core keyswitch: eight byte planes as signed bytes, B-fragment order
+    int ks_kchunks = 0, ks_ctiles = 0, ks_mfma = 1; // HELM_HIP_KS_MFMA=0: the vector-ALU keyswitch for every launch
+    DevBuf<int8_t> d_ksdig;
+    DevBuf<int32_t> d_ksdsum;
+    DevBuf<uint64_t> d_ksbody;
     bool have_bsk = false, have_ksk = false;
     uint64_t delta = 0;
     int n_cus = 256;
@@ -1148,6 +1256,31 @@ hipError_t launch_ks64(helm_si_ctx *ctx, const Ks64Job *jobs, int64_t count, con
     // `out` is the small-LWE scratch: rows 0..count-1 (job g writes row g)
     const helm_si_params &P = ctx->P;
     const int kN = P.k * P.N;
+    // narrow batches stay on the vector-ALU kernel, whose key rows are split over workgroup slices: a matrix-core
+    // wave walks the whole key column by column tile (0.23 ms whatever the width; vector ALU: 0.11 ms for 64, 0.37 ms
+    // for 256 ciphertexts under PARAM_MESSAGE_2_CARRY_2)
+    if (ctx->ksk_planes && ctx->ks_mfma && count >= 160) {
+        const int64_t padded = (count + 63) / 64 * 64;
+        const int LP = P.ks_l <= 1 ? 1 : P.ks_l <= 2 ? 2 : P.ks_l <= 4 ? 4 : 8;
+        if (ctx->d_ksdig.ensure((size_t)padded * kN * LP) || ctx->d_ksdsum.ensure((size_t)padded) || ctx->d_ksbody.ensure((size_t)padded))
+            return hipErrorOutOfMemory;
+#define KSD_CASE(LV)                                                                                                  \
+    case LV:                                                                                                          \
+        hipLaunchKernelGGL(k_ks64_digits<LV>, dim3((unsigned)padded), dim3(256), 0, ctx->stream, jobs, big, ctx->d_ksdig.p, \
+                           ctx->d_ksdsum.p, ctx->d_ksbody.p, kN, P.ks_logB, (int)count, ctx->ks_kchunks);                 \
+        break;
+        switch (P.ks_l) {
+            KSD_CASE(1) KSD_CASE(2) KSD_CASE(3) KSD_CASE(4) KSD_CASE(5) KSD_CASE(6) KSD_CASE(7) KSD_CASE(8)
+        default: return hipErrorInvalidValue;
+        }
+#undef KSD_CASE
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_ks64_mfma, dim3((unsigned)(padded / 64), (unsigned)ctx->ks_ctiles), dim3(64), 0, ctx->stream, jobs,
+                           ctx->d_ksdig.p, ctx->d_ksdsum.p, ctx->d_ksbody.p, ctx->ksk_planes, out, P.n, (int)count,
+                           ctx->ks_kchunks, ctx->ks_ctiles);
+        return hipGetLastError();
+    }
     const unsigned gx = (unsigned)((count + 3) / 4), gy = (unsigned)((P.n + 1 + 255) / 256);
     int slices = 1;
     while (slices < 16 && (int64_t)gx * gy * slices < 2 * (int64_t)ctx->n_cus && kN / (slices * 2) >= 64) slices *= 2;
@@ -1422,6 +1555,7 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
     }
     // eight-wave kernel (split transforms) where it exists: N >= 1024, one level (HELM_SI_SPLIT=0: off)
     ctx->use_split = P.pbs_l == 1 && N >= 1024;
+    if (const char *v = getenv("HELM_HIP_KS_MFMA")) ctx->ks_mfma = atoi(v);
     if (const char *v = getenv("HELM_SI_SPLIT")) ctx->use_split = (ctx->use_split && atoi(v) != 0) || group > 1;
     if (ctx->use_split) {
         // half h of field f, stage with m' groups, group i': full table entry 2m' + h m' + i'
@@ -1462,6 +1596,10 @@ int helm_si_ctx_destroy(helm_si_ctx *ctx)
     (void)hipFree(ctx->expo);
     (void)hipFree(ctx->psi_pow);
     (void)hipFree(ctx->ksk);
+    (void)hipFree(ctx->ksk_planes);
+    ctx->d_ksdig.release();
+    ctx->d_ksdsum.release();
+    ctx->d_ksbody.release();
     ctx->d_pbs.release();
     ctx->d_ks.release();
     ctx->d_small.release();
@@ -1563,6 +1701,35 @@ int helm_si_load_keyswitch_key(helm_si_ctx *ctx, const uint64_t *ksk, size_t n_w
     if (!ctx->ksk) HIP_TRY(hipMalloc(&ctx->ksk, want * sizeof(uint64_t)));
     HIP_TRY(hipMemcpyAsync(ctx->ksk, ksk, want * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    {
+        // byte planes for the matrix-core keyswitch (levels padded to LP: the padding rows pair zero digits with -128)
+        const int LP = P.ks_l <= 1 ? 1 : P.ks_l <= 2 ? 2 : P.ks_l <= 4 ? 4 : 8;
+        const int R = P.k * P.N * LP;
+        if (R % 64 == 0) {
+            const int kchunks = R / 64, ctiles = (P.n + 1 + 15) / 16;
+            const size_t frag_per_plane = (size_t)ctiles * kchunks * 64;
+            std::vector<int8_t> planes(8 * frag_per_plane * 16, (int8_t)-128);
+            const size_t krow = (size_t)P.n + 1;
+            for (int ct = 0; ct < ctiles; ct++)
+                for (int kc = 0; kc < kchunks; kc++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int c = ct * 16 + (lane & 15);
+                        if (c > P.n) continue;
+                        for (int j = 0; j < 16; j++) {
+                            const int r = kc * 64 + 16 * (lane >> 4) + j, t = r / LP, lev = r % LP;
+                            if (lev >= P.ks_l) continue;
+                            const uint64_t w = ksk[((size_t)t * P.ks_l + lev) * krow + c];
+                            for (int b = 0; b < 8; b++)
+                                planes[((size_t)b * frag_per_plane + ((size_t)ct * kchunks + kc) * 64 + lane) * 16 + j] =
+                                    (int8_t)((int)((w >> (8 * b)) & 255u) - 128);
+                        }
+                    }
+            if (!ctx->ksk_planes) HIP_TRY(hipMalloc(&ctx->ksk_planes, planes.size()));
+            HIP_TRY(hipMemcpy(ctx->ksk_planes, planes.data(), planes.size(), hipMemcpyHostToDevice));
+            ctx->ks_kchunks = kchunks;
+            ctx->ks_ctiles = ctiles;
+        }
+    }
     ctx->have_ksk = true;
     return 0;
 }
