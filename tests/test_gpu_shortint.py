@@ -181,3 +181,28 @@ def test_golden_vectors_on_gpu(fixture):
     w.eval_lut_level(g["arity"], g["in_idx"], g["table"], out_idx)
     assert np.array_equal(w.download(out_idx), g["expected"])
     sk.close()
+
+
+@pytest.mark.parametrize("name", ["si_toy_512", "si_toy_2048", "si_toy_2048_l2", "si_toy_2048_mb3"])  # ks_l = 3, 4, 5
+def test_matrix_core_keyswitch_bit_exact(name, monkeypatch):
+    """Batches of 160 ciphertexts or more keyswitch on the matrix cores (eight int8 GEMMs over the key's byte planes,
+    the level count padded to a power of two); narrower ones and HELM_HIP_KS_MFMA=0 use the vector-ALU kernel.  Both
+    give the oracle's words on a batch that is wide enough for the matrix-core path and not a multiple of its tiles."""
+    ck = helm_amd.SiClientKey.generate(name, seed=9)
+    orc = oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk)
+    sk = helm_amd.SiServerKey(ck)
+    monkeypatch.setenv("HELM_HIP_KS_MFMA", "0")
+    sk_valu = helm_amd.SiServerKey(ck)
+    rng = np.random.default_rng(4)
+    count = 203
+    cts = ck.encrypt(rng.integers(0, ck.t, count).astype(np.uint64))
+    cts[1] = 0
+    cts[2] = rng.integers(0, 2**64, size=cts.shape[1], dtype=np.uint64)  # not a ciphertext at all: every digit pattern
+    got = sk.keyswitch_batch(cts)
+    assert np.array_equal(got, sk_valu.keyswitch_batch(cts))
+    for g in (0, 1, 2, 63, 64, 159, 160, count - 1):
+        assert np.array_equal(got[g], orc.keyswitch(cts[g])), (name, g)
+    narrow = sk.keyswitch_batch(cts[:7])  # the vector-ALU path of the same context
+    assert np.array_equal(narrow, got[:7])
+    sk.close()
+    sk_valu.close()
