@@ -618,9 +618,12 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
     // A/B in tools/ab_wide.py).
     int r = w / L, lev = w - r * L;
     if (K1 == 3 && L == 3 && wave_map) {
-        constexpr int RR[9] = {0, 0, 1, 2, 1, 0, 1, 2, 2}, LL[9] = {2, 0, 0, 0, 2, 1, 1, 1, 2};
-        r = RR[w];
-        lev = LL[w];
+        // w:  0  1  2  3  4  5  6  7  8      (two bits per wave, packed: a table indexed by w would live in scratch)
+        // r:  0  0  1  2  1  0  1  2  2      lev:  2  0  0  0  2  1  1  1  2
+        constexpr unsigned RR = 0u | 0u << 2 | 1u << 4 | 2u << 6 | 1u << 8 | 0u << 10 | 1u << 12 | 2u << 14 | 2u << 16;
+        constexpr unsigned LL = 2u | 0u << 2 | 0u << 4 | 0u << 6 | 2u << 8 | 1u << 10 | 1u << 12 | 1u << 14 | 2u << 16;
+        r = (int)((RR >> (2 * w)) & 3u);
+        lev = (int)((LL >> (2 * w)) & 3u);
     }
     const PbsJob job = jobs[blockIdx.x];
     const size_t row = (size_t)n + 1;
