@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
     // different SIMDs (wave_map = 0 keeps the plain (polynomial, level) order: 3.6 - 4.6 % slower, same-process
     // A/B in tools/ab_wide.py).
     int r = w / L, lev = w - r * L;
-    if (K1 == 3 && L == 3 && wave_map) {
+    if (K1 == 3 && L == 3 && (wave_map & 1)) {
         // w:  0  1  2  3  4  5  6  7  8      (two bits per wave, packed: a table indexed by w would live in scratch)
         // r:  0  0  1  2  1  0  1  2  2      lev:  2  0  0  0  2  1  1  1  2
         constexpr unsigned RR = 0u | 0u << 2 | 1u << 4 | 2u << 6 | 1u << 8 | 0u << 10 | 1u << 12 | 2u << 14 | 2u << 16;
@@ -694,17 +694,27 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
 
     STAMP_DECL
     if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
-    for (int i = 0; i < n; i++) {
-        const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
-        if (a == 0) continue; // uniform over the workgroup
-        STAMP_BEGIN
-        // this step's key words (k+1 polynomials of this wave's row and level)
-        double2 kw[K1][E / 2];
-        const unsigned so = (unsigned)i * step_bytes + wave_off;
+    // Key words (k+1 polynomials of this wave's row and level).  Nine waves x 12 loads of 1 KiB per step keep the CU's
+    // vector-memory path busy for ~1.7 k cycles, and a wave cannot start its arithmetic until its loads are accepted:
+    // finer per-phase stamps showed the load issue alone taking 0.3 k (oldest wave) to 1.6 k cycles (youngest) at the
+    // top of a step.  The six waves that idle during the inverse transforms therefore fetch the NEXT step's words
+    // right after barrier 1, into the registers their products have just released; only the three inverse waves
+    // still load at the top of the step (wave_map bit 1 set: every wave loads at the top, the round-1 order, for A/B).
+    double2 kw[K1][E / 2];
+    auto load_keys = [&](int ii) {
+        const unsigned so = (unsigned)ii * step_bytes + wave_off;
 #pragma unroll
         for (int c = 0; c < K1; c++)
 #pragma unroll
             for (int e2 = 0; e2 < E / 2; e2++) kw[c][e2] = kb.load(so + (unsigned)(c * L) * poly_bytes, e2 * 1024);
+    };
+    const bool ahead = !(wave_map & 2) && lev != 0;
+    int i = 0, a = 0;
+    while (i < n && (a = __builtin_amdgcn_readfirstlane((int)MS[i])) == 0) i++; // a zero rotation adds nothing
+    if (i < n && ahead) load_keys(i);
+    while (i < n) {
+        STAMP_BEGIN
+        if (!ahead) load_keys(i);
         // rotate / subtract, run the signed decomposition down to this wave's level
         double x[1][E];
         {
@@ -743,8 +753,11 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
             }
         }
         STAMP(2) // products
+        int inext = i + 1, anext = 0;
+        while (inext < n && (anext = __builtin_amdgcn_readfirstlane((int)MS[inext])) == 0) inext++; // uniform over the workgroup
         lds_block_sync(); // every product of the step is in its column
         STAMP(3) // barrier 1
+        if (ahead && inext < n) load_keys(inext);
         if (lev == 0) {
             double mine[E];
             double *col = COL + (size_t)r * N + lane;
@@ -762,6 +775,8 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
         lds_block_sync(); // accumulator copies published, columns cleared
         STAMP(5) // barrier 2
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
+        i = inext;
+        a = anext;
     }
     STAMP_END(w)
 
