@@ -624,6 +624,14 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
         constexpr unsigned LL = 2u | 0u << 2 | 0u << 4 | 0u << 6 | 2u << 8 | 1u << 10 | 1u << 12 | 1u << 14 | 2u << 16;
         r = (int)((RR >> (2 * w)) & 3u);
         lev = (int)((LL >> (2 * w)) & 3u);
+    } else if (K1 == 2 && L == 3 && (wave_map & 1)) {
+        // six waves sit 2 / 2 / 1 / 1 on the SIMDs: the two inverse waves (level 0) alone on SIMDs 2 and 3, the
+        // last-level units on SIMD 0, the level-1 units on SIMD 1
+        // w:  0  1  2  3  4  5        r:  0  0  0  1  1  1        lev:  2  1  0  0  2  1
+        constexpr unsigned RR = 0u | 0u << 2 | 0u << 4 | 1u << 6 | 1u << 8 | 1u << 10;
+        constexpr unsigned LL = 2u | 1u << 2 | 0u << 4 | 0u << 6 | 2u << 8 | 1u << 10;
+        r = (int)((RR >> (2 * w)) & 3u);
+        lev = (int)((LL >> (2 * w)) & 3u);
     }
     const PbsJob job = jobs[blockIdx.x];
     const size_t row = (size_t)n + 1;
@@ -1447,6 +1455,11 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
         // lockstep build (level at a time, four bootstraps per workgroup, the two waves of a bootstrap on
         // one SIMD): the full rounds of wide launches (HELM_HIP_PBS_VARIANT=1 keeps the build above)
         using Lock = PbsCfg<F, LOGN, K, L, 1, TW_LANE, false, 1, 4>;
+        // launches of at most one bootstrap per CU (a single netlist's levels): the wide build, (k+1) L waves per
+        // bootstrap - 2.6 ms instead of 5.6 ms per bootstrap on helm_cuda (HELM_HIP_PBS_VARIANT=4 forces it,
+        // HELM_HIP_NARROW=1 keeps the two-wave build)
+        if (ctx->pbs_variant == 4 || (ctx->pbs_variant == 0 && count <= ctx->n_cus && ctx->narrow_variant == 4))
+            return launch_pbs_wide<WideCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (ctx->pbs_variant != 1) {
             const int64_t round = 4 * (int64_t)ctx->n_cus;
             int64_t full = ctx->pbs_variant == 5 ? count : count / round * round;
@@ -1465,6 +1478,8 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
                 count -= full;
             }
         }
+        if (ctx->pbs_variant == 0 && count <= ctx->n_cus && ctx->narrow_variant == 4)
+            return launch_pbs_wide<WideCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
         return launch_pbs_v<Big>(ctx, jobs, count, wires, raw, tvs, out_big);
     }
 }

@@ -1,5 +1,5 @@
 """Same-process A/B of k_pbs_wide wave placements: one context per HELM_HIP_WIDE_MAP value, alternating launches
-of B bootstraps.  Usage: [MAPS=0,1] ab_wide.py [B] [reps]"""
+of B bootstraps.  Usage: [PARAMS=boolean_default] [MAPS=0,1] ab_wide.py [B] [reps]"""
 import os
 import sys
 import time
@@ -10,7 +10,8 @@ import helm_amd, oracle  # noqa
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 MAPS = [int(x) for x in os.environ.get("MAPS", "0,1").split(",")]
-ck = helm_amd.ClientKey.generate("boolean_default", seed=1)
+PARAMS = os.environ.get("PARAMS", "boolean_default")
+ck = helm_amd.ClientKey.generate(PARAMS, seed=1)
 rng = np.random.default_rng(0)
 bits = rng.integers(0, 2, size=2 * B).astype(bool)
 cts = ck.encrypt(bits)
