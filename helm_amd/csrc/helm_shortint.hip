@@ -1133,6 +1133,19 @@ struct helm_si_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pbs, ev_ks, ev_lin;
     helm_si_timing tacc{};
     std::vector<helm_si_wires *> child_wires; // released with the context (see helm_hip.hip)
+    // Call slots: helm_si_lincomb / helm_si_apply_luts copy their index arrays into a slot's pinned arena, issue ONE
+    // asynchronous copy of it and launch - no stream synchronisation inside the call, so the host plans the next
+    // batched round of the radix layer while the GPU runs this one (a round used to leave the GPU idle for ~1 ms of
+    // host planning, copies and synchronisations out of ~8 ms).  A slot is reused three calls later, after its event.
+    struct CallSlot {
+        char *host = nullptr, *dev = nullptr;
+        size_t cap = 0, used = 0;
+        hipEvent_t done = nullptr;
+        bool busy = false;
+    } slots[3];
+    int next_slot = 0;
+    uint64_t luts_hash = 0; // of the look-up tables resident in d_luts (re-uploaded only when they change)
+    size_t luts_words = 0;
     // multi-GPU (helm_si_set_exchange): every bootstrap batch of at least x_min ciphertexts is split
     // into x_world contiguous chunks, this rank bootstraps chunk x_rank into x_stage, the caller's
     // collective fills x_gather with every rank's chunk and the rows are scattered into the table
@@ -1338,6 +1351,62 @@ int upload(helm_si_ctx *ctx, DevBuf<T> &buf, const T *host, size_t n)
     return 0;
 }
 
+// ---- call slots (see helm_si_ctx) -------------------------------------------------------------------------
+int slot_begin(helm_si_ctx *ctx, size_t need, helm_si_ctx::CallSlot **out)
+{
+    helm_si_ctx::CallSlot &S = ctx->slots[ctx->next_slot];
+    ctx->next_slot = (ctx->next_slot + 1) % 3;
+    if (!S.done) HIP_TRY(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+    if (S.busy) HIP_TRY(hipEventSynchronize(S.done)); // two calls later at the earliest: normally long complete
+    S.busy = false;
+    need += 4096;
+    if (need > S.cap) {
+        if (S.host) (void)hipHostFree(S.host);
+        if (S.dev) (void)hipFree(S.dev);
+        S.host = S.dev = nullptr;
+        S.cap = 0;
+        const size_t want = std::max(need * 2, (size_t)1 << 20);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&S.host), want, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&S.dev), want));
+        S.cap = want;
+    }
+    S.used = 0;
+    *out = &S;
+    return 0;
+}
+template <typename T> T *slot_put(helm_si_ctx::CallSlot &S, const T *src, size_t n)
+{
+    S.used = (S.used + 255) / 256 * 256;
+    std::memcpy(S.host + S.used, src, n * sizeof(T));
+    T *d = reinterpret_cast<T *>(S.dev + S.used);
+    S.used += n * sizeof(T);
+    return d;
+}
+int slot_flush(helm_si_ctx *ctx, helm_si_ctx::CallSlot &S)
+{
+    if (S.used) HIP_TRY(hipMemcpyAsync(S.dev, S.host, S.used, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+int slot_end(helm_si_ctx *ctx, helm_si_ctx::CallSlot &S)
+{
+    HIP_TRY(hipEventRecord(S.done, ctx->stream));
+    S.busy = true;
+    return 0;
+}
+// the look-up tables of a call: resident already (same words as the last upload) or uploaded after a drain
+int luts_resident(helm_si_ctx *ctx, const uint64_t *luts_host, size_t words)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ words;
+    for (size_t i = 0; i < words; i++) h = (h ^ luts_host[i]) * 0x100000001B3ull + (h >> 29);
+    if (ctx->d_luts.p && ctx->luts_words == words && ctx->luts_hash == h) return 0;
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // a running bootstrap may still read the old tables
+    if (ctx->d_luts.ensure(words)) return fail(HELM_ERR_OOM, "look-up tables");
+    HIP_TRY(hipMemcpy(ctx->d_luts.p, luts_host, words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    ctx->luts_hash = h;
+    ctx->luts_words = words;
+    return 0;
+}
+
 // keyswitch + bootstrap of `count` rows of `src` (big) into rows of `dst` (big)
 int apply_luts_device(helm_si_ctx *ctx, const uint64_t *src, uint64_t *dst, const std::vector<Ks64Job> &ks,
                       const std::vector<Pbs64Job> &pbs, const uint64_t *luts_host, int64_t n_luts)
@@ -1346,22 +1415,27 @@ int apply_luts_device(helm_si_ctx *ctx, const uint64_t *src, uint64_t *dst, cons
     if (!ctx->have_bsk || !ctx->have_ksk) return fail(HELM_ERR_STATE, "bootstrapping / keyswitching key not loaded");
     const int64_t count = (int64_t)pbs.size();
     if (count == 0) return 0;
-    if (int rc = drain(ctx)) return rc;
-    if (ctx->d_small.ensure((size_t)count * ((size_t)P.n + 1))) return fail(HELM_ERR_OOM, "small-LWE scratch");
-    if (int rc = upload(ctx, ctx->d_ks, ks.data(), ks.size())) return rc;
-    if (int rc = upload(ctx, ctx->d_pbs, pbs.data(), pbs.size())) return rc;
-    if (int rc = upload(ctx, ctx->d_luts, luts_host, (size_t)n_luts * P.N)) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream)); // host vectors may go out of scope
+    if (ctx->d_small.cap < (size_t)count * ((size_t)P.n + 1)) {
+        if (int rc = drain(ctx)) return rc; // growing the scratch frees the old one
+        if (ctx->d_small.ensure((size_t)count * ((size_t)P.n + 1))) return fail(HELM_ERR_OOM, "small-LWE scratch");
+    }
+    if (int rc = luts_resident(ctx, luts_host, (size_t)n_luts * P.N)) return rc;
+    helm_si_ctx::CallSlot *S = nullptr;
+    if (int rc = slot_begin(ctx, ks.size() * sizeof(Ks64Job) + pbs.size() * sizeof(Pbs64Job), &S)) return rc;
+    const Ks64Job *d_ks = slot_put(*S, ks.data(), ks.size());
+    const Pbs64Job *d_pbs = slot_put(*S, pbs.data(), pbs.size());
+    if (int rc = slot_flush(ctx, *S)) return rc;
     {
         Timed t(ctx, &ctx->ev_ks);
-        HIP_TRY(launch_ks64(ctx, ctx->d_ks.p, count, src, ctx->d_small.p));
+        HIP_TRY(launch_ks64(ctx, d_ks, count, src, ctx->d_small.p));
     }
     ctx->tacc.ks_launches++;
     ctx->tacc.ks_count += count;
     {
         Timed t(ctx, &ctx->ev_pbs);
-        HIP_TRY(launch_pbs64(ctx, ctx->d_pbs.p, count, ctx->d_small.p, ctx->d_luts.p, dst));
+        HIP_TRY(launch_pbs64(ctx, d_pbs, count, ctx->d_small.p, ctx->d_luts.p, dst));
     }
+    if (int rc = slot_end(ctx, *S)) return rc;
     ctx->tacc.pbs_launches++;
     ctx->tacc.pbs_count += count;
     return 0;
@@ -1597,6 +1671,11 @@ int helm_si_ctx_destroy(helm_si_ctx *ctx)
     (void)hipFree(ctx->psi_pow);
     (void)hipFree(ctx->ksk);
     (void)hipFree(ctx->ksk_planes);
+    for (auto &S : ctx->slots) {
+        if (S.host) (void)hipHostFree(S.host);
+        if (S.dev) (void)hipFree(S.dev);
+        if (S.done) (void)hipEventDestroy(S.done);
+    }
     ctx->d_ksdig.release();
     ctx->d_ksdsum.release();
     ctx->d_ksbody.release();
@@ -1860,29 +1939,33 @@ int helm_si_lincomb(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, c
     if (int rc = check_rows(w, in_idx, count * terms, true)) return rc;
     if (int rc = check_rows(w, out_idx, count, false)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (int rc = drain(ctx)) return rc;
     const int dim = ctx->P.k * ctx->P.N;
     std::vector<uint64_t> body((size_t)count, 0);
     if (const_add)
         for (int64_t g = 0; g < count; g++) body[(size_t)g] = (uint64_t)const_add[g] * ctx->delta;
-    if (int rc = upload(ctx, ctx->d_body, body.data(), body.size())) return rc;
-    if (int rc = upload(ctx, ctx->d_idx, in_idx, (size_t)count * terms)) return rc;
-    if (int rc = upload(ctx, ctx->d_idx2, out_idx, (size_t)count)) return rc;
-    if (int rc = upload(ctx, ctx->d_coef, coef, (size_t)count * terms)) return rc;
     // sums are staged (rows 0..count-1) and then scattered, so that a gate may overwrite a
     // row another gate of the same call still reads
-    if (ctx->d_stage.ensure((size_t)count * (dim + 1))) return fail(HELM_ERR_OOM, "staging");
-    HIP_TRY(hipStreamSynchronize(ctx->stream)); // host vectors may go out of scope
+    if (ctx->d_stage.cap < (size_t)count * (dim + 1)) {
+        if (int rc = drain(ctx)) return rc; // growing the staging area frees the old one
+        if (ctx->d_stage.ensure((size_t)count * (dim + 1))) return fail(HELM_ERR_OOM, "staging");
+    }
+    helm_si_ctx::CallSlot *S = nullptr;
+    if (int rc = slot_begin(ctx, (size_t)count * (8 + 4) + (size_t)count * terms * (4 + 8), &S)) return rc;
+    const uint64_t *d_body = slot_put(*S, body.data(), body.size());
+    const int32_t *d_in = slot_put(*S, in_idx, (size_t)count * terms);
+    const int32_t *d_out = slot_put(*S, out_idx, (size_t)count);
+    const int64_t *d_coef = slot_put(*S, coef, (size_t)count * terms);
+    if (int rc = slot_flush(ctx, *S)) return rc;
     {
         Timed t(ctx, &ctx->ev_lin);
-        hipLaunchKernelGGL(k_lincomb64, dim3((unsigned)count), dim3(256), 0, ctx->stream, ctx->d_idx.p, ctx->d_coef.p,
-                           ctx->d_body.p, (const int32_t *)nullptr, w->d, ctx->d_stage.p, terms, dim);
+        hipLaunchKernelGGL(k_lincomb64, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_in, d_coef, d_body,
+                           (const int32_t *)nullptr, w->d, ctx->d_stage.p, terms, dim);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_rows64, dim3((unsigned)count), dim3(256), 0, ctx->stream, ctx->d_stage.p,
-                           (const int32_t *)nullptr, w->d, ctx->d_idx2.p, dim);
+                           (const int32_t *)nullptr, w->d, d_out, dim);
         HIP_TRY(hipGetLastError());
     }
-    return 0;
+    return slot_end(ctx, *S);
 }
 
 int helm_si_make_lut(const helm_si_ctx *ctx, const uint64_t *f_values, uint64_t *tv)
@@ -2084,6 +2167,7 @@ int helm_si_pbs_batch(helm_si_ctx *ctx, const uint64_t *in_small, const uint64_t
         jobs[(size_t)g] = Pbs64Job{(int32_t)g, lut_idx[g], (int32_t)g, 0};
     }
     if (int rc = upload(ctx, ctx->d_small, in_small, (size_t)count * row)) return rc;
+    ctx->luts_words = 0; // the resident tables of the call slots are overwritten
     if (int rc = upload(ctx, ctx->d_luts, luts, (size_t)n_luts * P.N)) return rc;
     if (int rc = upload(ctx, ctx->d_pbs, jobs.data(), jobs.size())) return rc;
     if (ctx->d_stage.ensure((size_t)count * brow)) return fail(HELM_ERR_OOM, "staging");
