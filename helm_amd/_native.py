@@ -53,6 +53,23 @@ class SiParams(C.Structure):
         return "SiParams(" + ", ".join(f"{f}={getattr(self, f)}" for f, _ in self._fields_) + ")"
 
 
+class WopParams(C.Structure):  # helm_wop_params
+    _fields_ = [(f, C.c_int32) for f in ("n", "k", "N", "pbs_l", "pbs_logB", "ks_l", "ks_logB", "pfks_l", "pfks_logB",
+                                         "cbs_l", "cbs_logB", "message_modulus", "carry_modulus")]
+
+    def as_tuple(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+    def __repr__(self):
+        return "WopParams(" + ", ".join(f"{f}={getattr(self, f)}" for f, _ in self._fields_) + ")"
+
+
+class WopTiming(C.Structure):  # helm_wop_timing
+    _fields_ = [(f, C.c_double) for f in ("clean_ms", "to_wopbs_ms", "extract_ms", "cbs_pbs_ms", "pfpks_ms",
+                                          "convert_ms", "packing_ms", "to_pbs_ms")] + \
+               [("gates", C.c_int64), ("bootstraps", C.c_int64)]
+
+
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
 i32p = C.POINTER(C.c_int32)
@@ -137,11 +154,33 @@ SI_API = {
     "helm_si_get_timing": (C.c_int, [vp, C.POINTER(Timing), C.c_int]),
 }
 
+WOP_CLIENT_API = {
+    "helm_wop_client_named_params": (C.c_int, [C.c_char_p, C.POINTER(WopParams), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "helm_wop_client_keygen": (C.c_int, [vp, C.POINTER(WopParams), C.c_double, C.c_double, C.c_uint64, C.POINTER(vp)]),
+    "helm_wop_client_key_free": (None, [vp]),
+    "helm_wop_client_key_part": (C.c_int, [vp, C.c_int, C.POINTER(u64p), C.POINTER(C.c_size_t)]),
+}
+
+# every symbol include/helm_wopbs.h declares: device side (libhelm_hip.so) and client side (libhelm_host.so)
+WOP_API = {
+    "helm_wop_ctx_create": (C.c_int, [vp, C.POINTER(WopParams), C.POINTER(vp)]),
+    "helm_wop_ctx_destroy": (C.c_int, [vp]),
+    "helm_wop_get_params": (C.c_int, [vp, C.POINTER(WopParams)]),
+    "helm_wop_load_key": (C.c_int, [vp, C.c_int, u64p, C.c_size_t, C.c_int32, C.c_int32]),
+    "helm_wop_table_words": (C.c_size_t, [C.POINTER(WopParams), C.c_int32]),
+    "helm_wop_make_table": (C.c_int, [C.POINTER(WopParams), C.c_int32, C.c_int32, u64p, C.c_size_t, u64p]),
+    "helm_wop_eval_luts": (C.c_int, [vp, vp, i32p, C.c_int32, C.c_int32, u64p, i32p, C.c_int64]),
+    "helm_wop_extract_bits_batch": (C.c_int, [vp, u64p, C.c_int32, C.c_int32, u64p, C.c_int64]),
+    "helm_wop_circuit_bootstrap_batch": (C.c_int, [vp, u64p, u64p, C.c_int64]),
+    "helm_wop_vertical_packing_batch": (C.c_int, [vp, u64p, C.c_int32, u64p, u64p, C.c_int64]),
+    "helm_wop_get_timing": (C.c_int, [vp, C.POINTER(WopTiming), C.c_int]),
+}
 SI_CLIENT_API = {
     "helm_si_client_named_params": (C.c_int, [C.c_char_p, C.POINTER(SiParams), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "helm_si_client_keygen": (C.c_int, [C.POINTER(SiParams), C.c_double, C.c_double, C.c_uint64, C.POINTER(vp)]),
     "helm_si_client_key_free": (None, [vp]),
     "helm_si_client_params": (C.c_int, [vp, C.POINTER(SiParams)]),
+    "helm_si_client_noise": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "helm_si_client_bsk_words": (C.c_size_t, [vp]),
     "helm_si_client_ksk_words": (C.c_size_t, [vp]),
     "helm_si_client_bsk": (u64p, [vp]),
@@ -183,7 +222,8 @@ KEYS_API = {
     "helm_keys_ksk64_to_tfhe": (C.c_int, [C.POINTER(SiParams), u64p, u64p, C.c_size_t]),
 }
 
-for _lib, _api in ((hip, HIP_API), (host, CLIENT_API), (hip, SI_API), (host, SI_CLIENT_API), (host, KEYS_API)):
+for _lib, _api in ((hip, HIP_API), (host, CLIENT_API), (hip, SI_API), (host, SI_CLIENT_API), (host, KEYS_API),
+                   (hip, WOP_API), (host, WOP_CLIENT_API)):
     for _name, (_res, _args) in _api.items():
         _fn = getattr(_lib, _name)  # AttributeError here = header/library mismatch
         _fn.restype = _res

@@ -186,6 +186,14 @@ int helm_si_client_params(const helm_si_client_key *key, helm_si_params *out)
     *out = key->P;
     return 0;
 }
+int helm_si_client_noise(const helm_si_client_key *key, double *lwe_noise_std, double *glwe_noise_std)
+{
+    if (!key || !lwe_noise_std || !glwe_noise_std) return fail64(HELM_ERR_INVALID, "null argument");
+    *lwe_noise_std = key->lwe_std;
+    *glwe_noise_std = key->glwe_std;
+    return 0;
+}
+
 size_t helm_si_client_bsk_words(const helm_si_client_key *key) { return key ? key->bsk.size() : 0; }
 size_t helm_si_client_ksk_words(const helm_si_client_key *key) { return key ? key->ksk.size() : 0; }
 const uint64_t *helm_si_client_bsk(const helm_si_client_key *key) { return key ? key->bsk.data() : nullptr; }

@@ -116,9 +116,10 @@ struct Pbs64Cfg {
     static constexpr size_t BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
 };
 
-template <typename C, typename F>
+template <typename C, typename F, int MODE>
 __device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__restrict__ bsk, int n, int logB,
-                                           double p0inv_mod_p1, int p, int f, int lane)
+                                           double p0inv_mod_p1, int p, int f, int lane,
+                                           const uint64_t *__restrict__ alt_p)
 {
     constexpr int LOGN = C::LOGN, L = C::L, K1 = C::K1;
     using G = Geo<LOGN>;
@@ -155,9 +156,14 @@ __device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 const int j = G::jA(lane, e);
-                const int src = (j - a) & (2 * N - 1);
-                uint64_t v = acc_p[src & (N - 1)];
-                if (src >= N) v = 0ull - v;
+                uint64_t v;
+                if constexpr (MODE == 2) {
+                    v = alt_p[j]; // CMUX of two given ciphertexts: c1 - c0
+                } else {
+                    const int src = (j - a) & (2 * N - 1);
+                    v = acc_p[src & (N - 1)];
+                    if (src >= N) v = 0ull - v;
+                }
                 v -= acc_p[j];
                 state[e] = (uint32_t)((v + (1ull << (63 - rep))) >> (64 - rep));
             }
@@ -254,7 +260,13 @@ __device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__
     STAMP_END(p * 2 + f)
 }
 
-template <typename C>
+// MODE 0: programmable bootstrap (job: in_row of `small`, lut row of N words, out_row of k*N+1 words).
+// MODE 1: blind rotation of a given GLWE with a per-job GGSW stack, sample extract - the tail of vertical packing
+//         (job: in_row = row of `small` holding the synthetic rotation amounts, lut = row of (k+1) N words in
+//         `luts`, pad = index of the job's key, key_stride doubles apart).
+// MODE 2: one CMUX  out = c0 + GGSW (x) (c1 - c0)  (job: lut = row of c0, in_row = row of c1, both rows of
+//         (k+1) N words of `luts`; pad = key index; the GGSW is entry key_first of that key; out rows of (k+1) N).
+template <typename C, int MODE>
 __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restrict__ jobs,
                                                          const uint64_t *__restrict__ small, // rows of n+1
                                                          const uint64_t *__restrict__ luts,  // rows of N
@@ -262,7 +274,8 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
                                                          const double *__restrict__ tw0,
                                                          const double *__restrict__ tw1,
                                                          uint64_t *__restrict__ out, // rows of k*N+1
-                                                         int n, int logB, double p0inv_mod_p1)
+                                                         int n, int logB, double p0inv_mod_p1, size_t key_stride,
+                                                         int key_first)
 {
     constexpr int LOGN = C::LOGN, K = C::K;
     using G = Geo<LOGN>;
@@ -276,8 +289,12 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = w >> 1, f = w & 1;
     const Pbs64Job job = jobs[blockIdx.x];
-    const uint64_t *lwe = small + (size_t)job.in_row * ((size_t)n + 1);
-    for (int i = tid; i <= n; i += 64 * C::NW) MS[i] = (uint16_t)modswitch64(lwe[i], LOGN + 1);
+    if constexpr (MODE == 2) {
+        if (tid == 0) MS[0] = 1, MS[1] = 0;
+    } else {
+        const uint64_t *lwe = small + (size_t)job.in_row * ((size_t)n + 1);
+        for (int i = tid; i <= n; i += 64 * C::NW) MS[i] = (uint16_t)modswitch64(lwe[i], LOGN + 1);
+    }
     for (int i = tid; i < C::TW_IDX; i += 64 * C::NW) {
         TW[i] = tw0[i];
         TW[C::TW_FIELD + i] = tw1[i];
@@ -288,8 +305,8 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
         TW[C::TW_FIELD + C::TW_IDX + r * 64 + lane] = tw1[idx];
     }
     __syncthreads();
-    // accumulator: (0, X^{-b~} * lut)
-    {
+    // accumulator: (0, X^{-b~} * lut); MODE 1, 2: the given GLWE as it is
+    if constexpr (MODE == 0) {
         const int bt = (int)MS[n];
         const uint64_t *tv = luts + (size_t)job.lut * N;
         for (int j = tid; j < (K + 1) * N; j += 64 * C::NW) {
@@ -301,15 +318,32 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
             }
             ACC[j] = v;
         }
+    } else {
+        const uint64_t *c0 = luts + (size_t)job.lut * ((size_t)(K + 1) * N);
+        for (int j = tid; j < (K + 1) * N; j += 64 * C::NW) ACC[j] = c0[j];
     }
     __syncthreads();
 
-    if (f == 0) pbs64_body<C, F0>(smem, bsk, n, logB, p0inv_mod_p1, p, 0, lane);
-    else pbs64_body<C, F1>(smem, bsk, n, logB, p0inv_mod_p1, p, 1, lane);
+    const double *key = bsk;
+    const uint64_t *alt_p = nullptr;
+    if constexpr (MODE != 0) key += (size_t)job.pad * key_stride + (size_t)key_first * ((size_t)(K + 1) * (K + 1) * C::L * 2 * N);
+    if constexpr (MODE == 2) alt_p = luts + (size_t)job.in_row * ((size_t)(K + 1) * N) + (size_t)p * N;
+    const int steps = MODE == 2 ? 1 : n;
+    if (f == 0) pbs64_body<C, F0, MODE>(smem, key, steps, logB, p0inv_mod_p1, p, 0, lane, alt_p);
+    else pbs64_body<C, F1, MODE>(smem, key, steps, logB, p0inv_mod_p1, p, 1, lane, alt_p);
 
+    const uint64_t *acc_p = ACC + (size_t)p * N;
+    if constexpr (MODE == 2) { // the whole GLWE
+        uint64_t *og = out + (size_t)job.out_row * ((size_t)(K + 1) * N) + (size_t)p * N;
+#pragma unroll
+        for (int e = 0; e < H; e++) {
+            const int j = G::jA(lane, f * H + e);
+            og[j] = acc_p[j];
+        }
+        return;
+    }
     // ---- sample extract (coefficient 0); wave (p, f) writes its half of the slots ------
     uint64_t *ob = out + (size_t)job.out_row * ((size_t)K * N + 1);
-    const uint64_t *acc_p = ACC + (size_t)p * N;
     if (p < K) {
 #pragma unroll
         for (int e = 0; e < H; e++) {
@@ -1187,20 +1221,22 @@ bool si_supported(const helm_si_params &P)
     return P.pbs_l == 1 || P.pbs_l == 2;
 }
 
-template <typename C>
+template <typename C, int MODE = 0>
 hipError_t launch_pbs64_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
-                          const uint64_t *luts, uint64_t *out)
+                          const uint64_t *luts, uint64_t *out, const double *key = nullptr, int n_steps = -1,
+                          int logB = 0, size_t key_stride = 0, int key_first = 0)
 {
     static bool attr_done[64] = {false};
-    auto kern = k_pbs64<C>;
+    auto kern = k_pbs64<C, MODE>;
     if (!attr_done[ctx->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
         if (e != hipSuccess) return e;
         attr_done[ctx->device & 63] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, small, luts, ctx->bsk,
-                       ctx->tw[0], ctx->tw[1], out, ctx->P.n, ctx->P.pbs_logB, ctx->p0inv_mod_p1);
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, small, luts,
+                       key ? key : ctx->bsk, ctx->tw[0], ctx->tw[1], out, n_steps >= 0 ? n_steps : ctx->P.n,
+                       logB ? logB : ctx->P.pbs_logB, ctx->p0inv_mod_p1, key_stride, key_first);
 #ifdef HELM_WIDE_STAMPS
     {
         unsigned long long v[8 * 8];
@@ -1264,15 +1300,24 @@ hipError_t launch_pbs64(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, c
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_ks64(helm_si_ctx *ctx, const Ks64Job *jobs, int64_t count, const uint64_t *big, uint64_t *out)
+// A keyswitching key on the device: in_dim input words (+ body) -> out_dim mask words + body.  The context's own
+// key (big -> small) and the WoP-PBS path's extra keys go through the same kernels.
+struct KsKey {
+    const uint64_t *key = nullptr; // [in_dim][l][out_dim+1]
+    const int8_t *planes = nullptr; // byte planes for the matrix-core kernel, or null
+    int in_dim = 0, out_dim = 0, l = 0, logB = 0, kchunks = 0, ctiles = 0;
+};
+
+hipError_t launch_ks64_key(helm_si_ctx *ctx, const KsKey &K, const Ks64Job *jobs, int64_t count, const uint64_t *big,
+                           uint64_t *out)
 {
-    // `out` is the small-LWE scratch: rows 0..count-1 (job g writes row g)
-    const helm_si_params &P = ctx->P;
-    const int kN = P.k * P.N;
+    // `out`: rows of out_dim+1 words (job g writes row jobs[g].out_row)
+    struct { int n, ks_l, ks_logB; } P{K.out_dim, K.l, K.logB};
+    const int kN = K.in_dim;
     // narrow batches stay on the vector-ALU kernel, whose key rows are split over workgroup slices: a matrix-core
     // wave walks the whole key column by column tile (0.23 ms whatever the width; vector ALU: 0.11 ms for 64, 0.37 ms
     // for 256 ciphertexts under PARAM_MESSAGE_2_CARRY_2)
-    if (ctx->ksk_planes && ctx->ks_mfma && count >= 160) {
+    if (K.planes && ctx->ks_mfma && count >= 160) {
         const int64_t padded = (count + 63) / 64 * 64;
         const int LP = P.ks_l <= 1 ? 1 : P.ks_l <= 2 ? 2 : P.ks_l <= 4 ? 4 : 8;
         if (ctx->d_ksdig.ensure((size_t)padded * kN * LP) || ctx->d_ksdsum.ensure((size_t)padded) || ctx->d_ksbody.ensure((size_t)padded))
@@ -1280,7 +1325,7 @@ hipError_t launch_ks64(helm_si_ctx *ctx, const Ks64Job *jobs, int64_t count, con
 #define KSD_CASE(LV)                                                                                                  \
     case LV:                                                                                                          \
         hipLaunchKernelGGL(k_ks64_digits<LV>, dim3((unsigned)padded), dim3(256), 0, ctx->stream, jobs, big, ctx->d_ksdig.p, \
-                           ctx->d_ksdsum.p, ctx->d_ksbody.p, kN, P.ks_logB, (int)count, ctx->ks_kchunks);                 \
+                           ctx->d_ksdsum.p, ctx->d_ksbody.p, kN, P.ks_logB, (int)count, K.kchunks);                 \
         break;
         switch (P.ks_l) {
             KSD_CASE(1) KSD_CASE(2) KSD_CASE(3) KSD_CASE(4) KSD_CASE(5) KSD_CASE(6) KSD_CASE(7) KSD_CASE(8)
@@ -1289,9 +1334,9 @@ hipError_t launch_ks64(helm_si_ctx *ctx, const Ks64Job *jobs, int64_t count, con
 #undef KSD_CASE
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_ks64_mfma, dim3((unsigned)(padded / 64), (unsigned)ctx->ks_ctiles), dim3(64), 0, ctx->stream, jobs,
-                           ctx->d_ksdig.p, ctx->d_ksdsum.p, ctx->d_ksbody.p, ctx->ksk_planes, out, P.n, (int)count,
-                           ctx->ks_kchunks, ctx->ks_ctiles);
+        hipLaunchKernelGGL(k_ks64_mfma, dim3((unsigned)(padded / 64), (unsigned)K.ctiles), dim3(64), 0, ctx->stream, jobs,
+                           ctx->d_ksdig.p, ctx->d_ksdsum.p, ctx->d_ksbody.p, K.planes, out, P.n, (int)count,
+                           K.kchunks, K.ctiles);
         return hipGetLastError();
     }
     const unsigned gx = (unsigned)((count + 3) / 4), gy = (unsigned)((P.n + 1 + 255) / 256);
@@ -1313,7 +1358,7 @@ hipError_t launch_ks64(helm_si_ctx *ctx, const Ks64Job *jobs, int64_t count, con
             if (e != hipSuccess) return e;                                                                          \
             done = true;                                                                                            \
         }                                                                                                           \
-        hipLaunchKernelGGL(k_keyswitch64<LV>, grid, dim3(256), lds, ctx->stream, jobs, big, ctx->ksk, out, P.n, kN, \
+        hipLaunchKernelGGL(k_keyswitch64<LV>, grid, dim3(256), lds, ctx->stream, jobs, big, K.key, out, P.n, kN,   \
                            P.ks_logB, (int)count, t_chunk);                                                         \
         break;                                                                                                      \
     }
@@ -1323,6 +1368,20 @@ hipError_t launch_ks64(helm_si_ctx *ctx, const Ks64Job *jobs, int64_t count, con
     }
 #undef KS_CASE
     return hipGetLastError();
+}
+
+hipError_t launch_ks64(helm_si_ctx *ctx, const Ks64Job *jobs, int64_t count, const uint64_t *big, uint64_t *out)
+{
+    KsKey K;
+    K.key = ctx->ksk;
+    K.planes = ctx->ksk_planes;
+    K.in_dim = ctx->P.k * ctx->P.N;
+    K.out_dim = ctx->P.n;
+    K.l = ctx->P.ks_l;
+    K.logB = ctx->P.ks_logB;
+    K.kchunks = ctx->ks_kchunks;
+    K.ctiles = ctx->ks_ctiles;
+    return launch_ks64_key(ctx, K, jobs, count, big, out);
 }
 
 int check_rows(const helm_si_wires *w, const int32_t *idx, int64_t count, bool allow_neg)
@@ -1409,10 +1468,12 @@ int luts_resident(helm_si_ctx *ctx, const uint64_t *luts_host, size_t words)
 
 // keyswitch + bootstrap of `count` rows of `src` (big) into rows of `dst` (big)
 int apply_luts_device(helm_si_ctx *ctx, const uint64_t *src, uint64_t *dst, const std::vector<Ks64Job> &ks,
-                      const std::vector<Pbs64Job> &pbs, const uint64_t *luts_host, int64_t n_luts)
+                      const std::vector<Pbs64Job> &pbs, const uint64_t *luts_host, int64_t n_luts,
+                      const KsKey *other_key = nullptr) // other_key: keyswitch from another big key (WoP-PBS path)
 {
     const helm_si_params &P = ctx->P;
-    if (!ctx->have_bsk || !ctx->have_ksk) return fail(HELM_ERR_STATE, "bootstrapping / keyswitching key not loaded");
+    if (!ctx->have_bsk || !(ctx->have_ksk || other_key))
+        return fail(HELM_ERR_STATE, "bootstrapping / keyswitching key not loaded");
     const int64_t count = (int64_t)pbs.size();
     if (count == 0) return 0;
     if (ctx->d_small.cap < (size_t)count * ((size_t)P.n + 1)) {
@@ -1427,7 +1488,8 @@ int apply_luts_device(helm_si_ctx *ctx, const uint64_t *src, uint64_t *dst, cons
     if (int rc = slot_flush(ctx, *S)) return rc;
     {
         Timed t(ctx, &ctx->ev_ks);
-        HIP_TRY(launch_ks64(ctx, d_ks, count, src, ctx->d_small.p));
+        if (other_key) HIP_TRY(launch_ks64_key(ctx, *other_key, d_ks, count, src, ctx->d_small.p));
+        else HIP_TRY(launch_ks64(ctx, d_ks, count, src, ctx->d_small.p));
     }
     ctx->tacc.ks_launches++;
     ctx->tacc.ks_count += count;
@@ -2213,3 +2275,7 @@ int helm_si_get_timing(helm_si_ctx *ctx, helm_si_timing *out, int reset)
 }
 
 } // extern "C"
+
+// the WoP-PBS wide-LUT path (include/helm_wopbs.h): same translation unit, it is built from the kernels and launch
+// helpers above
+#include "helm_wopbs.inc"

@@ -84,6 +84,8 @@ int helm_si_client_keygen(const helm_si_params *params, double lwe_noise_std, do
                           uint64_t seed, helm_si_client_key **out);
 void helm_si_client_key_free(helm_si_client_key *key);
 int helm_si_client_params(const helm_si_client_key *key, helm_si_params *out);
+/* the noise standard deviations the key was generated with (fractions of the torus) */
+int helm_si_client_noise(const helm_si_client_key *key, double *lwe_noise_std, double *glwe_noise_std);
 size_t helm_si_client_bsk_words(const helm_si_client_key *key);
 size_t helm_si_client_ksk_words(const helm_si_client_key *key);
 const uint64_t *helm_si_client_bsk(const helm_si_client_key *key); /* [n][pbs_l][k+1][k+1][N]; multi-bit: [n/g][2^g][...] */

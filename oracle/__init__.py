@@ -281,3 +281,157 @@ class Oracle64:
         sk = np.ascontiguousarray(glwe_sk_bits, dtype=np.uint64)
         ct = np.ascontiguousarray(ct, dtype=np.uint64)
         return int(lib64().orc64_decrypt(C.byref(self.p), _u64(sk), _u64(ct)))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# WoP-PBS wide-LUT path (oracle/wopbs_oracle.c)
+# ---------------------------------------------------------------------------------------------------------
+class ParamsW(C.Structure):
+    _fields_ = [(f, C.c_int32) for f in ("n", "k", "N", "pbs_l", "pbs_logB", "ks_l", "ks_logB", "pfks_l", "pfks_logB",
+                                         "cbs_l", "cbs_logB", "message_modulus", "carry_modulus")]
+
+
+_LIBW = None
+
+
+def libw():
+    global _LIBW
+    if _LIBW is None:
+        path = os.path.join(_HERE, "liborcw.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "liborcw.so"])
+        L = C.CDLL(path)
+        u64p = C.POINTER(C.c_uint64)
+        P = C.POINTER(ParamsW)
+        vp = C.c_void_p
+        L.orcw_keyswitch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u64p, u64p, u64p]
+        L.orcw_pfpks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u64p, u64p, u64p]
+        L.orcw_ggsw_new.restype = vp
+        L.orcw_ggsw_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.c_int, C.c_int]
+        L.orcw_ggsw_free.argtypes = [vp]
+        L.orcw_ggsw_part_bits.argtypes = [vp]
+        L.orcw_extprod_add.argtypes = [vp, C.c_int, u64p, u64p]
+        L.orcw_cmux.argtypes = [vp, C.c_int, u64p, u64p]
+        L.orcw_bootstrap.argtypes = [vp, C.c_int, u64p, u64p, u64p]
+        L.orcw_extract_bits.argtypes = [P, vp, u64p, C.c_int, C.c_int, u64p, u64p]
+        L.orcw_circuit_bootstrap.argtypes = [P, vp, u64p, u64p, u64p]
+        L.orcw_vertical_packing.argtypes = [vp, C.c_int, u64p, u64p]
+        _LIBW = L
+    return _LIBW
+
+
+class Ggsw:
+    """A stack of GGSWs ([count][l][k+1][k+1][N], standard domain) ready for external products: the Goldilocks
+    NTT route (default) or the schoolbook route (use_ntt=False)."""
+
+    def __init__(self, N, k, l, logB, ggsw_std, use_ntt=True):
+        self.std = np.ascontiguousarray(ggsw_std, dtype=np.uint64).reshape(-1)
+        self.N, self.k, self.l, self.logB = N, k, l, logB
+        per = l * (k + 1) * (k + 1) * N
+        assert self.std.size % per == 0
+        self.count = self.std.size // per
+        self._h = libw().orcw_ggsw_new(N, k, l, logB, _u64(self.std), self.count, int(use_ntt))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            libw().orcw_ggsw_free(self._h)
+            self._h = None
+
+    def part_bits(self):
+        return libw().orcw_ggsw_part_bits(self._h)
+
+    def extprod_add(self, i, diff, acc):
+        diff = np.ascontiguousarray(diff, dtype=np.uint64)
+        assert acc.dtype == np.uint64 and acc.flags["C_CONTIGUOUS"]
+        libw().orcw_extprod_add(self._h, i, _u64(diff), _u64(acc))
+
+    def bootstrap(self, small, tv):
+        """small: count+1 words (the stack is a bootstrapping key), tv: N words -> k*N+1 words"""
+        small = np.ascontiguousarray(small, dtype=np.uint64)
+        tv = np.ascontiguousarray(tv, dtype=np.uint64)
+        out = np.zeros(self.k * self.N + 1, dtype=np.uint64)
+        libw().orcw_bootstrap(self._h, small.size - 1, _u64(small), _u64(tv), _u64(out))
+        return out
+
+    def vertical_packing(self, bits, lut):
+        """the stack holds `bits` GGSWs, index 0 = MOST significant bit (tfhe's list order)"""
+        assert self.count == bits
+        lut = np.ascontiguousarray(lut, dtype=np.uint64)
+        assert lut.size == max(1 << bits, self.N)
+        out = np.zeros(self.k * self.N + 1, dtype=np.uint64)
+        libw().orcw_vertical_packing(self._h, bits, _u64(lut), _u64(out))
+        return out
+
+
+class OracleW:
+    """high_precision_lut() (reference src/gates.rs:787-815) with given keys: `pbs` is the Oracle64 of the PBS side
+    (cleaning bootstrap, final bootstrap), the WoP side's keys in the layouts of include/helm_wopbs.h."""
+
+    def __init__(self, params13, bsk, ksk, pfpksk, pbs=None, ksk_to_wopbs=None, ksk_to_pbs=None, use_ntt=True):
+        self.p = ParamsW(*[int(x) for x in params13])
+        p = self.p
+        self.dim = p.k * p.N
+        self.bsk = Ggsw(p.N, p.k, p.pbs_l, p.pbs_logB, bsk, use_ntt)
+        self.ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
+        self.pfpksk = np.ascontiguousarray(pfpksk, dtype=np.uint64)
+        self.pbs = pbs
+        self.to_wop = None if ksk_to_wopbs is None else np.ascontiguousarray(ksk_to_wopbs, dtype=np.uint64)
+        self.to_pbs = None if ksk_to_pbs is None else np.ascontiguousarray(ksk_to_pbs, dtype=np.uint64)
+        self.use_ntt = use_ntt
+        self.t = p.message_modulus * p.carry_modulus
+        self.delta = (1 << 63) // self.t
+        self.delta_log = self.delta.bit_length() - 1
+
+    def keyswitch(self, key, in_dim, out_dim, l, logB, ct):
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        out = np.zeros(out_dim + 1, dtype=np.uint64)
+        libw().orcw_keyswitch(in_dim, out_dim, l, logB, _u64(key), _u64(ct), _u64(out))
+        return out
+
+    def extract_bits(self, big, delta_log, nb):
+        """-> [nb][n+1], row 0 = MOST significant extracted bit (tfhe's order)"""
+        big = np.ascontiguousarray(big, dtype=np.uint64)
+        out = np.zeros((nb, self.p.n + 1), dtype=np.uint64)
+        libw().orcw_extract_bits(C.byref(self.p), self.bsk._h, _u64(self.ksk), delta_log, nb, _u64(big), _u64(out))
+        return out
+
+    def circuit_bootstrap(self, small):
+        """-> [cbs_l][k+1][(k+1) N]"""
+        small = np.ascontiguousarray(small, dtype=np.uint64)
+        k1 = self.p.k + 1
+        out = np.zeros((self.p.cbs_l, k1, k1 * self.p.N), dtype=np.uint64)
+        libw().orcw_circuit_bootstrap(C.byref(self.p), self.bsk._h, _u64(self.pfpksk), _u64(small), _u64(out))
+        return out
+
+    def vertical_packing(self, ggsws_msb_first, lut):
+        g = Ggsw(self.p.N, self.p.k, self.p.cbs_l, self.p.cbs_logB, np.ascontiguousarray(ggsws_msb_first), self.use_ntt)
+        return g.vertical_packing(g.count, lut)
+
+    def make_table(self, n_blocks, bits_per_block, truth):
+        """generate_high_precision_lut_radix_helm (src/gates.rs:817-864), block 0, in plain Python."""
+        basis, total = self.p.message_modulus, n_blocks * bits_per_block
+        modulus = basis ** n_blocks
+        out = np.zeros(max(1 << total, self.p.N), dtype=np.uint64)
+        for v in range(1 << total):
+            fields = [(v >> (j * bits_per_block)) & ((1 << bits_per_block) - 1) for j in range(n_blocks)]
+            x = sum(f * basis ** j for j, f in enumerate(fields)) % modulus
+            f_val = (int(truth[x]) & 1) if x < len(truth) else 0
+            out[v] = ((f_val % modulus) % basis) * self.delta
+        return out
+
+    def wide_lut(self, inputs, truth, bits_per_block):
+        """inputs: PBS-side big ciphertexts, first = most significant block; -> PBS-side big ciphertext"""
+        assert self.pbs is not None and self.to_wop is not None and self.to_pbs is not None
+        P, S = self.p, self.pbs.p
+        ident = self.pbs.make_lut(lambda x: x)
+        blocks = list(inputs)[::-1]  # radix block 0 = last input (gates.rs:795-799)
+        bits_msb_first = []
+        for blk in reversed(blocks):  # most significant block first (WopbsKey::wopbs)
+            clean = self.pbs.apply_lut(blk, ident)
+            wbig = self.keyswitch(self.to_wop, S.k * S.N, self.dim, S.ks_l, S.ks_logB, clean)
+            bits_msb_first.extend(self.extract_bits(wbig, self.delta_log, bits_per_block))
+        ggsws = np.stack([self.circuit_bootstrap(b) for b in bits_msb_first])
+        table = self.make_table(len(blocks), bits_per_block, truth)
+        vp = self.vertical_packing(ggsws, table)
+        small = self.keyswitch(self.to_pbs, self.dim, S.n, S.ks_l, S.ks_logB, vp)
+        return self.pbs.bootstrap(small, ident)

@@ -179,99 +179,7 @@ static void extprod_add_schoolbook(const orc_params *P, const u32 *bsk_i,
 /* ------------------------------------------------------------------------- */
 /* Route 2: Goldilocks NTT.                                                    */
 /* ------------------------------------------------------------------------- */
-#define GL_P 0xFFFFFFFF00000001ull
-/* branch-free (data-dependent branches mispredict on random residues) */
-static inline u64 gl_add(u64 a, u64 b)
-{
-    u64 r = a + b;
-    r += (0 - (u64)(r < a)) & 0xFFFFFFFFull;  /* wrapped past 2^64: 2^64 = 2^32 - 1 */
-    r -= (0 - (u64)(r >= GL_P)) & GL_P;
-    return r;
-}
-static inline u64 gl_sub(u64 a, u64 b)
-{
-    u64 r = a - b;
-    r -= (0 - (u64)(a < b)) & 0xFFFFFFFFull;  /* borrowed: subtract 2^32 - 1, i.e. add p */
-    return r;
-}
-/* 128-bit product reduced with 2^64 = 2^32 - 1 and 2^96 = -1 (mod p); result canonical. */
-static inline u64 gl_mul(u64 a, u64 b)
-{
-    u128 t = (u128)a * b;
-    u64 lo = (u64)t, hi = (u64)(t >> 64);
-    u64 hh = hi >> 32, hl = hi & 0xFFFFFFFFull;
-    u64 r = lo - hh;
-    r -= (0 - (u64)(lo < hh)) & 0xFFFFFFFFull;
-    u64 m = hl * 0xFFFFFFFFull;
-    u64 s = r + m;
-    s += (0 - (u64)(s < m)) & 0xFFFFFFFFull;
-    s -= (0 - (u64)(s >= GL_P)) & GL_P;
-    return s;
-}
-static u64 gl_pow(u64 a, u64 e) { u64 r = 1; while (e) { if (e & 1) r = gl_mul(r, a); a = gl_mul(a, a); e >>= 1; } return r; }
-static inline u64 gl_from_i64(int64_t v) { return v >= 0 ? (u64)v : GL_P - (u64)(-v); }
-
-typedef struct {
-    int N, logN;
-    u64 *psi_rev, *psi_inv_rev; /* bit-reversed powers of the 2N-th root */
-    u64 n_inv;
-} gl_tables;
-
-static int bitrev(int x, int bits) { int r = 0; for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
-
-static gl_tables *gl_tables_new(int N)
-{
-    gl_tables *T = (gl_tables *)malloc(sizeof(*T));
-    int logN = 0; while ((1 << logN) < N) logN++;
-    T->N = N; T->logN = logN;
-    T->psi_rev = (u64 *)malloc(sizeof(u64) * N);
-    T->psi_inv_rev = (u64 *)malloc(sizeof(u64) * N);
-    /* 7 generates the multiplicative group of Goldilocks */
-    u64 psi = gl_pow(7, (GL_P - 1) / (2 * (u64)N));
-    u64 psi_inv = gl_pow(psi, GL_P - 2);
-    u64 a = 1, b = 1;
-    for (int i = 0; i < N; i++) {
-        T->psi_rev[bitrev(i, logN)] = a; T->psi_inv_rev[bitrev(i, logN)] = b;
-        a = gl_mul(a, psi); b = gl_mul(b, psi_inv);
-    }
-    T->n_inv = gl_pow((u64)N, GL_P - 2);
-    return T;
-}
-static void gl_tables_free(gl_tables *T) { free(T->psi_rev); free(T->psi_inv_rev); free(T); }
-
-/* forward negacyclic NTT, natural in -> bit-reversed out */
-static void gl_ntt_fwd(const gl_tables *T, u64 *a)
-{
-    int N = T->N, t = N;
-    for (int m = 1; m < N; m <<= 1) {
-        t >>= 1;
-        for (int i = 0; i < m; i++) {
-            u64 S = T->psi_rev[m + i];
-            int j1 = 2 * i * t;
-            for (int j = j1; j < j1 + t; j++) {
-                u64 U = a[j], V = gl_mul(a[j + t], S);
-                a[j] = gl_add(U, V); a[j + t] = gl_sub(U, V);
-            }
-        }
-    }
-}
-/* inverse, bit-reversed in -> natural out; the 1/N factor is folded into the key */
-static void gl_ntt_inv(const gl_tables *T, u64 *a)
-{
-    int N = T->N, t = 1;
-    for (int m = N; m > 1; m >>= 1) {
-        int h = m >> 1, j1 = 0;
-        for (int i = 0; i < h; i++) {
-            u64 S = T->psi_inv_rev[h + i];
-            for (int j = j1; j < j1 + t; j++) {
-                u64 U = a[j], V = a[j + t];
-                a[j] = gl_add(U, V); a[j + t] = gl_mul(gl_sub(U, V), S);
-            }
-            j1 += 2 * t;
-        }
-        t <<= 1;
-    }
-}
+#include "goldilocks.inc"
 
 /* Bootstrapping key in the oracle's NTT domain. */
 typedef struct {

@@ -15,23 +15,26 @@ from helm_amd import _host
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared(header, prefix):
+def _declared(header, prefix, exclude=None):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(" + prefix + r"\w+)\s*\(", text)))
+    names = sorted(set(re.findall(r"\b(" + prefix + r"\w+)\s*\(", text)))
+    return [n for n in names if not (exclude and n.startswith(exclude))]
 
 
-@pytest.mark.parametrize("header,prefix,lib,table", [
-    ("helm_hip.h", "helm_hip_", nv.hip, nv.HIP_API),
-    ("helm_client.h", "helm_client_", nv.host, nv.CLIENT_API),
-    ("helm_client.h", "helm_si_client_", nv.host, nv.SI_CLIENT_API),
-    ("helm_shortint.h", "helm_si_", nv.hip, nv.SI_API),
-    ("helm_host.h", "helm_host_", nv.host, _host.HOST_API),
-    ("helm_client.h", "helm_keys_", nv.host, nv.KEYS_API),
+@pytest.mark.parametrize("header,prefix,lib,table,exclude", [
+    ("helm_hip.h", "helm_hip_", nv.hip, nv.HIP_API, None),
+    ("helm_client.h", "helm_client_", nv.host, nv.CLIENT_API, None),
+    ("helm_client.h", "helm_si_client_", nv.host, nv.SI_CLIENT_API, None),
+    ("helm_shortint.h", "helm_si_", nv.hip, nv.SI_API, None),
+    ("helm_host.h", "helm_host_", nv.host, _host.HOST_API, None),
+    ("helm_client.h", "helm_keys_", nv.host, nv.KEYS_API, None),
+    ("helm_wopbs.h", "helm_wop_", nv.hip, nv.WOP_API, "helm_wop_client_"),
+    ("helm_wopbs.h", "helm_wop_client_", nv.host, nv.WOP_CLIENT_API, None),
 ])
-def test_every_declared_symbol_is_exported_and_bound(header, prefix, lib, table):
-    names = _declared(header, prefix)
-    assert len(names) >= 9
+def test_every_declared_symbol_is_exported_and_bound(header, prefix, lib, table, exclude):
+    names = _declared(header, prefix, exclude)
+    assert len(names) >= 4
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/{header} but not exported"
         assert n in table, f"{n} declared in include/{header} but not bound in the Python layer"
@@ -40,7 +43,7 @@ def test_every_declared_symbol_is_exported_and_bound(header, prefix, lib, table)
 
 
 def test_no_torch_types_in_the_abi():
-    for h in ("helm_hip.h", "helm_shortint.h", "helm_client.h", "helm_host.h"):
+    for h in ("helm_hip.h", "helm_shortint.h", "helm_client.h", "helm_host.h", "helm_wopbs.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
         assert "torch" not in text.lower() and "at::" not in text and "#include <hip" not in text
 
@@ -48,11 +51,12 @@ def test_no_torch_types_in_the_abi():
 def test_product_package_never_touches_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "helm_amd")):
         for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", ".inc")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "liborc" not in src, f
                 assert "tfhe_oracle" not in src.replace("oracle/tfhe_oracle.c header", ""), f
                 assert "shortint_oracle" not in src and "orc64_" not in src, f
+                assert "wopbs_oracle" not in src and "orcw_" not in src, f
 
 
 def test_parameter_validation_needs_no_device():

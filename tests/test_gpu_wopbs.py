@@ -1,0 +1,147 @@
+"""GPU parity of the WoP-PBS wide-LUT path (include/helm_wopbs.h) against oracle/wopbs_oracle.c: every stage and the
+whole of high_precision_lut() (reference src/gates.rs:787-815) bit for bit on the same keys and inputs, and at the full
+parameter sets the decrypted result against the truth table.  All calls go through the C ABI."""
+import numpy as np
+import pytest
+
+import helm_amd
+import oracle
+from helm_amd import wopbs
+from helm_amd.shortint import si_named_params
+
+pytestmark = [pytest.mark.gpu, pytest.mark.filterwarnings("ignore:overflow encountered")]
+U64 = np.uint64
+
+
+def make_keys(pbs_name, wop_name, seed, moduli=None):
+    sp, a, b = si_named_params(pbs_name)
+    wp, c, d = wopbs.wop_named_params(wop_name)
+    if moduli is not None:
+        sp.message_modulus, sp.carry_modulus = moduli
+        wp.message_modulus, wp.carry_modulus = moduli
+    ck = helm_amd.SiClientKey(sp, a, b, seed=seed)
+    wk = wopbs.WopClientKey(ck, wp, c, d, seed=seed + 1)
+    sk = helm_amd.SiServerKey(ck)
+    wsk = wopbs.WopServerKey(sk, wk)
+    o64 = oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk)
+    ow = oracle.OracleW(wp.as_tuple(), wk.bsk, wk.ksk, wk.pfpksk, pbs=o64, ksk_to_wopbs=wk.ksk_to_wopbs,
+                        ksk_to_pbs=wk.ksk_to_pbs)
+    return ck, wk, sk, wsk, ow
+
+
+def encrypt_wop_big(wk, values, rng):
+    sk = wk.glwe_secret.astype(bool)
+    cts = rng.integers(0, 1 << 64, size=(len(values), wk.dim + 1), dtype=U64)
+    cts[:, -1] = (cts[:, :-1] * sk).sum(axis=1, dtype=U64) + np.array(values, dtype=U64) * U64(wk.delta)
+    return cts
+
+
+def encrypt_bits_small(wk, bits, rng):
+    sk = wk.lwe_secret.astype(bool)
+    cts = rng.integers(0, 1 << 64, size=(len(bits), wk.params.n + 1), dtype=U64)
+    cts[:, -1] = (cts[:, :-1] * sk).sum(axis=1, dtype=U64) + (np.array(bits, dtype=U64) << U64(63)) + U64(999)
+    return cts
+
+
+@pytest.fixture(scope="module", params=[("si_toy_512", "wop_toy_512"), ("si_toy_1024", "wop_toy_1024")])
+def toy(request):
+    keys = make_keys(*request.param, seed=11)
+    yield keys
+    keys[3].close()
+    keys[2].close()
+
+
+def test_extract_bits_bit_exact(toy):
+    ck, wk, sk, wsk, ow = toy
+    rng = np.random.default_rng(1)
+    vals = [0b1011, 0b0110, 0b1111, 0, 0b1000, 0b0001, 0b0101]
+    cts = encrypt_wop_big(wk, vals, rng)
+    for nb in (1, 4):
+        got = wsk.extract_bits(cts, wk.delta_log, nb)  # [row][bit, least significant first][n+1]
+        for r in range(len(vals)):
+            want = ow.extract_bits(cts[r], wk.delta_log, nb)[::-1]  # the oracle lists the most significant first
+            assert np.array_equal(got[r], want), (nb, r)
+        ph = wk.phase(got.reshape(-1, wk.params.n + 1), small=True)
+        dec = ((ph + U64(1 << 62)) >> U64(63)).reshape(len(vals), nb)
+        assert [[int(b) for b in row] for row in dec] == [[(v >> i) & 1 for i in range(nb)] for v in vals]
+
+
+def test_circuit_bootstrap_bit_exact(toy):
+    ck, wk, sk, wsk, ow = toy
+    rng = np.random.default_rng(2)
+    bits = [0, 1, 1, 0, 1]
+    small = encrypt_bits_small(wk, bits, rng)
+    got = wsk.circuit_bootstrap(small)
+    for r in range(len(bits)):
+        assert np.array_equal(got[r], ow.circuit_bootstrap(small[r])), r
+
+
+@pytest.mark.parametrize("bits", [2, 7, 11, 12])
+def test_vertical_packing_bit_exact(toy, bits):
+    """bits <= log2 N: blind rotation only; above: a CMUX tree (two levels deep at N = 512 / 1024 for 11 / 12 bits)"""
+    ck, wk, sk, wsk, ow = toy
+    rng = np.random.default_rng(bits)
+    P = wk.params
+    count = 3
+    values = [0, (1 << bits) - 1, int(rng.integers(0, 1 << bits))]
+    words = max(1 << bits, P.N)
+    tables = rng.integers(0, ck.t, size=(count, words), dtype=U64) * U64(wk.delta)
+    tables[:, (1 << bits):] = 0
+    flat_bits = [(v >> i) & 1 for v in values for i in range(bits)]  # least significant first
+    ggsw = wsk.circuit_bootstrap(encrypt_bits_small(wk, flat_bits, rng))
+    ggsw = ggsw.reshape(count, bits, *ggsw.shape[1:])
+    got = wsk.vertical_packing(ggsw, tables)
+    for g in range(count):
+        want = ow.vertical_packing(ggsw[g][::-1], tables[g])  # the oracle takes the most significant first
+        assert np.array_equal(got[g], want), g
+        assert abs(int((wk.phase(got[g])[0] - tables[g, values[g]]).astype(np.int64))) < 1 << 56
+
+
+@pytest.mark.parametrize("n_inputs,bits_per_block", [(3, 1), (5, 2), (3, 4)])
+def test_wide_lut_gates_bit_exact(toy, n_inputs, bits_per_block):
+    """helm_wop_eval_luts = high_precision_lut() per gate: ciphertexts equal the oracle's, and decrypt to the table
+    entry the reference's index rule selects (basis message_modulus = 4 here: sum bit_j 4^j, src/gates.rs:845-848)."""
+    ck, wk, sk, wsk, ow = toy
+    rng = np.random.default_rng(n_inputs * 10 + bits_per_block)
+    count = 4
+    truth = rng.integers(0, 2, size=(count, 4 ** n_inputs), dtype=U64)
+    xs = rng.integers(0, 1 << n_inputs, size=count)
+    bits_in = np.array([[(x >> (n_inputs - 1 - q)) & 1 for q in range(n_inputs)] for x in xs], dtype=U64)
+    w = sk.wires(count * (n_inputs + 1))
+    cts = ck.encrypt(bits_in.reshape(-1))
+    w.upload(np.arange(count * n_inputs), cts)
+    in_idx = np.arange(count * n_inputs, dtype=np.int32).reshape(count, n_inputs)
+    out_idx = np.arange(count * n_inputs, count * (n_inputs + 1), dtype=np.int32)
+    wsk.eval_luts(w, in_idx, truth, out_idx, bits_per_block=bits_per_block)
+    got = w.download(out_idx)
+    for g in range(count):
+        idx = sum(int(b) * 4 ** j for j, b in enumerate(bits_in[g][::-1]))
+        assert int(ck.decrypt_message_and_carry(got[g:g + 1])[0]) == int(truth[g, idx])
+        if g < 2:
+            want = ow.wide_lut(cts[g * n_inputs:(g + 1) * n_inputs], truth[g], bits_per_block)
+            assert np.array_equal(got[g], want), g
+
+
+def test_reference_encoding_two_bits_per_block():
+    """The encoding the reference's LUT mode names (helm.rs:301: message_modulus = carry_modulus = 2): six-input
+    gates, two bits per block as tfhe extracts after the cleaning bootstrap = 12 index bits = a CMUX tree over
+    eight polynomials at N = 512; first input = most significant (gates.rs:795-799)."""
+    ck, wk, sk, wsk, ow = make_keys("si_toy_512", "wop_toy_512", seed=21, moduli=(2, 2))
+    rng = np.random.default_rng(5)
+    m, count = 6, 8
+    truth = rng.integers(0, 2, size=1 << m, dtype=U64)
+    xs = rng.integers(0, 1 << m, size=count)
+    bits_in = np.array([[(x >> (m - 1 - q)) & 1 for q in range(m)] for x in xs], dtype=U64)
+    w = sk.wires(count * (m + 1))
+    cts = ck.encrypt(bits_in.reshape(-1))
+    w.upload(np.arange(count * m), cts)
+    in_idx = np.arange(count * m, dtype=np.int32).reshape(count, m)
+    out_idx = np.arange(count * m, count * (m + 1), dtype=np.int32)
+    wsk.eval_luts(w, in_idx, truth, out_idx)  # default: log2(message_modulus * carry_modulus) = 2 bits per block
+    got = w.download(out_idx)
+    assert [int(v) for v in ck.decrypt_message_and_carry(got)] == [int(truth[x]) for x in xs]
+    assert np.array_equal(got[0], ow.wide_lut(cts[:m], truth, 2))
+    t = wsk.timing()
+    assert t["gates"] == count and t["bootstraps"] == count * (m + m + 2 * m * wk.params.cbs_l + 1)
+    wsk.close()
+    sk.close()
