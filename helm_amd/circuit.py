@@ -240,6 +240,15 @@ class LutCircuit(_SiCircuit):
     """reference src/circuit.rs:75-79, 969-1120"""
     MODE = 0
 
+    def set_wide_lut_key(self, wop_server_key, bits_per_block=1):
+        """LUT gates with more inputs than one block's index bits go through the WoP-PBS path
+        (Gate::evaluate_encrypted_high_precision_lut, reference src/gates.rs:721-742).  bits_per_block: 1 when every
+        wire holds one bit (LUT mode's wires do); log2(message_modulus * carry_modulus) is what tfhe's degree
+        bookkeeping would extract.  None switches the path off."""
+        H.check(H.host.helm_host_si_circuit_set_wopbs(self._h, wop_server_key._h if wop_server_key is not None else None,
+                                                      int(bits_per_block)))
+        self._wop = wop_server_key  # keep alive
+
 
 class ArithCircuit(_SiCircuit):
     """reference src/circuit.rs:81-85, 1112-1500"""

@@ -340,6 +340,14 @@ int helm_host_si_circuit_decrypt_outputs(helm_si_circuit *c, const helm_si_enc_m
 {
     return guard([&] { *out_map = dup(map_text(c->ec()->decrypt_outputs(*enc_wire_map->m, verbose != 0))); });
 }
+int helm_host_si_circuit_set_wopbs(helm_si_circuit *c, helm_wop_ctx *wop, int bits_per_block)
+{
+    if (!c || !c->lut) {
+        g_err = "set_wopbs: not a LUT-mode circuit";
+        return -1;
+    }
+    return guard([&] { c->lut->set_wide_lut_key(wop, bits_per_block); });
+}
 char *helm_host_si_circuit_log(helm_si_circuit *c) { return dup(c->lut ? c->lut->log() : c->arith->log()); }
 int64_t helm_host_si_circuit_pbs_per_cycle(const helm_si_circuit *c)
 {

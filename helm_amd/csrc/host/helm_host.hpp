@@ -22,8 +22,10 @@
 #include <vector>
 
 #include "../../../include/helm_client.h"
+#include "../../../include/helm_wopbs.h"
 #include "../../../include/helm_hip.h"
 #include "../../../include/helm_shortint.h"
+#include "../../../include/helm_wopbs.h"
 
 namespace helm {
 
@@ -275,10 +277,15 @@ class LutCircuit : public EvalCircuit<SiEncWireMap> {
     std::map<std::string, PtxtType> decrypt_outputs(const SiEncWireMap &enc_wire_map, bool verbose) override;
     int64_t pbs_per_cycle() const { return pbs_count_; }
     std::string log() { std::string s; s.swap(log_); return s; }
+    // Gate::evaluate_encrypted_high_precision_lut (gates.rs:721-742): LUT gates whose index does not fit one block
+    // (more inputs than log2(message_modulus * carry_modulus)) go through the WoP-PBS path once a key is set
+    void set_wide_lut_key(helm_wop_ctx *wop, int bits_per_block);
 
   private:
     helm_si_client_key *client_key_;
     helm_si_ctx *server_key_;
+    helm_wop_ctx *wop_ = nullptr;
+    int wop_bits_per_block_ = 1;
     Circuit circuit_;
     helm_si_params P_{};
     int64_t pbs_count_ = 0;

@@ -245,6 +245,22 @@ void LutCircuit::evaluate_ready(const SiEncWireMap &enc_wire_map, SiEncWireMap &
     for (auto &k : keys) valid_outputs.insert(k, tmp.get("e:" + k).data());
 }
 
+void LutCircuit::set_wide_lut_key(helm_wop_ctx *wop, int bits_per_block)
+{
+    if (wop) {
+        helm_wop_params W{};
+        si_ok(helm_wop_get_params(wop, &W), "wop_get_params");
+        // generate_high_precision_lut_radix_helm indexes the gate's table with sum block_j * message_modulus^j
+        // (gates.rs:845-848): for inputs that hold one bit each that is the LUT index only when the basis is 2 -
+        // the encoding the reference's LUT mode names (helm.rs:301); a larger basis runs past the table (a panic there)
+        if (W.message_modulus != 2)
+            throw Panic("wide LUT gates need message_modulus = 2 (the table rule of gates.rs:845-848)");
+        if (bits_per_block < 1) throw Panic("bits_per_block must be positive");
+    }
+    wop_ = wop;
+    wop_bits_per_block_ = bits_per_block;
+}
+
 // reference src/circuit.rs:1032-1083
 std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap &enc_wire_map, size_t /*cycle*/,
                                                              const std::string & /*ptxt_type*/)
@@ -254,18 +270,43 @@ std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap 
     auto eval_values = enc_wire_map.clone(0);
     const size_t total_levels = circuit_.level_map().size();
     pbs_count_ = 0;
+    int capacity = 0; // index bits one block holds: gates::lut() packs sum in_i << (arity-1-i) into a single block
+    while ((2 << capacity) <= P_.message_modulus * P_.carry_modulus) capacity++;
     for (auto &kv : circuit_.level_map()) {
         const auto &gates = kv.second;
         int max_in = 1;
-        for (auto &g : gates) max_in = std::max<int>(max_in, (int)g.get_input_wires().size());
-        std::vector<int32_t> arity, in_idx((size_t)gates.size() * max_in, -1), out;
+        for (auto &g : gates)
+            if (!(wop_ && g.get_gate_type() == GateType::Lut && (int)g.get_input_wires().size() > capacity))
+                max_in = std::max<int>(max_in, (int)g.get_input_wires().size());
+        std::vector<int32_t> arity, in_idx, out;
         std::vector<uint64_t> table;
+        // wide gates of the level, grouped by input count: in_idx rows, tables, out rows
+        struct Wide {
+            std::vector<int32_t> in, out;
+            std::vector<uint64_t> tables;
+        };
+        std::map<int, Wide> wide;
         for (size_t gi = 0; gi < gates.size(); gi++) {
             const Gate &g = gates[gi];
             const auto &ins = g.get_input_wires();
-            for (size_t q = 0; q < ins.size(); q++) in_idx[gi * max_in + q] = eval_values->row(ins[q]);
             if (g.get_gate_type() == GateType::Lut) {
                 if (!g.get_lut_const()) throw Panic("Lut const not provided");
+                if (wop_ && (int)ins.size() > capacity) {
+                    helm_wop_params W{};
+                    si_ok(helm_wop_get_params(wop_, &W), "wop_get_params");
+                    const int m = (int)ins.size();
+                    Wide &wg = wide[m];
+                    for (auto &w : ins) wg.in.push_back(eval_values->row(w));
+                    wg.out.push_back(eval_values->row(g.get_output_wire()));
+                    const size_t words = helm_wop_table_words(&W, m * wop_bits_per_block_);
+                    wg.tables.resize(wg.tables.size() + words);
+                    si_ok(helm_wop_make_table(&W, m, wop_bits_per_block_, g.get_lut_const()->data(),
+                                              g.get_lut_const()->size(), wg.tables.data() + wg.tables.size() - words),
+                          "wop_make_table");
+                    // cleaning + bit removal + circuit bootstraps + the final one
+                    pbs_count_ += m + m * (wop_bits_per_block_ - 1) + (int64_t)m * wop_bits_per_block_ * W.cbs_l + 1;
+                    continue;
+                }
                 if (ins.size() > 6) throw Panic("LUT with more than 6 inputs does not fit the truth-table word");
                 uint64_t bits = 0;
                 for (size_t i = 0; i < g.get_lut_const()->size() && i < 64; i++)
@@ -278,11 +319,19 @@ std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap 
                 arity.push_back(0);
                 table.push_back(0);
             }
+            const size_t slot = in_idx.size();
+            in_idx.resize(slot + (size_t)max_in, -1);
+            for (size_t q = 0; q < ins.size(); q++) in_idx[slot + q] = eval_values->row(ins[q]);
             out.push_back(eval_values->row(g.get_output_wire()));
         }
-        if (!gates.empty())
+        // wide gates first: they read the level's inputs before a state copy of the same level overwrites one
+        for (auto &wk : wide)
+            si_ok(helm_wop_eval_luts(wop_, eval_values->table(), wk.second.in.data(), wk.first, wop_bits_per_block_,
+                                     wk.second.tables.data(), wk.second.out.data(), (int64_t)wk.second.out.size()),
+                  "wop_eval_luts");
+        if (!arity.empty())
             si_ok(helm_si_eval_lut_level(server_key_, eval_values->table(), arity.data(), in_idx.data(), max_in,
-                                         table.data(), out.data(), (int64_t)gates.size()),
+                                         table.data(), out.data(), (int64_t)arity.size()),
                   "eval_lut_level");
         std::ostringstream os;
         os << "  Evaluated gates in level [" << kv.first << "/" << total_levels << "]\n";

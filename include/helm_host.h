@@ -21,6 +21,7 @@
 #include "helm_client.h"
 #include "helm_hip.h"
 #include "helm_shortint.h"
+#include "helm_wopbs.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -116,6 +117,10 @@ int helm_host_si_circuit_evaluate_ready(helm_si_circuit *c, const helm_si_enc_ma
                                         helm_si_enc_map *valid_outputs);
 int helm_host_si_circuit_decrypt_outputs(helm_si_circuit *c, const helm_si_enc_map *enc_wire_map, int verbose,
                                          char **out_map);
+/* LUT mode: gates with more inputs than one block holds (log2(message_modulus * carry_modulus) index bits) go
+ * through the WoP-PBS path of include/helm_wopbs.h - Gate::evaluate_encrypted_high_precision_lut (gates.rs:721-742),
+ * which the reference defines but never calls.  wop = NULL switches it off again. */
+int helm_host_si_circuit_set_wopbs(helm_si_circuit *c, helm_wop_ctx *wop, int bits_per_block);
 char *helm_host_si_circuit_log(helm_si_circuit *c);
 /* bootstraps of the last evaluate_encrypted, and (arithmetic) the number of batched rounds */
 int64_t helm_host_si_circuit_pbs_per_cycle(const helm_si_circuit *c);

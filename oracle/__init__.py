@@ -375,6 +375,9 @@ class OracleW:
         self.ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
         self.pfpksk = np.ascontiguousarray(pfpksk, dtype=np.uint64)
         self.pbs = pbs
+        # the PBS side's bootstraps on the same exact route as this side's (pinned equal to Oracle64.bootstrap, the
+        # schoolbook one, by tests/test_wopbs_oracle.py)
+        self.pbs_bsk = None if pbs is None else Ggsw(pbs.p.N, pbs.p.k, pbs.p.pbs_l, pbs.p.pbs_logB, pbs.bsk, use_ntt)
         self.to_wop = None if ksk_to_wopbs is None else np.ascontiguousarray(ksk_to_wopbs, dtype=np.uint64)
         self.to_pbs = None if ksk_to_pbs is None else np.ascontiguousarray(ksk_to_pbs, dtype=np.uint64)
         self.use_ntt = use_ntt
@@ -427,11 +430,11 @@ class OracleW:
         blocks = list(inputs)[::-1]  # radix block 0 = last input (gates.rs:795-799)
         bits_msb_first = []
         for blk in reversed(blocks):  # most significant block first (WopbsKey::wopbs)
-            clean = self.pbs.apply_lut(blk, ident)
+            clean = self.pbs_bsk.bootstrap(self.pbs.keyswitch(blk), ident)
             wbig = self.keyswitch(self.to_wop, S.k * S.N, self.dim, S.ks_l, S.ks_logB, clean)
             bits_msb_first.extend(self.extract_bits(wbig, self.delta_log, bits_per_block))
         ggsws = np.stack([self.circuit_bootstrap(b) for b in bits_msb_first])
         table = self.make_table(len(blocks), bits_per_block, truth)
         vp = self.vertical_packing(ggsws, table)
         small = self.keyswitch(self.to_pbs, self.dim, S.n, S.ks_l, S.ks_logB, vp)
-        return self.pbs.bootstrap(small, ident)
+        return self.pbs_bsk.bootstrap(small, ident)

@@ -145,3 +145,75 @@ def test_reference_encoding_two_bits_per_block():
     assert t["gates"] == count and t["bootstraps"] == count * (m + m + 2 * m * wk.params.cbs_l + 1)
     wsk.close()
     sk.close()
+
+
+def test_full_parameter_sets_m2c2():
+    """PARAM_MESSAGE_2_CARRY_2_KS_PBS beside WOPBS_PARAM_MESSAGE_2_CARRY_2_KS_PBS [dimensions recalled] at full size:
+    a circuit bootstrap and two whole gates bit for bit against the oracle, and batches of wide gates - up to eight
+    inputs, one to four bits per block, with and without a CMUX tree - decrypted against their truth tables."""
+    ck, wk, sk, wsk, ow = make_keys("shortint_m2c2", "wopbs_m2c2", seed=31)
+    P = wk.params
+    assert (P.n, P.N, P.pbs_l, P.cbs_l, P.pfks_l) == (769, 2048, 2, 3, 2)
+    rng = np.random.default_rng(9)
+    small = encrypt_bits_small(wk, [1, 0], rng)
+    got = wsk.circuit_bootstrap(small)
+    assert np.array_equal(got[0], ow.circuit_bootstrap(small[0]))
+    for n_inputs, bits_per_block, count, check in ((3, 1, 8, True), (2, 2, 4, True), (8, 1, 32, False), (3, 4, 6, False),
+                                                   (6, 2, 16, False)):
+        truth = rng.integers(0, 2, size=(count, 4 ** n_inputs), dtype=U64)
+        xs = rng.integers(0, 1 << n_inputs, size=count)
+        bits_in = np.array([[(x >> (n_inputs - 1 - q)) & 1 for q in range(n_inputs)] for x in xs], dtype=U64)
+        w = sk.wires(count * (n_inputs + 1))
+        cts = ck.encrypt(bits_in.reshape(-1))
+        w.upload(np.arange(count * n_inputs), cts)
+        in_idx = np.arange(count * n_inputs, dtype=np.int32).reshape(count, n_inputs)
+        out_idx = np.arange(count * n_inputs, count * (n_inputs + 1), dtype=np.int32)
+        wsk.eval_luts(w, in_idx, truth, out_idx, bits_per_block=bits_per_block)
+        got = w.download(out_idx)
+        want = [int(truth[g, sum(int(b) * 4 ** j for j, b in enumerate(bits_in[g][::-1]))]) for g in range(count)]
+        assert [int(v) for v in ck.decrypt_message_and_carry(got)] == want, (n_inputs, bits_per_block)
+        if check:
+            assert np.array_equal(got[1], ow.wide_lut(cts[n_inputs:2 * n_inputs], truth[1], bits_per_block))
+        w.free()
+    wsk.close()
+    sk.close()
+
+
+def test_lut_circuit_routes_wide_gates_through_wopbs():
+    """LutCircuit with a wide-LUT key: gates whose index does not fit one block (here: more than two inputs under
+    message_modulus = carry_modulus = 2, the reference's LUT-mode encoding) go through the WoP-PBS path -
+    Gate::evaluate_encrypted_high_precision_lut (gates.rs:721-742) - and every wire equals the plaintext evaluation,
+    as the reference's LUT test checks for the narrow path (circuit_test.rs:308-310)."""
+    from helm_amd import Circuit, LutCircuit, PtxtType, verilog_parser
+    ck, wk, sk, wsk, ow = make_keys("si_toy_512", "wop_toy_512", seed=41, moduli=(2, 2))
+    text = """input a, b, c, d, e, f;
+output y, z, p, q;
+lut g0(0x6996966996696996, a, b, c, d, e, f, y);
+lut g1(0xFEE8E880, a, b, c, d, e, t);
+lut g2(0x6, t, f, z);
+lut g3(0x96, y, z, t, p);
+lut g4(0x8000000000000001, y, z, t, p, a, b, q);
+"""
+    gates_set, wire_set, input_wires, output_wires, dffs, _, _ = verilog_parser.read_verilog_text(text, False)
+    circuit = Circuit(gates_set, input_wires, output_wires, dffs)
+    circuit.sort_circuit()
+    circuit.compute_levels()
+    lc = LutCircuit(ck, sk, circuit)
+    lc.set_wide_lut_key(wsk, bits_per_block=1)
+    for x in (0b101101, 0b000000, 0b111111, 0b010011):
+        inputs = {n: PtxtType.Bool((x >> (5 - i)) & 1) for i, n in enumerate("abcdef")}
+        ptxt = circuit.evaluate(circuit.initialize_wire_map(wire_set, inputs, "bool"))
+        enc = lc.evaluate_encrypted(lc.encrypt_inputs(wire_set, inputs), 1, "bool")
+        for wire, want in ptxt.items():
+            assert ck.decrypt(enc[wire]) == int(bool(want)), (x, wire)
+    # g2 is the one narrow gate (1 bootstrap); the four wide ones: m cleaning + m * cbs_l circuit + 1 final each
+    L = wk.params.cbs_l
+    assert lc.pbs_per_cycle() == 1 + sum(m + m * L + 1 for m in (6, 5, 3, 6))
+    # without the key the wide gates fall to gates::lut()'s single-block packing, which cannot hold their index:
+    # the engine refuses instead of returning a wrong ciphertext
+    from helm_amd._host import Panic
+    lc.set_wide_lut_key(None)
+    with pytest.raises(Panic, match="do not fit the plaintext space"):
+        lc.evaluate_encrypted(lc.encrypt_inputs(wire_set, {n: PtxtType.Bool(1) for n in "abcdef"}), 1, "bool")
+    wsk.close()
+    sk.close()
