@@ -410,6 +410,52 @@ def other_modes(device):
     mb = _other_modes_set(device, "shortint_m2c2_multibit3", "dimensions of PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS "
                           "(helm.rs:83) [recalled; LWE noise extrapolated, not tfhe's value: approximate set]")
     res["lut_mode_multibit3"], res["arith_mode_multibit3"] = mb["lut_mode"], mb["arith_mode"]
+    res["wide_lut_wopbs"] = _wide_lut_leg(device)
+    return res
+
+
+def _wide_lut_leg(device):
+    """Wide LUT gates through the WoP-PBS path (high_precision_lut, reference src/gates.rs:787-815; never called by
+    the reference): 256 six-input gates under the LUT-mode encoding the reference names (message_modulus =
+    carry_modulus = 2, helm.rs:301), two bits extracted per block as tfhe's degree bookkeeping gives after the
+    cleaning bootstrap, and one bit per block (enough for LUT mode's one-bit wires)."""
+    import helm_amd
+    from helm_amd import wopbs
+    from helm_amd.shortint import si_named_params
+    sp, sa, sb = si_named_params("shortint_m2c2")
+    wp, wa, wb = wopbs.wop_named_params("wopbs_m1c1")
+    sp.message_modulus, sp.carry_modulus = wp.message_modulus, wp.carry_modulus
+    ck = helm_amd.SiClientKey(sp, sa, sb, seed=1)
+    wk = wopbs.WopClientKey(ck, wp, wa, wb, seed=2)
+    sk = helm_amd.SiServerKey(ck, device=device)
+    wsk = wopbs.WopServerKey(sk, wk)
+    rng = np.random.default_rng(0)
+    G, m = 256, 6
+    truth = rng.integers(0, 2, size=1 << m, dtype=np.uint64)
+    xs = rng.integers(0, 1 << m, size=G)
+    bits_in = np.array([[(x >> (m - 1 - q)) & 1 for q in range(m)] for x in xs], dtype=np.uint64)
+    w = sk.wires(G * (m + 1))
+    w.upload(np.arange(G * m), ck.encrypt(bits_in.reshape(-1)))
+    in_idx = np.arange(G * m, dtype=np.int32).reshape(G, m)
+    out_idx = np.arange(G * m, G * (m + 1), dtype=np.int32)
+    res = {"workload": f"{G} independent {m}-input LUT gates through bit extraction, circuit bootstrap and vertical packing; "
+                       "PBS side: dimensions of PARAM_MESSAGE_2_CARRY_2_KS_PBS with message_modulus = carry_modulus = 2, "
+                       "WoP side: WOPBS_PARAM_MESSAGE_1_CARRY_1_KS_PBS [dimensions recalled]"}
+    for b in (2, 1):
+        wsk.eval_luts(w, in_idx, truth, out_idx, bits_per_block=b)
+        sk.sync()
+        wsk.timing(reset=True)
+        t0 = time.perf_counter()
+        wsk.eval_luts(w, in_idx, truth, out_idx, bits_per_block=b)
+        sk.sync()
+        dt = time.perf_counter() - t0
+        t = wsk.timing()
+        ok = [int(v) for v in ck.decrypt_message_and_carry(w.download(out_idx))] == [int(truth[x]) for x in xs]
+        res[f"bits_per_block_{b}"] = {"gates_per_s": round(G / dt, 1), "wall_s": round(dt, 4), "bootstraps": t["bootstraps"],
+                                      "bootstraps_per_s": round(t["bootstraps"] / dt, 1), "decrypt_ok": ok,
+                                      "stage_ms": {k[:-3]: round(v, 2) for k, v in t.items() if k.endswith("_ms")}}
+    wsk.close()
+    sk.close()
     return res
 
 

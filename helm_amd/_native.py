@@ -220,6 +220,7 @@ KEYS_API = {
     "helm_keys_bsk64_to_tfhe": (C.c_int, [C.POINTER(SiParams), u64p, u64p, C.c_size_t]),
     "helm_keys_ksk64_from_tfhe": (C.c_int, [C.POINTER(SiParams), u64p, u64p, C.c_size_t]),
     "helm_keys_ksk64_to_tfhe": (C.c_int, [C.POINTER(SiParams), u64p, u64p, C.c_size_t]),
+    "helm_keys_levels64_reverse": (C.c_int, [C.c_size_t, C.c_int32, C.c_size_t, u64p, u64p, C.c_size_t]),
 }
 
 for _lib, _api in ((hip, HIP_API), (host, CLIENT_API), (hip, SI_API), (host, SI_CLIENT_API), (host, KEYS_API),

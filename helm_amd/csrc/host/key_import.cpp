@@ -19,6 +19,11 @@
 //       `(1..=l).rev()`; the keyswitch zips the block with the decomposition iterator, which yields the
 //       least significant level first); each ciphertext n mask words then the body.
 //       This ABI: [k*N][ks_l][n+1] with level index 0 = level 1 -> the level order is reversed.
+//   WoP-PBS keys (include/helm_wopbs.h)   [RECALLED] the two LweKeyswitchKeys between the parameter sets are
+//       ordinary keyswitching keys (levels reversed, as above); LwePrivateFunctionalPackingKeyswitchKeyList:
+//       key r major, then the kN+1 input elements (the body's element last), then the levels stored from the
+//       LAST to the first as in a keyswitching key, each a GLWE ciphertext (k mask polynomials, body) ->
+//       helm_keys_levels64_reverse(blocks = (k+1)(kN+1), levels = pfks_l, row = (k+1) N).
 //   Fourier-domain keys (what boolean::ServerKey / shortint::ServerKey hold for the BSK) cannot be
 //       imported: the shim regenerates the standard-domain key from the ClientKey's secret keys
 //       (rust/helm-hip/src/keys.rs).
@@ -59,6 +64,19 @@ template <typename T> int ksk_reverse_levels(int kN, int l, int n, const T *src,
 extern "C" {
 
 const char *helm_keys_last_error(void) { return g_kerr.c_str(); }
+
+int helm_keys_levels64_reverse(size_t blocks, int32_t levels, size_t row_words, const uint64_t *src, uint64_t *dst,
+                               size_t n_words)
+{
+    if (!src || !dst) return kfail("null argument");
+    if (levels < 1 || n_words != blocks * (size_t)levels * row_words) return kfail("key: wrong number of words for these dimensions");
+    if (src == dst) return kfail("key conversion is not in place");
+    for (size_t t = 0; t < blocks; t++)
+        for (int j = 0; j < levels; j++)
+            std::memcpy(dst + (t * levels + j) * row_words, src + (t * levels + (levels - 1 - j)) * row_words,
+                        row_words * sizeof(uint64_t));
+    return 0;
+}
 
 int helm_keys_bsk32_from_tfhe(const helm_hip_params *p, const uint32_t *tfhe, uint32_t *abi, size_t n_words)
 {

@@ -115,6 +115,11 @@ int helm_keys_bsk64_from_tfhe(const helm_si_params *p, const uint64_t *tfhe, uin
 int helm_keys_bsk64_to_tfhe(const helm_si_params *p, const uint64_t *abi, uint64_t *tfhe, size_t n_words);
 int helm_keys_ksk64_from_tfhe(const helm_si_params *p, const uint64_t *tfhe, uint64_t *abi, size_t n_words);
 int helm_keys_ksk64_to_tfhe(const helm_si_params *p, const uint64_t *abi, uint64_t *tfhe, size_t n_words);
+/* Any 64-bit key stored as `blocks` x `levels` x rows of row_words words whose levels tfhe keeps last-to-first:
+ * the keyswitching keys between two parameter sets and the private functional packing keyswitching keys of
+ * include/helm_wopbs.h ([RECALLED] order).  Its own inverse. */
+int helm_keys_levels64_reverse(size_t blocks, int32_t levels, size_t row_words, const uint64_t *src, uint64_t *dst,
+                               size_t n_words);
 
 #ifdef __cplusplus
 }

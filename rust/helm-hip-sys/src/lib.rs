@@ -94,4 +94,36 @@ extern "C" {
     pub fn helm_si_eval_lut_level(ctx: *mut helm_si_ctx, w: *mut helm_si_wires, arity: *const i32, in_idx: *const i32, max_in: c_int,
                                   table: *const u64, out_idx: *const i32, count: i64) -> c_int;
     pub fn helm_si_sync(ctx: *mut helm_si_ctx) -> c_int;
+
+    // ---- include/helm_wopbs.h (WoP-PBS wide-LUT path) ------------------------------------------
+    pub fn helm_wop_ctx_create(pbs_side: *mut helm_si_ctx, params: *const helm_wop_params, out: *mut *mut helm_wop_ctx) -> c_int;
+    pub fn helm_wop_ctx_destroy(ctx: *mut helm_wop_ctx) -> c_int;
+    pub fn helm_wop_load_key(ctx: *mut helm_wop_ctx, which: c_int, words: *const u64, n_words: usize, l: i32, log_b: i32) -> c_int;
+    pub fn helm_wop_table_words(params: *const helm_wop_params, total_bits: i32) -> usize;
+    pub fn helm_wop_make_table(params: *const helm_wop_params, n_blocks: i32, bits_per_block: i32, truth: *const u64,
+                               truth_len: usize, table_out: *mut u64) -> c_int;
+    pub fn helm_wop_eval_luts(ctx: *mut helm_wop_ctx, w: *mut helm_si_wires, in_idx: *const i32, n_inputs: i32,
+                              bits_per_block: i32, tables: *const u64, out_idx: *const i32, count: i64) -> c_int;
+    pub fn helm_keys_levels64_reverse(blocks: usize, levels: i32, row_words: usize, src: *const u64, dst: *mut u64,
+                                      n_words: usize) -> c_int;
 }
+
+/// include/helm_wopbs.h: tfhe::shortint::WopbsParameters, runtime values
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+#[allow(non_snake_case)]
+pub struct helm_wop_params {
+    pub n: i32, pub k: i32, pub N: i32,
+    pub pbs_l: i32, pub pbs_logB: i32,
+    pub ks_l: i32, pub ks_logB: i32,
+    pub pfks_l: i32, pub pfks_logB: i32,
+    pub cbs_l: i32, pub cbs_logB: i32,
+    pub message_modulus: i32, pub carry_modulus: i32,
+}
+#[repr(C)]
+pub struct helm_wop_ctx { _private: [u8; 0] }
+pub const HELM_WOP_KEY_BSK: c_int = 0;
+pub const HELM_WOP_KEY_KSK: c_int = 1;
+pub const HELM_WOP_KEY_KSK_TO_WOPBS: c_int = 2;
+pub const HELM_WOP_KEY_KSK_TO_PBS: c_int = 3;
+pub const HELM_WOP_KEY_PFPKSK: c_int = 4;

@@ -88,3 +88,20 @@ def test_key_through_tfhe_order_and_back_bootstraps_bit_identically():
     v = [True, False]
     want = [v[0] & v[1], v[1] ^ v[1], not (v[0] | v[0]), v[1] if v[0] else v[0], not (v[1] & v[0])]  # MUX: sel ? in0 : in1
     assert list(ck.decrypt(tables[1][2:])) == want
+
+
+def test_wopbs_key_level_order_converter():
+    """The keys of include/helm_wopbs.h whose levels tfhe keeps last-to-first ([RECALLED]): converter is its own
+    inverse, not the identity, refuses wrong sizes and in-place use."""
+    from helm_amd import _native as nv
+    rng = np.random.default_rng(4)
+    blocks, levels, row = 6, 3, 10
+    src = rng.integers(0, 1 << 64, size=blocks * levels * row, dtype=np.uint64)
+    mid, back = np.zeros_like(src), np.zeros_like(src)
+    assert nv.host.helm_keys_levels64_reverse(blocks, levels, row, nv.as_u64p(src), nv.as_u64p(mid), src.size) == 0
+    assert nv.host.helm_keys_levels64_reverse(blocks, levels, row, nv.as_u64p(mid), nv.as_u64p(back), src.size) == 0
+    assert np.array_equal(back, src) and not np.array_equal(mid, src)
+    v = src.reshape(blocks, levels, row)
+    assert np.array_equal(mid.reshape(blocks, levels, row), v[:, ::-1, :])
+    assert nv.host.helm_keys_levels64_reverse(blocks, levels, row, nv.as_u64p(src), nv.as_u64p(mid), src.size - 1) != 0
+    assert nv.host.helm_keys_levels64_reverse(blocks, levels, row, nv.as_u64p(src), nv.as_u64p(src), src.size) != 0
