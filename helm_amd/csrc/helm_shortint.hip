@@ -25,6 +25,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace helm;
@@ -372,9 +373,9 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
 // coefficients, accumulate.  Seven workgroup barriers per step, no redundant work except the
 // 16 stage-1 products per lane.
 // ------------------------------------------------------------------------------------
-template <int LOGN_>
+template <int LOGN_, int L_ = 1>
 struct Pbs64sCfg {
-    static constexpr int LOGN = LOGN_, L = 1, K = 1, K1 = 2, NW = 8;
+    static constexpr int LOGN = LOGN_, L = L_, K = 1, K1 = 2, NW = 8;
     using G = Geo<LOGN>;      // decomposition geometry: E coefficients per lane
     using GS = Geo<LOGN - 1>; // half transforms
     static constexpr int MAX_SMALL_N = 1024;
@@ -386,8 +387,11 @@ struct Pbs64sCfg {
     static constexpr size_t X_OFF = 0;                                              // double [NW][GS::XPAD]
     static constexpr size_t TW_OFF = X_OFF + sizeof(double) * NW * GS::XPAD;        // double [2][2][TW_PART]
     static constexpr size_t ACC_OFF = TW_OFF + sizeof(double) * 4 * TW_PART;        // u64 [K1][N]
-    static constexpr size_t DIG_OFF = ACC_OFF + sizeof(uint64_t) * K1 * G::N;       // i32 [K1][N]
-    static constexpr size_t MS_OFF = DIG_OFF + sizeof(int32_t) * K1 * G::N;         // u16 [n+1]
+    // digits: int32 for one level (23-bit digits), int16 for two (pbs_logB <= 15: |digit| <= 2^14) - the LDS of a CU
+    // does not hold two levels of int32 next to the rest at N = 2048
+    using dig_t = std::conditional_t<L == 1, int32_t, int16_t>;
+    static constexpr size_t DIG_OFF = ACC_OFF + sizeof(uint64_t) * K1 * G::N;       // dig_t [K1][L][N]
+    static constexpr size_t MS_OFF = DIG_OFF + sizeof(dig_t) * K1 * L * G::N;       // u16 [n+1]
     static constexpr size_t BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
 };
 
@@ -395,13 +399,14 @@ template <typename C, typename F, int h>
 __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *__restrict__ bsk, int n, int logB,
                                             double p0inv_mod_p1, double w1, int p, int f, int lane)
 {
-    constexpr int LOGN = C::LOGN, K1 = C::K1;
+    constexpr int LOGN = C::LOGN, K1 = C::K1, L = C::L;
     using G = typename C::G;
     using GS = typename C::GS;
     constexpr int N = G::N, E = G::E, EH = GS::E, Q = E / 4, HC = EH / 2;
     double *X = reinterpret_cast<double *>(smem + C::X_OFF);
     uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
-    int32_t *DIG = reinterpret_cast<int32_t *>(smem + C::DIG_OFF);
+    using dig_t = typename C::dig_t;
+    dig_t *DIG = reinterpret_cast<dig_t *>(smem + C::DIG_OFF);
     const uint16_t *MS = reinterpret_cast<const uint16_t *>(smem + C::MS_OFF);
     auto wave_of = [](int pp, int ff, int hh) { return (pp * 2 + ff) * 2 + hh; };
     double *xb = X + (size_t)wave_of(p, f, h) * GS::XPAD;
@@ -409,17 +414,17 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
     const double *x_half = X + (size_t)wave_of(p, f, 1 - h) * GS::XPAD;  // same polynomial and field, other half
     const double *x_field = X + (size_t)wave_of(p, 1 - f, h) * GS::XPAD; // same polynomial and half, other field
     uint64_t *acc_p = ACC + (size_t)p * N;
-    int32_t *dig_p = DIG + (size_t)p * N;
+    dig_t *dig_p = DIG + (size_t)p * L * N; // [level][N]
     const double *twt = reinterpret_cast<const double *>(smem + C::TW_OFF);
     const double *tw_own = twt + (size_t)(f * 2 + h) * C::TW_PART, *tw_oth = twt + (size_t)(f * 2 + (1 - h)) * C::TW_PART;
     TwHybrid<LOGN - 1, false> twf{tw_own, tw_own + C::TW_IDX + lane};
     TwHybrid<LOGN - 1, true> twi{tw_oth, tw_oth + C::TW_IDX + (63 - lane)};
     const int quarter = f * 2 + h; // which E/4 slots of the polynomial this wave decomposes
 
-    // key words of this wave: [i][row p][c][f][h][e/2][lane] as double2 (L = 1)
+    // key words of this wave: [i][row p][c][level][f][h][e/2][lane] as double2
     const size_t part = (size_t)(GS::N / 2);
-    const size_t bsk_step = (size_t)K1 * K1 * 4 * part;
-    const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * 4 + f * 2 + h) * part + lane;
+    const size_t bsk_step = (size_t)K1 * K1 * L * 4 * part;
+    const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * L * 4 + f * 2 + h) * part + lane;
     const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
 
     STAMP_DECL
@@ -436,14 +441,25 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
             uint64_t v = acc_p[src & (N - 1)];
             if (src >= N) v = 0ull - v;
             v -= acc_p[j];
-            const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
-            // L = 1: nothing is left above the digit, the carry decides between d and d - B (d > B/2)
-            dig_p[j] = (int)st - (int)(((st + half_m1) >> logB) << logB);
+            if constexpr (L == 1) {
+                const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
+                // nothing is left above the digit, the carry decides between d and d - B (d > B/2)
+                dig_p[j] = (int)st - (int)(((st + half_m1) >> logB) << logB);
+            } else { // least significant level first, the one-addition carry rule of pbs64_body
+                const int rep = logB * L;
+                uint32_t st = (uint32_t)((v + (1ull << (63 - rep))) >> (64 - rep));
+#pragma unroll
+                for (int lev = L - 1; lev >= 0; lev--) {
+                    const uint32_t next = (st + half_m1 + __builtin_amdgcn_ubfe(st, 2 * logB - 1, 1)) >> logB;
+                    dig_p[lev * N + j] = (dig_t)((int)st - (int)(next << logB));
+                    st = next;
+                }
+            }
         }
         // first key column of this wave's half (E/4 double2 per column)
         double2 kw[K1][HC];
 #pragma unroll
-        for (int u = 0; u < HC; u++) kw[0][u] = (bp_i + (size_t)0 * 4 * part)[u * 64];
+        for (int u = 0; u < HC; u++) kw[0][u] = (bp_i + (size_t)0 * L * 4 * part)[u * 64];
         STAMP(0) // quarter decomposition
         lds_block_sync(); // digits published
         STAMP(1) // barrier 1
@@ -451,37 +467,46 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         // the two waves of a SIMD (polynomials 0 and 1 of one field and half) run every phase together;
         // stepping the issue priority down block by block keeps them abreast, so that neither finishes
         // the phase alone (a lone wave cannot hide its LDS latencies)
-        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
-        double x[1][EH];
-        {
-            const int32_t *dg = dig_p + lane;
-#pragma unroll
-            for (int e = 0; e < EH; e++) {
-                const double U = (double)dg[64 * e], V = mulmod<F>((double)dg[64 * (e + EH)], w1);
-                x[0][e] = h ? U - V : U + V;
-            }
-        }
-        ntt_forward<F, LOGN - 1, 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
-        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
-        STAMP(2) // digits read, stage 1, half transform
-#pragma unroll
-        for (int u = 0; u < HC; u++) kw[1][u] = (bp_i + (size_t)1 * 4 * part)[u * 64];
         double mine[EH], other[EH];
 #pragma unroll
-        for (int c = 0; c < K1; c++)
+        for (int lev = 0; lev < L; lev++) {
+            if (lev > 0) {
 #pragma unroll
-            for (int u = 0; u < HC; u++) {
-                const double t0 = mulmod<F>(x[0][2 * u], kw[c][u].x), t1 = mulmod<F>(x[0][2 * u + 1], kw[c][u].y);
-                if (c == p) {
-                    mine[2 * u] = t0;
-                    mine[2 * u + 1] = t1;
-                } else {
-                    other[2 * u] = t0;
-                    other[2 * u + 1] = t1;
+                for (int u = 0; u < HC; u++) kw[0][u] = (bp_i + (size_t)(0 * L + lev) * 4 * part)[u * 64];
+            }
+            if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
+            double x[1][EH];
+            {
+                const dig_t *dg = dig_p + lev * N + lane;
+#pragma unroll
+                for (int e = 0; e < EH; e++) {
+                    const double U = (double)dg[64 * e], V = mulmod<F>((double)dg[64 * (e + EH)], w1);
+                    x[0][e] = h ? U - V : U + V;
                 }
             }
-        // a product is below 1.5 p (mulmod: (0.5 + 0.75 |a| 2^-52) p with |a| <= 9.6 p): two of them are summed
-        // as they are and recentred once
+            ntt_forward<F, LOGN - 1, 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
+            if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
+            if (lev == 0) {
+                STAMP(2) // digits read, stage 1, half transform
+            }
+#pragma unroll
+            for (int u = 0; u < HC; u++) kw[1][u] = (bp_i + (size_t)(1 * L + lev) * 4 * part)[u * 64];
+#pragma unroll
+            for (int c = 0; c < K1; c++)
+#pragma unroll
+                for (int u = 0; u < HC; u++) {
+                    const double t0 = mulmod<F>(x[0][2 * u], kw[c][u].x), t1 = mulmod<F>(x[0][2 * u + 1], kw[c][u].y);
+                    if (c == p) {
+                        mine[2 * u] = lev == 0 ? t0 : mine[2 * u] + t0;
+                        mine[2 * u + 1] = lev == 0 ? t1 : mine[2 * u + 1] + t1;
+                    } else {
+                        other[2 * u] = lev == 0 ? t0 : other[2 * u] + t0;
+                        other[2 * u + 1] = lev == 0 ? t1 : other[2 * u + 1] + t1;
+                    }
+                }
+        }
+        // a product is below 1.5 p (mulmod: (0.5 + 0.75 |a| 2^-52) p with |a| <= 9.6 p): the 2 L of a column are
+        // summed as they are and recentred once (L <= 2: below 6 p)
 #pragma unroll
         for (int e = 0; e < EH; e++) xb[e * 64 + lane] = other[e];
         STAMP(3) // products
@@ -551,7 +576,8 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
     constexpr int N = G::N, E = G::E, EH = GS::E, Q = E / 4, HC = EH / 2;
     double *X = reinterpret_cast<double *>(smem + C::X_OFF);
     uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
-    int32_t *DIG = reinterpret_cast<int32_t *>(smem + C::DIG_OFF);
+    using dig_t = typename C::dig_t;
+    dig_t *DIG = reinterpret_cast<dig_t *>(smem + C::DIG_OFF);
     const uint16_t *MS = reinterpret_cast<const uint16_t *>(smem + C::MS_OFF);
     auto wave_of = [](int pp, int ff, int hh) { return (pp * 2 + ff) * 2 + hh; };
     double *xb = X + (size_t)wave_of(p, f, h) * GS::XPAD;
@@ -559,7 +585,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
     const double *x_half = X + (size_t)wave_of(p, f, 1 - h) * GS::XPAD;
     const double *x_field = X + (size_t)wave_of(p, 1 - f, h) * GS::XPAD;
     uint64_t *acc_p = ACC + (size_t)p * N;
-    int32_t *dig_p = DIG + (size_t)p * N;
+    dig_t *dig_p = DIG + (size_t)p * N;
     const double *twt = reinterpret_cast<const double *>(smem + C::TW_OFF);
     const double *tw_own = twt + (size_t)(f * 2 + h) * C::TW_PART, *tw_oth = twt + (size_t)(f * 2 + (1 - h)) * C::TW_PART;
     TwHybrid<LOGN - 1, false> twf{tw_own, tw_own + C::TW_IDX + lane};
@@ -596,7 +622,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
         double x[1][EH];
         {
-            const int32_t *dg = dig_p + lane;
+            const dig_t *dg = dig_p + lane;
 #pragma unroll
             for (int e = 0; e < EH; e++) {
                 const double U = (double)dg[64 * e], V = mulmod<F>((double)dg[64 * (e + EH)], w1);
@@ -795,11 +821,11 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64s(const Pbs64Job *__rest
 }
 
 // key conversion for k_pbs64s: standard-domain u64 -> field F, stage 1 + half transform h, times N^-1:
-//   dst[i][r][c][f][h][e/2][lane][e&1]    (src is [i][lev = 0][r][c][N]); one wave per (polynomial, half)
+//   dst[i][r][c][lev][f][h][e/2][lane][e&1]    (src is [i][lev][r][c][N]); one wave per (polynomial, half)
 template <typename F, int LOGN>
 __global__ __launch_bounds__(64) void k_bsk_convert64s(const uint64_t *__restrict__ src, double *__restrict__ dst,
                                                        const double *__restrict__ tw_full, const double *__restrict__ tw_sub_f,
-                                                       double n_inv, double two32, int K1, int f)
+                                                       double n_inv, double two32, int K1, int f, int L)
 {
     using G = Geo<LOGN>;
     using GS = Geo<LOGN - 1>;
@@ -810,7 +836,8 @@ __global__ __launch_bounds__(64) void k_bsk_convert64s(const uint64_t *__restric
     const int h = blockIdx.x & 1;
     const int c = poly % K1;
     const int r = (poly / K1) % K1;
-    const size_t i = poly / ((size_t)K1 * K1);
+    const int lev = (poly / ((size_t)K1 * K1)) % L;
+    const size_t i = poly / ((size_t)K1 * K1 * L);
     const double w1 = tw_full[1];
     auto load = [&](int j) {
         const uint64_t v = src[poly * N + j];
@@ -824,7 +851,7 @@ __global__ __launch_bounds__(64) void k_bsk_convert64s(const uint64_t *__restric
         x[0][e] = reduce<F>(h ? U - V : U + V);
     }
     ntt_forward<F, LOGN - 1, 1>(x, xbuf, TwMem{tw_sub_f + (size_t)h * GS::N}, lane);
-    const size_t dpoly = ((((i * K1 + r) * K1 + c) * 2 + f) * 2 + h);
+    const size_t dpoly = (((((i * K1 + r) * K1 + c) * L + lev) * 2 + f) * 2 + h);
     double *d = dst + dpoly * GS::N;
 #pragma unroll
     for (int e = 0; e < EH; e++) d[((e >> 1) * 64 + lane) * 2 + (e & 1)] = reduce<F>(mulmod<F>(x[0][e], n_inv));
@@ -1290,8 +1317,13 @@ hipError_t launch_pbs64(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, c
             if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10>, true>(ctx, jobs, count, small, luts, out);
             if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11>, true>(ctx, jobs, count, small, luts, out);
         }
-        if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10>, false>(ctx, jobs, count, small, luts, out);
-        if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11>, false>(ctx, jobs, count, small, luts, out);
+        if (P.pbs_l == 1) {
+            if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10>, false>(ctx, jobs, count, small, luts, out);
+            if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11>, false>(ctx, jobs, count, small, luts, out);
+        } else {
+            if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10, 2>, false>(ctx, jobs, count, small, luts, out);
+            if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11, 2>, false>(ctx, jobs, count, small, luts, out);
+        }
     }
 #define PBS64_CASE(LN, LV) \
     if (ctx->logN == LN && P.pbs_l == LV) return launch_pbs64_c<Pbs64Cfg<LN, LV>>(ctx, jobs, count, small, luts, out);
@@ -1525,9 +1557,9 @@ int probe_spectrum_positions(helm_si_ctx *ctx)
 #define PROBE(LN)                                                                                                        \
     if (ctx->logN == LN) {                                                                                              \
         hipLaunchKernelGGL((k_bsk_convert64s<F0, LN>), dim3(2), dim3(64), 0, ctx->stream, d_x, d_out, ctx->tw[0],        \
-                           ctx->tw_sub, 1.0, ctx->two32[0], 1, 0);                                                       \
+                           ctx->tw_sub, 1.0, ctx->two32[0], 1, 0, 1);                                                    \
         hipLaunchKernelGGL((k_bsk_convert64s<F1, LN>), dim3(2), dim3(64), 0, ctx->stream, d_x, d_out, ctx->tw[1],        \
-                           ctx->tw_sub + (size_t)2 * H, 1.0, ctx->two32[1], 1, 1);                                       \
+                           ctx->tw_sub + (size_t)2 * H, 1.0, ctx->two32[1], 1, 1, 1);                                    \
     }
     PROBE(10) PROBE(11)
 #undef PROBE
@@ -1689,8 +1721,9 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
         HIP_TRY(hipMalloc(&ctx->psi_pow, pw.size() * sizeof(double)));
         HIP_TRY(hipMemcpy(ctx->psi_pow, pw.data(), pw.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    // eight-wave kernel (split transforms) where it exists: N >= 1024, one level (HELM_SI_SPLIT=0: off)
-    ctx->use_split = P.pbs_l == 1 && N >= 1024;
+    // eight-wave kernel (split transforms) where it exists: N >= 1024, one or two levels (HELM_SI_SPLIT=0: off)
+    static_assert(Pbs64sCfg<11, 2>::BYTES <= 160 * 1024, "k_pbs64s<11, 2> must fit the LDS of a CU");
+    ctx->use_split = (P.pbs_l == 1 || (P.pbs_l == 2 && P.pbs_logB <= 15)) && N >= 1024;
     if (const char *v = getenv("HELM_HIP_KS_MFMA")) ctx->ks_mfma = atoi(v);
     if (const char *v = getenv("HELM_SI_SPLIT")) ctx->use_split = (ctx->use_split && atoi(v) != 0) || group > 1;
     if (ctx->use_split) {
@@ -1813,10 +1846,10 @@ int helm_si_load_bootstrap_key(helm_si_ctx *ctx, const uint64_t *bsk_std, size_t
 #define CONVS(LN)                                                                                                       \
     if (ctx->logN == LN) {                                                                                              \
         hipLaunchKernelGGL((k_bsk_convert64s<F0, LN>), dim3((unsigned)(polys * 2)), dim3(64), 0, ctx->stream, d_std,     \
-                           ctx->bsk_split, ctx->tw[0], ctx->tw_sub, ctx->n_inv[0], ctx->two32[0], (int)K1, 0);           \
+                           ctx->bsk_split, ctx->tw[0], ctx->tw_sub, ctx->n_inv[0], ctx->two32[0], (int)K1, 0, P.pbs_l);  \
         hipLaunchKernelGGL((k_bsk_convert64s<F1, LN>), dim3((unsigned)(polys * 2)), dim3(64), 0, ctx->stream, d_std,     \
                            ctx->bsk_split, ctx->tw[1], ctx->tw_sub + (size_t)2 * (P.N / 2), ctx->n_inv[1], ctx->two32[1], \
-                           (int)K1, 1);                                                                                  \
+                           (int)K1, 1, P.pbs_l);                                                                         \
     }
         CONVS(10) CONVS(11)
 #undef CONVS
