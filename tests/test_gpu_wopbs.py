@@ -217,3 +217,43 @@ lut g4(0x8000000000000001, y, z, t, p, a, b, q);
         lc.evaluate_encrypted(lc.encrypt_inputs(wire_set, {n: PtxtType.Bool(1) for n in "abcdef"}), 1, "bool")
     wsk.close()
     sk.close()
+
+
+def test_argument_validation_and_edge_cases(toy):
+    """Empty batches are no-ops; a one-input gate works (one block, one GGSW); missing keys, foreign wire tables, too
+    many index bits and bad rows fail loudly with HELM_ERR_* (no silent fallback)."""
+    from helm_amd import _native as nv
+    ck, wk, sk, wsk, ow = toy
+    w = sk.wires(8)
+    w.upload(np.arange(2), ck.encrypt(np.array([1, 0], dtype=U64)))
+    # empty batch
+    wsk.eval_luts(w, np.zeros((0, 3), np.int32), np.zeros((0, 64), U64), np.zeros(0, np.int32), bits_per_block=1)
+    # one input: NOT through the wide path
+    wsk.eval_luts(w, np.array([[0], [1]], np.int32), np.array([1, 0], dtype=U64), np.array([2, 3], np.int32),
+                  bits_per_block=1)
+    assert [int(v) for v in ck.decrypt_message_and_carry(w.download(np.array([2, 3])))] == [0, 1]
+    # in place: output row = input row of the same gate
+    wsk.eval_luts(w, np.array([[2]], np.int32), np.array([1, 0], dtype=U64), np.array([2], np.int32), bits_per_block=1)
+    assert int(ck.decrypt_message_and_carry(w.download(np.array([2])))[0]) == 1
+    with pytest.raises(nv.HelmError, match="out of range"):
+        wsk.eval_luts(w, np.array([[0, 9]], np.int32), np.zeros(16, U64), np.array([4], np.int32), bits_per_block=1)
+    with pytest.raises(nv.HelmError, match="bits_per_block"):
+        wsk.eval_luts(w, np.array([[0, 1]], np.int32), np.zeros(16, U64), np.array([4], np.int32), bits_per_block=5)
+    too_many = wsk.logN + 7
+    with pytest.raises(nv.HelmError, match="index bits"):
+        hip_tables = np.zeros(1 << too_many, U64)
+        nv.hip_check(nv.hip.helm_wop_eval_luts(wsk._h, w._h, nv.as_i32p(np.zeros(too_many, np.int32)), too_many, 1,
+                                               nv.as_u64p(hip_tables), nv.as_i32p(np.array([4], np.int32)), 1))
+    # a table of another context
+    other = helm_amd.SiServerKey(ck)
+    w2 = other.wires(4)
+    with pytest.raises(nv.HelmError, match="another context"):
+        wsk.eval_luts(w2, np.array([[0]], np.int32), np.array([0, 1], dtype=U64), np.array([1], np.int32), bits_per_block=1)
+    # a context without its keys
+    bare = wopbs.WopServerKey(other, params=wk.params)
+    with pytest.raises(nv.HelmError, match="not loaded"):
+        bare.eval_luts(w2, np.array([[0]], np.int32), np.array([0, 1], dtype=U64), np.array([1], np.int32), bits_per_block=1)
+    with pytest.raises(nv.HelmError, match="expected"):
+        bare.load_key(wopbs.KEY_PFPKSK, np.zeros(10, U64))
+    bare.close()
+    other.close()

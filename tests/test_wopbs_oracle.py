@@ -206,3 +206,27 @@ def test_make_table_follows_the_reference_index_rule():
         fields = [(v >> (2 * j)) & 3 for j in range(3)]
         x = (fields[0] + 2 * fields[1] + 4 * fields[2]) % 8
         assert int(t2[v]) == int(truth[x]) * delta
+
+
+def test_parameter_and_table_validation_needs_no_device():
+    import ctypes as C
+    from helm_amd import _native as nv
+    p, lwe, glwe = wopbs.wop_named_params("wopbs_m2c2")
+    assert p.as_tuple() == (769, 1, 2048, 2, 15, 5, 2, 2, 15, 3, 5, 4, 4)
+    p1, _, _ = wopbs.wop_named_params("wopbs_m1c1")
+    assert (p1.n, p1.message_modulus, p1.carry_modulus) == (653, 2, 2)
+    with pytest.raises(nv.HelmError):
+        wopbs.wop_named_params("no_such_set")
+    assert nv.hip.helm_wop_table_words(C.byref(p), 3) == 2048 and nv.hip.helm_wop_table_words(C.byref(p), 13) == 8192
+    out = np.zeros(2048, dtype=U64)
+    truth = np.zeros(8, dtype=U64)
+    assert nv.hip.helm_wop_make_table(C.byref(p), 0, 1, nv.as_u64p(truth), 8, nv.as_u64p(out)) != 0
+    assert nv.hip.helm_wop_make_table(C.byref(p), 3, 0, nv.as_u64p(truth), 8, nv.as_u64p(out)) != 0
+    assert nv.hip.helm_wop_make_table(C.byref(p), 3, 1, None, 8, nv.as_u64p(out)) != 0
+    # no device here: creating the context fails loudly (no CPU fallback), with a null PBS side as an invalid argument
+    h = nv.vp()
+    assert nv.hip.helm_wop_ctx_create(None, C.byref(p), C.byref(h)) == -1
+    # the two parameter sets must share one encoding
+    ck = helm_amd.SiClientKey.generate("si_toy_512", seed=5)  # message_modulus * carry_modulus = 16
+    with pytest.raises(nv.HelmError):
+        wopbs.WopClientKey(ck, p1, lwe, glwe, seed=6)
