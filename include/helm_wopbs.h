@@ -96,7 +96,10 @@ int helm_wop_make_table(const helm_wop_params *params, int32_t n_blocks, int32_t
  * bits_per_block: bits extracted per block - log2(message_modulus * carry_modulus) is what tfhe's degree
  * bookkeeping extracts after the cleaning bootstrap; 1 is enough when every input holds a single bit;
  * tables [count][helm_wop_table_words(n_inputs * bits_per_block)];  out_idx [count] rows of `w`.
- * n_inputs * bits_per_block <= log2(N) + 6. */
+ * n_inputs * bits_per_block <= log2(N) + 6.
+ * Multi-GPU: after helm_si_set_exchange() on the PBS-side context a batch of at least min_batch gates is split over the
+ * ranks by gate (every stage of a gate on one rank), the result rows go through the same all-gather callback and are
+ * scattered into every rank's table; identical ciphertexts to the unsharded call. */
 int helm_wop_eval_luts(helm_wop_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, int32_t n_inputs,
                        int32_t bits_per_block, const uint64_t *tables, const int32_t *out_idx, int64_t count);
 
