@@ -74,6 +74,12 @@ def test_circuit_bootstrap_bit_exact(toy):
     got = wsk.circuit_bootstrap(small)
     for r in range(len(bits)):
         assert np.array_equal(got[r], ow.circuit_bootstrap(small[r])), r
+    # a batch wide enough for the matrix-core packing keyswitch (64 bootstraps and more): same ciphertexts
+    many = encrypt_bits_small(wk, list(rng.integers(0, 2, size=40)), rng)
+    wide = wsk.circuit_bootstrap(many)
+    for r in (0, 17, 39):
+        assert np.array_equal(wide[r], ow.circuit_bootstrap(many[r])), r
+    assert np.array_equal(wsk.circuit_bootstrap(many[:5]), wide[:5])  # narrow batch: the vector-ALU kernel
 
 
 @pytest.mark.parametrize("bits", [2, 7, 11, 12])
