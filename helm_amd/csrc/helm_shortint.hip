@@ -489,6 +489,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
             if (lev == 0) {
                 STAMP(2) // digits read, stage 1, half transform
             }
+            // (fetching this column before the transform was measured 1 % slower: profiles/r02/si_kernel_experiments.txt)
 #pragma unroll
             for (int u = 0; u < HC; u++) kw[1][u] = (bp_i + (size_t)(1 * L + lev) * 4 * part)[u * 64];
 #pragma unroll
