@@ -382,6 +382,9 @@ struct Pbs64sCfg {
 #ifndef HELM_SI_PRIO
 #define HELM_SI_PRIO 1
 #endif
+#ifndef HELM_SI_FUSED_XCHG
+#define HELM_SI_FUSED_XCHG 1 // one exchange for the last inverse stage and the CRT (two barriers instead of four)
+#endif
     static constexpr bool PRIO = HELM_SI_PRIO != 0;
     static constexpr int TW_IDX = GS::N >> GS::BC, TW_PART = TW_IDX + GS::TWC * 64; // per (field, half)
     static constexpr size_t X_OFF = 0;                                              // double [NW][GS::XPAD]
@@ -397,7 +400,7 @@ struct Pbs64sCfg {
 
 template <typename C, typename F, int h>
 __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *__restrict__ bsk, int n, int logB,
-                                            double p0inv_mod_p1, double w1, int p, int f, int lane)
+                                            double p0inv_mod_p1, double w1, double w1o, int p, int f, int lane)
 {
     constexpr int LOGN = C::LOGN, K1 = C::K1, L = C::L;
     using G = typename C::G;
@@ -524,6 +527,29 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
 #pragma unroll
         for (int e = 0; e < EH; e++) xb[e * 64 + lane] = mine[e];
         lds_block_sync();
+#if HELM_SI_FUSED_XCHG
+        // ---- (3b, 4) one exchange: every wave publishes its half inverse; the wave that lifts a slot computes the
+        //      last inverse stage of that slot in BOTH fields (its own from registers + the other half, the other
+        //      field's from the two waves that hold it) and the CRT.  Same values as the two-exchange form.
+        {
+            using FO = std::conditional_t<std::is_same<F, F0>::value, F1, F0>;
+            const double *x_fh = X + (size_t)wave_of(p, 1 - f, 1 - h) * GS::XPAD; // other field, other half
+            constexpr int HH = EH / 2;
+#pragma unroll
+            for (int e = 0; e < HH; e++) {
+                const int s = f * HH + e;
+                const double a = mine[s], o = x_half[s * 64 + lane];
+                const double own = h ? reduce<F>(mulmod<F>(a - o, w1)) : reduce<F>(a + o);
+                const double a2 = x_field[s * 64 + lane], o2 = x_fh[s * 64 + lane];
+                const double oth = h ? reduce<FO>(mulmod<FO>(a2 - o2, w1o)) : reduce<FO>(a2 + o2);
+                const double r0 = f == 0 ? own : oth, r1 = f == 0 ? oth : own;
+                const double t = mulmod<F1>(r1 - r0, p0inv_mod_p1);
+                const uint64_t xv = (uint64_t)to_int64(r0) + F0::P_U64 * (uint64_t)to_int64(t);
+                acc_p[h * (N / 2) + s * 64 + lane] += xv;
+            }
+        }
+        lds_block_sync(); // accumulator complete, scratch free again
+#else
 #pragma unroll
         for (int e = 0; e < EH; e++) {
             const double o = x_half[e * 64 + lane];
@@ -546,6 +572,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
             acc_p[h * (N / 2) + (f * HH + e) * 64 + lane] += xv;
         }
         lds_block_sync(); // accumulator complete
+#endif
         STAMP(7) // CRT, barriers 6 and 7
     }
     STAMP_END((p * 2 + f) * 2 + h)
@@ -568,7 +595,7 @@ __host__ __device__ constexpr int bitrev_c(int v, int bits)
 // accumulator is replaced instead of added to.
 template <typename C, typename F, int h>
 __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double *__restrict__ bsk, int n, int logB,
-                                               double p0inv_mod_p1, double w1, int p, int f, int lane, int g,
+                                               double p0inv_mod_p1, double w1, double w1o, int p, int f, int lane, int g,
                                                const uint16_t *__restrict__ expo, const double *__restrict__ psi_pow)
 {
     constexpr int LOGN = C::LOGN, K1 = C::K1;
@@ -716,6 +743,29 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
 #pragma unroll
         for (int e = 0; e < EH; e++) xb[e * 64 + lane] = mine[e];
         lds_block_sync();
+#if HELM_SI_FUSED_XCHG
+        // ---- (3b, 4) one exchange: every wave publishes its half inverse; the wave that lifts a slot computes the
+        //      last inverse stage of that slot in BOTH fields (its own from registers + the other half, the other
+        //      field's from the two waves that hold it) and the CRT.  Same values as the two-exchange form.
+        {
+            using FO = std::conditional_t<std::is_same<F, F0>::value, F1, F0>;
+            const double *x_fh = X + (size_t)wave_of(p, 1 - f, 1 - h) * GS::XPAD; // other field, other half
+            constexpr int HH = EH / 2;
+#pragma unroll
+            for (int e = 0; e < HH; e++) {
+                const int s = f * HH + e;
+                const double a = mine[s], o = x_half[s * 64 + lane];
+                const double own = h ? reduce<F>(mulmod<F>(a - o, w1)) : reduce<F>(a + o);
+                const double a2 = x_field[s * 64 + lane], o2 = x_fh[s * 64 + lane];
+                const double oth = h ? reduce<FO>(mulmod<FO>(a2 - o2, w1o)) : reduce<FO>(a2 + o2);
+                const double r0 = f == 0 ? own : oth, r1 = f == 0 ? oth : own;
+                const double t = mulmod<F1>(r1 - r0, p0inv_mod_p1);
+                const uint64_t xv = (uint64_t)to_int64(r0) + F0::P_U64 * (uint64_t)to_int64(t);
+                acc_p[h * (N / 2) + s * 64 + lane] = xv;
+            }
+        }
+        lds_block_sync(); // accumulator complete, scratch free again
+#else
 #pragma unroll
         for (int e = 0; e < EH; e++) {
             const double o = x_half[e * 64 + lane];
@@ -735,6 +785,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
             acc_p[h * (N / 2) + (f * HH + e) * 64 + lane] = (uint64_t)to_int64(r0) + F0::P_U64 * (uint64_t)to_int64(tt);
         }
         lds_block_sync(); // accumulator complete
+#endif
     }
 }
 
@@ -787,22 +838,22 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64s(const Pbs64Job *__rest
     }
     __syncthreads();
     // psi^(N/2): entry 1 of the full forward table of this wave's field
-    const double w1 = f == 0 ? tw0[1] : tw1[1];
+    const double w1 = f == 0 ? tw0[1] : tw1[1], w1o = f == 0 ? tw1[1] : tw0[1];
     // one specialisation per (field, transform half): both are uniform over the wave
     if constexpr (MB) {
         if (f == 0) {
-            if (h == 0) pbs64s_mb_body<C, F0, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 0, lane, g, expo, psi_pow);
-            else pbs64s_mb_body<C, F0, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 0, lane, g, expo, psi_pow);
+            if (h == 0) pbs64s_mb_body<C, F0, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 0, lane, g, expo, psi_pow);
+            else pbs64s_mb_body<C, F0, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 0, lane, g, expo, psi_pow);
         } else {
-            if (h == 0) pbs64s_mb_body<C, F1, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 1, lane, g, expo, psi_pow + 2 * N);
-            else pbs64s_mb_body<C, F1, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 1, lane, g, expo, psi_pow + 2 * N);
+            if (h == 0) pbs64s_mb_body<C, F1, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 1, lane, g, expo, psi_pow + 2 * N);
+            else pbs64s_mb_body<C, F1, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 1, lane, g, expo, psi_pow + 2 * N);
         }
     } else if (f == 0) {
-        if (h == 0) pbs64s_body<C, F0, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 0, lane);
-        else pbs64s_body<C, F0, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 0, lane);
+        if (h == 0) pbs64s_body<C, F0, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 0, lane);
+        else pbs64s_body<C, F0, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 0, lane);
     } else {
-        if (h == 0) pbs64s_body<C, F1, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 1, lane);
-        else pbs64s_body<C, F1, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, p, 1, lane);
+        if (h == 0) pbs64s_body<C, F1, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 1, lane);
+        else pbs64s_body<C, F1, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 1, lane);
     }
 
     uint64_t *ob = out + (size_t)job.out_row * ((size_t)K * N + 1);
