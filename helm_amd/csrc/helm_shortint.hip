@@ -496,7 +496,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
 #pragma unroll
             for (int u = 0; u < HC; u++) kw[1][u] = (bp_i + (size_t)(1 * L + lev) * 4 * part)[u * 64];
 #pragma unroll
-            for (int c = 0; c < K1; c++)
+            for (int c = 0; c < K1; c++) {
 #pragma unroll
                 for (int u = 0; u < HC; u++) {
                     const double t0 = mulmod<F>(x[0][2 * u], kw[c][u].x), t1 = mulmod<F>(x[0][2 * u + 1], kw[c][u].y);
@@ -508,6 +508,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
                         other[2 * u + 1] = lev == 0 ? t1 : other[2 * u + 1] + t1;
                     }
                 }
+            }
         }
         // a product is below 1.5 p (mulmod: (0.5 + 0.75 |a| 2^-52) p with |a| <= 9.6 p): the 2 L of a column are
         // summed as they are and recentred once (L <= 2: below 6 p)
