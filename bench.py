@@ -492,6 +492,17 @@ def _other_modes_set(device, set_name, tfhe_name):
     res["arith_mode"] = {"workload": "chi_squared_arith.v, u32 (16 radix blocks per integer), " + tfhe_name, "wall_s": round(dt, 4),
                          "bootstraps": ac.pbs_per_cycle(), "batched_rounds": ac.pbs_rounds_per_cycle(),
                          "decrypt_ok": dec == {"alpha": 529, "beta1": 242, "beta2": 275, "beta3": 1250}}
+    # the same evaluation with the two sub-circuits that share no wire (alpha's and the betas') on two lanes
+    # (helm_si_ctx_fork): concurrent instead of level by level, identical ciphertexts
+    ac.set_lanes(2)
+    ac.evaluate_encrypted(enc, 1, "u32")
+    t0 = time.perf_counter()
+    outl = ac.evaluate_encrypted(enc, 1, "u32")
+    dtl = time.perf_counter() - t0
+    decl = {k: int(v.value) for k, v in ac.decrypt_outputs(outl, True).items()}
+    res["arith_mode"]["two_lanes"] = {"wall_s": round(dtl, 4), "rounds_in_a_row": ac.pbs_rounds_per_cycle(),
+                                      "bit_identical_to_level_by_level": all(np.array_equal(outm[k], outl[k]) for k in outm.keys()),
+                                      "decrypt_ok": decl == dec}
     sk.close()
     return res
 

@@ -52,6 +52,7 @@ HOST_API = {
     "helm_host_si_circuit_evaluate_ready": (C.c_int, [vp, vp, vp]),
     "helm_host_si_circuit_decrypt_outputs": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
     "helm_host_si_circuit_set_wopbs": (C.c_int, [vp, vp, C.c_int]),
+    "helm_host_si_circuit_add_lane": (C.c_int, [vp, vp]),
     "helm_host_si_circuit_log": (vp, [vp]),
     "helm_host_si_circuit_pbs_per_cycle": (C.c_int64, [vp]),
     "helm_host_si_circuit_pbs_rounds_per_cycle": (C.c_int64, [vp]),

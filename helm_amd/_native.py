@@ -131,6 +131,7 @@ SI_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int64)
 SI_API = {
     "helm_si_ctx_create": (C.c_int, [C.c_int, C.POINTER(SiParams), C.POINTER(vp)]),
     "helm_si_ctx_destroy": (C.c_int, [vp]),
+    "helm_si_ctx_fork": (C.c_int, [vp, C.POINTER(vp)]),
     "helm_si_get_params": (C.c_int, [vp, C.POINTER(SiParams)]),
     "helm_si_set_stream": (C.c_int, [vp, vp]),
     "helm_si_sync": (C.c_int, [vp]),

@@ -253,3 +253,11 @@ class LutCircuit(_SiCircuit):
 class ArithCircuit(_SiCircuit):
     """reference src/circuit.rs:81-85, 1112-1500"""
     MODE = 1
+
+    def set_lanes(self, n):
+        """Evaluate sub-circuits that share no wire concurrently on `n` contexts in all (the server key and n - 1 lanes
+        forked from it) instead of level by level; identical ciphertexts.  n = 1 switches lanes off."""
+        H.check(H.host.helm_host_si_circuit_add_lane(self._h, None))
+        self._lane_keys = [self._sk.fork() for _ in range(max(0, int(n) - 1))]
+        for lane in self._lane_keys:
+            H.check(H.host.helm_host_si_circuit_add_lane(self._h, lane._h))

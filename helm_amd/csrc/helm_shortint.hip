@@ -1215,6 +1215,7 @@ struct helm_si_wires {
 
 struct helm_si_ctx {
     int device = 0;
+    helm_si_ctx *lane_of = nullptr; // helm_si_ctx_fork(): the context whose keys and tables this one shares
     helm_si_params P{};
     int logN = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -1272,6 +1273,12 @@ struct helm_si_ctx {
 };
 
 namespace {
+
+// a lane works on the tables of the context it was forked from
+bool owns(const helm_si_ctx *ctx, const helm_si_wires *w)
+{
+    return w->owner == ctx || (ctx->lane_of && w->owner == ctx->lane_of);
+}
 
 struct Timed {
     helm_si_ctx *ctx;
@@ -1795,6 +1802,50 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
     return 0;
 }
 
+int helm_si_ctx_fork(helm_si_ctx *primary, helm_si_ctx **out)
+{
+    if (!primary || !out) return fail(HELM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (primary->lane_of) return fail(HELM_ERR_INVALID, "fork the primary context, not one of its lanes");
+    if (!primary->have_bsk || !primary->have_ksk) return fail(HELM_ERR_STATE, "load the keys before forking a lane");
+    HIP_TRY(hipSetDevice(primary->device));
+    helm_si_ctx *ctx = new (std::nothrow) helm_si_ctx();
+    if (!ctx) return fail(HELM_ERR_OOM, "ctx");
+    ctx->device = primary->device;
+    ctx->lane_of = primary;
+    ctx->P = primary->P;
+    ctx->logN = primary->logN;
+    for (int f = 0; f < 2; f++) {
+        ctx->tw[f] = primary->tw[f];
+        ctx->n_inv[f] = primary->n_inv[f];
+        ctx->two32[f] = primary->two32[f];
+    }
+    ctx->p0inv_mod_p1 = primary->p0inv_mod_p1;
+    ctx->bsk = primary->bsk;
+    ctx->bsk_split = primary->bsk_split;
+    ctx->tw_sub = primary->tw_sub;
+    ctx->group = primary->group;
+    ctx->expo = primary->expo;
+    ctx->psi_pow = primary->psi_pow;
+    ctx->use_split = primary->use_split;
+    ctx->ksk = primary->ksk;
+    ctx->ksk_planes = primary->ksk_planes;
+    ctx->ks_kchunks = primary->ks_kchunks;
+    ctx->ks_ctiles = primary->ks_ctiles;
+    ctx->ks_mfma = primary->ks_mfma;
+    ctx->have_bsk = ctx->have_ksk = true;
+    ctx->delta = primary->delta;
+    ctx->n_cus = primary->n_cus;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(HELM_ERR_HIP, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e));
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return 0;
+}
+
 int helm_si_ctx_destroy(helm_si_ctx *ctx)
 {
     if (!ctx) return 0;
@@ -1810,15 +1861,17 @@ int helm_si_ctx_destroy(helm_si_ctx *ctx)
         w->d = nullptr;
         w->owner = nullptr;
     }
-    (void)hipFree(ctx->tw[0]);
-    (void)hipFree(ctx->tw[1]);
-    (void)hipFree(ctx->bsk);
-    (void)hipFree(ctx->bsk_split);
-    (void)hipFree(ctx->tw_sub);
-    (void)hipFree(ctx->expo);
-    (void)hipFree(ctx->psi_pow);
-    (void)hipFree(ctx->ksk);
-    (void)hipFree(ctx->ksk_planes);
+    if (!ctx->lane_of) { // a lane borrows its keys and tables
+        (void)hipFree(ctx->tw[0]);
+        (void)hipFree(ctx->tw[1]);
+        (void)hipFree(ctx->bsk);
+        (void)hipFree(ctx->bsk_split);
+        (void)hipFree(ctx->tw_sub);
+        (void)hipFree(ctx->expo);
+        (void)hipFree(ctx->psi_pow);
+        (void)hipFree(ctx->ksk);
+        (void)hipFree(ctx->ksk_planes);
+    }
     for (auto &S : ctx->slots) {
         if (S.host) (void)hipHostFree(S.host);
         if (S.dev) (void)hipFree(S.dev);
@@ -1999,7 +2052,7 @@ int helm_si_wires_free(helm_si_ctx *ctx, helm_si_wires *w)
 int helm_si_wires_upload(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx, const uint64_t *lwe_host, int64_t count)
 {
     if (!ctx || !w || !idx || !lwe_host || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
-    if (w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (!owns(ctx, w)) return fail(HELM_ERR_STATE, "table belongs to another context");
     if (count == 0) return 0;
     if (int rc = check_rows(w, idx, count, false)) return rc;
     {
@@ -2023,7 +2076,7 @@ int helm_si_wires_upload(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx,
 int helm_si_wires_download(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx, uint64_t *lwe_host, int64_t count)
 {
     if (!ctx || !w || !idx || !lwe_host || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
-    if (w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (!owns(ctx, w)) return fail(HELM_ERR_STATE, "table belongs to another context");
     if (count == 0) return 0;
     if (int rc = check_rows(w, idx, count, false)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -2044,7 +2097,7 @@ int helm_si_wires_copy(helm_si_ctx *ctx, helm_si_wires *src, const int32_t *src_
                        const int32_t *dst_idx, int64_t count)
 {
     if (!ctx || !src || !dst || !src_idx || !dst_idx || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
-    if (src->owner != ctx || dst->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (!owns(ctx, src) || !owns(ctx, dst)) return fail(HELM_ERR_STATE, "table belongs to another context");
     if (count == 0) return 0;
     if (int rc = check_rows(src, src_idx, count, false)) return rc;
     if (int rc = check_rows(dst, dst_idx, count, false)) return rc;
@@ -2062,7 +2115,7 @@ int helm_si_wires_copy(helm_si_ctx *ctx, helm_si_wires *src, const int32_t *src_
 int helm_si_wires_set_trivial(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx, const uint64_t *value, int64_t count)
 {
     if (!ctx || !w || !idx || !value || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
-    if (w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (!owns(ctx, w)) return fail(HELM_ERR_STATE, "table belongs to another context");
     if (count == 0) return 0;
     if (int rc = check_rows(w, idx, count, false)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -2082,7 +2135,7 @@ int helm_si_lincomb(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, c
                     const int64_t *const_add, const int32_t *out_idx, int32_t terms, int64_t count)
 {
     if (!ctx || !w || !in_idx || !coef || !out_idx || terms < 1 || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
-    if (w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (!owns(ctx, w)) return fail(HELM_ERR_STATE, "table belongs to another context");
     if (count == 0) return 0;
     if (int rc = check_rows(w, in_idx, count * terms, true)) return rc;
     if (int rc = check_rows(w, out_idx, count, false)) return rc;
@@ -2134,7 +2187,7 @@ int helm_si_apply_luts(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx
 {
     if (!ctx || !w || !in_idx || !lut_idx || !out_idx || !luts || count < 0 || n_luts <= 0)
         return fail(HELM_ERR_INVALID, "bad argument");
-    if (w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (!owns(ctx, w)) return fail(HELM_ERR_STATE, "table belongs to another context");
     if (count == 0) return 0;
     if (int rc = check_rows(w, in_idx, count, false)) return rc;
     if (int rc = check_rows(w, out_idx, count, false)) return rc;
@@ -2190,7 +2243,7 @@ int helm_si_eval_lut_level(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *ar
 {
     if (!ctx || !w || !arity || !in_idx || !table || !out_idx || max_in < 1 || count < 0)
         return fail(HELM_ERR_INVALID, "bad argument");
-    if (w->owner != ctx) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (!owns(ctx, w)) return fail(HELM_ERR_STATE, "table belongs to another context");
     if (count == 0) return 0;
     if (int rc = check_rows(w, out_idx, count, false)) return rc;
     const helm_si_params &P = ctx->P;

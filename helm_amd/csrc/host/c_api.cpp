@@ -348,6 +348,17 @@ int helm_host_si_circuit_set_wopbs(helm_si_circuit *c, helm_wop_ctx *wop, int bi
     }
     return guard([&] { c->lut->set_wide_lut_key(wop, bits_per_block); });
 }
+int helm_host_si_circuit_add_lane(helm_si_circuit *c, helm_si_ctx *lane)
+{
+    if (!c || !c->arith) {
+        g_err = "add_lane: not an arithmetic-mode circuit";
+        return -1;
+    }
+    return guard([&] {
+        if (lane) c->arith->add_lane(lane);
+        else c->arith->clear_lanes();
+    });
+}
 char *helm_host_si_circuit_log(helm_si_circuit *c) { return dup(c->lut ? c->lut->log() : c->arith->log()); }
 int64_t helm_host_si_circuit_pbs_per_cycle(const helm_si_circuit *c)
 {

@@ -342,11 +342,16 @@ class ArithCircuit : public EvalCircuit<SiEncWireMap> {
     int64_t pbs_per_cycle() const { return pbs_count_; }
     int64_t pbs_rounds_per_cycle() const { return pbs_rounds_; }
     std::string log() { std::string s; s.swap(log_); return s; }
+    // Lanes (helm_si_ctx_fork): sub-circuits that share no wire are evaluated concurrently, one lane each, instead of
+    // meeting at every level boundary (circuit.rs:1321 joins the whole level).  Same ciphertexts, fewer rounds in a row.
+    void add_lane(helm_si_ctx *lane) { lanes_.push_back(lane); }
+    void clear_lanes() { lanes_.clear(); }
 
   private:
     void encrypt_value(SiEncWireMap &m, const std::string &wire, unsigned __int128 value);
     helm_si_client_key *client_key_;
     helm_si_ctx *server_key_;
+    std::vector<helm_si_ctx *> lanes_;
     Circuit circuit_;
     helm_si_params P_{};
     std::string global_ptxt_type_;

@@ -12,6 +12,8 @@
 // the ones here are level-batched restatements with the same results mod 2^bits (what the
 // reference's tests pin: tests/gates_test.rs:127-310, tests/circuit_test.rs:349-368).
 #include "helm_host.hpp"
+#include <functional>
+#include <thread>
 
 #include <algorithm>
 #include <sstream>
@@ -1102,8 +1104,97 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
         max_scratch = std::max(max_scratch, eng.scratch_rows(ops));
         plan.push_back(std::move(ops));
     }
-    const int scratch = eval_values->scratch(max_scratch);
     const size_t total_levels = circuit_.level_map().size();
+    if (!lanes_.empty()) {
+        // ---- lanes: connected components of the operator graph (wires produced by an operator connect it to its
+        //      consumers; primary inputs and scalars connect nothing), each component's levels compacted, components
+        //      spread over the contexts by their bootstrap estimate, one host thread per context.
+        std::vector<int> parent;
+        std::vector<std::pair<size_t, size_t>> where; // op id -> (level, index)
+        std::map<int, int> producer;                  // first row of an output -> op id
+        for (size_t l = 0; l < plan.size(); l++)
+            for (size_t q = 0; q < plan[l].size(); q++) {
+                producer[plan[l][q].out] = (int)where.size();
+                parent.push_back((int)where.size());
+                where.push_back({l, q});
+            }
+        std::function<int(int)> find = [&](int x) { return parent[(size_t)x] == x ? x : parent[(size_t)x] = find(parent[(size_t)x]); };
+        for (size_t id = 0; id < where.size(); id++) {
+            const RadixOp &op = plan[where[id].first][where[id].second];
+            for (int row : {op.a, op.b}) {
+                auto it = row >= 0 ? producer.find(row) : producer.end();
+                if (it != producer.end()) parent[(size_t)find((int)id)] = find(it->second);
+            }
+        }
+        std::map<int, std::vector<int>> comps;
+        for (size_t id = 0; id < where.size(); id++) comps[find((int)id)].push_back((int)id);
+        auto cost = [&](const RadixOp &op) -> int64_t {
+            switch (op.kind) {
+            case RadixOp::Mul: return (int64_t)nb * nb * 2;
+            case RadixOp::Div: case RadixOp::DivScalar: return (int64_t)nb * nb * 8;
+            case RadixOp::Copy: return 0;
+            default: return (int64_t)nb * 6;
+            }
+        };
+        std::vector<std::pair<int64_t, int>> order; // (cost, root), heaviest first
+        for (auto &c : comps) {
+            int64_t w = 0;
+            for (int id : c.second) w += cost(plan[where[(size_t)id].first][where[(size_t)id].second]);
+            order.push_back({w, c.first});
+        }
+        std::sort(order.begin(), order.end(), [](auto &x, auto &y) { return x.first > y.first; });
+        const size_t n_ctx = 1 + lanes_.size();
+        std::vector<int64_t> load(n_ctx, 0);
+        std::vector<std::vector<std::vector<RadixOp>>> lane_plan(n_ctx, std::vector<std::vector<RadixOp>>(plan.size()));
+        for (auto &oc : order) {
+            const size_t lane = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+            load[lane] += oc.first;
+            for (int id : comps[oc.second]) lane_plan[lane][where[(size_t)id].first].push_back(plan[where[(size_t)id].first][where[(size_t)id].second]);
+        }
+        std::vector<std::unique_ptr<RadixEngine>> engines;
+        std::vector<int64_t> lane_scratch(n_ctx, 0);
+        int64_t total_scratch = 0;
+        for (size_t lane = 0; lane < n_ctx; lane++) {
+            engines.emplace_back(new RadixEngine(lane == 0 ? server_key_ : lanes_[lane - 1], nb));
+            for (auto &ops : lane_plan[lane]) lane_scratch[lane] = std::max(lane_scratch[lane], engines[lane]->scratch_rows(ops));
+            total_scratch += lane_scratch[lane];
+        }
+        int base = eval_values->scratch(total_scratch);
+        std::vector<int> lane_base(n_ctx);
+        for (size_t lane = 0; lane < n_ctx; lane++) {
+            lane_base[lane] = base;
+            base += (int)lane_scratch[lane];
+        }
+        si_ok(helm_si_sync(server_key_), "sync"); // the inputs are in place before any lane reads them
+        std::vector<std::string> errors(n_ctx);
+        auto run_lane = [&](size_t lane) {
+            try {
+                for (auto &ops : lane_plan[lane])
+                    if (!ops.empty()) engines[lane]->run_level(eval_values->table(), ops, lane_base[lane]);
+                si_ok(helm_si_sync(lane == 0 ? server_key_ : lanes_[lane - 1]), "sync");
+            } catch (const std::exception &e) {
+                errors[lane] = e.what();
+            }
+        };
+        std::vector<std::thread> threads;
+        for (size_t lane = 1; lane < n_ctx; lane++) threads.emplace_back(run_lane, lane);
+        run_lane(0);
+        for (auto &t : threads) t.join();
+        for (auto &e : errors)
+            if (!e.empty()) throw Panic(e);
+        pbs_count_ = 0;
+        pbs_rounds_ = 0;
+        for (auto &e : engines) {
+            pbs_count_ += e->pbs_count();
+            pbs_rounds_ = std::max(pbs_rounds_, e->pbs_rounds()); // rounds in a row: the longest lane
+        }
+        std::ostringstream os;
+        os << "  Evaluated " << comps.size() << " independent sub-circuit(s) of " << total_levels << " level(s) on " << n_ctx
+           << " lane(s)\n";
+        log_ += os.str();
+        return eval_values;
+    }
+    const int scratch = eval_values->scratch(max_scratch);
     size_t li = 0;
     for (auto &kv : circuit_.level_map()) {
         eng.run_level(eval_values->table(), plan[li++], scratch);

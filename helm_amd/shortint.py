@@ -125,7 +125,21 @@ class SiServerKey:
             ksk = np.ascontiguousarray(ksk, dtype=np.uint64).reshape(-1)
             hip_check(hip.helm_si_load_keyswitch_key(self._h, nv.as_u64p(ksk), ksk.size))
 
+    def fork(self):
+        """A lane (helm_si_ctx_fork): shares this key's device-resident keys and wire tables, own stream and scratch."""
+        lane = SiServerKey.__new__(SiServerKey)
+        lane.params, lane.dim = self.params, self.dim
+        h = nv.vp()
+        hip_check(hip.helm_si_ctx_fork(self._h, C.byref(h)))
+        lane._h = h
+        lane._primary = self  # keep alive; lanes are closed before their primary
+        self._lanes = getattr(self, "_lanes", []) + [lane]
+        return lane
+
     def close(self):
+        for lane in getattr(self, "_lanes", []):
+            lane.close()
+        self._lanes = []
         if getattr(self, "_h", None):
             hip.helm_si_ctx_destroy(self._h)
             self._h = None

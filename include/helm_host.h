@@ -121,6 +121,10 @@ int helm_host_si_circuit_decrypt_outputs(helm_si_circuit *c, const helm_si_enc_m
  * through the WoP-PBS path of include/helm_wopbs.h - Gate::evaluate_encrypted_high_precision_lut (gates.rs:721-742),
  * which the reference defines but never calls.  wop = NULL switches it off again. */
 int helm_host_si_circuit_set_wopbs(helm_si_circuit *c, helm_wop_ctx *wop, int bits_per_block);
+/* Arithmetic mode: one more lane (helm_si_ctx_fork of the circuit's server key).  Sub-circuits that share no wire are
+ * then evaluated concurrently, one lane each, instead of meeting at every level boundary; identical ciphertexts.
+ * lane = NULL removes all lanes.  helm_host_si_circuit_pbs_rounds_per_cycle() then reports the longest lane. */
+int helm_host_si_circuit_add_lane(helm_si_circuit *c, helm_si_ctx *lane);
 char *helm_host_si_circuit_log(helm_si_circuit *c);
 /* bootstraps of the last evaluate_encrypted, and (arithmetic) the number of batched rounds */
 int64_t helm_host_si_circuit_pbs_per_cycle(const helm_si_circuit *c);

@@ -71,6 +71,13 @@ typedef struct {
 /* Replaces shortint ServerKey construction (helm.rs:301: gen_keys(PARAM_...)). */
 int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx **out);
 int helm_si_ctx_destroy(helm_si_ctx *ctx);
+/* A lane: a second context on the same device that shares `primary`'s keys and may work on its wire tables, with
+ * its own stream and scratch - independent parts of a circuit can then be evaluated concurrently (one host thread
+ * per lane; the GPU overlaps their launches).  The reference's unit of parallelism is the level
+ * (src/circuit.rs:1057, 1321: par_iter over the gates of a level); lanes add parallelism ACROSS levels for
+ * sub-circuits that share no wire.  Fork after the keys are loaded; destroy every lane before its primary.
+ * Rows written through one lane must not be touched through another until both have been synchronised. */
+int helm_si_ctx_fork(helm_si_ctx *primary, helm_si_ctx **lane_out);
 int helm_si_get_params(const helm_si_ctx *ctx, helm_si_params *out);
 int helm_si_set_stream(helm_si_ctx *ctx, void *hip_stream);
 int helm_si_sync(helm_si_ctx *ctx);

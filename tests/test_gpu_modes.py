@@ -138,6 +138,37 @@ def test_chi_squared_u32(keys):  # circuit_test.rs:313-370, inputs K-5 (2, 7, 9)
     assert ac.pbs_per_cycle() > 0 and ac.pbs_rounds_per_cycle() > 0
 
 
+def test_chi_squared_on_lanes_is_bit_identical_and_shorter(keys):
+    """Lanes (helm_si_ctx_fork): the two sub-circuits of chi-squared that share no wire (alpha's and the betas') run
+    concurrently instead of meeting at every level boundary: the same ciphertexts on every wire, fewer rounds in a row
+    (39 level-synchronous rounds -> the longer sub-circuit's 29)."""
+    import time
+    client_key, server_key = keys
+    circuit, wire_set, _, _ = _circuit(f"{NET}/chi_squared_arith.v", is_arith=True)
+    inputs = verilog_parser.read_input_wires(os.path.join(HERE, "golden", "chi_squared_arith_1.inputs.csv"), "u32")
+    ac = ArithCircuit(client_key, server_key, circuit)
+    enc_in = ac.encrypt_inputs(wire_set, inputs)
+    t0 = time.perf_counter()
+    one = ac.evaluate_encrypted(enc_in, 1, "u32")
+    t_one, rounds_one, pbs_one = time.perf_counter() - t0, ac.pbs_rounds_per_cycle(), ac.pbs_per_cycle()
+    ac.set_lanes(2)
+    ac.evaluate_encrypted(enc_in, 1, "u32")  # warm-up of the lane's scratch
+    t0 = time.perf_counter()
+    two = ac.evaluate_encrypted(enc_in, 1, "u32")
+    t_two = time.perf_counter() - t0
+    assert sorted(one.keys()) == sorted(two.keys())
+    for wire in one.keys():
+        assert np.array_equal(one[wire], two[wire]), wire
+    assert {k: v.value for k, v in ac.decrypt_outputs(two, True).items()} == {"alpha": 529, "beta1": 242, "beta2": 275, "beta3": 1250}
+    assert ac.pbs_per_cycle() == pbs_one and rounds_one == 39 and ac.pbs_rounds_per_cycle() == 29
+    assert "2 independent sub-circuit(s)" in ac.log()
+    print(f"chi-squared u32: {t_one:.3f} s level by level, {t_two:.3f} s on two lanes")
+    assert t_two < t_one
+    ac.set_lanes(1)
+    again = ac.evaluate_encrypted(enc_in, 1, "u32")
+    assert ac.pbs_rounds_per_cycle() == 39 and np.array_equal(again["alpha"], one["alpha"])
+
+
 def test_shifts_and_division_u8(keys):  # gates.rs:386-452, 488-700 (div, shl, shr and their plain forms)
     client_key, server_key = keys
     text = """input [7:0] A, B;
