@@ -84,6 +84,7 @@ extern "C" {
     // ---- include/helm_shortint.h (LUT / arithmetic modes) -------------------------------------
     pub fn helm_si_ctx_create(device_id: c_int, params: *const helm_si_params, out: *mut *mut helm_si_ctx) -> c_int;
     pub fn helm_si_ctx_destroy(ctx: *mut helm_si_ctx) -> c_int;
+    pub fn helm_si_ctx_fork(primary: *mut helm_si_ctx, lane_out: *mut *mut helm_si_ctx) -> c_int;
     pub fn helm_si_load_bootstrap_key(ctx: *mut helm_si_ctx, bsk_std: *const u64, n_words: usize) -> c_int;
     pub fn helm_si_load_keyswitch_key(ctx: *mut helm_si_ctx, ksk: *const u64, n_words: usize) -> c_int;
     pub fn helm_si_wires_alloc(ctx: *mut helm_si_ctx, n_rows: i64, out: *mut *mut helm_si_wires) -> c_int;
