@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-pack", action="store_true", help="level-synchronous launches (the round-1 schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the LUT-mode / arithmetic-mode side measurements")
+    ap.add_argument("--strong-leg-timeout", type=float, default=240.0,
+                    help="N > 1: seconds after which the extra strong-scaling pass is abandoned and the line printed without it")
     ap.add_argument("--no-strong-leg", action="store_true", help="N > 1, weak: skip the short strong-scaling pass")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="CPU baseline: stop after the level that passes this time")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = the cores this process may use)")
@@ -184,15 +186,34 @@ def main():
     # ---- correctness of what was timed: every block decrypts to AES(key, pt) ------------
     check_outputs(ck, wires, index, nw, keys_pt, f"rank {rank}")
 
-    # ---- N > 1, weak: a short strong-scaling pass on a fixed job (outside the timed region) ----
-    strong_leg = None
-    if world > 1 and not strong and not args.no_strong_leg:
-        # a fixed job of 2 x --blocks blocks: its launches hold >= 8 x 1,024 ready bootstraps, so that up to 8 ranks
-        # each get whole lockstep rounds (a 32-block job leaves 640 per rank per launch at N = 8)
-        strong_leg = strong_scaling_leg(sk, ck, circuit, wire_names, index, nw, 2 * args.blocks, quantum, rank, world, dist, torch)
+    # ---- N > 1, weak: a short strong-scaling pass on a fixed job (outside the timed region), AFTER rank 0 has the
+    #      headline line ready.  It must never cost that line: an exception is caught on every rank, and a collective
+    #      that hangs is cut off by a watchdog (rank 0 then prints the line without this leg and every rank exits).
+    want_strong_leg = world > 1 and not strong and not args.no_strong_leg
+
+    def guarded_strong_leg(on_timeout):
+        import threading
+        finished = threading.Event()
+
+        def watchdog():
+            if not finished.wait(args.strong_leg_timeout):
+                on_timeout()
+                sys.stdout.flush()
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            # a fixed job of 2 x --blocks blocks: its launches hold >= 8 x 1,024 ready bootstraps, so that up to 8 ranks
+            # each get whole lockstep rounds (a 32-block job leaves 640 per rank per launch at N = 8)
+            return strong_scaling_leg(sk, ck, circuit, wire_names, index, nw, 2 * args.blocks, quantum, rank, world, dist, torch)
+        except Exception as e:
+            return {"error": repr(e)}
+        finally:
+            finished.set()
 
     if rank != 0:
         if world > 1:
+            if want_strong_leg:
+                guarded_strong_leg(lambda: None)
             dist.destroy_process_group()
         return
 
@@ -284,8 +305,6 @@ def main():
         },
         "setup_s": {"keygen_upload": round(t_keys, 2)},
     }
-    if strong_leg:
-        result["strong_scaling"] = strong_leg
 
     # ---- wall-clock of ONE AES-128 evaluation (latency; levels are 80-256 gates wide, so the
     #      GPU is far from full: this is the n-step blind-rotation chain, 207 levels deep) ------
@@ -311,6 +330,9 @@ def main():
             result["other_modes"] = other_modes(local_rank)
         except Exception as e:  # the headline line must survive a failure here
             result["other_modes"] = {"error": repr(e)}
+    if want_strong_leg:
+        result["strong_scaling"] = guarded_strong_leg(
+            lambda: print(json.dumps(dict(result, strong_scaling={"error": f"no answer within {args.strong_leg_timeout} s"}))))
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
