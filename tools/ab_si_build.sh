@@ -1,6 +1,7 @@
 # same-box A/B of a compile-time switch of helm_shortint.hip: builds the alternative in the box's scratch copy and runs
-# the LUT micro-benchmark with both libraries.  Usage: ab_si_build.sh "-DHELM_SI_KW1_EARLY=0"
-ALT="$1"
+# the LUT micro-benchmark with both libraries (or, with a second argument, that command: e.g. "python3 tools/wop_bench.py
+# 256 6 1" for the two-level build).  Usage: ab_si_build.sh "-DHELM_SI_PRIO=0" ["command"]
+ALT="$1"; CMD="$2"
 cd $GRAFT_REPO_ROOT/helm_amd/csrc && cp libhelm_hip.so /tmp/libhelm_hip_base.so &&
 hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -fPIC $ALT -c -o /tmp/helm_shortint_alt.o helm_shortint.hip &&
 hipcc -O3 --offload-arch=gfx950 -fPIC -shared -o /tmp/libhelm_hip_alt.so helm_hip.o /tmp/helm_shortint_alt.o &&
@@ -9,6 +10,7 @@ for round in 1 2; do
   for v in base alt; do
     cp /tmp/libhelm_hip_$v.so helm_amd/csrc/libhelm_hip.so
     echo "== $v (round $round)"
+    if [ -n "$CMD" ]; then timeout -k 10 300 $CMD 2>&1 | tail -1 | cut -c1-330; continue; fi
     timeout -k 10 200 python3 - <<'PY'
 import time, numpy as np
 import helm_amd
