@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — encrypted gate-bootstraps/sec on the AES-128 gates-mode netlist.
 
-A step = one full evaluation of the (generated, stand-in) AES-128 netlist over a batch of independent input
-blocks, inputs already encrypted and resident in HBM.  The level schedule of the batch is launch-packed
+A step = one full evaluation of the (generated, stand-in) AES-128 netlist over a batch of `--blocks` independent
+input blocks, inputs already encrypted and resident in HBM.  The level schedule of the batch is launch-packed
 (helm_amd/csrc/host/level_pack.cpp): the blocks share no wires, so launches hold whole lockstep rounds and only
 the drain at the end of a pass is partial.
 
-  --scaling weak   (default)  every GPU evaluates its own `--blocks` blocks: the partition the workload offers
-                   (independent blocks), no data-path collective; N GPUs = N x blocks.
-  --scaling strong            `--blocks` blocks in total, every launch sharded across the N GPUs, keys and wire
-                   table replicated, the launch's output ciphertexts all-gathered over RCCL
-                   (helm_amd/distributed.py) - the north star's per-level shard, the mode that shortens ONE job.
-With N > 1 the weak run also times a short strong-scaling pass (outside the timed region) and reports it under
-"strong_scaling", so one driver invocation exercises RCCL.
+    python3 bench.py --gpus N --steps K --warmup W
 
-Contract: python bench.py --gpus N --steps K --warmup W   (N>1 under torch.distributed.run)
-prints ONE JSON line on rank 0.
+With N > 1 and no RANK in the environment this process is only a launcher: it has not touched the GPU (it imports
+nothing beyond the standard library), starts `python -m torch.distributed.run --nproc-per-node N ... bench.py` as a
+CHILD process (never an exec), relays its ONE JSON line and leaves with its exit code.  Started under
+torch.distributed.run directly (RANK set), the process is a worker.
+
+One line, every result named:
+  value / scaling "strong"   the north star's per-level shard: a FIXED job of `--blocks` blocks, every packed launch
+                             split into N contiguous chunks, keys and wire table replicated, the launch's output
+                             ciphertexts all-gathered over RCCL (helm_amd/distributed.py); EXACTLY K timed steps
+  weak                       independent blocks: every GPU evaluates its own `--blocks` blocks, no data-path collective
+  sharded_weak               the sharded path at fixed work per GPU: ONE job of N x `--blocks` blocks, every launch
+                             sharded and all-gathered (whole lockstep rounds per rank: what the exchange itself costs)
+  rccl_ranks                 dist.get_world_size() and the backend that carried the collectives
+`--scaling weak` makes the independent-block run the headline instead (the strong run moves under "strong").
+
+A worker that fails - an exception, a wrong decryption, a collective that does not come back within
+`--leg-timeout` seconds - ends with a non-zero exit code and its error in the line; nothing is retried.
 """
 import argparse
 import json
@@ -23,18 +32,124 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_CLOCK_GHZ = 2.4          # MI355X engine clock the nominal peaks are quoted at
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")  # tools/pmc_traffic.sh, separate --pmc passes
+# measured fabric traffic of the dominant kernels (tools/pmc_traffic.sh: separate --pmc passes); the file is
+# rewritten by every round's profiling run, the per-round copies live under profiles/rNN/
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+METRIC = "encrypted gate-bootstraps/sec on AES-128 gates-mode netlist"
+RESULT_FILE_ENV = "HELM_BENCH_RESULT_FILE"
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--blocks", type=int, default=32, help="AES blocks of the fixed job (strong) / per GPU (weak)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="which N > 1 run is the headline `value`")
+    ap.add_argument("--params", default="boolean_default")
+    ap.add_argument("--no-pack", action="store_true", help="level-synchronous launches (the round-1 schedule)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the LUT-mode / arithmetic-mode side measurements")
+    ap.add_argument("--no-side-legs", action="store_true", help="N > 1: only the headline run")
+    ap.add_argument("--side-steps", type=int, default=3, help="N > 1: timed steps of the runs that are not the headline")
+    ap.add_argument("--leg-timeout", type=float, default=900.0,
+                    help="N > 1: seconds one run may take before it counts as hung (the line is printed with the error, rc 3)")
+    ap.add_argument("--launch-timeout", type=float, default=3300.0, help="launcher: seconds before the worker group is stopped")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="CPU baseline: stop after the level that passes this time")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = the cores this process may use)")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# launcher (N > 1, started as `python3 bench.py --gpus N`): standard library only, never touches the GPU
+# ----------------------------------------------------------------------------------------------------------------
+def launch_workers(args, argv):
+    import signal
+    import socket
+    import subprocess
+    import tempfile
+    import threading
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    fd, result_file = tempfile.mkstemp(prefix="helm_bench_", suffix=".json")
+    os.close(fd)
+    env = dict(os.environ)
+    env[RESULT_FILE_ENV] = result_file
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    lines = []
+
+    def relay():
+        for ln in proc.stdout:
+            ln = ln.rstrip("\n")
+            try:
+                ok = isinstance(json.loads(ln), dict) and ln.startswith('{"metric"')
+            except ValueError:
+                ok = False
+            if ok:
+                lines.append(ln)
+            elif ln:
+                print(ln, file=sys.stderr)  # stdout carries the ONE line only
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    error = None
+    try:
+        rc = proc.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        error = f"launcher: worker group still running after {args.launch_timeout:.0f} s, stopped"
+        for sig in (signal.SIGTERM, signal.SIGKILL):  # exactly the process group started above
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=20)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        rc = 3
+    t.join(timeout=10)
+    if lines:
+        line = lines[-1]
+        if rc != 0 and "error" not in json.loads(line):
+            line = json.dumps(dict(json.loads(line), error=error or f"worker group left with exit code {rc}"))
+    else:  # no line from rank 0: whatever it had checkpointed, with the error
+        partial = {}
+        try:
+            with open(result_file) as f:
+                partial = json.load(f)
+        except (OSError, ValueError):
+            pass
+        partial.setdefault("metric", METRIC)
+        partial.setdefault("value", None)
+        partial.setdefault("n_gpus", args.gpus)
+        partial["error"] = error or partial.get("error") or f"worker group left with exit code {rc} and no result line"
+        line = json.dumps(partial)
+        rc = rc or 1
+    try:
+        os.unlink(result_file)
+    except OSError:
+        pass
+    print(line)
+    sys.stdout.flush()
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# worker
+# ----------------------------------------------------------------------------------------------------------------
 def build_program_arrays(circuit, wire_names, blocks):
     """Tile the one-block level schedule over `blocks` copies of the wire table."""
+    import numpy as np
     from helm_amd.distributed import level_arrays
     index = {w: i for i, w in enumerate(wire_names)}
     ops, i0, i1, i2, out, off = level_arrays(circuit, index)
@@ -60,6 +175,7 @@ def make_program(sk, circuit, wire_names, blocks, quantum, pack=True):
 
 
 def upload_inputs(ck, wires, index, nw, keys_pt, first_block=0):
+    import numpy as np
     in_rows, in_bits = [], []
     for b, (key, pt) in enumerate(keys_pt):
         kv, pv = int.from_bytes(key, "big"), int.from_bytes(pt, "big")
@@ -69,157 +185,224 @@ def upload_inputs(ck, wires, index, nw, keys_pt, first_block=0):
     wires.upload(np.array(in_rows, np.int32), ck.encrypt(np.array(in_bits, dtype=bool)))
 
 
+class WrongResult(RuntimeError):
+    pass
+
+
 def check_outputs(ck, wires, index, nw, keys_pt, what):
+    import numpy as np
     from helm_amd.netlists import aes128_reference_encrypt
     out_rows = np.array([b * nw + index[f"ct[{i}]"] for b in range(len(keys_pt)) for i in range(128)], np.int32)
     dec = ck.decrypt(wires.download(out_rows)).reshape(len(keys_pt), 128)
     for b, (key, pt) in enumerate(keys_pt):
         got = sum(int(dec[b, i]) << i for i in range(128)).to_bytes(16, "big")
         if got != aes128_reference_encrypt(key, pt):
-            raise SystemExit(f"{what}: decrypted AES output of block {b} is WRONG")
+            raise WrongResult(f"{what}: decrypted AES output of block {b} is WRONG")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=32, help="AES blocks per GPU (weak) / in total (strong)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--params", default="boolean_default")
-    ap.add_argument("--no-pack", action="store_true", help="level-synchronous launches (the round-1 schedule)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-modes", action="store_true", help="skip the LUT-mode / arithmetic-mode side measurements")
-    ap.add_argument("--strong-leg-timeout", type=float, default=240.0,
-                    help="N > 1: seconds after which the extra strong-scaling pass is abandoned and the line printed without it")
-    ap.add_argument("--no-strong-leg", action="store_true", help="N > 1, weak: skip the short strong-scaling pass")
-    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="CPU baseline: stop after the level that passes this time")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = the cores this process may use)")
-    args = ap.parse_args()
+class Bench:
+    """State shared by the runs of one worker."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    def __init__(self, args):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        import helm_amd
+        from helm_amd import Circuit, verilog_parser
+        from helm_amd.netlists import aes128
+        self.args, self.np, self.torch, self.dist = args, np, torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # rehearsal of the N > 1 path on a one-GPU box: HELM_BENCH_REHEARSE=1 puts every rank on cuda:0 and
+        # carries the collectives over gloo (RCCL needs one GPU per rank); never used for reported numbers
+        self.rehearse = os.environ.get("HELM_BENCH_REHEARSE") == "1"
+        if self.rehearse:
+            local_rank = 0
+        self.local_rank = local_rank
+        torch.cuda.set_device(local_rank)
+        if self.world > 1:
+            if self.rehearse:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # keys (identical on every rank: same deterministic benchmark seed) and engine
+        t0 = time.time()
+        self.ck = helm_amd.ClientKey.generate(args.params, seed=1)
+        self.sk = helm_amd.ServerKey(self.ck, device=local_rank)
+        self.sk.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.t_keys = time.time() - t0
+        self.quantum = self.sk.launch_quantum()
+        gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_text(aes128(), False)
+        self.circuit = Circuit(gates, inputs, outputs, dffs)
+        self.circuit.sort_circuit()
+        self.circuit.compute_levels()
+        self.wire_names = list(inputs) + sorted(wire_set)
+        self.nw = len(self.wire_names)
+        self.index = {w: i for i, w in enumerate(self.wire_names)}
 
-    import torch
-    import torch.distributed as dist
-    import helm_amd
-    from helm_amd import Circuit, verilog_parser
-    from helm_amd.distributed import GpuLevelExecutor, ShardedRunner
-    from helm_amd.netlists import aes128
+    def sync_all(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
 
-    # rehearsal of the N > 1 path on a one-GPU box: HELM_BENCH_REHEARSE=1 puts every rank on cuda:0 and
-    # carries the collectives over gloo (RCCL needs one GPU per rank); never used for reported numbers
-    rehearse = os.environ.get("HELM_BENCH_REHEARSE") == "1"
-    if rehearse:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if rehearse:
-            dist.init_process_group("gloo")
+    def run(self, kind, steps, warmup, keep=False):
+        """One measured run.  kind: "strong" (fixed job of --blocks blocks, every launch sharded over the ranks),
+        "weak" (this rank's own --blocks blocks, nothing exchanged), "sharded_weak" (one job of world x --blocks
+        blocks, every launch sharded).  W untimed steps, then exactly `steps` timed ones between barrier +
+        synchronize on both sides; the elapsed time is the maximum over the ranks."""
+        from helm_amd.distributed import GpuLevelExecutor, ShardedRunner
+        a, np, torch, dist = self.args, self.np, self.torch, self.dist
+        sharded = kind != "weak" and self.world > 1
+        blocks = a.blocks * (self.world if kind == "sharded_weak" else 1)   # blocks in this rank's wire table
+        prog, launches, levels = make_program(self.sk, self.circuit, self.wire_names, blocks,
+                                              self.quantum * (self.world if sharded else 1), pack=not a.no_pack)
+        rng = np.random.default_rng(0x48454C4D + (0 if sharded else self.rank))
+        keys_pt = [(bytes(rng.integers(0, 256, 16, dtype=np.uint8)), bytes(rng.integers(0, 256, 16, dtype=np.uint8)))
+                   for _ in range(blocks)]
+        if self.rank == 0 or sharded:
+            keys_pt[0] = (bytes(range(16)), bytes.fromhex("00112233445566778899aabbccddeeff"))  # FIPS-197 C.1
+        # synthetic inputs: encrypted on the host, uploaded once: resident in HBM before the timed region
+        wires = self.sk.wires(self.nw * blocks)
+        upload_inputs(self.ck, wires, self.index, self.nw, keys_pt)
+        runner = ShardedRunner(GpuLevelExecutor(prog, wires), self.rank, self.world if sharded else 1,
+                               dist if sharded else None, time_collective=sharded)
+        for _ in range(warmup):
+            runner.run()
+        self.sync_all()
+        runner.collective_ms(reset=True)
+        self.sk.timing_enable(True)
+        self.sk.timing(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner.run()
+        self.sync_all()
+        elapsed = time.perf_counter() - t0
+        tm = self.sk.timing(reset=True)
+        self.sk.timing_enable(False)
+        clock_ghz = self.sk.kernel_clock_ghz()
+        if self.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        # correctness of what was timed: every block of this rank's table decrypts to AES(key, pt)
+        check_outputs(self.ck, wires, self.index, self.nw, keys_pt, f"{kind} run, rank {self.rank}")
+        pbs = prog.total_pbs()
+        job_pbs = pbs * (self.world if kind == "weak" else 1)
+        r = {"kind": kind, "elapsed": elapsed, "steps": steps, "warmup": warmup, "job_pbs": int(job_pbs),
+             "value": job_pbs * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
+             "blocks_per_table": blocks, "blocks_total": blocks * (self.world if kind == "weak" else 1),
+             "launches": launches, "levels": levels, "sharded_launches": len(runner.sharded_levels),
+             "exchanged_MB_per_step": runner.exchanged_bytes_per_pass() / 1e6,
+             "collective_ms_per_step": runner.collective_ms(reset=True) / steps if sharded else 0.0,
+             "tm": tm, "clock_ghz": clock_ghz}
+        if keep:
+            r.update(prog=prog, wires=wires, keys_pt=keys_pt)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            prog.destroy()
+            wires.free()
+        return r
 
-    # ---- keys (identical on every rank: same deterministic benchmark seed) and engine ---
-    t0 = time.time()
-    ck = helm_amd.ClientKey.generate(args.params, seed=1)
-    sk = helm_amd.ServerKey(ck, device=local_rank)
-    sk.set_stream(torch.cuda.current_stream().cuda_stream)
-    p = ck.params
-    t_keys = time.time() - t0
-    quantum = sk.launch_quantum()
+    def describe(self, r):
+        """The named summary of a run that is not the headline."""
+        w = self.world
+        what = {"strong": f"fixed job of {r['blocks_total']} AES-128 block(s), every packed launch sharded over {w} GPU(s), "
+                          "output ciphertexts all-gathered",
+                "weak": f"{self.args.blocks} independent AES-128 block(s) per GPU ({r['blocks_total']} in total), keys replicated, "
+                        "no data-path collective",
+                "sharded_weak": f"ONE job of {r['blocks_total']} AES-128 blocks ({self.args.blocks} per GPU), every packed launch "
+                                f"sharded over {w} GPU(s), output ciphertexts all-gathered"}[r["kind"]]
+        return {"workload": what, "scaling": "strong" if r["kind"] == "strong" else "weak",
+                "value": round(r["value"], 1), "unit": "gate-bootstraps/s", "steps": r["steps"], "warmup": r["warmup"],
+                "ms_per_step": round(r["ms_per_step"], 3), "bootstraps_per_step": r["job_pbs"],
+                "launches_per_step": r["launches"], "sharded_launches": r["sharded_launches"],
+                "exchanged_MB_per_step": round(r["exchanged_MB_per_step"], 2),
+                "collective_ms_per_step": round(r["collective_ms_per_step"], 3),
+                "decrypt_check": "all blocks == software AES on every rank"}
 
-    # ---- netlist -> launch schedule over this rank's batch -----------------------------
-    gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_text(aes128(), False)
-    circuit = Circuit(gates, inputs, outputs, dffs)
-    circuit.sort_circuit()
-    circuit.compute_levels()
-    wire_names = list(inputs) + sorted(wire_set)
-    nw = len(wire_names)
-    index = {w: i for i, w in enumerate(wire_names)}
-    strong = args.scaling == "strong" and world > 1
-    my_blocks = args.blocks                         # blocks in this rank's wire table
-    total_blocks = args.blocks if (strong or world == 1) else args.blocks * world
-    prog, launches, levels = make_program(sk, circuit, wire_names, my_blocks, quantum * (world if strong else 1),
-                                          pack=not args.no_pack)
-    pbs_per_pass = prog.total_pbs()                 # of this rank's table (strong: the whole job)
 
-    # ---- synthetic inputs: seeded random key / plaintext per block, encrypted on the host,
-    #      uploaded once: resident in HBM before the timed region ------------------------
-    rng = np.random.default_rng(0x48454C4D + (0 if strong else rank))
-    keys_pt = [(bytes(rng.integers(0, 256, 16, dtype=np.uint8)), bytes(rng.integers(0, 256, 16, dtype=np.uint8)))
-               for _ in range(my_blocks)]
-    if rank == 0 or strong:
-        keys_pt[0] = (bytes(range(16)), bytes.fromhex("00112233445566778899aabbccddeeff"))  # FIPS-197 C.1
-    wires = sk.wires(nw * my_blocks)
-    upload_inputs(ck, wires, index, nw, keys_pt)
+_emit_state = {"done": False}
 
-    runner = ShardedRunner(GpuLevelExecutor(prog, wires), rank, world if strong else 1, dist if strong else None)
 
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+def checkpoint(result):
+    """Rank 0: what is known so far, for the launcher to print if this process does not live to print it."""
+    path = os.environ.get(RESULT_FILE_ENV)
+    if path:
+        tmp = path + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(result, f)
+        os.replace(tmp, path)
 
-    for _ in range(args.warmup):
-        runner.run()
-    sync_all()
-    sk.timing_enable(True)
-    sk.timing(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.run()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    tm = sk.timing(reset=True)
-    sk.timing_enable(False)
-    clock_ghz = sk.kernel_clock_ghz()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # ---- correctness of what was timed: every block decrypts to AES(key, pt) ------------
-    check_outputs(ck, wires, index, nw, keys_pt, f"rank {rank}")
-
-    # ---- N > 1, weak: a short strong-scaling pass on a fixed job (outside the timed region), AFTER rank 0 has the
-    #      headline line ready.  It must never cost that line: an exception is caught on every rank, and a collective
-    #      that hangs is cut off by a watchdog (rank 0 then prints the line without this leg and every rank exits).
-    want_strong_leg = world > 1 and not strong and not args.no_strong_leg
-
-    def guarded_strong_leg(on_timeout):
-        import threading
-        finished = threading.Event()
-
-        def watchdog():
-            if not finished.wait(args.strong_leg_timeout):
-                on_timeout()
-                sys.stdout.flush()
-                os._exit(0)
-        threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            # a fixed job of 2 x --blocks blocks: its launches hold >= 8 x 1,024 ready bootstraps, so that up to 8 ranks
-            # each get whole lockstep rounds (a 32-block job leaves 640 per rank per launch at N = 8)
-            return strong_scaling_leg(sk, ck, circuit, wire_names, index, nw, 2 * args.blocks, quantum, rank, world, dist, torch)
-        except Exception as e:
-            return {"error": repr(e)}
-        finally:
-            finished.set()
-
-    if rank != 0:
-        if world > 1:
-            if want_strong_leg:
-                guarded_strong_leg(lambda: None)
-            dist.destroy_process_group()
+def emit(result):
+    """Rank 0 prints THE line, once."""
+    if _emit_state["done"]:
         return
+    _emit_state["done"] = True
+    checkpoint(result)
+    print(json.dumps(result))
+    sys.stdout.flush()
 
-    ms_per_step = elapsed / args.steps * 1e3
-    job_pbs = pbs_per_pass if (strong or world == 1) else pbs_per_pass * world
-    value = job_pbs * args.steps / elapsed
+
+def guarded(bench, result, what, fn):
+    """Run one leg under a watchdog: a collective that never comes back must not pass for a finished run.
+    On timeout rank 0 prints the line with what it has and the error, and EVERY rank leaves with exit code 3."""
+    import threading
+    if bench.world == 1:
+        return fn()
+    finished = threading.Event()
+
+    def watchdog():
+        if not finished.wait(bench.args.leg_timeout):
+            if bench.rank == 0:
+                result["error"] = f"{what}: no answer within {bench.args.leg_timeout:.0f} s (hung collective?)"
+                emit(result)
+            sys.stderr.write(f"[bench rank {bench.rank}] {what}: timed out, leaving with exit code 3\n")
+            sys.stderr.flush()
+            os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        return fn()
+    finally:
+        finished.set()
+
+
+def worker(args):
+    import signal
+    result = {"metric": METRIC, "value": None, "unit": "gate-bootstraps/s", "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
+              "steps": args.steps, "warmup": args.warmup}
+    rank = int(os.environ.get("RANK", "0"))
+    if rank == 0:
+        def on_term(signum, _frame):  # torch.distributed.run stops the group when another rank dies
+            result.setdefault("error", f"rank 0 stopped by signal {signum} (another rank failed?)")
+            emit(result)
+            os._exit(128 + signum)
+        signal.signal(signal.SIGTERM, on_term)
+    rc = 0
+    bench = None
+    try:
+        bench = Bench(args)
+        fill_result(bench, result)
+    except BaseException as e:  # incl. SystemExit / KeyboardInterrupt: the line carries the error, rc != 0
+        import traceback
+        traceback.print_exc()
+        result["error"] = f"rank {rank}: {e!r}"
+        rc = 1
+    if rank == 0:
+        emit(result)
+    if bench is not None and bench.world > 1 and rc == 0:
+        bench.dist.destroy_process_group()
+    return rc
+
+
+def fill_result(bench, result):
+    args, np = bench.args, bench.np
+    world, rank = bench.world, bench.rank
+    p = bench.ck.params
+    head_kind = args.scaling if world > 1 else "strong"
+    head = guarded(bench, result, f"{head_kind} run", lambda: bench.run(head_kind, args.steps, args.warmup, keep=True))
+    tm, clock_ghz, quantum = head["tm"], head["clock_ghz"], bench.quantum
+    sharded = head_kind != "weak" and world > 1
 
     # ---- roofline of the dominant kernel (lockstep build of k_pbs), HIP events on its own stream ----
     K1 = p.k + 1
@@ -251,33 +434,40 @@ def main():
         # bytes per bootstrap measured at the launch size of the committed profile, scaled to this run's average launch
         traffic_bytes = int(traffic["bytes_per_launch"] * avg_pbs_per_launch / traffic["bootstraps_per_launch"])
 
-    result = {
-        "metric": "encrypted gate-bootstraps/sec on AES-128 gates-mode netlist",
-        "value": round(value, 1),
-        "unit": "gate-bootstraps/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3),
+    if rank != 0:
+        # the other ranks only take part in the remaining runs
+        if world > 1 and not args.no_side_legs:
+            for kind in side_kinds(head_kind):
+                guarded(bench, result, f"{kind} run", lambda k=kind: bench.run(k, args.side_steps, 1))
+        return
+
+    result.update({
+        "value": round(head["value"], 1),
+        "ms_per_step": round(head["ms_per_step"], 3),
         "higher_is_better": True,
-        "scaling": "strong" if strong else "weak",
+        # the job is `--blocks` blocks whatever N: total work fixed (N > 1 with --scaling weak: per-GPU work fixed)
+        "scaling": "weak" if head_kind == "weak" else "strong",
         "vs_baseline": None,
         "dtype": "u32 torus (exact NTT in f64 FMA over a 49-bit prime)",
         "data": "synthetic: generated AES-128 netlist (stand-in for HELM's), seeded random keys/plaintexts, "
-                "fresh encryptions resident in HBM" + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearse else ""),
+                "fresh encryptions resident in HBM" + (" [REHEARSAL: all ranks on one GPU, gloo]" if bench.rehearse else ""),
         "config": {
-            "workload": f"AES-128 gates-mode netlist, {my_blocks} block(s) " + ("in total, every launch sharded" if strong else "per GPU")
+            "workload": (f"AES-128 gates-mode netlist, fixed job of {head['blocks_total']} block(s)"
+                         + (f", every launch sharded over {world} GPUs" if sharded else "") if head_kind != "weak" else
+                         f"AES-128 gates-mode netlist, {args.blocks} independent block(s) per GPU")
                         + (", launch-packed" if not args.no_pack else ", level-synchronous"),
             "params": args.params, "n": p.n, "k": p.k, "N": p.N, "pbs_l": p.pbs_l, "pbs_logB": p.pbs_logB,
             "ks_l": p.ks_l, "ks_logB": p.ks_logB,
-            "levels": levels, "launches_per_step": launches, "bootstraps_per_step": int(job_pbs), "blocks_total": total_blocks,
+            "levels": head["levels"], "launches_per_step": head["launches"], "bootstraps_per_step": head["job_pbs"],
+            "blocks_total": head["blocks_total"],
             "parallelism": ("single GPU" if world == 1 else
-                            f"launch-shard x{world} + all-gather of launch outputs (RCCL)" if strong else
+                            f"launch-shard x{world} + all-gather of launch outputs (RCCL), keys and wire table replicated" if sharded else
                             f"block-parallel x{world}: independent blocks per GPU, keys replicated, no data-path collective"),
-            "sharded_launches": len(runner.sharded_levels),
-            "exchanged_MB_per_step": round(runner.exchanged_bytes_per_pass() / 1e6, 2),
+            "sharded_launches": head["sharded_launches"],
+            "exchanged_MB_per_step": round(head["exchanged_MB_per_step"], 2),
+            "collective_ms_per_step": round(head["collective_ms_per_step"], 3),
         },
-        "wall_s_per_step": round(elapsed / args.steps, 4),
+        "wall_s_per_step": round(head["elapsed"] / head["steps"], 4),
         "decrypt_check": "all blocks == software AES (FIPS-197 C.1 vector in block 0)",
         "kernel_ms_per_step": {"k_pbs": round(tm.pbs_ms / args.steps, 3),
                                "k_pbs_lockstep_build": round(tm.pbs_main_ms / args.steps, 3),
@@ -303,75 +493,65 @@ def main():
                     "algorithmic_bytes_per_launch": int(algo_bytes),
                     "note": "BSK (shared by every ciphertext of a launch) + per-bootstrap LWE rows; not the binding resource"},
         },
-        "setup_s": {"keygen_upload": round(t_keys, 2)},
-    }
+        "setup_s": {"keygen_upload": round(bench.t_keys, 2)},
+    })
+    if world > 1:
+        result["rccl_ranks"] = {"world_size": bench.dist.get_world_size(), "backend": bench.dist.get_backend(),
+                                "one_process_per_gpu": not bench.rehearse}
+        result[head_kind] = bench.describe(head)   # the headline under its own name as well
+    checkpoint(result)
+
+    # ---- N > 1: the runs that are not the headline, each under its own name -----------------------------
+    if world > 1 and not args.no_side_legs:
+        for kind in side_kinds(head_kind):
+            r = guarded(bench, result, f"{kind} run", lambda k=kind: bench.run(k, args.side_steps, 1))
+            result[kind] = bench.describe(r)
+            checkpoint(result)
 
     # ---- wall-clock of ONE AES-128 evaluation (latency; levels are 80-256 gates wide, so the
     #      GPU is far from full: this is the n-step blind-rotation chain, 207 levels deep) ------
     if world == 1:
-        prog1, _, _ = make_program(sk, circuit, wire_names, 1, quantum)
-        prog1.run(wires)
-        sync_all()
+        prog1, _, _ = make_program(bench.sk, bench.circuit, bench.wire_names, 1, quantum)
+        prog1.run(head["wires"])
+        bench.sync_all()
         t0 = time.perf_counter()
-        prog1.run(wires)
-        sync_all()
+        prog1.run(head["wires"])
+        bench.sync_all()
         t1 = time.perf_counter() - t0
         result["single_block"] = {"wall_s": round(t1, 4), "gate_bootstraps_per_s": round(prog1.total_pbs() / t1, 1),
                                   "bootstraps": int(prog1.total_pbs())}
         prog1.destroy()
+        checkpoint(result)
 
     # ---- CPU baseline: the oracle (a port, not tfhe-rs) on this box's host cores --------
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, ck, circuit, wire_names, index, nw, wires, keys_pt)
+        result["cpu_baseline"] = cpu_baseline(args, bench.ck, bench.circuit, bench.wire_names, bench.index, bench.nw,
+                                              head["wires"], head["keys_pt"], gpu_value=head["value"],
+                                              gpu_single_block=result["single_block"]["gate_bootstraps_per_s"])
+        checkpoint(result)
     # ---- the other two modes of the reference, same GPU, outside the timed region: 3-input LUT
     #      gates (BASELINE config 3's primitive) and the chi-squared u32 netlist (config 5) ------
     if world == 1 and not args.no_other_modes:
         try:
-            result["other_modes"] = other_modes(local_rank)
+            result["other_modes"] = other_modes(bench.local_rank)
         except Exception as e:  # the headline line must survive a failure here
             result["other_modes"] = {"error": repr(e)}
-    if want_strong_leg:
-        result["strong_scaling"] = guarded_strong_leg(
-            lambda: print(json.dumps(dict(result, strong_scaling={"error": f"no answer within {args.strong_leg_timeout} s"}))))
-    print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
 
 
-def strong_scaling_leg(sk, ck, circuit, wire_names, index, nw, blocks, quantum, rank, world, dist, torch, steps=2):
-    """A fixed job of `blocks` AES blocks, every packed launch sharded across the ranks (helm_amd/distributed.py):
-    the regime launch-sharding exists for.  Same inputs on every rank (replicated wire table)."""
-    from helm_amd.distributed import GpuLevelExecutor, ShardedRunner
-    prog, launches, _ = make_program(sk, circuit, wire_names, blocks, quantum * world)
-    rng = np.random.default_rng(0x57A0)
-    keys_pt = [(bytes(rng.integers(0, 256, 16, dtype=np.uint8)), bytes(rng.integers(0, 256, 16, dtype=np.uint8)))
-               for _ in range(blocks)]
-    wires = sk.wires(nw * blocks)
-    upload_inputs(ck, wires, index, nw, keys_pt)
-    runner = ShardedRunner(GpuLevelExecutor(prog, wires), rank, world, dist, time_collective=True)
-    runner.run()
-    dist.barrier()
-    torch.cuda.synchronize()
-    runner.collective_ms(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        runner.run()
-    dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    t = torch.tensor([el], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
-    check_outputs(ck, wires, index, nw, keys_pt, f"strong-scaling leg, rank {rank}")
-    res = {"workload": f"{blocks} AES-128 blocks in total, every launch sharded over {world} GPUs", "steps": steps,
-           "ms_per_step": round(el / steps * 1e3, 3), "value": round(prog.total_pbs() * steps / el, 1),
-           "unit": "gate-bootstraps/s", "launches_per_step": launches, "sharded_launches": len(runner.sharded_levels),
-           "exchanged_MB_per_step": round(runner.exchanged_bytes_per_pass() / 1e6, 2),
-           "collective_ms_per_step": round(runner.collective_ms(reset=True) / steps, 3),
-           "decrypt_check": "all blocks == software AES on every rank"}
-    prog.destroy()
-    wires.free()
-    return res
+def side_kinds(head_kind):
+    return [k for k in ("strong", "weak", "sharded_weak") if k != head_kind]
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch_workers(args, argv))
+    globals()["np"] = __import__("numpy")  # workers only: the launcher stays on the standard library
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        args.gpus = world
+    sys.exit(worker(args))
 
 
 def granted_cores():
@@ -388,7 +568,7 @@ def granted_cores():
     return n
 
 
-def cpu_baseline(args, ck, circuit, wire_names, index, nw, wires, keys_pt, cpu_blocks=8):
+def cpu_baseline(args, ck, circuit, wire_names, index, nw, wires, keys_pt, cpu_blocks=8, gpu_value=None, gpu_single_block=None):
     """The oracle's SIMD route (oracle/fp_route.inc: exact fp64-FMA NTT, one gate per SIMD lane, OpenMP over
     groups of gates like rayon over a level) on the first levels of the same netlist, `cpu_blocks` blocks of the
     GPU's batch, on the cores this process is granted; the GPU's ciphertexts of those levels must be bit-identical
@@ -414,14 +594,54 @@ def cpu_baseline(args, ck, circuit, wire_names, index, nw, wires, keys_pt, cpu_b
     same = bool(np.array_equal(wires.download(o_out[:o_off[L]]), host[o_out[:o_off[L]]]))
     if not same:
         raise SystemExit("GPU ciphertexts differ from the CPU oracle on the sampled levels")
-    return {
-        "value": round(n_pbs / cpu_s, 2), "unit": "gate-bootstraps/s", "cores": threads, "kind": "port",
-        "per_core": round(n_pbs / cpu_s / threads, 2), "ms_per_gate_per_thread": round(cpu_s * threads / n_pbs * 1e3, 2),
+    value = n_pbs / cpu_s
+    share = f"{granted} of {os.cpu_count()} logical CPUs (affinity mask capped by the cgroup quota)"
+    res = {
+        # the portable figures first: one thread's rate does not depend on the share of the host this run was granted
+        "per_core": round(value / threads, 2), "ms_per_gate_per_thread": round(cpu_s * threads / n_pbs * 1e3, 2),
+        "value": round(value, 2), "unit": "gate-bootstraps/s", "cores": threads, "kind": "port",
+        "host_share": share,
         "sample": f"first {L} level(s) of the same AES-128 netlist, {cpu_blocks} block(s) of the GPU's batch ({n_pbs} gate-bootstraps, "
                   f"{cpu_s:.1f} s); {oracle.ntt_route_name()}; prime {orc.fp_prime():#x}; OpenMP over groups of gates of a level; NOT tfhe-rs",
         "gpu_ciphertexts_bit_identical_on_sample": same,
-        "host": f"{os.cpu_count()} logical CPUs, {granted} granted to this process (affinity mask capped by the cgroup quota)",
     }
+    if gpu_value:
+        res["gpu_over_cpu"] = {"batched": round(gpu_value / value, 1),
+                               "one_aes_block": round(gpu_single_block / value, 1) if gpu_single_block else None,
+                               "against": f"{threads} threads on {share}: the ratio scales with the share, the per-core figures do not",
+                               "gpu_over_one_core": round(gpu_value / (value / threads), 0)}
+    return res
+
+
+def si_algo_ops(n, k, N, pbs_l, g=1):
+    """ALGORITHMIC fp64 lane-operations of one 64-bit-torus bootstrap: two CRT fields; per blind-rotation step
+    ((k+1) l forward + (k+1) inverse) transforms of N/2 log2 N butterflies (x 8: exact 6-operation modular
+    multiplication + add + sub) and (k+1)^2 l N multiply-accumulates (x 7); n steps, or n/g group steps for the
+    multi-bit rotation, whose key of a step is the sum over the 2^g subsets of monomial x GGSW:
+    2^g (k+1)^2 l N more multiply-accumulates per field."""
+    K1, logN = k + 1, N.bit_length() - 1
+    bfly = (K1 * pbs_l + K1) * (N // 2) * logN * 2
+    macs = K1 * K1 * pbs_l * N * 2
+    steps = n
+    if g > 1:
+        macs += (1 << g) * K1 * K1 * pbs_l * N * 2
+        steps = n // g
+    return steps * (bfly * 8 + macs * 7)
+
+
+def si_roofline(kernel, algo_ops, bootstraps, kernel_ms, launches, n_cus, bsk_bytes, io_bytes):
+    """`roofline` of a 64-bit-torus bootstrap kernel from the engine's own HIP events (helm_si_get_timing)."""
+    peak = n_cus * 64 * PEAK_CLOCK_GHZ * 1e9 / 1e12
+    ach = algo_ops * bootstraps / (kernel_ms * 1e-3) / 1e12
+    algo_bytes = bsk_bytes * launches + bootstraps * io_bytes
+    return {"kernel": kernel, "bound": "fp64_valu", "achieved": round(ach, 2), "peak": round(peak, 2),
+            "unit": "T fp64 lane-op/s (FMA = 1)", "frac": round(ach / peak, 4),
+            "algorithmic_lane_ops_per_bootstrap": int(algo_ops), "bootstraps": int(bootstraps),
+            "kernel_ms": round(kernel_ms, 3), "launches": int(launches),
+            "traffic": None,
+            "hbm": {"achieved": round(algo_bytes / (kernel_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "algorithmic_bytes": int(algo_bytes), "note": "key once per launch + rows and tables; not the binding resource"}}
 
 
 def other_modes(device):
@@ -452,6 +672,8 @@ def _wide_lut_leg(device):
     sk = helm_amd.SiServerKey(ck, device=device)
     wsk = wopbs.WopServerKey(sk, wk)
     rng = np.random.default_rng(0)
+    import torch
+    n_cus = torch.cuda.get_device_properties(device).multi_processor_count
     G, m = 256, 6
     truth = rng.integers(0, 2, size=1 << m, dtype=np.uint64)
     xs = rng.integers(0, 1 << m, size=G)
@@ -476,6 +698,13 @@ def _wide_lut_leg(device):
         res[f"bits_per_block_{b}"] = {"gates_per_s": round(G / dt, 1), "wall_s": round(dt, 4), "bootstraps": t["bootstraps"],
                                       "bootstraps_per_s": round(t["bootstraps"] / dt, 1), "decrypt_ok": ok,
                                       "stage_ms": {k[:-3]: round(v, 2) for k, v in t.items() if k.endswith("_ms")}}
+        # the stage that is the path: G x (m b) x cbs_l WoP-side bootstraps (N = 2048, two levels) on k_pbs64s
+        n_cbs = G * m * b * wp.cbs_l
+        K1 = wp.k + 1
+        res[f"bits_per_block_{b}"]["roofline"] = si_roofline(
+            "k_pbs64s<Pbs64sCfg<11, 2>> (circuit-bootstrap stage)", si_algo_ops(wp.n, wp.k, wp.N, wp.pbs_l), n_cbs,
+            t["cbs_pbs_ms"], max(1, -(-n_cbs // 4096)), n_cus, wp.n * wp.pbs_l * K1 * K1 * wp.N * 8 * 2,
+            (wp.n + 1) * 8 + (wp.k * wp.N + 1) * 8 + wp.N * 8)
     wsk.close()
     sk.close()
     return res
@@ -493,13 +722,28 @@ def _other_modes_set(device, set_name, tfhe_name):
     ar, tb, out = np.full(B, 3, np.int32), np.full(B, 0xE8, np.uint64), np.arange(3 * B, 4 * B, dtype=np.int32)
     w.eval_lut_level(ar, in_idx, tb, out)
     sk.sync()
+    sk.timing_enable(True)
+    sk.timing(reset=True)
     t0 = time.perf_counter()
     w.eval_lut_level(ar, in_idx, tb, out)
     sk.sync()
     dt = time.perf_counter() - t0
+    tm = sk.timing(reset=True)
+    sk.timing_enable(False)
     ok = bool(np.array_equal(ck.decrypt(w.download(out)), (bits[:B] + bits[B:2 * B] + bits[2 * B:]) >= 2))
+    p = ck.params
+    import torch
+    n_cus = torch.cuda.get_device_properties(device).multi_processor_count
+    g = max(1, p.grouping_factor)
+    K1 = p.k + 1
+    bsk_bytes = (p.n // g) * (1 << g if g > 1 else 1) * p.pbs_l * K1 * K1 * p.N * 8 * 2
+    io_bytes = (p.n + 1) * 8 + (p.k * p.N + 1) * 8 + p.N * 8     # small LWE in, big LWE out, test polynomial
     res = {"lut_mode": {"workload": f"{B} independent 3-input LUT gates (keyswitch + programmable bootstrap), " + tfhe_name,
-                        "luts_per_s": round(B / dt, 1), "decrypt_ok": ok}}
+                        "luts_per_s": round(B / dt, 1), "decrypt_ok": ok,
+                        "kernel_ms": {"k_pbs64s": round(tm.pbs_ms, 3), "keyswitch": round(tm.ks_ms, 3), "linear": round(tm.linear_ms, 3)},
+                        "roofline": si_roofline("k_pbs64s" + (f" (multi-bit, g = {g})" if g > 1 else ""),
+                                                si_algo_ops(p.n, p.k, p.N, p.pbs_l, g), tm.pbs_count, tm.pbs_ms,
+                                                tm.pbs_launches, n_cus, bsk_bytes, io_bytes)}}
     g, ws, i, o, d, _, _ = verilog_parser.read_verilog_file(os.path.join(ROOT, "tests", "netlists", "chi_squared_arith.v"), True)
     c = Circuit(g, i, o, d)
     c.sort_circuit()

@@ -1,0 +1,82 @@
+"""bench.py's N > 1 contract: `python3 bench.py --gpus N` starts its own workers from a parent that has not touched
+the GPU, prints ONE JSON line whatever happens, and a failing / hung worker group shows as a non-zero exit code with
+the error in the line.  The sharded unit is the netlist level, reference
+src/circuit.rs:531."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run_bench(args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, BENCH] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    return p.returncode, lines, p.stderr
+
+
+def test_launcher_imports_nothing_that_touches_the_gpu():
+    """The launcher path must stay on the standard library: no torch / helm_amd / numpy at module level."""
+    import ast
+    tree = ast.parse(open(BENCH).read())
+    top = set()
+    for node in tree.body:
+        if isinstance(node, ast.Import):
+            top |= {a.name.split(".")[0] for a in node.names}
+        elif isinstance(node, ast.ImportFrom):
+            top.add(node.module.split(".")[0])
+    assert top <= {"argparse", "json", "os", "sys", "time"}, top
+    # and inside launch_workers only standard-library modules
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "launch_workers")
+    inner = {a.name.split(".")[0] for n in ast.walk(fn) if isinstance(n, ast.Import) for a in n.names}
+    assert inner <= {"signal", "socket", "subprocess", "tempfile", "threading"}, inner
+    assert "execv" not in open(BENCH).read().replace("never an exec", "")
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="failure path: needs a box without a GPU")
+def test_failing_workers_give_one_line_with_error_and_nonzero_rc():
+    rc, lines, err = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--blocks", "1"])
+    assert rc != 0
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["metric"].startswith("encrypted gate-bootstraps/sec")
+    assert line["n_gpus"] == 2 and line["value"] is None
+    assert "error" in line and "rank" in line["error"]
+
+
+def test_hung_worker_group_is_stopped_and_reported():
+    """A group that outlives --launch-timeout is stopped (its own process group only) and reported: rc 3, one line."""
+    rc, lines, err = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--blocks", "1", "--launch-timeout", "0.2"])
+    assert rc == 3
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert "still running" in line["error"] and line["value"] is None
+
+
+@pytest.mark.gpu
+def test_rehearsal_two_ranks_on_one_gpu_reports_every_named_result():
+    """HELM_BENCH_REHEARSE=1: both ranks on cuda:0, collectives over gloo - the whole N > 1 path of bench.py, launcher
+    included: strong (headline), weak and sharded_weak each under its own name, rc 0."""
+    rc, lines, err = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "4", "--side-steps", "1"],
+                               {"HELM_BENCH_REHEARSE": "1"}, timeout=1100)
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert "error" not in line, line.get("error")
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2
+    assert line["rccl_ranks"]["world_size"] == 2 and line["rccl_ranks"]["backend"] == "gloo"
+    assert line["config"]["sharded_launches"] > 0 and line["config"]["exchanged_MB_per_step"] > 0
+    for kind in ("strong", "weak", "sharded_weak"):
+        assert line[kind]["value"] > 0, kind
+    assert line["strong"]["value"] == line["value"]
+    assert line["weak"]["exchanged_MB_per_step"] == 0 and line["sharded_weak"]["sharded_launches"] > 0
+    assert line["sharded_weak"]["bootstraps_per_step"] == 2 * line["strong"]["bootstraps_per_step"]
