@@ -752,7 +752,7 @@ def _other_modes_set(device, set_name, tfhe_name):
     enc = ac.encrypt_inputs(ws, {"N0": PtxtType.U32(2), "N1": PtxtType.U32(7), "N2": PtxtType.U32(9)})
     ac.evaluate_encrypted(enc, 1, "u32")
     t0 = time.perf_counter()
-    outm = ac.evaluate_encrypted(enc, 1, "u32")
+    outm = ac.evaluate_encrypted(enc, 2, "u32")  # a new cycle each time: the same-cycle memo (gates.rs:307-312) must not answer
     dt = time.perf_counter() - t0
     dec = {k: int(v.value) for k, v in ac.decrypt_outputs(outm, True).items()}
     res["arith_mode"] = {"workload": "chi_squared_arith.v, u32 (16 radix blocks per integer), " + tfhe_name, "wall_s": round(dt, 4),
@@ -761,9 +761,9 @@ def _other_modes_set(device, set_name, tfhe_name):
     # the same evaluation with the two sub-circuits that share no wire (alpha's and the betas') on two lanes
     # (helm_si_ctx_fork): concurrent instead of level by level, identical ciphertexts
     ac.set_lanes(2)
-    ac.evaluate_encrypted(enc, 1, "u32")
+    ac.evaluate_encrypted(enc, 3, "u32")
     t0 = time.perf_counter()
-    outl = ac.evaluate_encrypted(enc, 1, "u32")
+    outl = ac.evaluate_encrypted(enc, 4, "u32")
     dtl = time.perf_counter() - t0
     decl = {k: int(v.value) for k, v in ac.decrypt_outputs(outl, True).items()}
     res["arith_mode"]["two_lanes"] = {"wall_s": round(dtl, 4), "rounds_in_a_row": ac.pbs_rounds_per_cycle(),

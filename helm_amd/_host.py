@@ -44,6 +44,7 @@ HOST_API = {
     "helm_host_gate_circuit_decrypt_outputs": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
     "helm_host_gate_circuit_log": (vp, [vp]),
     "helm_host_gate_circuit_pbs_per_cycle": (C.c_int64, [vp]),
+    "helm_host_gate_circuit_memo_hits": (C.c_int64, [vp]),
     "helm_host_si_circuit_new": (C.c_int, [C.c_int, vp, vp, vp, C.POINTER(vp)]),
     "helm_host_si_circuit_free": (None, [vp]),
     "helm_host_si_circuit_encrypt_inputs": (C.c_int, [vp, cp, cp, C.POINTER(vp)]),
@@ -56,6 +57,7 @@ HOST_API = {
     "helm_host_si_circuit_log": (vp, [vp]),
     "helm_host_si_circuit_pbs_per_cycle": (C.c_int64, [vp]),
     "helm_host_si_circuit_pbs_rounds_per_cycle": (C.c_int64, [vp]),
+    "helm_host_si_circuit_memo_hits": (C.c_int64, [vp]),
     "helm_host_si_enc_map_new": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
     "helm_host_si_enc_map_free": (None, [vp]),
     "helm_host_si_enc_map_blocks": (C.c_int, [vp]),

@@ -106,6 +106,7 @@ HIP_API = {
     "helm_hip_wires_upload": (C.c_int, [vp, vp, i32p, u32p, C.c_int64]),
     "helm_hip_wires_download": (C.c_int, [vp, vp, i32p, u32p, C.c_int64]),
     "helm_hip_wires_set_trivial": (C.c_int, [vp, vp, i32p, u8p, C.c_int64]),
+    "helm_hip_wires_copy": (C.c_int, [vp, vp, i32p, vp, i32p, C.c_int64]),
     "helm_hip_wires_device_ptr": (C.c_int, [vp, vp, C.POINTER(vp), i64p]),
     "helm_hip_eval_gate_level": (C.c_int, [vp, vp, i32p, i32p, i32p, i32p, i32p, C.c_int64]),
     "helm_hip_program_create": (C.c_int, [vp, i32p, i32p, i32p, i32p, i32p, i64p, C.c_int64, C.POINTER(vp)]),

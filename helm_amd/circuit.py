@@ -147,6 +147,10 @@ class GateCircuit(EvalCircuit):
     def pbs_per_cycle(self):
         return int(H.host.helm_host_gate_circuit_pbs_per_cycle(self._h))
 
+    def memo_hits(self):
+        """evaluate_encrypted calls answered from the same-cycle memo (reference src/gates.rs:55-59)."""
+        return int(H.host.helm_host_gate_circuit_memo_hits(self._h))
+
 
 class SiEncWireMap:
     """HashMap<String, CtxtShortInt> / HashMap<String, FheType> whose values live in an HBM table of
@@ -234,6 +238,10 @@ class _SiCircuit(EvalCircuit):
 
     def pbs_rounds_per_cycle(self):
         return int(H.host.helm_host_si_circuit_pbs_rounds_per_cycle(self._h))
+
+    def memo_hits(self):
+        """evaluate_encrypted calls answered from the same-cycle memo (reference src/gates.rs:288-292, 307-312)."""
+        return int(H.host.helm_host_si_circuit_memo_hits(self._h))
 
 
 class LutCircuit(_SiCircuit):

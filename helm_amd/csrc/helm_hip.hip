@@ -1049,6 +1049,16 @@ __global__ __launch_bounds__(256) void k_gather_rows(const uint32_t *__restrict_
         packed[row * (size_t)blockIdx.x + i] = s < 0 ? 0u : wires[row * (size_t)s + i];
 }
 
+// wire dst_row[r] of `dst` <- wire src_row[r] of `src` (Ciphertext::clone of whole rows)
+__global__ __launch_bounds__(256) void k_copy_rows(const uint32_t *__restrict__ src, const int32_t *__restrict__ src_row,
+                                                   uint32_t *__restrict__ dst, const int32_t *__restrict__ dst_row, int n)
+{
+    const size_t row = (size_t)n + 1;
+    const uint32_t *s = src + row * (size_t)src_row[blockIdx.x];
+    uint32_t *d = dst + row * (size_t)dst_row[blockIdx.x];
+    for (int i = threadIdx.x; i <= n; i += 256) d[i] = s[i];
+}
+
 __global__ __launch_bounds__(256) void k_set_trivial(const int32_t *__restrict__ idx, const uint8_t *__restrict__ val,
                                                      uint32_t *__restrict__ wires, int n)
 {
@@ -1927,6 +1937,36 @@ int helm_hip_wires_download(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t 
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)count), dim3(256), 0, ctx->stream, w->d, d_idx.p, d_rows.p, ctx->P.n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(lwe_host, d_rows.p, (size_t)count * row * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int helm_hip_wires_copy(helm_hip_ctx *ctx, helm_hip_wires *src, const int32_t *src_idx, helm_hip_wires *dst,
+                        const int32_t *dst_idx, int64_t count)
+{
+    if (!ctx || !src || !dst || !src_idx || !dst_idx || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
+    if (src->owner != ctx || dst->owner != ctx) return fail(HELM_ERR_STATE, "wire table belongs to another context");
+    if (count == 0) return 0;
+    if (int rc = check_idx(src, src_idx, count, false)) return rc;
+    if (int rc = check_idx(dst, dst_idx, count, false)) return rc;
+    {
+        std::vector<int32_t> sorted(dst_idx, dst_idx + count);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+            return fail(HELM_ERR_INVALID, "copy names the same destination wire twice");
+        if (src == dst)
+            for (int64_t r = 0; r < count; r++)
+                if (std::binary_search(sorted.begin(), sorted.end(), src_idx[r]) && src_idx[r] != dst_idx[r])
+                    return fail(HELM_ERR_INVALID, "copy within one table: source and destination rows overlap");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    Scratch<int32_t> d_src, d_dst;
+    HIP_TRY(d_src.alloc((size_t)count));
+    HIP_TRY(d_dst.alloc((size_t)count));
+    HIP_TRY(hipMemcpyAsync(d_src.p, src_idx, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_dst.p, dst_idx, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)count), dim3(256), 0, ctx->stream, src->d, d_src.p, dst->d, d_dst.p, ctx->P.n);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }

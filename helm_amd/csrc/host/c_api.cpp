@@ -277,6 +277,7 @@ int helm_host_gate_circuit_decrypt_outputs(helm_gate_circuit *gc, const helm_enc
 }
 char *helm_host_gate_circuit_log(helm_gate_circuit *gc) { return dup(gc->gc->log()); }
 int64_t helm_host_gate_circuit_pbs_per_cycle(const helm_gate_circuit *gc) { return gc->gc->pbs_per_cycle(); }
+int64_t helm_host_gate_circuit_memo_hits(const helm_gate_circuit *gc) { return gc->gc->memo_hits(); }
 
 void helm_host_enc_map_free(helm_enc_map *m) { delete m; }
 int helm_host_enc_map_insert(helm_enc_map *m, const char *wire, const uint32_t *lwe)
@@ -368,6 +369,7 @@ int64_t helm_host_si_circuit_pbs_rounds_per_cycle(const helm_si_circuit *c)
 {
     return c->lut ? 0 : c->arith->pbs_rounds_per_cycle();
 }
+int64_t helm_host_si_circuit_memo_hits(const helm_si_circuit *c) { return c->lut ? c->lut->memo_hits() : c->arith->memo_hits(); }
 int helm_host_si_enc_map_new(helm_si_ctx *server_key, int blocks, helm_si_enc_map **out)
 {
     return guard([&] {

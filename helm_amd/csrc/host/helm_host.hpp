@@ -154,6 +154,20 @@ int pack_levels(const int32_t *op, const int32_t *in0, const int32_t *in1, const
                 const int64_t *off, int64_t n_levels, int64_t quantum, std::vector<int64_t> &order,
                 std::vector<int64_t> &new_off);
 
+uint64_t next_map_id(); // process-wide counter behind EncWireMap::id() / SiEncWireMap::id()
+
+// Same-cycle memo of an evaluator (reference src/gates.rs:55-59: every Gate keeps `cycle` and its last encrypted
+// output, and gates.rs:288-292, 307-312 return it when called again in that cycle).  All gates of a circuit are
+// evaluated with the same cycle, so the memo lives once per circuit: the wire map the cycle produced.
+template <typename MapT> struct CycleMemo {
+    bool valid = false;
+    size_t cycle = 0;
+    uint64_t in_id = 0, in_gen = 0; // the input map the outputs were computed from
+    std::unique_ptr<MapT> out;
+    bool hit(size_t c) const { return valid && cycle == c; }
+    bool hit(size_t c, const MapT &in) const { return hit(c) && in_id == in.id() && in_gen == in.generation(); }
+};
+
 // Device-resident replacement of HashMap<String, Ciphertext> (circuit.rs:517-520):
 // wire name -> row of an HBM wire table owned by the engine context.
 class EncWireMap {
@@ -173,9 +187,16 @@ class EncWireMap {
     helm_hip_ctx *ctx() const { return ctx_; }
     // build with a fixed key set (rows in iteration order of `names`)
     void reserve_keys(const std::vector<std::string> &names);
+    // identity of this map object and a counter of its host-side modifications: what the evaluators' same-cycle
+    // memo (gates.rs:55-59) compares instead of the ciphertext rows themselves
+    uint64_t id() const { return id_; }
+    uint64_t generation() const { return gen_; }
+    void touch() { gen_++; } // a caller that wrote rows through table() says so
 
   private:
     void grow(int64_t rows);
+    const uint64_t id_ = next_map_id();
+    uint64_t gen_ = 0;
     helm_hip_ctx *ctx_;
     int n_;
     helm_hip_wires *wires_ = nullptr;
@@ -227,6 +248,14 @@ class GateCircuit : public EvalCircuit<EncWireMap> {
     int64_t prog_launches_ = 0;
     bool packed_ = false; // the program's launches are packed rounds, not the circuit's levels
     std::string log_;
+    // Same cycle AND the very input map (unmodified): the cached wire map is returned without a launch.  The
+    // reference's boolean path has its cache probe commented out (gates.rs:247-252), so the memo must not be
+    // observable there: requiring unchanged inputs makes it return exactly what a re-evaluation would.
+    CycleMemo<EncWireMap> memo_;
+    int64_t memo_hits_ = 0;
+
+  public:
+    int64_t memo_hits() const { return memo_hits_; }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -254,9 +283,14 @@ class SiEncWireMap {
     void reserve_keys(const std::vector<std::string> &names, int64_t scratch_rows);
     int scratch(int64_t rows); // first row of a scratch region behind the named rows
     helm_si_wires *table() const { return wires_; }
+    uint64_t id() const { return id_; }
+    uint64_t generation() const { return gen_; }
+    void touch() { gen_++; }
 
   private:
     void grow(int64_t rows);
+    const uint64_t id_ = next_map_id();
+    uint64_t gen_ = 0;
     helm_si_ctx *ctx_;
     int blocks_, dim_ = 0;
     helm_si_wires *wires_ = nullptr;
@@ -290,6 +324,13 @@ class LutCircuit : public EvalCircuit<SiEncWireMap> {
     helm_si_params P_{};
     int64_t pbs_count_ = 0;
     std::string log_;
+    // As GateCircuit's: same cycle and the very input map.  (The reference's evaluate_encrypted_lut probes its cache
+    // but never stores `cycle`, gates.rs:282-304, so there it only ever hits for cycle 0.)
+    CycleMemo<SiEncWireMap> memo_;
+    int64_t memo_hits_ = 0;
+
+  public:
+    int64_t memo_hits() const { return memo_hits_; }
 };
 
 // One integer operator of a level: rows a, b, out are the first rows of radix integers.
@@ -357,6 +398,14 @@ class ArithCircuit : public EvalCircuit<SiEncWireMap> {
     std::string global_ptxt_type_;
     int64_t pbs_count_ = 0, pbs_rounds_ = 0;
     std::string log_;
+    // The reference's arithmetic gates return their cached output whenever the cycle repeats, WHATEVER the inputs
+    // (gates.rs:307-312; tests/gates_test.rs:196-223 calls again with other operands and expects the first result;
+    // tests/circuit_test.rs:314-474 passes cycles 1..4 "to defeat the cache"): keyed on the cycle alone.
+    CycleMemo<SiEncWireMap> memo_;
+    int64_t memo_hits_ = 0;
+
+  public:
+    int64_t memo_hits() const { return memo_hits_; }
 };
 
 } // namespace helm

@@ -16,6 +16,7 @@
 #include <thread>
 
 #include <algorithm>
+#include <chrono>
 #include <sstream>
 
 namespace helm {
@@ -121,6 +122,7 @@ void SiEncWireMap::insert(const std::string &k, const uint64_t *lwe)
     std::vector<int32_t> idx((size_t)blocks_);
     for (int b = 0; b < blocks_; b++) idx[(size_t)b] = r + b;
     si_ok(helm_si_wires_upload(ctx_, wires_, idx.data(), lwe, blocks_), "wires_upload");
+    gen_++;
 }
 
 std::unique_ptr<SiEncWireMap> SiEncWireMap::clone(int64_t scratch_rows) const
@@ -261,14 +263,21 @@ void LutCircuit::set_wide_lut_key(helm_wop_ctx *wop, int bits_per_block)
     }
     wop_ = wop;
     wop_bits_per_block_ = bits_per_block;
+    memo_.valid = false; // wide gates now take another path
 }
 
 // reference src/circuit.rs:1032-1083
-std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap &enc_wire_map, size_t /*cycle*/,
+std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap &enc_wire_map, size_t cycle,
                                                              const std::string & /*ptxt_type*/)
 {
     if (!circuit_.gates_empty()) throw Panic("assertion failed: self.circuit.gates.is_empty()");
     if (!circuit_.get_ordered_gates().empty()) throw Panic("assertion failed: self.circuit.ordered_gates.is_empty()");
+    // same-cycle memo (gates.rs:288-292): this cycle was already evaluated on this very map -> no launch
+    if (memo_.hit(cycle, enc_wire_map)) {
+        memo_hits_++;
+        log_ += "  Cycle " + std::to_string(cycle) + " already evaluated on these inputs: cached wire map returned\n";
+        return memo_.out->clone(0);
+    }
     auto eval_values = enc_wire_map.clone(0);
     const size_t total_levels = circuit_.level_map().size();
     pbs_count_ = 0;
@@ -326,6 +335,7 @@ std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap 
             for (size_t q = 0; q < ins.size(); q++) in_idx[slot + q] = eval_values->row(ins[q]);
             out.push_back(eval_values->row(g.get_output_wire()));
         }
+        const auto level_start = std::chrono::steady_clock::now();
         // wide gates first: they read the level's inputs before a state copy of the same level overwrites one
         for (auto &wk : wide)
             si_ok(helm_wop_eval_luts(wop_, eval_values->table(), wk.second.in.data(), wk.first, wop_bits_per_block_,
@@ -336,10 +346,22 @@ std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap 
                                          table.data(), out.data(), (int64_t)arity.size()),
                   "eval_lut_level");
         std::ostringstream os;
+        // gates.rs:293-302 prints the time of every gate's lut() call; the gates of a level are one batched dispatch
+        // here, so each of them took the level's time (one synchronisation per level: microseconds next to the
+        // milliseconds of a bootstrap round)
+        si_ok(helm_si_sync(server_key_), "sync");
+        const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - level_start).count();
+        for (auto &g : gates)
+            if (g.get_gate_type() == GateType::Lut) os << "PBS time: " << us << " us\n";
         os << "  Evaluated gates in level [" << kv.first << "/" << total_levels << "]\n";
         log_ += os.str();
     }
     si_ok(helm_si_sync(server_key_), "sync");
+    memo_.out = eval_values->clone(0);
+    memo_.cycle = cycle;
+    memo_.in_id = enc_wire_map.id();
+    memo_.in_gen = enc_wire_map.generation();
+    memo_.valid = true;
     return eval_values;
 }
 
@@ -1041,13 +1063,41 @@ void ArithCircuit::evaluate_ready(const SiEncWireMap &enc_wire_map, SiEncWireMap
 }
 
 // reference src/circuit.rs:1299-1454
-std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMap &enc_wire_map, size_t /*cycle*/,
+std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMap &enc_wire_map, size_t cycle,
                                                                const std::string &ptxt_type)
 {
     if (!circuit_.gates_empty()) throw Panic("assertion failed: self.circuit.gates.is_empty()");
     if (!circuit_.get_ordered_gates().empty()) throw Panic("assertion failed: self.circuit.ordered_gates.is_empty()");
     const int nb = blocks_of(ptxt_type);
     if (nb != enc_wire_map.blocks()) throw Panic("ptxt_type does not match the encrypted inputs");
+    // Same-cycle memo, keyed on the cycle ALONE as in the reference (gates.rs:307-312 and every *_block method: `if
+    // self.cycle == cycle { return cached }`, the operands are not looked at; tests/gates_test.rs:196-223).  Every gate
+    // then hands back its cached output: the result is the given map with the gate outputs of that cycle, no launch.
+    if (memo_.hit(cycle) && memo_.out->blocks() == nb) {
+        memo_hits_++;
+        auto cached = enc_wire_map.clone(0);
+        std::vector<int32_t> src, dst;
+        for (auto &kv : circuit_.level_map())
+            for (auto &g : kv.second) {
+                const int32_t s0 = memo_.out->row(g.get_output_wire()), d0 = cached->row(g.get_output_wire());
+                for (int b = 0; b < nb; b++) {
+                    src.push_back(s0 + b);
+                    dst.push_back(d0 + b);
+                }
+            }
+        if (!src.empty())
+            si_ok(helm_si_wires_copy(server_key_, memo_.out->table(), src.data(), cached->table(), dst.data(), (int64_t)src.size()),
+                  "wires_copy");
+        log_ += "  Cycle " + std::to_string(cycle) + " already evaluated: cached gate outputs returned\n";
+        return cached;
+    }
+    auto remember = [&](SiEncWireMap &values) {
+        memo_.out = values.clone(0);
+        memo_.cycle = cycle;
+        memo_.in_id = enc_wire_map.id();
+        memo_.in_gen = enc_wire_map.generation();
+        memo_.valid = true;
+    };
     const int bits = 2 * nb;
     const unsigned __int128 vmask = bits >= 128 ? ~(unsigned __int128)0 : (((unsigned __int128)1 << bits) - 1);
     RadixEngine eng(server_key_, nb);
@@ -1192,6 +1242,7 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
         os << "  Evaluated " << comps.size() << " independent sub-circuit(s) of " << total_levels << " level(s) on " << n_ctx
            << " lane(s)\n";
         log_ += os.str();
+        remember(*eval_values);
         return eval_values;
     }
     const int scratch = eval_values->scratch(max_scratch);
@@ -1205,6 +1256,7 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
     si_ok(helm_si_sync(server_key_), "sync");
     pbs_count_ = eng.pbs_count();
     pbs_rounds_ = eng.pbs_rounds();
+    remember(*eval_values);
     return eval_values;
 }
 

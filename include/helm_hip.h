@@ -133,6 +133,10 @@ int helm_hip_wires_download(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t 
 /* ServerKey::trivial_encrypt(value) (circuit.rs:455-458): zero mask, body = encoding. */
 int helm_hip_wires_set_trivial(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t *idx,
                                const uint8_t *value, int64_t count);
+/* Ciphertext::clone of rows (circuit.rs:517-520, 535): dst wire dst_idx[r] <- src wire src_idx[r], on the device;
+ * src and dst may be the same table when the two index sets do not overlap. */
+int helm_hip_wires_copy(helm_hip_ctx *ctx, helm_hip_wires *src, const int32_t *src_idx, helm_hip_wires *dst,
+                        const int32_t *dst_idx, int64_t count);
 /* Raw device pointer of the table (for collectives driven by the host). */
 int helm_hip_wires_device_ptr(helm_hip_ctx *ctx, helm_hip_wires *w, void **dev_ptr, int64_t *n_wires);
 

@@ -99,6 +99,11 @@ int helm_host_gate_circuit_decrypt_outputs(helm_gate_circuit *gc, const helm_enc
 /* progress / output lines the reference prints (circuit.rs:542, 562-573); drains the buffer */
 char *helm_host_gate_circuit_log(helm_gate_circuit *gc);
 int64_t helm_host_gate_circuit_pbs_per_cycle(const helm_gate_circuit *gc);
+/* Same-cycle memo (reference src/gates.rs:55-59: a Gate keeps `cycle` and its last encrypted output): evaluate_encrypted
+ * called again with the same cycle on the very same, unmodified map returns the cached wire map without a launch; this
+ * counts those calls.  (The reference's boolean cache probe is commented out, gates.rs:247-252, so the memo is only
+ * allowed where it cannot be observed: identical inputs.) */
+int64_t helm_host_gate_circuit_memo_hits(const helm_gate_circuit *gc);
 
 /* ---- LUT mode / arithmetic mode (include/helm_shortint.h) ------------------------------
  * LutCircuit (circuit.rs:969-1120) and ArithCircuit (circuit.rs:1112-1500); `mode` 0 = LUT,
@@ -129,6 +134,11 @@ char *helm_host_si_circuit_log(helm_si_circuit *c);
 /* bootstraps of the last evaluate_encrypted, and (arithmetic) the number of batched rounds */
 int64_t helm_host_si_circuit_pbs_per_cycle(const helm_si_circuit *c);
 int64_t helm_host_si_circuit_pbs_rounds_per_cycle(const helm_si_circuit *c);
+/* Same-cycle memo.  LUT mode: as helm_host_gate_circuit_memo_hits (same cycle, same unmodified map).  Arithmetic mode:
+ * keyed on the cycle ALONE, as the reference's *_block methods are (src/gates.rs:307-312; tests/gates_test.rs:196-223
+ * evaluates other operands in the same cycle and expects the first result; tests/circuit_test.rs:314-474 passes cycles
+ * 1..4 to defeat it): pass a new cycle number for new inputs. */
+int64_t helm_host_si_circuit_memo_hits(const helm_si_circuit *c);
 int helm_host_si_enc_map_new(helm_si_ctx *server_key, int blocks, helm_si_enc_map **out);
 void helm_host_si_enc_map_free(helm_si_enc_map *m);
 int helm_host_si_enc_map_blocks(const helm_si_enc_map *m);

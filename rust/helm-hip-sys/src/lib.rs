@@ -61,6 +61,7 @@ extern "C" {
     pub fn helm_hip_wires_upload(ctx: *mut helm_hip_ctx, w: *mut helm_hip_wires, idx: *const i32, lwe_host: *const u32, count: i64) -> c_int;
     pub fn helm_hip_wires_download(ctx: *mut helm_hip_ctx, w: *mut helm_hip_wires, idx: *const i32, lwe_host: *mut u32, count: i64) -> c_int;
     pub fn helm_hip_wires_set_trivial(ctx: *mut helm_hip_ctx, w: *mut helm_hip_wires, idx: *const i32, value: *const u8, count: i64) -> c_int;
+    pub fn helm_hip_wires_copy(ctx: *mut helm_hip_ctx, src: *mut helm_hip_wires, src_idx: *const i32, dst: *mut helm_hip_wires, dst_idx: *const i32, count: i64) -> c_int;
     pub fn helm_hip_eval_gate_level(ctx: *mut helm_hip_ctx, w: *mut helm_hip_wires, opcode: *const i32, in0: *const i32,
                                     in1: *const i32, in2: *const i32, out: *const i32, count: i64) -> c_int;
     pub fn helm_hip_program_create(ctx: *mut helm_hip_ctx, opcode: *const i32, in0: *const i32, in1: *const i32, in2: *const i32,

@@ -114,9 +114,9 @@ mult g4(A, 27, M);
 """
     circuit, wire_set, _, _ = _circuit(text, is_arith=True, is_text=True)
     ac = ArithCircuit(client_key, server_key, circuit)
-    for a, b in ((200, 100), (3, 250), (255, 255), (0, 0)):
+    for cycle, (a, b) in enumerate(((200, 100), (3, 250), (255, 255), (0, 0)), start=1):  # a new cycle defeats the memo
         enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U8(a), "B": PtxtType.U8(b)})
-        out = ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, "u8"), True)
+        out = ac.decrypt_outputs(ac.evaluate_encrypted(enc, cycle, "u8"), True)
         assert out["S"].value == (a + b) % 256 and out["D"].value == (a - b) % 256
         assert out["P"].value == (a * b) % 256 and out["C"].value == a and out["M"].value == (a * 27) % 256
 
@@ -152,9 +152,9 @@ def test_chi_squared_on_lanes_is_bit_identical_and_shorter(keys):
     one = ac.evaluate_encrypted(enc_in, 1, "u32")
     t_one, rounds_one, pbs_one = time.perf_counter() - t0, ac.pbs_rounds_per_cycle(), ac.pbs_per_cycle()
     ac.set_lanes(2)
-    ac.evaluate_encrypted(enc_in, 1, "u32")  # warm-up of the lane's scratch
+    ac.evaluate_encrypted(enc_in, 2, "u32")  # warm-up of the lane's scratch (a new cycle each time: the memo is per cycle)
     t0 = time.perf_counter()
-    two = ac.evaluate_encrypted(enc_in, 1, "u32")
+    two = ac.evaluate_encrypted(enc_in, 3, "u32")
     t_two = time.perf_counter() - t0
     assert sorted(one.keys()) == sorted(two.keys())
     for wire in one.keys():
@@ -165,7 +165,7 @@ def test_chi_squared_on_lanes_is_bit_identical_and_shorter(keys):
     print(f"chi-squared u32: {t_one:.3f} s level by level, {t_two:.3f} s on two lanes")
     assert t_two < t_one
     ac.set_lanes(1)
-    again = ac.evaluate_encrypted(enc_in, 1, "u32")
+    again = ac.evaluate_encrypted(enc_in, 4, "u32")
     assert ac.pbs_rounds_per_cycle() == 39 and np.array_equal(again["alpha"], one["alpha"])
 
 
@@ -184,9 +184,9 @@ shr g7(A, B, RV);
 """
     circuit, wire_set, _, _ = _circuit(text, is_arith=True, is_text=True)
     ac = ArithCircuit(client_key, server_key, circuit)
-    for a, b in ((201, 13), (77, 3), (5, 0)):
+    for cycle, (a, b) in enumerate(((201, 13), (77, 3), (5, 0)), start=1):
         enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U8(a), "B": PtxtType.U8(b)})
-        out = {k: v.value for k, v in ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, "u8"), True).items()}
+        out = {k: v.value for k, v in ac.decrypt_outputs(ac.evaluate_encrypted(enc, cycle, "u8"), True).items()}
         assert out["Q"] == (a // b if b else 255), (a, b, out)  # x / 0 = all ones, as tfhe's
         assert out["QS"] == a // 7
         assert out["L3"] == (a << 3) % 256 and out["R3"] == a >> 3 and out["L2"] == (a << 2) % 256 and out["R1"] == a >> 1
@@ -223,10 +223,10 @@ shr g11(A, 5, SR);
     circuit, wire_set, _, _ = _circuit(text, is_arith=True, is_text=True)
     ac = ArithCircuit(client_key, server_key, circuit)
     rng = np.random.default_rng(2024)
-    for _ in range(3):
+    for cycle in (1, 2, 3):
         a, b = int(rng.integers(0, 256)), int(rng.integers(1, 256))
         enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U8(a), "B": PtxtType.U8(b)})
-        out = {k: v.value for k, v in ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, "u8"), True).items()}
+        out = {k: v.value for k, v in ac.decrypt_outputs(ac.evaluate_encrypted(enc, cycle, "u8"), True).items()}
         want = {"S": (a + b) % 256, "D": (a - b) % 256, "P": (a * b) % 256, "Q": a // b, "L": (a << (b % 8)) % 256,
                 "R": a >> (b % 8), "SA": (a + 77) % 256, "SS": (a - 77) % 256, "SM": (a * 77) % 256, "SQ": a // 11,
                 "SL": (a << 5) % 256, "SR": a >> 5}

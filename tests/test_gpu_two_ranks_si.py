@@ -42,7 +42,7 @@ def _both_ways(circ, sk, wire_set, inputs, ptxt_type, blocks, rank, world):
     again = SiEncWireMap(sk, blocks=blocks)
     for w, ct in saved.items():
         again[w] = ct
-    out1 = circ.evaluate_encrypted(again, 1, ptxt_type)
+    out1 = circ.evaluate_encrypted(again, 2, ptxt_type)  # a new cycle: arithmetic circuits memoise per cycle (gates.rs:307-312)
     single = {w: np.array(out1[w], copy=True) for w in out1.keys()}
     return sharded, single, batches, out
 

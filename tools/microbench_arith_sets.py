@@ -27,7 +27,7 @@ for rep in range(2):
     enc = EvalCircuit.encrypt_inputs(ac, wire_set, inputs)
     sk.sync()
     t0 = time.perf_counter()
-    enc = EvalCircuit.evaluate_encrypted(ac, enc, 1, "u32")
+    enc = EvalCircuit.evaluate_encrypted(ac, enc, 1 + rep, "u32")  # a new cycle each time (same-cycle memo)
     sk.sync()
     dt = time.perf_counter() - t0
 out = {k: v.value for k, v in EvalCircuit.decrypt_outputs(ac, enc, True).items()}
