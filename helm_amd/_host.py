@@ -55,6 +55,8 @@ HOST_API = {
     "helm_host_si_circuit_set_wopbs": (C.c_int, [vp, vp, C.c_int]),
     "helm_host_si_circuit_add_lane": (C.c_int, [vp, vp]),
     "helm_host_si_circuit_log": (vp, [vp]),
+    "helm_host_radix_scratch_rows": (C.c_int64, [vp, C.c_int32, vp, C.c_int64]),
+    "helm_host_radix_level": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "helm_host_si_circuit_pbs_per_cycle": (C.c_int64, [vp]),
     "helm_host_si_circuit_pbs_rounds_per_cycle": (C.c_int64, [vp]),
     "helm_host_si_circuit_memo_hits": (C.c_int64, [vp]),

@@ -79,14 +79,18 @@ vp = C.c_void_p
 
 
 def _load(name):
-    path = os.path.join(_CSRC, name)
+    path = name if os.path.isabs(name) else os.path.join(_CSRC, name)
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: build it with `make -C {_CSRC}` "
                           "(or __graft_entry__.build()); helm_amd has no fallback path")
     return C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
-hip = _load("libhelm_hip.so")
+# HELM_HIP_LIB: another build of libhelm_hip.so (same-box A/B of compile-time switches, tools/ab_variants.py) - a file
+# name under csrc/ or an absolute path; loaded first, so libhelm_host.so's references bind to it as well.  The
+# Makefile's library stays untouched (round 2's script copied the alternative over it).
+_alt = os.environ.get("HELM_HIP_LIB")
+hip = _load(_alt if _alt else "libhelm_hip.so")
 host = _load("libhelm_host.so")
 
 # every symbol include/helm_hip.h declares: (restype, argtypes)

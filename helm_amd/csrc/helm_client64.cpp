@@ -61,6 +61,23 @@ int helm_si_client_named_params(const char *name, helm_si_params *p, double *lwe
         p->grouping_factor = 3;
         *lwe_std = 1e-9;
         *glwe_std = 1e-16;
+    } else if (s == "shortint_m1c1") {
+        // tfhe 0.4 shortint PARAM_MESSAGE_1_CARRY_1_KS_PBS, the set the reference binary installs for LUT mode
+        // (src/bin/helm.rs:301) [dimensions recalled, SURVEY.md App. B: n = 684, k = 3, N = 512, PBS 18 x 1,
+        // KS 4 x 3, message_modulus = carry_modulus = 2; LWE noise recalled; GLWE noise interpolated along tfhe's
+        // security line between its k N = 1024 (4.99e-8) and k N = 2048 (2.94e-16) values: an approximate set]
+        p->n = 684; p->k = 3; p->N = 512; p->pbs_l = 1; p->pbs_logB = 18; p->ks_l = 3; p->ks_logB = 4;
+        p->message_modulus = 2; p->carry_modulus = 2;
+        *lwe_std = 0.00002043357207216175;
+        *glwe_std = 0.0000000000038;
+    } else if (s == "si_toy_512_k3") { // the k = 3 kernel at toy size (oracle-sized; 16 plaintext values like the other toys)
+        p->n = 10; p->k = 3; p->N = 512; p->pbs_l = 1; p->pbs_logB = 18; p->ks_l = 3; p->ks_logB = 4;
+        *lwe_std = 1e-9;
+        *glwe_std = 1e-15;
+    } else if (s == "si_toy_512_k2") {
+        p->n = 9; p->k = 2; p->N = 512; p->pbs_l = 1; p->pbs_logB = 20; p->ks_l = 4; p->ks_logB = 3;
+        *lwe_std = 1e-9;
+        *glwe_std = 1e-15;
     } else if (s == "si_toy_1024_mb2") {
         p->n = 8; p->N = 1024; p->pbs_l = 1; p->pbs_logB = 22; p->ks_l = 5; p->ks_logB = 3;
         p->grouping_factor = 2;

@@ -359,6 +359,183 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
 }
 
 // ------------------------------------------------------------------------------------
+// k_pbs64k<LOGN, K>: the programmable bootstrap for k > 1 and one decomposition level - the
+// parameter set the reference binary installs for LUT mode, PARAM_MESSAGE_1_CARRY_1_KS_PBS
+// (reference src/bin/helm.rs:301: k = 3, N = 512 [dimensions recalled]).  2 (k+1) waves:
+// wave w = (polynomial p = w >> 1, field f = w & 1), as k_pbs64; what changes with k + 1 > 2
+// polynomials is the hand-over: a wave's product with key column c belongs to polynomial c, and
+// the k foreign ones are summed into SUM[c][f] with ds_add_f64 - exact integers below 2^53, so
+// the sum does not depend on the order the waves arrive in.  Three workgroup barriers per step.
+// ------------------------------------------------------------------------------------
+template <int LOGN_, int K_>
+struct Pbs64kCfg {
+    static constexpr int LOGN = LOGN_, L = 1, K = K_, K1 = K_ + 1, NW = 2 * K1;
+    using G = Geo<LOGN>;
+    static constexpr int MAX_SMALL_N = 1024;
+    static constexpr size_t X_OFF = 0;                                            // double [NW][XPAD]
+    static constexpr int TW_IDX = G::N >> G::BC, TW_FIELD = TW_IDX + G::TWC * 64;
+    static constexpr size_t TW_OFF = X_OFF + sizeof(double) * NW * G::XPAD;       // double [2][TW_FIELD]
+    static constexpr size_t ACC_OFF = TW_OFF + sizeof(double) * 2 * TW_FIELD;     // u64 [K1][N]
+    static constexpr size_t SUM_OFF = ACC_OFF + sizeof(uint64_t) * K1 * G::N;     // double [K1][2][N]
+    static constexpr size_t MS_OFF = SUM_OFF + sizeof(double) * K1 * 2 * G::N;    // u16 [n+1]
+    static constexpr size_t BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
+    static_assert(NW <= 16, "a workgroup holds at most 16 waves");
+};
+
+template <typename C, typename F>
+__device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *__restrict__ bsk, int n, int logB,
+                                            double p0inv_mod_p1, int p, int f, int lane)
+{
+    constexpr int LOGN = C::LOGN, K1 = C::K1;
+    using G = Geo<LOGN>;
+    constexpr int N = G::N, E = G::E, H = E / 2;
+    double *X = reinterpret_cast<double *>(smem + C::X_OFF);
+    uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
+    double *SUM = reinterpret_cast<double *>(smem + C::SUM_OFF);
+    const uint16_t *MS = reinterpret_cast<const uint16_t *>(smem + C::MS_OFF);
+    double *xb = X + (size_t)(p * 2 + f) * G::XPAD;                          // own scratch
+    const double *x_field = X + (size_t)(p * 2 + (1 - f)) * G::XPAD;         // same polynomial, other field
+    uint64_t *acc_p = ACC + (size_t)p * N;
+    const double *twt = reinterpret_cast<const double *>(smem + C::TW_OFF) + (size_t)f * C::TW_FIELD;
+    TwHybrid<LOGN, false> twf{twt, twt + C::TW_IDX + lane};
+    TwHybrid<LOGN, true> twi{twt, twt + C::TW_IDX + (63 - lane)};
+    // key words of step i for this wave: [i][row p][c][f][e/2][lane] as double2 (the layout k_bsk_convert64 writes)
+    const size_t per_poly = (size_t)2 * (N / 2); // both fields
+    const size_t bsk_step = (size_t)K1 * K1 * per_poly;
+    const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * 2 + f) * (N / 2) + lane;
+    const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+    for (int i = 0; i < n; i++) {
+        const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
+        if (a == 0) continue; // uniform over the workgroup
+        const double2 *bp_i = bsk_w + (size_t)i * bsk_step;
+        double2 kw[K1][H];
+#pragma unroll
+        for (int c = 0; c < K1; c++)
+#pragma unroll
+            for (int u = 0; u < H; u++) kw[c][u] = (bp_i + (size_t)c * per_poly)[u * 64];
+        // ---- rotate / subtract, one signed digit per coefficient (pbs_l = 1) ------------------
+        double x[1][E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int j = G::jA(lane, e);
+            const int src = (j - a) & (2 * N - 1);
+            uint64_t v = acc_p[src & (N - 1)];
+            if (src >= N) v = 0ull - v;
+            v -= acc_p[j];
+            const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
+            x[0][e] = (double)((int)st - (int)(((st + half_m1) >> logB) << logB));
+        }
+        ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+        // ---- products: column p stays, the others go to the waves of their polynomials --------
+        double mine[E];
+#pragma unroll
+        for (int c = 0; c < K1; c++) {
+            double *sum_c = SUM + ((size_t)c * 2 + f) * N + lane;
+#pragma unroll
+            for (int u = 0; u < H; u++) {
+                const double t0 = mulmod<F>(x[0][2 * u], kw[c][u].x), t1 = mulmod<F>(x[0][2 * u + 1], kw[c][u].y);
+                if (c == p) {
+                    mine[2 * u] = t0;
+                    mine[2 * u + 1] = t1;
+                } else { // |t| <= 1.5 p, k of them and the own one: <= 6 p < 2^53, every partial sum exact
+                    lds_add_wg(sum_c + (2 * u) * 64, t0);
+                    lds_add_wg(sum_c + (2 * u + 1) * 64, t1);
+                }
+            }
+        }
+        lds_block_sync(); // every foreign product is in
+        {
+            double *sum_p = SUM + ((size_t)p * 2 + f) * N + lane;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                mine[e] = reduce<F>(mine[e] + sum_p[e * 64]);
+                sum_p[e * 64] = 0.0; // for the next step: its additions come after two more barriers
+            }
+        }
+        ntt_inverse<F, LOGN>(mine, xb, twi, lane);
+        // ---- CRT: field-f wave lifts slots [f*H, f*H+H) of its polynomial ---------------------
+#pragma unroll
+        for (int e = 0; e < H; e++) xb[e * 64 + lane] = mine[(1 - f) * H + e];
+        lds_block_sync();
+#pragma unroll
+        for (int e = 0; e < H; e++) {
+            const double own = mine[f * H + e], oth = x_field[e * 64 + lane];
+            const double r0 = f == 0 ? own : oth, r1 = f == 0 ? oth : own;
+            const double t = mulmod<F1>(r1 - r0, p0inv_mod_p1);
+            const uint64_t xv = (uint64_t)to_int64(r0) + F0::P_U64 * (uint64_t)to_int64(t);
+            acc_p[G::jA(lane, f * H + e)] += xv;
+        }
+        lds_block_sync(); // accumulator complete before the next step's rotated reads
+    }
+}
+
+template <typename C>
+__global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64k(const Pbs64Job *__restrict__ jobs,
+                                                          const uint64_t *__restrict__ small, // rows of n+1
+                                                          const uint64_t *__restrict__ luts,  // rows of N
+                                                          const double *__restrict__ bsk,     // NTT domain, both fields
+                                                          const double *__restrict__ tw0, const double *__restrict__ tw1,
+                                                          uint64_t *__restrict__ out, // rows of k*N+1
+                                                          int n, int logB, double p0inv_mod_p1)
+{
+    constexpr int LOGN = C::LOGN, K = C::K;
+    using G = Geo<LOGN>;
+    constexpr int N = G::N, E = G::E, H = E / 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
+    double *SUM = reinterpret_cast<double *>(smem + C::SUM_OFF);
+    uint16_t *MS = reinterpret_cast<uint16_t *>(smem + C::MS_OFF);
+    double *TW = reinterpret_cast<double *>(smem + C::TW_OFF);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = w >> 1, f = w & 1;
+    const Pbs64Job job = jobs[blockIdx.x];
+    const uint64_t *lwe = small + (size_t)job.in_row * ((size_t)n + 1);
+    for (int i = tid; i <= n; i += 64 * C::NW) MS[i] = (uint16_t)modswitch64(lwe[i], LOGN + 1);
+    for (int i = tid; i < C::TW_IDX; i += 64 * C::NW) {
+        TW[i] = tw0[i];
+        TW[C::TW_FIELD + i] = tw1[i];
+    }
+    for (int r = w; r < G::TWC; r += C::NW) { // lane-table rows of block C
+        const int idx = tw_lane_index<LOGN>(G::TWB + r, lane);
+        TW[C::TW_IDX + r * 64 + lane] = tw0[idx];
+        TW[C::TW_FIELD + C::TW_IDX + r * 64 + lane] = tw1[idx];
+    }
+    for (int j = tid; j < (K + 1) * 2 * N; j += 64 * C::NW) SUM[j] = 0.0;
+    __syncthreads();
+    { // accumulator: (0, ..., 0, X^{-b~} * lut)
+        const int bt = (int)MS[n];
+        const uint64_t *tv = luts + (size_t)job.lut * N;
+        for (int j = tid; j < (K + 1) * N; j += 64 * C::NW) {
+            uint64_t v = 0;
+            if (j >= K * N) {
+                const int idx = ((j - K * N) + bt) & (2 * N - 1);
+                v = tv[idx & (N - 1)];
+                if (idx >= N) v = 0ull - v;
+            }
+            ACC[j] = v;
+        }
+    }
+    __syncthreads();
+    if (f == 0) pbs64k_body<C, F0>(smem, bsk, n, logB, p0inv_mod_p1, p, 0, lane);
+    else pbs64k_body<C, F1>(smem, bsk, n, logB, p0inv_mod_p1, p, 1, lane);
+    // ---- sample extract (coefficient 0); wave (p, f) writes its half of the slots ------
+    const uint64_t *acc_p = ACC + (size_t)p * N;
+    uint64_t *ob = out + (size_t)job.out_row * ((size_t)K * N + 1);
+    if (p < K) {
+#pragma unroll
+        for (int e = 0; e < H; e++) {
+            const int j = G::jA(lane, f * H + e);
+            const uint64_t v = acc_p[j];
+            if (j == 0) ob[p * N] = v;
+            else ob[p * N + (N - j)] = 0ull - v;
+        }
+    } else if (f == 0 && lane == 0) {
+        ob[K * N] = acc_p[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // k_pbs64s<LOGN>: the same bootstrap with EIGHT waves per ciphertext (two per SIMD), L = 1:
 // wave w = (polynomial p, field f, half h).  A size-N negacyclic transform splits, after its
 // first butterfly stage (pairs j, j + N/2, twiddle psi^(N/2)), into two independent size-N/2
@@ -373,6 +550,20 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
 // coefficients, accumulate.  Seven workgroup barriers per step, no redundant work except the
 // 16 stage-1 products per lane.
 // ------------------------------------------------------------------------------------
+// LDS flags between two waves of a workgroup (LDS-only fences, as lds_block_sync: global loads stay in flight).
+// set: everything this wave wrote to or read from LDS before is done when the value shows; wait: nothing this wave does
+// to LDS afterwards starts before the value was seen.
+[[maybe_unused]] __device__ __forceinline__ void lds_flag_set(uint32_t *flag, uint32_t v)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+[[maybe_unused]] __device__ __forceinline__ void lds_flag_wait(const uint32_t *flag, uint32_t v)
+{
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int LOGN_, int L_ = 1>
 struct Pbs64sCfg {
     static constexpr int LOGN = LOGN_, L = L_, K = 1, K1 = 2, NW = 8;
@@ -385,6 +576,16 @@ struct Pbs64sCfg {
 #ifndef HELM_SI_FUSED_XCHG
 #define HELM_SI_FUSED_XCHG 1 // one exchange for the last inverse stage and the CRT (two barriers instead of four)
 #endif
+#ifndef HELM_SI_KW1_EARLY
+#define HELM_SI_KW1_EARLY 1 // second key column fetched before the LAST block of the forward half transform
+#endif
+#ifndef HELM_SI_PAIR_FLAG
+#define HELM_SI_PAIR_FLAG 0 // hand-over between the two waves of a SIMD through LDS flags instead of two workgroup barriers:
+                            // measured 2.2 % SLOWER (profiles/r03/si_kernel_experiments.txt), kept as a switch
+#endif
+#ifndef HELM_SI_LAZY_INV
+#define HELM_SI_LAZY_INV 1 // the half inverse leaves its outputs uncentred: the last stage recentres anyway
+#endif
     static constexpr bool PRIO = HELM_SI_PRIO != 0;
     static constexpr int TW_IDX = GS::N >> GS::BC, TW_PART = TW_IDX + GS::TWC * 64; // per (field, half)
     static constexpr size_t X_OFF = 0;                                              // double [NW][GS::XPAD]
@@ -395,7 +596,8 @@ struct Pbs64sCfg {
     using dig_t = std::conditional_t<L == 1, int32_t, int16_t>;
     static constexpr size_t DIG_OFF = ACC_OFF + sizeof(uint64_t) * K1 * G::N;       // dig_t [K1][L][N]
     static constexpr size_t MS_OFF = DIG_OFF + sizeof(dig_t) * K1 * L * G::N;       // u16 [n+1]
-    static constexpr size_t BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
+    static constexpr size_t FLAG_OFF = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16; // u32 [2][NW]
+    static constexpr size_t BYTES = FLAG_OFF + sizeof(uint32_t) * 2 * NW;
 };
 
 template <typename C, typename F, int h>
@@ -423,6 +625,11 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
     TwHybrid<LOGN - 1, false> twf{tw_own, tw_own + C::TW_IDX + lane};
     TwHybrid<LOGN - 1, true> twi{tw_oth, tw_oth + C::TW_IDX + (63 - lane)};
     const int quarter = f * 2 + h; // which E/4 slots of the polynomial this wave decomposes
+#if HELM_SI_PAIR_FLAG
+    uint32_t *flags = reinterpret_cast<uint32_t *>(smem + C::FLAG_OFF); // zeroed by the kernel before the first barrier
+    uint32_t *flag_mine = flags + wave_of(p, f, h), *flag_partner = flags + wave_of(1 - p, f, h);
+    uint32_t seq = 0;
+#endif
 
     // key words of this wave: [i][row p][c][level][f][h][e/2][lane] as double2
     const size_t part = (size_t)(GS::N / 2);
@@ -487,14 +694,25 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
                     x[0][e] = h ? U - V : U + V;
                 }
             }
+            // the second column is asked for between the transform's second transpose and its last block: behind both
+            // LDS round trips (fetching it before the transform was measured 1 % slower,
+            // profiles/r02/si_kernel_experiments.txt), with a block of arithmetic to cover the latency
+            auto fetch_kw1 = [&]() {
+#pragma unroll
+                for (int u = 0; u < HC; u++) kw[1][u] = (bp_i + (size_t)(1 * L + lev) * 4 * part)[u * 64];
+            };
+#if HELM_SI_KW1_EARLY
+            ntt_forward<F, LOGN - 1, 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane, fetch_kw1);
+#else
             ntt_forward<F, LOGN - 1, 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
+#endif
             if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
             if (lev == 0) {
                 STAMP(2) // digits read, stage 1, half transform
             }
-            // (fetching this column before the transform was measured 1 % slower: profiles/r02/si_kernel_experiments.txt)
-#pragma unroll
-            for (int u = 0; u < HC; u++) kw[1][u] = (bp_i + (size_t)(1 * L + lev) * 4 * part)[u * 64];
+#if !HELM_SI_KW1_EARLY
+            fetch_kw1();
+#endif
 #pragma unroll
             for (int c = 0; c < K1; c++) {
 #pragma unroll
@@ -515,6 +733,24 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
 #pragma unroll
         for (int e = 0; e < EH; e++) xb[e * 64 + lane] = other[e];
         STAMP(3) // products
+#if HELM_SI_PAIR_FLAG
+        // The hand-over concerns two waves only: (p, f, h) and (1 - p, f, h), which share a SIMD and run the same
+        // instruction stream.  Two flags per wave in LDS (sequence numbers of the step) replace the two workgroup
+        // barriers: "my sums are written" (release after the writes; the partner acquires before it reads) and "I have
+        // read yours" (release after the reads; the partner acquires before its inverse transform first writes into
+        // its scratch).  The other six waves are not held up.
+        seq++;
+        lds_flag_set(flag_mine, seq);
+        lds_flag_wait(flag_partner, seq);
+#pragma unroll
+        for (int e = 0; e < EH; e++) mine[e] = reduce<F>(mine[e] + x_poly[e * 64 + lane]);
+        lds_flag_set(flag_mine + C::NW, seq);
+        STAMP(4) // flag 1, sum
+        auto partner_has_read = [&]() { lds_flag_wait(flag_partner + C::NW, seq); };
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
+        ntt_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane, partner_has_read);
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
+#else
         lds_block_sync();
 #pragma unroll
         for (int e = 0; e < EH; e++) mine[e] = reduce<F>(mine[e] + x_poly[e * 64 + lane]);
@@ -522,8 +758,9 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         STAMP(4) // barrier 2, sum, barrier 3
         // ---- (3) half inverse, meet the other half, last stage -------------------------------
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
-        ntt_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0>(mine, xb, twi, lane); // a_h[e * 64 + lane], centred
+        ntt_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane); // a_h[e * 64 + lane], centred
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
+#endif
         STAMP(5) // half inverse
 #pragma unroll
         for (int e = 0; e < EH; e++) xb[e * 64 + lane] = mine[e];
@@ -739,7 +976,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
         lds_block_sync(); // hand-over read: scratch free again
         // ---- (3) half inverse, meet the other half, last stage -----------------------------------
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
-        ntt_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0>(mine, xb, twi, lane);
+        ntt_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane);
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int e = 0; e < EH; e++) xb[e * 64 + lane] = mine[e];
@@ -816,6 +1053,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64s(const Pbs64Job *__rest
     const Pbs64Job job = jobs[blockIdx.x];
     const uint64_t *lwe = small + (size_t)job.in_row * ((size_t)n + 1);
     for (int i = tid; i <= n; i += 64 * C::NW) MS[i] = (uint16_t)modswitch64(lwe[i], LOGN + 1);
+    if (tid < 2 * C::NW) reinterpret_cast<uint32_t *>(smem + C::FLAG_OFF)[tid] = 0u;
     // derived tables: index part for blocks A, B and lane table for block C, per (field, half)
     for (int q = 0; q < 4; q++) {
         const double *src = tw_sub + (size_t)q * GS::N;
@@ -1303,9 +1541,28 @@ struct Timed {
 
 bool si_supported(const helm_si_params &P)
 {
+    // k > 1: k_pbs64k, one level, N = 512 (PARAM_MESSAGE_1_CARRY_1_KS_PBS of helm.rs:301 has k = 3)
+    if (P.k == 2 || P.k == 3) return P.N == 512 && P.pbs_l == 1 && P.grouping_factor <= 1;
     if (P.k != 1) return false;
     if (!(P.N == 512 || P.N == 1024 || P.N == 2048)) return false;
     return P.pbs_l == 1 || P.pbs_l == 2;
+}
+
+template <typename C>
+hipError_t launch_pbs64k_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
+                           const uint64_t *luts, uint64_t *out)
+{
+    static bool attr_done[64] = {false};
+    auto kern = k_pbs64k<C>;
+    if (!attr_done[ctx->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
+        if (e != hipSuccess) return e;
+        attr_done[ctx->device & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, small, luts, ctx->bsk,
+                       ctx->tw[0], ctx->tw[1], out, ctx->P.n, ctx->P.pbs_logB, ctx->p0inv_mod_p1);
+    return hipGetLastError();
 }
 
 template <typename C, int MODE = 0>
@@ -1372,6 +1629,8 @@ hipError_t launch_pbs64(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, c
                         const uint64_t *luts, uint64_t *out)
 {
     const helm_si_params &P = ctx->P;
+    if (P.k == 3) return launch_pbs64k_c<Pbs64kCfg<9, 3>>(ctx, jobs, count, small, luts, out);
+    if (P.k == 2) return launch_pbs64k_c<Pbs64kCfg<9, 2>>(ctx, jobs, count, small, luts, out);
     if (ctx->use_split) {
         if (ctx->group > 1) {
             if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10>, true>(ctx, jobs, count, small, luts, out);
@@ -1710,7 +1969,7 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
     *out = nullptr;
     const helm_si_params &P = *params;
     if (!si_supported(P))
-        return fail(HELM_ERR_INVALID, "unsupported (k,N,pbs_l): built variants are k = 1, N in {512,1024,2048}, pbs_l in {1,2}");
+        return fail(HELM_ERR_INVALID, "unsupported (k,N,pbs_l): built variants are k = 1, N in {512,1024,2048}, pbs_l in {1,2}; k in {2,3}, N = 512, pbs_l = 1");
     if (P.n < 1 || P.n > 1024) return fail(HELM_ERR_INVALID, "n must be in [1,1024]");
     if (P.pbs_logB < 2 || P.pbs_logB > 30 || P.pbs_logB * P.pbs_l > 31)
         return fail(HELM_ERR_INVALID, "bad PBS decomposition (pbs_logB * pbs_l <= 31: every tfhe shortint set)");
@@ -1783,7 +2042,7 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
     }
     // eight-wave kernel (split transforms) where it exists: N >= 1024, one or two levels (HELM_SI_SPLIT=0: off)
     static_assert(Pbs64sCfg<11, 2>::BYTES <= 160 * 1024, "k_pbs64s<11, 2> must fit the LDS of a CU");
-    ctx->use_split = (P.pbs_l == 1 || (P.pbs_l == 2 && P.pbs_logB <= 15)) && N >= 1024;
+    ctx->use_split = (P.pbs_l == 1 || (P.pbs_l == 2 && P.pbs_logB <= 15)) && N >= 1024 && P.k == 1;
     if (const char *v = getenv("HELM_HIP_KS_MFMA")) ctx->ks_mfma = atoi(v);
     if (const char *v = getenv("HELM_SI_SPLIT")) ctx->use_split = (ctx->use_split && atoi(v) != 0) || group > 1;
     if (ctx->use_split) {

@@ -360,6 +360,42 @@ int helm_host_si_circuit_add_lane(helm_si_circuit *c, helm_si_ctx *lane)
         else c->arith->clear_lanes();
     });
 }
+// FheUintN operators of one level (gates.rs:306-702) as one batched call: what a Rust HipArithCircuit forwards to
+static std::vector<RadixOp> to_radix_ops(const helm_radix_op *ops, int64_t count)
+{
+    if (!ops || count < 0) throw Panic("radix level: bad argument");
+    std::vector<RadixOp> v((size_t)count);
+    for (int64_t g = 0; g < count; g++) {
+        if (ops[g].kind < 0 || ops[g].kind > HELM_RADIX_SHR_SCALAR) throw Panic("radix level: unknown operator kind");
+        v[(size_t)g].kind = (RadixOp::Kind)ops[g].kind;
+        v[(size_t)g].a = ops[g].a;
+        v[(size_t)g].b = ops[g].b;
+        v[(size_t)g].out = ops[g].out;
+        v[(size_t)g].scalar = ((unsigned __int128)ops[g].scalar_hi << 64) | ops[g].scalar_lo;
+    }
+    return v;
+}
+int64_t helm_host_radix_scratch_rows(helm_si_ctx *ctx, int32_t blocks, const helm_radix_op *ops, int64_t count)
+{
+    int64_t rows = -1;
+    guard([&] {
+        if (!ctx || blocks < 1) throw Panic("radix level: bad argument");
+        RadixEngine eng(ctx, blocks);
+        rows = eng.scratch_rows(to_radix_ops(ops, count));
+    });
+    return rows;
+}
+int helm_host_radix_level(helm_si_ctx *ctx, helm_si_wires *wires, int32_t blocks, const helm_radix_op *ops, int64_t count,
+                          int32_t scratch_first_row, int64_t *pbs_out, int64_t *rounds_out)
+{
+    return guard([&] {
+        if (!ctx || !wires || blocks < 1 || scratch_first_row < 0) throw Panic("radix level: bad argument");
+        RadixEngine eng(ctx, blocks);
+        eng.run_level(wires, to_radix_ops(ops, count), scratch_first_row);
+        if (pbs_out) *pbs_out = eng.pbs_count();
+        if (rounds_out) *rounds_out = eng.pbs_rounds();
+    });
+}
 char *helm_host_si_circuit_log(helm_si_circuit *c) { return dup(c->lut ? c->lut->log() : c->arith->log()); }
 int64_t helm_host_si_circuit_pbs_per_cycle(const helm_si_circuit *c)
 {

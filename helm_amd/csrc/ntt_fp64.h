@@ -425,8 +425,14 @@ __device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const TW &t
 // xbuf: wave-private LDS scratch of M * Geo::XPAD doubles.
 // PRIO > 0: the wave enters at issue priority PRIO and steps down by one after each of the first two
 // blocks (waves that share a SIMD and run the same phase then advance block by block, see k_pbs).
-template <typename F, int LOGN, int M, typename TW, int PRIO = 0>
-__device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double *xbuf, const TW &tw, int lane)
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// before_last: called between the second transpose and the last block (both LDS round trips behind, a block of pure
+// arithmetic ahead): the place to issue global loads whose latency the block then covers.
+template <typename F, int LOGN, int M, typename TW, int PRIO = 0, typename HOOK = NoHook>
+__device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double *xbuf, const TW &tw, int lane,
+                                            const HOOK &before_last = HOOK())
 {
     using G = Geo<LOGN>;
     fwd_block<F, LOGN, M, 6, LOGN - 1, LOGN - G::BA, 0>(x, tw, G::jA(lane, 0));
@@ -454,17 +460,24 @@ __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double
 #pragma unroll
         for (int e = 0; e < G::E; e++) x[m][e] = pC[m * G::XPAD + e];
     lds_wave_sync();
+    before_last();
     fwd_block<F, LOGN, M, 0, G::BC - 1, 0, G::TWA + G::TWB>(x, tw, G::jC(lane, 0));
 }
 
 // Inverse (without the 1/N factor, which is folded into the bootstrapping key).
 // in : x[e] = transform word at jC(lane,e), |x| <= 0.5p.
 // out: x[e] = coefficient jA(lane,e), exactly centred (|x| <= p/2).
-template <typename F, int LOGN, typename TW, int PRIO = 0>
-__device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *xbuf, const TW &tw, int lane)
+// CENTRE = false leaves the outputs as the last block produced them (|x| <= 8 * 0.5 p after a three- or four-stage
+// block: for callers that recentre downstream anyway).
+// before_write: called after the first block, before the transform's first write into xbuf (a caller whose xbuf is
+// still being read by another wave waits there instead of before the transform).
+template <typename F, int LOGN, typename TW, int PRIO = 0, bool CENTRE = true, typename HOOK = NoHook>
+__device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *xbuf, const TW &tw, int lane,
+                                            const HOOK &before_write = HOOK())
 {
     using G = Geo<LOGN>;
     inv_block<F, LOGN, 0, 0, G::BC - 1, 0>(x, tw, G::jC(lane, 0));
+    before_write();
     if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);
     double *pA = xbuf + G::baseA(lane), *pB = xbuf + G::baseB(lane), *pC = xbuf + G::baseC(lane);
 #pragma unroll
@@ -482,8 +495,15 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *x
     for (int e = 0; e < G::E; e++) x[e] = pA[G::offA1(e)];
     lds_wave_sync();
     inv_block<F, LOGN, 6, LOGN - G::BA, LOGN - 1, G::TWC + G::TWB>(x, tw, G::jA(lane, 0));
+    if constexpr (CENTRE) {
 #pragma unroll
-    for (int e = 0; e < G::E; e++) x[e] = reduce<F>(x[e]);
+        for (int e = 0; e < G::E; e++) x[e] = reduce<F>(x[e]);
+    } else if constexpr (G::BA == 4) {
+        // four doublings from 0.5 p: the pure-sum slot reaches 8 p, every other slot passed a multiplication on the way
+        // (<= 4.8 p); recentring slot 0 keeps sums and differences of two such values below 2^53 = 14.2 p
+        static_assert(F::LAZY, "uncentred outputs need the headroom of the 49-bit fields");
+        x[0] = reduce<F>(x[0]);
+    }
 }
 
 } // namespace helm

@@ -130,6 +130,26 @@ int helm_host_si_circuit_set_wopbs(helm_si_circuit *c, helm_wop_ctx *wop, int bi
  * then evaluated concurrently, one lane each, instead of meeting at every level boundary; identical ciphertexts.
  * lane = NULL removes all lanes.  helm_host_si_circuit_pbs_rounds_per_cycle() then reports the longest lane. */
 int helm_host_si_circuit_add_lane(helm_si_circuit *c, helm_si_ctx *lane);
+/* One level of arithmetic-mode operators as ONE batched call on a table of radix integers - what the reference does
+ * gate by gate with the FheUintN operators (src/gates.rs:306-702: evaluate_encrypted_{copy,mul,div,add,sub,shift}_block
+ * and their _plain forms; level loop src/circuit.rs:1320-1441).  An integer is `blocks` consecutive rows (2 message bits
+ * per block, least significant first; 4..64 blocks for FheUint8..128); a, b, out are FIRST rows; an operator with a
+ * plaintext operand (an all-digit wire name, circuit.rs:1328-1334) carries it in scalar_lo / scalar_hi.  The call needs
+ * helm_host_radix_scratch_rows() rows of the same table from scratch_first_row on (beyond every integer).  What a Rust
+ * `impl EvalCircuit<FheType> for HipArithCircuit` forwards each level to. */
+typedef enum {
+    HELM_RADIX_COPY = 0, HELM_RADIX_ADD, HELM_RADIX_SUB, HELM_RADIX_MUL, HELM_RADIX_DIV, HELM_RADIX_SHL, HELM_RADIX_SHR,
+    HELM_RADIX_ADD_SCALAR, HELM_RADIX_SUB_SCALAR, HELM_RADIX_MUL_SCALAR, HELM_RADIX_DIV_SCALAR, HELM_RADIX_SHL_SCALAR,
+    HELM_RADIX_SHR_SCALAR
+} helm_radix_kind;
+typedef struct {
+    int32_t kind;      /* helm_radix_kind */
+    int32_t a, b, out; /* first rows; b = -1 for copy and the scalar forms */
+    uint64_t scalar_lo, scalar_hi;
+} helm_radix_op;
+int64_t helm_host_radix_scratch_rows(helm_si_ctx *ctx, int32_t blocks, const helm_radix_op *ops, int64_t count);
+int helm_host_radix_level(helm_si_ctx *ctx, helm_si_wires *wires, int32_t blocks, const helm_radix_op *ops, int64_t count,
+                          int32_t scratch_first_row, int64_t *pbs_out, int64_t *rounds_out);
 char *helm_host_si_circuit_log(helm_si_circuit *c);
 /* bootstraps of the last evaluate_encrypted, and (arithmetic) the number of batched rounds */
 int64_t helm_host_si_circuit_pbs_per_cycle(const helm_si_circuit *c);

@@ -54,6 +54,28 @@ def test_encrypted_8_bit_adder_lut(keys):  # circuit_test.rs:266-311
     assert "Evaluated gates in level [1/" in lc.log()
 
 
+def test_encrypted_8_bit_adder_lut_2_1_on_the_binarys_parameter_set():  # circuit_test.rs:266-311 + helm.rs:301
+    """The reference's LUT test netlist (8-bit-adder-lut-2-1.v: 2-input LUTs, circuit_test.rs:272) under the set the
+    reference BINARY installs for LUT mode, PARAM_MESSAGE_1_CARRY_1_KS_PBS (helm.rs:301; k = 3, N = 512): every wire
+    equals the plaintext evaluation."""
+    client_key, server_key = helm_amd.gen_keys_shortint("shortint_m1c1", seed=5)
+    try:
+        circuit, wire_set, input_wires, output_wires = _circuit(f"{NET}/8-bit-adder-lut-2-1.v")
+        inputs = verilog_parser.read_input_wires(os.path.join(HERE, "golden", "8-bit-adder.inputs.csv"), "bool")
+        ptxt = circuit.evaluate(circuit.initialize_wire_map(wire_set, inputs, "bool"))
+        lc = LutCircuit(client_key, server_key, circuit)
+        enc = EvalCircuit.evaluate_encrypted(lc, EvalCircuit.encrypt_inputs(lc, wire_set, inputs), 1, "bool")
+        assert lc.pbs_per_cycle() == 40
+        for wire, want in ptxt.items():
+            assert client_key.decrypt(enc[wire]) == int(bool(want)), wire
+        out = EvalCircuit.decrypt_outputs(lc, enc, True)
+        a = sum(int(bool(inputs[f"a[{i}]"])) << i for i in range(8))
+        b = sum(int(bool(inputs[f"b[{i}]"])) << i for i in range(8))
+        assert sum(out[f"sum[{i}]"].value << i for i in range(8)) + (out["cout"].value << 8) == a + b + int(bool(inputs["cin"]))
+    finally:
+        server_key.close()
+
+
 def test_lut_sequential_ready_latch(keys):
     """2-bit counter out of LUTs and DFFs, READY-latched outputs (circuit.rs:1002-1030)."""
     client_key, server_key = keys

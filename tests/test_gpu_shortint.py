@@ -10,7 +10,8 @@ import oracle
 
 pytestmark = pytest.mark.gpu
 
-TOYS = ["si_toy_512", "si_toy_1024", "si_toy_2048", "si_toy_2048_l2", "si_toy_1024_mb2", "si_toy_2048_mb3"]
+TOYS = ["si_toy_512", "si_toy_1024", "si_toy_2048", "si_toy_2048_l2", "si_toy_1024_mb2", "si_toy_2048_mb3",
+        "si_toy_512_k3", "si_toy_512_k2"]  # the last two: k > 1 (k_pbs64k, the kernel of PARAM_MESSAGE_1_CARRY_1)
 
 
 @pytest.fixture(scope="module", params=TOYS)
@@ -139,6 +140,45 @@ def test_full_parameter_set_m2c2():
         w.eval_lut_level(np.full(8, 3, np.int32), in_idx, np.full(8, tb, np.uint64), np.arange(56, 64))
         dec = ck.decrypt(w.download(np.arange(56, 64)))
         assert list(dec) == [int(fn(*r)) for r in bits.tolist()]
+    sk.close()
+
+
+def test_full_parameter_set_m1c1():
+    """PARAM_MESSAGE_1_CARRY_1_KS_PBS, the set the reference BINARY installs for LUT mode (src/bin/helm.rs:301:
+    n = 684, k = 3, N = 512, one level of 18 bits [dimensions recalled]): apply_lookup_table rows bit for bit against the
+    O(N^2) oracle, every plaintext value through a LUT, and the bivariate form gates::lut() uses for 2-input gates
+    (src/gates.rs:761-764)."""
+    ck = helm_amd.SiClientKey.generate("shortint_m1c1", seed=1)
+    assert (ck.params.n, ck.params.k, ck.params.N, ck.t) == (684, 3, 512, 4)
+    sk = helm_amd.SiServerKey(ck)
+    orc = oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk)
+    vals = np.arange(ck.t, dtype=np.uint64)
+    cts = ck.encrypt(vals)
+    w = sk.wires(3 * ck.t + 16)
+    w.upload(np.arange(ck.t), cts)
+    lut = sk.make_lut(lambda x: (3 * x + 1) % ck.t)
+    assert np.array_equal(lut, orc.make_lut(lambda x: (3 * x + 1) % ck.t))
+    w.apply_luts(np.arange(ck.t), lut, np.arange(ck.t) + ck.t)
+    got = w.download(np.arange(ck.t) + ck.t)
+    assert list(ck.decrypt_message_and_carry(got)) == [(3 * v + 1) % ck.t for v in range(ck.t)]
+    for g in (0, 3):
+        assert np.array_equal(got[g], orc.apply_lut(cts[g], lut)), f"row {g} of the batch differs from the oracle"
+    w.apply_luts([2], lut, [2 * ck.t])  # a batch of one
+    assert np.array_equal(w.download([2 * ck.t])[0], got[2])
+    # all four input pairs of XOR / AND / OR as 2-input LUT gates, one level, against the oracle and the truth tables
+    base = 3 * ck.t
+    bits = np.array([[a, b] for a in (0, 1) for b in (0, 1)], dtype=np.uint64)
+    host = np.zeros((base + 16, ck.dim + 1), dtype=np.uint64)
+    host[base:base + 8] = ck.encrypt(bits.reshape(-1))
+    w.upload(np.arange(base, base + 8), host[base:base + 8])
+    in_idx = np.arange(base, base + 8, dtype=np.int32).reshape(4, 2)
+    for tb, fn in ((0x6, lambda a, b: a ^ b), (0x8, lambda a, b: a & b), (0xE, lambda a, b: a | b)):
+        out = np.arange(base + 8, base + 12, dtype=np.int32)
+        w.eval_lut_level(np.full(4, 2, np.int32), in_idx, np.full(4, tb, np.uint64), out)
+        orc.eval_lut_level(host, np.full(4, 2, np.int32), in_idx, np.full(4, tb, np.uint64), out)
+        g = w.download(out)
+        assert np.array_equal(g, host[out]), hex(tb)
+        assert list(ck.decrypt(g)) == [fn(int(a), int(b)) for a, b in bits.tolist()]
     sk.close()
 
 

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Same-box A/B of builds of libhelm_hip.so: runs a micro-benchmark in a fresh process per build (HELM_HIP_LIB selects
+the library, helm_amd/_native.py), alternating the builds over several rounds.
+usage: ab_variants.py [--rounds R] [--bench lut|wop|chi] variant [variant ...]
+A variant is a file name under helm_amd/csrc/ (e.g. variants/libhelm_hip_base.so) or `default` (the Makefile's)."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+LUT = r'''
+import json, time, numpy as np, sys
+sys.path.insert(0, %r)
+import helm_amd
+res = {}
+for name, B in (("shortint_m2c2", 1024), ("shortint_m2c2", 64), ("shortint_m2c2_multibit3", 1024)):
+    ck, sk = helm_amd.gen_keys_shortint(name, seed=1)
+    bits = np.random.default_rng(0).integers(0, 2, size=3 * B).astype(np.uint64)
+    w = sk.wires(4 * B)
+    w.upload(np.arange(3 * B), ck.encrypt(bits))
+    in_idx = np.arange(3 * B, dtype=np.int32).reshape(3, B).T.copy()
+    ar, tb, out = np.full(B, 3, np.int32), np.full(B, 0xE8, np.uint64), np.arange(3 * B, 4 * B, dtype=np.int32)
+    w.eval_lut_level(ar, in_idx, tb, out); sk.sync()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter(); w.eval_lut_level(ar, in_idx, tb, out); sk.sync(); ts.append(time.perf_counter() - t0)
+    ok = bool(np.array_equal(ck.decrypt(w.download(out)), (bits[:B] + bits[B:2 * B] + bits[2 * B:]) >= 2))
+    res[f"{name}:{B}"] = {"ms": round(min(ts) * 1e3, 3), "luts_per_s": round(B / min(ts), 1), "ok": ok,
+                          "sha": __import__("hashlib").sha256(w.download(out).tobytes()).hexdigest()[:12]}
+    sk.close()
+print(json.dumps(res))
+'''
+
+WOP = r'''
+import json, subprocess, sys
+out = subprocess.run([sys.executable, %r + "/tools/wop_bench.py", "256", "6", "1"], capture_output=True, text=True).stdout
+print(json.dumps({"wop_256x6_b1": out.strip().splitlines()[-1][:300]}))
+'''
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--bench", default="lut")
+    ap.add_argument("variants", nargs="+")
+    a = ap.parse_args()
+    code = {"lut": LUT, "wop": WOP}[a.bench] % ROOT
+    for r in range(a.rounds):
+        for v in a.variants:
+            env = dict(os.environ)
+            if v != "default":
+                env["HELM_HIP_LIB"] = v
+            else:
+                env.pop("HELM_HIP_LIB", None)
+            p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=400)
+            line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else "FAILED: " + p.stderr[-400:]
+            print(f"round {r} {v}: {line}", flush=True)
+
+
+main()
