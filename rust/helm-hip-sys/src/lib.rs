@@ -40,10 +40,46 @@ pub struct helm_si_params {
 #[repr(C)] pub struct helm_si_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct helm_si_wires { _p: [u8; 0] }
 
-pub const HELM_GATE_AND: i32 = 0;  // = GateType discriminants, reference src/gates.rs:23-45
+// include/helm_hip.h `helm_gate_op` (declaration order of GateType, reference src/gates.rs:23-45; the shim maps the
+// enum with an explicit match, helm-hip/src/lib.rs::gate_opcode)
+pub const HELM_GATE_AND: i32 = 0;
 pub const HELM_GATE_DFF: i32 = 1;
+pub const HELM_GATE_LUT: i32 = 2;
 pub const HELM_GATE_MUX: i32 = 3;
+pub const HELM_GATE_NAND: i32 = 4;
+pub const HELM_GATE_NOR: i32 = 5;
 pub const HELM_GATE_NOT: i32 = 6;
+pub const HELM_GATE_OR: i32 = 7;
+pub const HELM_GATE_XNOR: i32 = 8;
+pub const HELM_GATE_XOR: i32 = 9;
+pub const HELM_GATE_BUF: i32 = 10;
+pub const HELM_GATE_CONST_ONE: i32 = 11;
+pub const HELM_GATE_CONST_ZERO: i32 = 12;
+
+// include/helm_host.h `helm_radix_kind` / `helm_radix_op`: one FheUintN operator of a level (gates.rs:306-702)
+pub const HELM_RADIX_COPY: i32 = 0;
+pub const HELM_RADIX_ADD: i32 = 1;
+pub const HELM_RADIX_SUB: i32 = 2;
+pub const HELM_RADIX_MUL: i32 = 3;
+pub const HELM_RADIX_DIV: i32 = 4;
+pub const HELM_RADIX_SHL: i32 = 5;
+pub const HELM_RADIX_SHR: i32 = 6;
+pub const HELM_RADIX_ADD_SCALAR: i32 = 7;
+pub const HELM_RADIX_SUB_SCALAR: i32 = 8;
+pub const HELM_RADIX_MUL_SCALAR: i32 = 9;
+pub const HELM_RADIX_DIV_SCALAR: i32 = 10;
+pub const HELM_RADIX_SHL_SCALAR: i32 = 11;
+pub const HELM_RADIX_SHR_SCALAR: i32 = 12;
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct helm_radix_op {
+    pub kind: i32,
+    pub a: i32,
+    pub b: i32,
+    pub out: i32,
+    pub scalar_lo: u64,
+    pub scalar_hi: u64,
+}
 
 extern "C" {
     // ---- include/helm_hip.h ---------------------------------------------------------------
@@ -74,6 +110,12 @@ extern "C" {
     pub fn helm_host_pack_levels(opcode: *const i32, in0: *const i32, in1: *const i32, in2: *const i32, out: *const i32,
                                  level_offsets: *const i64, n_levels: i64, quantum: i64, order: *mut i64,
                                  new_offsets: *mut i64, n_launches: *mut i64) -> c_int;
+
+    pub fn helm_host_last_error() -> *const c_char;
+    // one level of arithmetic-mode operators (FheUintN + - * / << >> and their scalar forms, copy) as one batched call
+    pub fn helm_host_radix_scratch_rows(ctx: *mut helm_si_ctx, blocks: i32, ops: *const helm_radix_op, count: i64) -> i64;
+    pub fn helm_host_radix_level(ctx: *mut helm_si_ctx, wires: *mut helm_si_wires, blocks: i32, ops: *const helm_radix_op,
+                                 count: i64, scratch_first_row: i32, pbs_out: *mut i64, rounds_out: *mut i64) -> c_int;
 
     // ---- include/helm_client.h: key import ---------------------------------------------------
     pub fn helm_keys_last_error() -> *const c_char;

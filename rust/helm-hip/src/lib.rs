@@ -5,8 +5,13 @@
 //!
 //! NOT COMPILED in this repository's image (no rustc); tests/c/shim_sequence.c issues the same calls in the
 //! same order from C and is run on the GPU by tests/test_shim_sequence.py.
+pub mod arith;
 pub mod keys;
+pub mod lut;
 pub mod wopbs;
+
+pub use arith::HipArithCircuit;
+pub use lut::HipLutCircuit;
 
 use helm::circuit::{Circuit, EvalCircuit};
 use helm::gates::GateType;
@@ -31,11 +36,40 @@ pub struct HipGateCircuit<'a> {
     lwe_words: usize, // n + 1
 }
 
-fn check(rc: i32) {
+pub(crate) fn check(rc: i32) {
     if rc != 0 {
         // the engine never aborts: a status + message, turned back into the reference's panic here
         let m = unsafe { CStr::from_ptr(sys::helm_hip_last_error()) };
         panic!("{}", m.to_string_lossy());
+    }
+}
+
+pub(crate) fn check_host(rc: i32) {
+    if rc != 0 {
+        let m = unsafe { CStr::from_ptr(sys::helm_host_last_error()) };
+        panic!("{}", m.to_string_lossy());
+    }
+}
+
+/// `GateType` -> the engine's opcode, spelled out: nothing relies on the enum's discriminant order
+/// (reference src/gates.rs:23-45; include/helm_hip.h `helm_gate_op`).
+fn gate_opcode(t: GateType) -> i32 {
+    match t {
+        GateType::And => sys::HELM_GATE_AND,
+        GateType::Dff => sys::HELM_GATE_DFF,
+        GateType::Lut => sys::HELM_GATE_LUT,
+        GateType::Mux => sys::HELM_GATE_MUX,
+        GateType::Nand => sys::HELM_GATE_NAND,
+        GateType::Nor => sys::HELM_GATE_NOR,
+        GateType::Not => sys::HELM_GATE_NOT,
+        GateType::Or => sys::HELM_GATE_OR,
+        GateType::Xnor => sys::HELM_GATE_XNOR,
+        GateType::Xor => sys::HELM_GATE_XOR,
+        GateType::Buf => sys::HELM_GATE_BUF,
+        GateType::ConstOne => sys::HELM_GATE_CONST_ONE,
+        GateType::ConstZero => sys::HELM_GATE_CONST_ZERO,
+        // arithmetic operators cannot appear in a boolean circuit: same panic as gates.rs:257-264
+        _ => panic!("Arithmetic gates can't be mixed with Boolean ones!"),
     }
 }
 
@@ -54,7 +88,7 @@ impl<'a> HipGateCircuit<'a> {
     }
 
     /// Flatten `circuit.level_map` (sorted by level) into index arrays, pack the launches and upload the
-    /// program once.  opcode = the `GateType` discriminant (gates.rs:23-45); MUX: in2 = select (gates.rs:265).
+    /// program once.  opcode = `gate_opcode(GateType)`; MUX: in2 = select (gates.rs:265).
     fn build_program(&mut self) {
         let (mut op, mut i0, mut i1, mut i2, mut out) = (vec![], vec![], vec![], vec![], vec![]);
         let mut off: Vec<i64> = vec![0];
@@ -64,7 +98,7 @@ impl<'a> HipGateCircuit<'a> {
             for g in gates {
                 let ins = g.get_input_wires();
                 let row = |i: usize| ins.get(i).map(|w| self.row_of[w]).unwrap_or(-1);
-                op.push(g.get_gate_type() as i32);
+                op.push(gate_opcode(g.get_gate_type()));
                 i0.push(row(0)); i1.push(row(1)); i2.push(row(2));
                 out.push(self.row_of[&g.get_output_wire()]);
             }

@@ -11,10 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "helm_amd", "csrc")
 
 
-def _build(tmp_path):
-    exe = str(tmp_path / "shim_sequence")
+def _build(tmp_path, name="shim_sequence"):
+    exe = str(tmp_path / name)
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "c", "shim_sequence.c"), "-o", exe, "-L", CSRC, "-lhelm_host", "-lhelm_hip",
+                           os.path.join(ROOT, "tests", "c", name + ".c"), "-o", exe, "-L", CSRC, "-lhelm_host", "-lhelm_hip",
                            f"-Wl,-rpath,{CSRC}"])
     return exe
 
@@ -33,4 +33,25 @@ def test_shim_sequence_builds_against_the_c_abi_and_refuses_to_run_without_a_gpu
 def test_shim_sequence_on_the_gpu(tmp_path, params):
     exe = _build(tmp_path)
     r = subprocess.run([exe, params], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+
+
+def test_shortint_shim_sequence_builds_and_refuses_to_run_without_a_gpu(tmp_path):
+    """tests/c/shim_sequence_si.c = the calls of rust/helm-hip's HipLutCircuit and HipArithCircuit (reference
+    src/circuit.rs:969-1111, 1113-1483) over include/helm_shortint.h + include/helm_host.h."""
+    from helm_amd import _native
+    exe = _build(tmp_path, "shim_sequence_si")
+    if _native.hip.helm_hip_device_count() > 0:
+        pytest.skip("a GPU is present: the run is covered by the gpu test")
+    r = subprocess.run([exe, "si_toy_1024"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "helm_si_ctx_create failed" in r.stderr and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("params", ["shortint_m2c2", "shortint_m2c2_multibit3"])
+def test_shortint_shim_sequence_on_the_gpu(tmp_path, params):
+    """8-bit LUT-3-1 adder + READY latch, then the FheUint16 known answers of tests/gates_test.rs:127-310, through the C
+    ABI alone, under the LUT-mode test set and the reference's arithmetic-mode set (helm.rs:83)."""
+    exe = _build(tmp_path, "shim_sequence_si")
+    r = subprocess.run([exe, params], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
