@@ -2489,6 +2489,8 @@ int helm_si_set_exchange(helm_si_ctx *ctx, int32_t rank, int32_t world, int64_t 
     return 0;
 }
 
+int helm_si_exchange_world(const helm_si_ctx *ctx) { return ctx ? ctx->x_world : 1; }
+
 int helm_si_exchange_stats(const helm_si_ctx *ctx, int64_t *batches, int64_t *rows)
 {
     if (!ctx) return fail(HELM_ERR_INVALID, "null context");

@@ -346,7 +346,7 @@ class RadixEngine {
   public:
     RadixEngine(helm_si_ctx *ctx, int blocks);
     int64_t scratch_rows(const std::vector<RadixOp> &ops) const;
-    void run_level(helm_si_wires *w, const std::vector<RadixOp> &ops, int scratch);
+    void run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in, int scratch);
     void propagate(helm_si_wires *w, const std::vector<int32_t> &bases, int scratch, int width,
                    const std::vector<int32_t> *carry_out_rows);
     int64_t pbs_count() const { return pbs_count_; }
@@ -367,12 +367,14 @@ class RadixEngine {
     int lut_msg_ = 0, lut_carry_ = 0, lut_state_ = 0, lut_state0_ = 0, lut_comb_ = 0, lut_mul_lo_ = 0, lut_mul_hi_ = 0;
     int lut_bit0_ = 0, lut_bit1_ = 0, lut_shl1_ = 0, lut_shr1_ = 0, lut_sel_ = 0;
     int64_t pbs_count_ = 0, pbs_rounds_ = 0;
+    std::vector<int32_t> pend_in_, pend_lut_, pend_out_; // look-ups waiting for the level's next batch
 };
 
 // reference src/circuit.rs:81-85, 1112-1500
 class ArithCircuit : public EvalCircuit<SiEncWireMap> {
   public:
     ArithCircuit(helm_si_client_key *client_key, helm_si_ctx *server_key, Circuit circuit);
+    ~ArithCircuit() override;
     std::unique_ptr<SiEncWireMap> encrypt_inputs(const std::set<std::string> &wire_set,
                                                  const std::map<std::string, PtxtType> &input_wire_map) override;
     std::unique_ptr<SiEncWireMap> evaluate_encrypted(const SiEncWireMap &enc_wire_map, size_t current_cycle,
@@ -385,14 +387,18 @@ class ArithCircuit : public EvalCircuit<SiEncWireMap> {
     std::string log() { std::string s; s.swap(log_); return s; }
     // Lanes (helm_si_ctx_fork): sub-circuits that share no wire are evaluated concurrently, one lane each, instead of
     // meeting at every level boundary (circuit.rs:1321 joins the whole level).  Same ciphertexts, fewer rounds in a row.
+    // Default: with two or more independent sub-circuits the circuit forks ONE lane of its own.  add_lane() installs
+    // the caller's lanes instead; clear_lanes() switches lanes off altogether (level by level, as the reference).
     void add_lane(helm_si_ctx *lane) { lanes_.push_back(lane); }
-    void clear_lanes() { lanes_.clear(); }
+    void clear_lanes() { lanes_.clear(); auto_lanes_ = false; }
 
   private:
     void encrypt_value(SiEncWireMap &m, const std::string &wire, unsigned __int128 value);
     helm_si_client_key *client_key_;
     helm_si_ctx *server_key_;
     std::vector<helm_si_ctx *> lanes_;
+    helm_si_ctx *own_lane_ = nullptr; // forked on first need when auto_lanes_
+    bool auto_lanes_ = true;
     Circuit circuit_;
     helm_si_params P_{};
     std::string global_ptxt_type_;

@@ -439,6 +439,18 @@ void RadixEngine::lincomb(helm_si_wires *w, const std::vector<int32_t> &in_idx, 
 void RadixEngine::apply(helm_si_wires *w, const std::vector<int32_t> &in, const std::vector<int32_t> &lut,
                         const std::vector<int32_t> &out)
 {
+    // look-ups that wait for a batch to ride in (shift_scalar): independent rows, so any batch of the level will do
+    if (!pend_in_.empty()) {
+        std::vector<int32_t> i2(in), l2(lut), o2(out);
+        i2.insert(i2.end(), pend_in_.begin(), pend_in_.end());
+        l2.insert(l2.end(), pend_lut_.begin(), pend_lut_.end());
+        o2.insert(o2.end(), pend_out_.begin(), pend_out_.end());
+        pend_in_.clear();
+        pend_lut_.clear();
+        pend_out_.clear();
+        apply(w, i2, l2, o2);
+        return;
+    }
     if (in.empty()) return;
     si_ok(helm_si_apply_luts(ctx_, w, in.data(), lut.data(), out.data(), (int64_t)in.size(), luts_.data(),
                              (int64_t)(luts_.size() / (size_t)P_.N)),
@@ -548,7 +560,10 @@ void RadixEngine::shift_scalar(helm_si_wires *w, const std::vector<RadixOp> &ops
     }
     // operands may alias outputs (out == a): lincomb stages every sum before writing any row
     lincomb(w, li, lc, {}, lo, 2);
-    apply(w, in, lut, out);
+    // the look-ups join the level's next batch (run_level flushes what is left at its end)
+    pend_in_.insert(pend_in_.end(), in.begin(), in.end());
+    pend_lut_.insert(pend_lut_.end(), lut.begin(), lut.end());
+    pend_out_.insert(pend_out_.end(), out.begin(), out.end());
 }
 
 // Shift by an encrypted amount (mod bits): the amount's bits select, stage by stage, between the
@@ -753,8 +768,21 @@ int64_t RadixEngine::scratch_rows(const std::vector<RadixOp> &ops) const
 }
 
 // One netlist level of integer operators (independent of each other), batched stage by stage.
-void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops, int scratch)
+void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in, int scratch)
 {
+    // a multiplication by a plaintext power of two IS a left shift: whole blocks move for free and an odd bit costs one
+    // look-up per block, where the digit-wise product (block values up to 6) would need a full carry propagation
+    // (x * 2: one round of bootstraps instead of six; same value mod 2^bits)
+    std::vector<RadixOp> ops(ops_in);
+    for (auto &op : ops)
+        if (op.kind == RadixOp::MulScalar && op.scalar >= 2 && (op.scalar & (op.scalar - 1)) == 0) {
+            int s = 0;
+            while (!((op.scalar >> s) & 1)) s++;
+            op.kind = RadixOp::ShlScalar;
+            op.scalar = (unsigned __int128)s;
+        }
+    // ---- shifts by a plaintext amount first: their one round of look-ups rides in the level's first batch -------
+    shift_scalar(w, ops);
     // ---- stage 1: block sums of add / sub, operand rows of the multiplications --------------
     struct Term { int base; int low; int maxv; }; // blocks below `low` are zero; block values <= maxv
     struct MulState { std::vector<Term> terms; int out; };
@@ -953,10 +981,10 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops, i
     }
     // ---- carry propagation of everything that needs it -------------------------------------------
     propagate(w, prop_bases, take(2 * nb_ * (int)prop_bases.size()), nb_, nullptr);
-    // ---- shifts and divisions (own round structure) ----------------------------------------------
-    shift_scalar(w, ops);
+    // ---- shifts by an encrypted amount and divisions (own round structure) ------------------------
     shift_encrypted(w, ops, sp);
     divide(w, ops, sp);
+    apply(w, {}, {}, {}); // shift look-ups no batch has taken along
 }
 
 // ---------------------------------------------------------------------------------------
@@ -987,6 +1015,35 @@ static PtxtType::Kind kind_of(const std::string &ptxt_type)
     if (ptxt_type == "u32") return PtxtType::U32;
     if (ptxt_type == "u64") return PtxtType::U64;
     return PtxtType::U128;
+}
+
+// connected components of the operator graph of a plan (wires produced by an operator connect it to its consumers;
+// primary inputs and scalars connect nothing)
+static size_t component_count(const std::vector<std::vector<RadixOp>> &plan)
+{
+    std::vector<int> parent;
+    std::map<int, int> producer;
+    std::vector<const RadixOp *> all;
+    for (auto &lvl : plan)
+        for (auto &op : lvl) {
+            producer[op.out] = (int)all.size();
+            parent.push_back((int)all.size());
+            all.push_back(&op);
+        }
+    std::function<int(int)> find = [&](int x) { return parent[(size_t)x] == x ? x : parent[(size_t)x] = find(parent[(size_t)x]); };
+    for (size_t id = 0; id < all.size(); id++)
+        for (int row : {all[id]->a, all[id]->b}) {
+            auto it = row >= 0 ? producer.find(row) : producer.end();
+            if (it != producer.end()) parent[(size_t)find((int)id)] = find(it->second);
+        }
+    std::set<int> roots;
+    for (size_t id = 0; id < all.size(); id++) roots.insert(find((int)id));
+    return roots.size();
+}
+
+ArithCircuit::~ArithCircuit()
+{
+    if (own_lane_) helm_si_ctx_destroy(own_lane_); // before its primary, which the caller owns
 }
 
 ArithCircuit::ArithCircuit(helm_si_client_key *client_key, helm_si_ctx *server_key, Circuit circuit)
@@ -1155,7 +1212,15 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
         plan.push_back(std::move(ops));
     }
     const size_t total_levels = circuit_.level_map().size();
-    if (!lanes_.empty()) {
+    // Lanes by default: an operator graph with two or more connected components runs them concurrently on the server key
+    // and ONE lane forked from it (identical ciphertexts, the rounds of the longest component in a row instead of the sum
+    // over the levels).  add_lane() / clear_lanes() override: explicit lanes, or none.
+    std::vector<helm_si_ctx *> lanes = lanes_;
+    if (lanes.empty() && auto_lanes_ && helm_si_exchange_world(server_key_) <= 1 && component_count(plan) >= 2) {
+        if (!own_lane_) si_ok(helm_si_ctx_fork(server_key_, &own_lane_), "ctx_fork");
+        lanes.push_back(own_lane_);
+    }
+    if (!lanes.empty()) {
         // ---- lanes: connected components of the operator graph (wires produced by an operator connect it to its
         //      consumers; primary inputs and scalars connect nothing), each component's levels compacted, components
         //      spread over the contexts by their bootstrap estimate, one host thread per context.
@@ -1193,7 +1258,7 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
             order.push_back({w, c.first});
         }
         std::sort(order.begin(), order.end(), [](auto &x, auto &y) { return x.first > y.first; });
-        const size_t n_ctx = 1 + lanes_.size();
+        const size_t n_ctx = 1 + lanes.size();
         std::vector<int64_t> load(n_ctx, 0);
         std::vector<std::vector<std::vector<RadixOp>>> lane_plan(n_ctx, std::vector<std::vector<RadixOp>>(plan.size()));
         for (auto &oc : order) {
@@ -1205,7 +1270,7 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
         std::vector<int64_t> lane_scratch(n_ctx, 0);
         int64_t total_scratch = 0;
         for (size_t lane = 0; lane < n_ctx; lane++) {
-            engines.emplace_back(new RadixEngine(lane == 0 ? server_key_ : lanes_[lane - 1], nb));
+            engines.emplace_back(new RadixEngine(lane == 0 ? server_key_ : lanes[lane - 1], nb));
             for (auto &ops : lane_plan[lane]) lane_scratch[lane] = std::max(lane_scratch[lane], engines[lane]->scratch_rows(ops));
             total_scratch += lane_scratch[lane];
         }
@@ -1221,7 +1286,7 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
             try {
                 for (auto &ops : lane_plan[lane])
                     if (!ops.empty()) engines[lane]->run_level(eval_values->table(), ops, lane_base[lane]);
-                si_ok(helm_si_sync(lane == 0 ? server_key_ : lanes_[lane - 1]), "sync");
+                si_ok(helm_si_sync(lane == 0 ? server_key_ : lanes[lane - 1]), "sync");
             } catch (const std::exception &e) {
                 errors[lane] = e.what();
             }

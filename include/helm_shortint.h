@@ -141,6 +141,9 @@ int helm_si_set_exchange(helm_si_ctx *ctx, int32_t rank, int32_t world, int64_t 
                          void *gather_dev, int64_t capacity_rows, helm_si_exchange_fn fn, void *user);
 /* batches sharded so far and rows moved through gather_dev (per rank) */
 int helm_si_exchange_stats(const helm_si_ctx *ctx, int64_t *batches, int64_t *rows);
+/* the `world` of helm_si_set_exchange (1: sharding off).  A lane does not inherit the exchange of its primary: callers
+ * that shard keep to the primary context (the host library's ArithCircuit does not fork its default lane then). */
+int helm_si_exchange_world(const helm_si_ctx *ctx);
 
 /* Primitive forms on host buffers (tests).  small: count x (n+1); big: count x (k*N+1). */
 int helm_si_keyswitch_batch(helm_si_ctx *ctx, const uint64_t *in_big, uint64_t *out_small, int64_t count);

@@ -158,9 +158,15 @@ int main(int argc, char **argv)
     /* keys::standard_keys64(): the words arrive in tfhe's container order and go through the converters */
     const size_t nb = helm_si_client_bsk_words(ck), nk = helm_si_client_ksk_words(ck);
     uint64_t *t_bsk = malloc(nb * 8), *t_ksk = malloc(nk * 8), *bsk = malloc(nb * 8), *ksk = malloc(nk * 8);
-    CHECK(helm_keys_bsk64_to_tfhe(&P, helm_si_client_bsk(ck), t_bsk, nb), "to tfhe order (bsk)");
+    if (P.grouping_factor > 1) {
+        /* multi-bit sets (helm.rs:83): tfhe's own multi-bit key layout is not importable word for word (the converter
+         * refuses it); the shim generates the bootstrapping key in this ABI's subset-indicator convention (keys.rs) */
+        memcpy(bsk, helm_si_client_bsk(ck), nb * 8);
+    } else {
+        CHECK(helm_keys_bsk64_to_tfhe(&P, helm_si_client_bsk(ck), t_bsk, nb), "to tfhe order (bsk)");
+        CHECK(helm_keys_bsk64_from_tfhe(&P, t_bsk, bsk, nb), "helm_keys_bsk64_from_tfhe");
+    }
     CHECK(helm_keys_ksk64_to_tfhe(&P, helm_si_client_ksk(ck), t_ksk, nk), "to tfhe order (ksk)");
-    CHECK(helm_keys_bsk64_from_tfhe(&P, t_bsk, bsk, nb), "helm_keys_bsk64_from_tfhe");
     CHECK(helm_keys_ksk64_from_tfhe(&P, t_ksk, ksk, nk), "helm_keys_ksk64_from_tfhe");
     /* HipLutCircuit::new / HipArithCircuit::new */
     helm_si_ctx *ctx = NULL;

@@ -163,16 +163,19 @@ def test_chi_squared_u32(keys):  # circuit_test.rs:313-370, inputs K-5 (2, 7, 9)
 def test_chi_squared_on_lanes_is_bit_identical_and_shorter(keys):
     """Lanes (helm_si_ctx_fork): the two sub-circuits of chi-squared that share no wire (alpha's and the betas') run
     concurrently instead of meeting at every level boundary: the same ciphertexts on every wire, fewer rounds in a row
-    (39 level-synchronous rounds -> the longer sub-circuit's 29)."""
+    (39 level-synchronous rounds -> the longer sub-circuit's 28).  Lanes are the DEFAULT when the operator graph has two or
+    more components; set_lanes(1) is the reference's level-by-level evaluation."""
     import time
     client_key, server_key = keys
     circuit, wire_set, _, _ = _circuit(f"{NET}/chi_squared_arith.v", is_arith=True)
     inputs = verilog_parser.read_input_wires(os.path.join(HERE, "golden", "chi_squared_arith_1.inputs.csv"), "u32")
     ac = ArithCircuit(client_key, server_key, circuit)
     enc_in = ac.encrypt_inputs(wire_set, inputs)
+    ac.set_lanes(1)
     t0 = time.perf_counter()
     one = ac.evaluate_encrypted(enc_in, 1, "u32")
     t_one, rounds_one, pbs_one = time.perf_counter() - t0, ac.pbs_rounds_per_cycle(), ac.pbs_per_cycle()
+    assert "Evaluated gates in level [1/4]" in ac.log()
     ac.set_lanes(2)
     ac.evaluate_encrypted(enc_in, 2, "u32")  # warm-up of the lane's scratch (a new cycle each time: the memo is per cycle)
     t0 = time.perf_counter()
@@ -182,13 +185,17 @@ def test_chi_squared_on_lanes_is_bit_identical_and_shorter(keys):
     for wire in one.keys():
         assert np.array_equal(one[wire], two[wire]), wire
     assert {k: v.value for k, v in ac.decrypt_outputs(two, True).items()} == {"alpha": 529, "beta1": 242, "beta2": 275, "beta3": 1250}
-    assert ac.pbs_per_cycle() == pbs_one and rounds_one == 39 and ac.pbs_rounds_per_cycle() == 29
+    # mult by 2 is one round (a shift), so the betas' chain is 1 + 6 + 11 + 1 rounds and alpha's 11 + 0 + 6 + 11 = 28
+    assert ac.pbs_per_cycle() == pbs_one and rounds_one == 39 and ac.pbs_rounds_per_cycle() == 28
     assert "2 independent sub-circuit(s)" in ac.log()
     print(f"chi-squared u32: {t_one:.3f} s level by level, {t_two:.3f} s on two lanes")
     assert t_two < t_one
-    ac.set_lanes(1)
-    again = ac.evaluate_encrypted(enc_in, 4, "u32")
-    assert ac.pbs_rounds_per_cycle() == 39 and np.array_equal(again["alpha"], one["alpha"])
+    # the default: a fresh circuit forks its own lane when there are two components
+    ac2 = ArithCircuit(client_key, server_key, circuit)
+    dflt = ac2.evaluate_encrypted(enc_in, 1, "u32")
+    assert ac2.pbs_rounds_per_cycle() == 28 and "2 independent sub-circuit(s)" in ac2.log()
+    for wire in one.keys():
+        assert np.array_equal(one[wire], dflt[wire]), wire
 
 
 def test_shifts_and_division_u8(keys):  # gates.rs:386-452, 488-700 (div, shl, shr and their plain forms)
