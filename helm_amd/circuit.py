@@ -262,6 +262,10 @@ class ArithCircuit(_SiCircuit):
     """reference src/circuit.rs:81-85, 1112-1500"""
     MODE = 1
 
+    def set_lazy_carries(self, on=True):
+        """Carry-save products feeding additions / subtractions (default on; helm_host_si_circuit_set_lazy_carries)."""
+        H.check(H.host.helm_host_si_circuit_set_lazy_carries(self._h, int(bool(on))))
+
     def set_lanes(self, n):
         """Evaluate sub-circuits that share no wire concurrently on `n` contexts in all (the server key and n - 1 lanes
         forked from it) instead of level by level; identical ciphertexts.  n = 1 switches lanes off."""

@@ -396,6 +396,15 @@ int helm_host_radix_level(helm_si_ctx *ctx, helm_si_wires *wires, int32_t blocks
         if (rounds_out) *rounds_out = eng.pbs_rounds();
     });
 }
+int helm_host_si_circuit_set_lazy_carries(helm_si_circuit *c, int on)
+{
+    if (!c || !c->arith) {
+        g_err = "set_lazy_carries: not an arithmetic-mode circuit";
+        return -1;
+    }
+    c->arith->set_lazy_carries(on != 0);
+    return 0;
+}
 char *helm_host_si_circuit_log(helm_si_circuit *c) { return dup(c->lut ? c->lut->log() : c->arith->log()); }
 int64_t helm_host_si_circuit_pbs_per_cycle(const helm_si_circuit *c)
 {

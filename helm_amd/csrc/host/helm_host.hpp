@@ -338,6 +338,10 @@ struct RadixOp {
     enum Kind { Copy, Add, Sub, Mul, Div, Shl, Shr, AddScalar, SubScalar, MulScalar, DivScalar, ShlScalar, ShrScalar } kind = Copy;
     int a = -1, b = -1, out = -1;
     unsigned __int128 scalar = 0;
+    // Carry-save form: an integer kept as the SUM of two rows of blocks <= 3 (what a multiplication's term reduction
+    // leaves before its final carry propagation).  a2 / b2 >= 0: that operand's second term (Add, Sub, and block shifts =
+    // MulScalar by a power of four); out2 >= 0: leave the result in that form (Mul, block shifts) - no propagation.
+    int a2 = -1, b2 = -1, out2 = -1;
 };
 
 // Level-batched FheUintN operators (add, sub, mul and their scalar forms, copy) over the two
@@ -391,6 +395,7 @@ class ArithCircuit : public EvalCircuit<SiEncWireMap> {
     // the caller's lanes instead; clear_lanes() switches lanes off altogether (level by level, as the reference).
     void add_lane(helm_si_ctx *lane) { lanes_.push_back(lane); }
     void clear_lanes() { lanes_.clear(); auto_lanes_ = false; }
+    void set_lazy_carries(bool on) { lazy_carries_ = on; }
 
   private:
     void encrypt_value(SiEncWireMap &m, const std::string &wire, unsigned __int128 value);
@@ -399,6 +404,7 @@ class ArithCircuit : public EvalCircuit<SiEncWireMap> {
     std::vector<helm_si_ctx *> lanes_;
     helm_si_ctx *own_lane_ = nullptr; // forked on first need when auto_lanes_
     bool auto_lanes_ = true;
+    bool lazy_carries_ = true; // carry-save products feeding additions / subtractions (HELM_LAZY_CARRIES=0: off)
     Circuit circuit_;
     helm_si_params P_{};
     std::string global_ptxt_type_;

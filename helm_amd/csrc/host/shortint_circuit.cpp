@@ -543,6 +543,16 @@ void RadixEngine::shift_scalar(helm_si_wires *w, const std::vector<RadixOp> &ops
         const bool left = op.kind == RadixOp::ShlScalar;
         if (!left && op.kind != RadixOp::ShrScalar) continue;
         const int s = (int)(op.scalar % (unsigned)(2 * nb_)), q = s >> 1, r = s & 1;
+        if (op.a2 >= 0) { // carry-save operand: whole blocks only, both terms move alike and stay in that form
+            if (!left || r || op.out2 < 0) throw Panic("internal error: carry-save operand of a shift that is not by whole blocks");
+            for (int i = 0; i < nb_; i++) {
+                li.push_back(i >= q ? op.a2 + (i - q) : -1);
+                lc.push_back(i >= q ? 1 : 0);
+                li.push_back(-1);
+                lc.push_back(0);
+                lo.push_back(op.out2 + i);
+            }
+        }
         for (int i = 0; i < nb_; i++) {
             const int xi = left ? i - q : i + q, yi = left ? xi - 1 : xi + 1; // y: the neighbour bits come from
             const bool xok = xi >= 0 && xi < nb_, yok = yi >= 0 && yi < nb_;
@@ -761,6 +771,7 @@ int64_t RadixEngine::scratch_rows(const std::vector<RadixOp> &ops) const
         // rounds (about 1.5 nb): 4 nb + 4 vectors of nb rows bound both
         if (op.kind == RadixOp::Mul || op.kind == RadixOp::MulScalar) rows += (int64_t)(4 * nb_ + 4) * nb_;
         if (op.kind == RadixOp::AddScalar || op.kind == RadixOp::SubScalar) rows += nb_;
+        if (op.a2 >= 0 || op.b2 >= 0) rows += 6 * nb_; // complemented terms and one reduction round of a carry-save sum
         if (op.kind == RadixOp::Shl || op.kind == RadixOp::Shr) rows += 4 * nb_ + 8;
         if (op.kind == RadixOp::Div || op.kind == RadixOp::DivScalar) rows += 4 * 2 * nb_ + 7 * (nb_ + 1);
     }
@@ -785,7 +796,7 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
     shift_scalar(w, ops);
     // ---- stage 1: block sums of add / sub, operand rows of the multiplications --------------
     struct Term { int base; int low; int maxv; }; // blocks below `low` are zero; block values <= maxv
-    struct MulState { std::vector<Term> terms; int out; };
+    struct MulState { std::vector<Term> terms; int out; int out2 = -1; };
     std::vector<MulState> muls;
     std::vector<int32_t> prop_bases; // integers waiting for the final propagation
     int sp = scratch;
@@ -803,6 +814,7 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
                 }
                 break;
             case RadixOp::Add: case RadixOp::Sub: case RadixOp::AddScalar: case RadixOp::SubScalar: {
+                if (op.a2 >= 0 || op.b2 >= 0) break; // an operand in carry-save form: summed with the term reduction below
                 // a + b, or a + ~b + 1 with ~b digit = 3 - b_i (two's complement, mod 2^bits)
                 const bool sub = op.kind == RadixOp::Sub || op.kind == RadixOp::SubScalar;
                 const bool scalar = op.kind == RadixOp::AddScalar || op.kind == RadixOp::SubScalar;
@@ -856,6 +868,7 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
                 // term L_j: block k = lo(a_{k-j} * b_j), term H_j: block k = hi(a_{k-1-j} * b_j)
                 MulState ms;
                 ms.out = op.out;
+                ms.out2 = op.out2;
                 for (int j = 0; j < nb_; j++) {
                     const int Lb = take(nb_), Hb = j + 1 < nb_ ? take(nb_) : -1;
                     for (int k = 0; k < nb_; k++) {
@@ -902,6 +915,39 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
         apply(w, in, lut, out);
     }
 
+    // ---- additions / subtractions with an operand in carry-save form: their two to four terms join the reduction.
+    //      x - y with y = y1 + y2: x + (~y1 + 1) + (~y2 + 1), ~t block = 3 - t block (mod 2^bits); the ones go to block 0
+    //      of the first complemented term -------------------------------------------------------------------------
+    {
+        std::vector<int32_t> li, lo;
+        std::vector<int64_t> lc, ca;
+        for (auto &op : ops) {
+            if (!((op.kind == RadixOp::Add || op.kind == RadixOp::Sub) && (op.a2 >= 0 || op.b2 >= 0))) continue;
+            MulState ms;
+            ms.out = op.out;
+            ms.out2 = op.out2;
+            ms.terms.push_back(Term{op.a, 0, 3});
+            if (op.a2 >= 0) ms.terms.push_back(Term{op.a2, 0, 3});
+            if (op.kind == RadixOp::Add) {
+                ms.terms.push_back(Term{op.b, 0, 3});
+                if (op.b2 >= 0) ms.terms.push_back(Term{op.b2, 0, 3});
+            } else {
+                const int nc = op.b2 >= 0 ? 2 : 1;
+                for (int t = 0; t < nc; t++) {
+                    const int src = t == 0 ? op.b : op.b2, base = take(nb_);
+                    for (int k = 0; k < nb_; k++) {
+                        li.push_back(src + k); lc.push_back(-1);
+                        li.push_back(-1); lc.push_back(0);
+                        lo.push_back(base + k);
+                        ca.push_back(3 + (t == 0 && k == 0 ? nc : 0));
+                    }
+                    ms.terms.push_back(Term{base, 0, t == 0 ? 3 + nc : 3});
+                }
+            }
+            muls.push_back(std::move(ms));
+        }
+        lincomb(w, li, lc, ca, lo, 2);
+    }
     // ---- multiplications: reduce the terms (sums of <= 15 per block, then message + carry) ----
     for (;;) {
         std::vector<int32_t> li, lo, in, lut, out, zero_rows;
@@ -967,6 +1013,18 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
         for (auto &ms : muls) {
             int s = 0;
             for (auto &t : ms.terms) s += t.maxv;
+            if (ms.out2 >= 0) { // carry-save result: the two terms as they are, no propagation
+                for (size_t u = 0; u < 2; u++)
+                    for (int k = 0; k < nb_; k++) {
+                        const bool on = u < ms.terms.size() && k >= ms.terms[u].low;
+                        li.push_back(on ? ms.terms[u].base + k : -1);
+                        lc.push_back(on ? 1 : 0);
+                        li.push_back(-1);
+                        lc.push_back(0);
+                        lo.push_back((u == 0 ? ms.out : ms.out2) + k);
+                    }
+                continue;
+            }
             for (int k = 0; k < nb_; k++) {
                 for (size_t u = 0; u < 2; u++) {
                     const bool on = u < ms.terms.size() && k >= ms.terms[u].low;
@@ -1208,9 +1266,97 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
             }
             ops.push_back(op);
         }
-        max_scratch = std::max(max_scratch, eng.scratch_rows(ops));
         plan.push_back(std::move(ops));
     }
+    // ---- carry-save planning: a product whose every consumer is an addition or a subtraction (possibly behind
+    //      multiplications by powers of four = block shifts) keeps the two terms its reduction ends with instead of
+    //      propagating carries (six rounds); the consumer sums the terms of both operands (one more reduction round)
+    //      and propagates once.  a * b - c * d: 11 + 7 rounds in a row instead of 11 + 6 + ... 6.  The wire's own
+    //      rows still receive the propagated value - in the level of the first adding consumer, where the rounds of
+    //      that propagation ride in the consumer's batches.
+    int64_t aux_total = 0;
+    if (lazy_carries_) {
+        const int aux_base = eval_values->scratch(0);
+        auto block_shift = [&](const RadixOp &op) {
+            if (op.kind != RadixOp::MulScalar || op.scalar < 4 || (op.scalar & (op.scalar - 1))) return false;
+            int sh = 0;
+            while (!((op.scalar >> sh) & 1)) sh++;
+            return sh % 2 == 0;
+        };
+        std::set<int> output_rows;
+        for (auto &wname : circuit_.output_wires())
+            if (eval_values->contains_key(wname)) output_rows.insert(eval_values->row(wname));
+        struct Use { size_t level, index; };
+        std::map<int, std::vector<Use>> uses; // first row of a wire -> the operators that read it
+        for (size_t l = 0; l < plan.size(); l++)
+            for (size_t q = 0; q < plan[l].size(); q++)
+                for (int row : {plan[l][q].a, plan[l][q].b})
+                    if (row >= 0) uses[row].push_back({l, q});
+        std::map<int, bool> lazy_ok; // the wire may be consumed in carry-save form
+        for (size_t l = plan.size(); l-- > 0;)
+            for (auto &op : plan[l]) {
+                auto it = uses.find(op.out);
+                bool ok = !output_rows.count(op.out) && it != uses.end();
+                if (ok)
+                    for (auto &u : it->second) {
+                        const RadixOp &c = plan[u.level][u.index];
+                        ok = ok && (c.kind == RadixOp::Add || c.kind == RadixOp::Sub || (block_shift(c) && lazy_ok[c.out]));
+                    }
+                lazy_ok[op.out] = ok;
+            }
+        struct Aux { int a, b, wire; };
+        std::map<int, Aux> aux; // wire row -> rows of its two terms
+        std::vector<std::vector<RadixOp>> finish(plan.size());
+        for (size_t l = 0; l < plan.size(); l++)
+            for (auto &op : plan[l]) {
+                // operands first: terms of carry-save wires
+                auto ia = op.a >= 0 ? aux.find(op.a) : aux.end(), ib = op.b >= 0 ? aux.find(op.b) : aux.end();
+                const bool from_cs = ia != aux.end() && block_shift(op);
+                const bool make = lazy_ok[op.out] && (op.kind == RadixOp::Mul || from_cs);
+                if (make) {
+                    const int base = aux_base + (int)aux_total;
+                    aux_total += 2 * nb;
+                    aux[op.out] = Aux{base, base + nb, op.out};
+                }
+                if (ia != aux.end() && (op.kind == RadixOp::Add || op.kind == RadixOp::Sub || from_cs)) {
+                    op.a2 = ia->second.b;
+                    op.a = ia->second.a;
+                }
+                if (ib != aux.end() && (op.kind == RadixOp::Add || op.kind == RadixOp::Sub)) {
+                    op.b2 = ib->second.b;
+                    op.b = ib->second.a;
+                }
+                if (make) {
+                    const Aux &x = aux[op.out];
+                    op.out = x.a;
+                    op.out2 = x.b;
+                }
+            }
+        // the propagated value of every carry-save wire, in the level of its first adding consumer (reached through
+        // block shifts if need be)
+        std::function<size_t(int)> first_adder = [&](int wire) -> size_t {
+            size_t best = plan.size();
+            for (auto &u : uses[wire]) {
+                const RadixOp &c = plan[u.level][u.index];
+                if (c.kind == RadixOp::Add || c.kind == RadixOp::Sub) best = std::min(best, u.level);
+                else if (c.out2 >= 0) // a block shift in carry-save form: its wire is the key of the entry holding these rows
+                    for (auto &kv : aux)
+                        if (kv.second.a == c.out) best = std::min(best, first_adder(kv.first));
+            }
+            return best;
+        };
+        for (auto &kv : aux) {
+            const size_t l = first_adder(kv.first);
+            RadixOp f{};
+            f.kind = RadixOp::Add;
+            f.a = kv.second.a;
+            f.b = kv.second.b;
+            f.out = kv.second.wire;
+            finish[std::min(l, plan.size() - 1)].push_back(f);
+        }
+        for (size_t l = 0; l < plan.size(); l++) plan[l].insert(plan[l].end(), finish[l].begin(), finish[l].end());
+    }
+    for (auto &ops : plan) max_scratch = std::max(max_scratch, eng.scratch_rows(ops));
     const size_t total_levels = circuit_.level_map().size();
     // Lanes by default: an operator graph with two or more connected components runs them concurrently on the server key
     // and ONE lane forked from it (identical ciphertexts, the rounds of the longest component in a row instead of the sum
@@ -1274,7 +1420,7 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
             for (auto &ops : lane_plan[lane]) lane_scratch[lane] = std::max(lane_scratch[lane], engines[lane]->scratch_rows(ops));
             total_scratch += lane_scratch[lane];
         }
-        int base = eval_values->scratch(total_scratch);
+        int base = eval_values->scratch(aux_total + total_scratch) + (int)aux_total; // carry-save terms first
         std::vector<int> lane_base(n_ctx);
         for (size_t lane = 0; lane < n_ctx; lane++) {
             lane_base[lane] = base;
@@ -1310,7 +1456,7 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
         remember(*eval_values);
         return eval_values;
     }
-    const int scratch = eval_values->scratch(max_scratch);
+    const int scratch = eval_values->scratch(aux_total + max_scratch) + (int)aux_total; // carry-save terms first
     size_t li = 0;
     for (auto &kv : circuit_.level_map()) {
         eng.run_level(eval_values->table(), plan[li++], scratch);

@@ -130,6 +130,11 @@ int helm_host_si_circuit_set_wopbs(helm_si_circuit *c, helm_wop_ctx *wop, int bi
  * then evaluated concurrently, one lane each, instead of meeting at every level boundary; identical ciphertexts.
  * lane = NULL removes all lanes.  helm_host_si_circuit_pbs_rounds_per_cycle() then reports the longest lane. */
 int helm_host_si_circuit_add_lane(helm_si_circuit *c, helm_si_ctx *lane);
+/* Arithmetic mode: carry-save products (default on).  A product whose every consumer is an addition or a subtraction
+ * (possibly behind multiplications by powers of four) hands over the two terms its reduction ends with; the consumer
+ * sums the terms of both operands and propagates carries once - a * b - c * d costs 11 + 7 rounds of bootstraps in a row
+ * instead of 11 + 6 + 6.  Same values mod 2^bits on every wire; 0 = every operator propagates (as round 2). */
+int helm_host_si_circuit_set_lazy_carries(helm_si_circuit *c, int on);
 /* One level of arithmetic-mode operators as ONE batched call on a table of radix integers - what the reference does
  * gate by gate with the FheUintN operators (src/gates.rs:306-702: evaluate_encrypted_{copy,mul,div,add,sub,shift}_block
  * and their _plain forms; level loop src/circuit.rs:1320-1441).  An integer is `blocks` consecutive rows (2 message bits

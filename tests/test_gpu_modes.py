@@ -163,7 +163,7 @@ def test_chi_squared_u32(keys):  # circuit_test.rs:313-370, inputs K-5 (2, 7, 9)
 def test_chi_squared_on_lanes_is_bit_identical_and_shorter(keys):
     """Lanes (helm_si_ctx_fork): the two sub-circuits of chi-squared that share no wire (alpha's and the betas') run
     concurrently instead of meeting at every level boundary: the same ciphertexts on every wire, fewer rounds in a row
-    (39 level-synchronous rounds -> the longer sub-circuit's 28).  Lanes are the DEFAULT when the operator graph has two or
+    (33 level-synchronous rounds -> the longer sub-circuit's 23).  Lanes are the DEFAULT when the operator graph has two or
     more components; set_lanes(1) is the reference's level-by-level evaluation."""
     import time
     client_key, server_key = keys
@@ -185,17 +185,83 @@ def test_chi_squared_on_lanes_is_bit_identical_and_shorter(keys):
     for wire in one.keys():
         assert np.array_equal(one[wire], two[wire]), wire
     assert {k: v.value for k, v in ac.decrypt_outputs(two, True).items()} == {"alpha": 529, "beta1": 242, "beta2": 275, "beta3": 1250}
-    # mult by 2 is one round (a shift), so the betas' chain is 1 + 6 + 11 + 1 rounds and alpha's 11 + 0 + 6 + 11 = 28
-    assert ac.pbs_per_cycle() == pbs_one and rounds_one == 39 and ac.pbs_rounds_per_cycle() == 28
+    # mult by 2 is one round (a shift): the betas' chain is 1 + 6 + 11 + 1 = 19 rounds; alpha's products hand their terms
+    # to the subtraction in carry-save form: 5 + 0 + 7 + 11 = 23 (round 2: 29; level by level 5 + 6 + 11 + 11 = 33, was 39)
+    assert ac.pbs_per_cycle() == pbs_one and rounds_one == 33 and ac.pbs_rounds_per_cycle() == 23
     assert "2 independent sub-circuit(s)" in ac.log()
     print(f"chi-squared u32: {t_one:.3f} s level by level, {t_two:.3f} s on two lanes")
     assert t_two < t_one
     # the default: a fresh circuit forks its own lane when there are two components
     ac2 = ArithCircuit(client_key, server_key, circuit)
     dflt = ac2.evaluate_encrypted(enc_in, 1, "u32")
-    assert ac2.pbs_rounds_per_cycle() == 28 and "2 independent sub-circuit(s)" in ac2.log()
+    assert ac2.pbs_rounds_per_cycle() == 23 and "2 independent sub-circuit(s)" in ac2.log()
     for wire in one.keys():
         assert np.array_equal(one[wire], dflt[wire]), wire
+
+
+def _decrypt_int(client_key, rows):
+    """blocks of 2 message bits, least significant first -> the integer (every block must be clean: value < 4)"""
+    vals = client_key.decrypt_message_and_carry(rows)
+    assert all(int(v) < 4 for v in vals), list(vals)
+    return sum(int(v) << (2 * i) for i, v in enumerate(vals))
+
+
+def test_carry_save_products_feed_additions(keys):
+    """Products whose consumers are additions / subtractions (possibly behind a multiplication by a power of four) hand
+    over the two terms their reduction ends with instead of propagating carries; the consumer sums all terms and
+    propagates once.  Every wire - the carry-save ones too - holds the same value as without the optimisation
+    (reference semantics: src/gates.rs:331-385, 453-487: `*`, `+`, `-` on FheUintN), in fewer rounds in a row."""
+    client_key, server_key = keys
+    text = """input [15:0] A, B, C, D;
+output [15:0] X, Y, Z, W;
+mult g0(A, B, t0);
+mult g1(C, D, t1);
+sub g2(t0, t1, X);
+mult g3(t0, 4, t2);
+add g4(t2, t1, Y);
+mult g5(A, C, t3);
+add g6(t3, D, Z);
+mult g7(t3, t3, W);
+"""
+    circuit, wire_set, _, _ = _circuit(text, is_arith=True, is_text=True)
+    a, b, c, d = 1234, 567, 89, 4321
+    m = 1 << 16
+    want = {"t0": a * b % m, "t1": c * d % m, "X": (a * b - c * d) % m, "t2": a * b * 4 % m, "Y": (a * b * 4 + c * d) % m,
+            "t3": a * c % m, "Z": (a * c + d) % m, "W": (a * c) ** 2 % m}
+    results = {}
+    for lazy in (True, False):
+        ac = ArithCircuit(client_key, server_key, circuit)
+        ac.set_lanes(1)
+        ac.set_lazy_carries(lazy)
+        enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U16(a), "B": PtxtType.U16(b), "C": PtxtType.U16(c), "D": PtxtType.U16(d)})
+        out = ac.evaluate_encrypted(enc, 1, "u16")
+        got = {w: _decrypt_int(client_key, out[w]) for w in want}
+        assert got == want, (lazy, got)
+        results[lazy] = (ac.pbs_rounds_per_cycle(), ac.pbs_per_cycle())
+    # here level 1 also holds a product that must propagate (t3 feeds a product), so the level costs its 9 rounds either
+    # way and the carry-save sums add one reduction round: 24 against 23 - the saving shows where the products are alone:
+    assert results == {True: (24, results[True][1]), False: (23, results[False][1])}, results
+    small, ws, _, _ = _circuit("input [15:0] A, B, C, D;\noutput [15:0] X;\nmult g0(A, B, t0);\nmult g1(C, D, t1);\nsub g2(t0, t1, X);\n",
+                               is_arith=True, is_text=True)
+    rounds = {}
+    for lazy in (True, False):
+        ac = ArithCircuit(client_key, server_key, small)
+        ac.set_lazy_carries(lazy)
+        enc = ac.encrypt_inputs(ws, {"A": PtxtType.U16(a), "B": PtxtType.U16(b), "C": PtxtType.U16(c), "D": PtxtType.U16(d)})
+        out = ac.evaluate_encrypted(enc, 1, "u16")
+        assert {w: _decrypt_int(client_key, out[w]) for w in ("t0", "t1", "X")} == {"t0": want["t0"], "t1": want["t1"], "X": want["X"]}
+        rounds[lazy] = ac.pbs_rounds_per_cycle()
+    # a * b - c * d on FheUint16: products 1 + 3 rounds, then 1 + 5 for the subtraction = 10; with every operator
+    # propagating: 9 + 5 = 14
+    assert rounds == {True: 10, False: 14}, rounds
+    # on lanes (the default) the same ciphertexts as level by level
+    ac = ArithCircuit(client_key, server_key, circuit)
+    enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U16(a), "B": PtxtType.U16(b), "C": PtxtType.U16(c), "D": PtxtType.U16(d)})
+    lanes = ac.evaluate_encrypted(enc, 1, "u16")
+    ac.set_lanes(1)
+    flat = ac.evaluate_encrypted(enc, 2, "u16")
+    for w in sorted(flat.keys()):
+        assert np.array_equal(lanes[w], flat[w]), w
 
 
 def test_shifts_and_division_u8(keys):  # gates.rs:386-452, 488-700 (div, shl, shr and their plain forms)

@@ -1,10 +1,10 @@
-"""Profiling driver: one level of B 3-input LUT gates (shortint_m2c2), repeated. Usage: prof_luts.py <B> <reps>"""
+"""Profiling driver: one level of B 3-input LUT gates, repeated. Usage: prof_luts.py <B> <reps> [set = shortint_m2c2]"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
 import helm_amd  # noqa
 B, reps = int(sys.argv[1]), int(sys.argv[2])
-ck = helm_amd.SiClientKey.generate("shortint_m2c2", seed=1)
+ck = helm_amd.SiClientKey.generate(sys.argv[3] if len(sys.argv) > 3 else "shortint_m2c2", seed=1)
 sk = helm_amd.SiServerKey(ck)
 bits = np.random.default_rng(0).integers(0, 2, size=3 * B).astype(np.uint64)
 w = sk.wires(4 * B)
