@@ -1498,6 +1498,7 @@ struct helm_si_ctx {
     } slots[3];
     int next_slot = 0;
     uint64_t luts_hash = 0; // of the look-up tables resident in d_luts (re-uploaded only when they change)
+    std::vector<uint64_t> luts_host; // host copy of the resident tables: compared word for word when the hash matches
     size_t luts_words = 0;
     // multi-GPU (helm_si_set_exchange): every bootstrap batch of at least x_min ciphertexts is split
     // into x_world contiguous chunks, this rank bootstraps chunk x_rank into x_stage, the caller's
@@ -1808,10 +1809,15 @@ int luts_resident(helm_si_ctx *ctx, const uint64_t *luts_host, size_t words)
 {
     uint64_t h = 0x9E3779B97F4A7C15ull ^ words;
     for (size_t i = 0; i < words; i++) h = (h ^ luts_host[i]) * 0x100000001B3ull + (h >> 29);
-    if (ctx->d_luts.p && ctx->luts_words == words && ctx->luts_hash == h) return 0;
+    // the hash only says "probably": the words themselves decide (a collision would bootstrap with the previous call's
+    // tables and return wrong ciphertexts without an error; the WoP-PBS path swaps tables on one context all the time)
+    if (ctx->d_luts.p && ctx->luts_words == words && ctx->luts_hash == h && ctx->luts_host.size() == words &&
+        std::memcmp(ctx->luts_host.data(), luts_host, words * sizeof(uint64_t)) == 0)
+        return 0;
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // a running bootstrap may still read the old tables
     if (ctx->d_luts.ensure(words)) return fail(HELM_ERR_OOM, "look-up tables");
     HIP_TRY(hipMemcpy(ctx->d_luts.p, luts_host, words * sizeof(uint64_t), hipMemcpyHostToDevice));
+    ctx->luts_host.assign(luts_host, luts_host + words);
     ctx->luts_hash = h;
     ctx->luts_words = words;
     return 0;

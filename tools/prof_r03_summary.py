@@ -38,9 +38,20 @@ for d in sorted(glob.glob(root + "/*")):
         if not any(x in k for x in ("k_pbs", "k_ks", "k_pfpks", "k_keyswitch")):
             continue
         line = "  " + k + ": " + ", ".join(f"{a} {v:.4g}" for a, v in sorted(c.items()))
-        if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("SQ_BUSY_CYCLES"):
-            # SQ_VALU_MFMA_BUSY_CYCLES counts per SIMD pipe (4 per CU); SQ_BUSY_CYCLES per SQ
-            line += f"  => MFMA pipe busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * c['SQ_BUSY_CYCLES']):.3f} of SQ-busy SIMD cycles"
+        g = c.get("GRBM_GUI_ACTIVE")
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and g:
+            # GRBM_GUI_ACTIVE sums the 8 XCDs: kernel cycles = / 8.  SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD
+            # (MI355X_MICROARCH.md: "counts cycles"), 4 SIMDs x 256 CUs.  SQ_INSTS_VALU_MFMA_MOPS_I8 counts 512 int8
+            # operations each (v_mfma_i32_16x16x64_i8 = 32,768 operations = 64 counts).
+            cycles = g / 8.0
+            line += f"  => matrix pipes busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (cycles * 1024):.4f} of the chip's SIMD-cycles"
+            if c.get("SQ_INSTS_VALU_MFMA_MOPS_I8"):
+                ops = c["SQ_INSTS_VALU_MFMA_MOPS_I8"] * 512.0
+                line += f", {ops / cycles:.0f} int8 op/cycle = {ops / cycles * 2.4e9 / 1e15:.3f} P int8-op/s at 2.4 GHz"
+            if c.get("SQ_WAVE_CYCLES"):
+                line += f"; {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * c['SQ_WAVE_CYCLES']):.3f} of the kernel's own wave-cycles"
         if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_WAVE_CYCLES"):
             line += f"  => VALU active {c['SQ_ACTIVE_INST_VALU'] / c['SQ_WAVE_CYCLES']:.3f} of wave-cycles"
-        print(line[:1200])
+        if c.get("SQ_LDS_IDX_ACTIVE") and g:
+            line += f"  => LDS pipe active {c['SQ_LDS_IDX_ACTIVE'] / (g / 8.0 * 256):.3f} of CU-cycles"
+        print(line[:1500])
