@@ -652,7 +652,45 @@ def other_modes(device):
     mb = _other_modes_set(device, "shortint_m2c2_multibit3", "dimensions of PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS "
                           "(helm.rs:83) [recalled; LWE noise extrapolated, not tfhe's value: approximate set]")
     res["lut_mode_multibit3"], res["arith_mode_multibit3"] = mb["lut_mode"], mb["arith_mode"]
+    res["lut_mode_m1c1"] = _lut_m1c1_leg(device)
     res["wide_lut_wopbs"] = _wide_lut_leg(device)
+    return res
+
+
+def _lut_m1c1_leg(device):
+    """LUT mode as the reference BINARY configures it (helm.rs:301: PARAM_MESSAGE_1_CARRY_1_KS_PBS, k = 3, N = 512): 1,024
+    independent 2-input LUT gates (XOR), the bivariate form of gates::lut() (gates.rs:761-764), on k_pbs64k."""
+    import helm_amd
+    import torch
+    ck, sk = helm_amd.gen_keys_shortint("shortint_m1c1", seed=1, device=device)
+    B = 1024
+    bits = np.random.default_rng(0).integers(0, 2, size=2 * B).astype(np.uint64)
+    w = sk.wires(3 * B)
+    w.upload(np.arange(2 * B), ck.encrypt(bits))
+    in_idx = np.arange(2 * B, dtype=np.int32).reshape(2, B).T.copy()
+    ar, tb, out = np.full(B, 2, np.int32), np.full(B, 0x6, np.uint64), np.arange(2 * B, 3 * B, dtype=np.int32)
+    w.eval_lut_level(ar, in_idx, tb, out)
+    sk.sync()
+    sk.timing_enable(True)
+    sk.timing(reset=True)
+    t0 = time.perf_counter()
+    w.eval_lut_level(ar, in_idx, tb, out)
+    sk.sync()
+    dt = time.perf_counter() - t0
+    tm = sk.timing(reset=True)
+    ok = bool(np.array_equal(ck.decrypt(w.download(out)), bits[:B] ^ bits[B:]))
+    p = ck.params
+    K1 = p.k + 1
+    n_cus = torch.cuda.get_device_properties(device).multi_processor_count
+    res = {"workload": f"{B} independent 2-input LUT gates (keyswitch + programmable bootstrap), PARAM_MESSAGE_1_CARRY_1_KS_PBS - the set "
+                       "the reference binary installs for LUT mode (helm.rs:301) [dimensions recalled; GLWE noise interpolated: approximate set]",
+           "params": {"n": p.n, "k": p.k, "N": p.N, "pbs_l": p.pbs_l, "pbs_logB": p.pbs_logB, "ks_l": p.ks_l, "ks_logB": p.ks_logB},
+           "luts_per_s": round(B / dt, 1), "decrypt_ok": ok,
+           "kernel_ms": {"k_pbs64k": round(tm.pbs_ms, 3), "keyswitch": round(tm.ks_ms, 3), "linear": round(tm.linear_ms, 3)},
+           "roofline": si_roofline("k_pbs64k<Pbs64kCfg<9, 3>>", si_algo_ops(p.n, p.k, p.N, p.pbs_l), tm.pbs_count, tm.pbs_ms,
+                                   tm.pbs_launches, n_cus, p.n * p.pbs_l * K1 * K1 * p.N * 8 * 2,
+                                   (p.n + 1) * 8 + (p.k * p.N + 1) * 8 + p.N * 8)}
+    sk.close()
     return res
 
 
