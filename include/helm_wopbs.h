@@ -97,8 +97,9 @@ int helm_wop_make_table(const helm_wop_params *params, int32_t n_blocks, int32_t
  * bookkeeping extracts after the cleaning bootstrap; 1 is enough when every input holds a single bit;
  * tables [count][helm_wop_table_words(n_inputs * bits_per_block)];  out_idx [count] rows of `w`.
  * n_inputs * bits_per_block <= log2(N) + 6.
- * The gates of a call are independent (one netlist level): an output row that is also an input row of the same call is
- * refused with HELM_ERR_INVALID - the batch runs in chunks, so such a call would depend on the chunking.
+ * The gates of a call are independent (one netlist level): an output row that is an input row of ANOTHER gate of the
+ * call is refused with HELM_ERR_INVALID - the batch runs in chunks, so such a call would depend on the chunking.  A gate
+ * may write over one of its own inputs.
  * Multi-GPU: after helm_si_set_exchange() on the PBS-side context a batch of at least min_batch gates is split over the
  * ranks by gate (every stage of a gate on one rank), the result rows go through the same all-gather callback and are
  * scattered into every rank's table; identical ciphertexts to the unsharded call. */

@@ -241,6 +241,9 @@ def test_argument_validation_and_edge_cases(toy):
     # in place: output row = input row of the same gate
     wsk.eval_luts(w, np.array([[2]], np.int32), np.array([1, 0], dtype=U64), np.array([2], np.int32), bits_per_block=1)
     assert int(ck.decrypt_message_and_carry(w.download(np.array([2])))[0]) == 1
+    # an output row that another gate of the same call reads: the result would depend on the chunking - refused
+    with pytest.raises(nv.HelmError, match="input row of another"):
+        wsk.eval_luts(w, np.array([[0], [4]], np.int32), np.array([0, 1], dtype=U64), np.array([4, 5], np.int32), bits_per_block=1)
     with pytest.raises(nv.HelmError, match="out of range"):
         wsk.eval_luts(w, np.array([[0, 9]], np.int32), np.zeros(16, U64), np.array([4], np.int32), bits_per_block=1)
     with pytest.raises(nv.HelmError, match="bits_per_block"):
