@@ -364,22 +364,24 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
 // (reference src/bin/helm.rs:301: k = 3, N = 512 [dimensions recalled]).  2 (k+1) waves:
 // wave w = (polynomial p = w >> 1, field f = w & 1), as k_pbs64; what changes with k + 1 > 2
 // polynomials is the hand-over: a wave's product with key column c belongs to polynomial c, and
-// the k foreign ones are summed into SUM[c][f] with ds_add_f64 - exact integers below 2^53, so
-// the sum does not depend on the order the waves arrive in.  Three workgroup barriers per step.
+// the k foreign ones are summed into the (cleared) transform scratch of wave (c, f) with ds_add_f64 -
+// exact integers below 2^53, so the sum does not depend on the order the waves arrive in.  Four
+// workgroup barriers per step; 64 KB of LDS and at most 128 registers: TWO ciphertexts per CU.
 // ------------------------------------------------------------------------------------
 template <int LOGN_, int K_>
 struct Pbs64kCfg {
     static constexpr int LOGN = LOGN_, L = 1, K = K_, K1 = K_ + 1, NW = 2 * K1;
     using G = Geo<LOGN>;
     static constexpr int MAX_SMALL_N = 1024;
-    static constexpr size_t X_OFF = 0;                                            // double [NW][XPAD]
+    static constexpr size_t X_OFF = 0;                                            // double [NW][XPAD]: transform scratch,
+                                                                                  // and between two barriers the column sums
     static constexpr int TW_IDX = G::N >> G::BC, TW_FIELD = TW_IDX + G::TWC * 64;
     static constexpr size_t TW_OFF = X_OFF + sizeof(double) * NW * G::XPAD;       // double [2][TW_FIELD]
     static constexpr size_t ACC_OFF = TW_OFF + sizeof(double) * 2 * TW_FIELD;     // u64 [K1][N]
-    static constexpr size_t SUM_OFF = ACC_OFF + sizeof(uint64_t) * K1 * G::N;     // double [K1][2][N]
-    static constexpr size_t MS_OFF = SUM_OFF + sizeof(double) * K1 * 2 * G::N;    // u16 [n+1]
+    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint64_t) * K1 * G::N;      // u16 [n+1]
     static constexpr size_t BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
     static_assert(NW <= 16, "a workgroup holds at most 16 waves");
+    static_assert(2 * BYTES <= 160 * 1024, "two ciphertexts per CU");
 };
 
 template <typename C, typename F>
@@ -391,7 +393,6 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
     constexpr int N = G::N, E = G::E, H = E / 2;
     double *X = reinterpret_cast<double *>(smem + C::X_OFF);
     uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
-    double *SUM = reinterpret_cast<double *>(smem + C::SUM_OFF);
     const uint16_t *MS = reinterpret_cast<const uint16_t *>(smem + C::MS_OFF);
     double *xb = X + (size_t)(p * 2 + f) * G::XPAD;                          // own scratch
     const double *x_field = X + (size_t)(p * 2 + (1 - f)) * G::XPAD;         // same polynomial, other field
@@ -400,19 +401,29 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
     TwHybrid<LOGN, false> twf{twt, twt + C::TW_IDX + lane};
     TwHybrid<LOGN, true> twi{twt, twt + C::TW_IDX + (63 - lane)};
     // key words of step i for this wave: [i][row p][c][f][e/2][lane] as double2 (the layout k_bsk_convert64 writes)
-    const size_t per_poly = (size_t)2 * (N / 2); // both fields
-    const size_t bsk_step = (size_t)K1 * K1 * per_poly;
-    const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * 2 + f) * (N / 2) + lane;
+    // read with buffer loads: one descriptor in scalar registers, a scalar byte offset per (step, column), one lane
+    // register and an immediate per word (plain pointers cost an address register pair per word and spill at 128)
+    const unsigned poly_bytes = (unsigned)(N / 2) * 16u;      // one key polynomial in one field
+    const unsigned col_bytes = 2u * poly_bytes;               // both fields
+    const unsigned step_bytes = (unsigned)(K1 * K1) * col_bytes;
+    const unsigned row_off = (unsigned)(p * K1) * col_bytes + (unsigned)f * poly_bytes;
+    KeyBuf kb;
+    kb.init(bsk, (size_t)n * step_bytes, lane);
     const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
     for (int i = 0; i < n; i++) {
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
         if (a == 0) continue; // uniform over the workgroup
-        const double2 *bp_i = bsk_w + (size_t)i * bsk_step;
-        double2 kw[K1][H];
+        const unsigned so_i = (unsigned)i * step_bytes + row_off;
+        // key words: all K1 columns of the first half of the spectrum slots at the top (the transform covers them), the
+        // second half slot pair by slot pair around the products (at most three quarters of the words live at once:
+        // the kernel must stay within 128 registers for two ciphertexts per CU)
+        double2 kw[H][K1];
+        auto fetch = [&](int u) {
 #pragma unroll
-        for (int c = 0; c < K1; c++)
+            for (int c = 0; c < K1; c++) kw[u][c] = kb.load(so_i + (unsigned)c * col_bytes, u * 1024);
+        };
 #pragma unroll
-            for (int u = 0; u < H; u++) kw[c][u] = (bp_i + (size_t)c * per_poly)[u * 64];
+        for (int u = 0; u < H / 2; u++) fetch(u);
         // ---- rotate / subtract, one signed digit per coefficient (pbs_l = 1) ------------------
         double x[1][E];
 #pragma unroll
@@ -426,14 +437,17 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
             x[0][e] = (double)((int)st - (int)(((st + half_m1) >> logB) << logB));
         }
         ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+        // the scratch becomes this wave's column sum: clear it, and wait until every wave is through its transform
+#pragma unroll
+        for (int e = 0; e < E; e++) xb[e * 64 + lane] = 0.0;
+        lds_block_sync();
         // ---- products: column p stays, the others go to the waves of their polynomials --------
         double mine[E];
+        auto products = [&](int u) {
 #pragma unroll
-        for (int c = 0; c < K1; c++) {
-            double *sum_c = SUM + ((size_t)c * 2 + f) * N + lane;
-#pragma unroll
-            for (int u = 0; u < H; u++) {
-                const double t0 = mulmod<F>(x[0][2 * u], kw[c][u].x), t1 = mulmod<F>(x[0][2 * u + 1], kw[c][u].y);
+            for (int c = 0; c < K1; c++) {
+                double *sum_c = X + (size_t)(c * 2 + f) * G::XPAD + lane;
+                const double t0 = mulmod<F>(x[0][2 * u], kw[u][c].x), t1 = mulmod<F>(x[0][2 * u + 1], kw[u][c].y);
                 if (c == p) {
                     mine[2 * u] = t0;
                     mine[2 * u + 1] = t1;
@@ -442,16 +456,19 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
                     lds_add_wg(sum_c + (2 * u + 1) * 64, t1);
                 }
             }
+        };
+#pragma unroll
+        for (int u = 0; u < H; u++) {
+            if (u + H / 2 < H) {
+                fetch(u + H / 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            products(u);
+            __builtin_amdgcn_sched_barrier(0);
         }
         lds_block_sync(); // every foreign product is in
-        {
-            double *sum_p = SUM + ((size_t)p * 2 + f) * N + lane;
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                mine[e] = reduce<F>(mine[e] + sum_p[e * 64]);
-                sum_p[e * 64] = 0.0; // for the next step: its additions come after two more barriers
-            }
-        }
+        for (int e = 0; e < E; e++) mine[e] = reduce<F>(mine[e] + xb[e * 64 + lane]);
         ntt_inverse<F, LOGN>(mine, xb, twi, lane);
         // ---- CRT: field-f wave lifts slots [f*H, f*H+H) of its polynomial ---------------------
 #pragma unroll
@@ -465,12 +482,12 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
             const uint64_t xv = (uint64_t)to_int64(r0) + F0::P_U64 * (uint64_t)to_int64(t);
             acc_p[G::jA(lane, f * H + e)] += xv;
         }
-        lds_block_sync(); // accumulator complete before the next step's rotated reads
+        lds_block_sync(); // accumulator complete before the next step's rotated reads; scratch free again
     }
 }
 
 template <typename C>
-__global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64k(const Pbs64Job *__restrict__ jobs,
+__global__ __launch_bounds__(64 * C::NW, C::NW / 2) void k_pbs64k(const Pbs64Job *__restrict__ jobs,
                                                           const uint64_t *__restrict__ small, // rows of n+1
                                                           const uint64_t *__restrict__ luts,  // rows of N
                                                           const double *__restrict__ bsk,     // NTT domain, both fields
@@ -483,7 +500,6 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64k(const Pbs64Job *__rest
     constexpr int N = G::N, E = G::E, H = E / 2;
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
-    double *SUM = reinterpret_cast<double *>(smem + C::SUM_OFF);
     uint16_t *MS = reinterpret_cast<uint16_t *>(smem + C::MS_OFF);
     double *TW = reinterpret_cast<double *>(smem + C::TW_OFF);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -501,7 +517,6 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64k(const Pbs64Job *__rest
         TW[C::TW_IDX + r * 64 + lane] = tw0[idx];
         TW[C::TW_FIELD + C::TW_IDX + r * 64 + lane] = tw1[idx];
     }
-    for (int j = tid; j < (K + 1) * 2 * N; j += 64 * C::NW) SUM[j] = 0.0;
     __syncthreads();
     { // accumulator: (0, ..., 0, X^{-b~} * lut)
         const int bt = (int)MS[n];
@@ -562,6 +577,27 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64k(const Pbs64Job *__rest
 {
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+#ifndef HELM_SI_SWAP_NTT
+#define HELM_SI_SWAP_NTT 0 // N = 2048: half transforms with one LDS transpose (lane-bit stages through row swaps, ntt_fp64.h):
+                           // bit-identical, 13 % fewer LDS instructions, +2.5 % vector instructions - measured -0.4 % (m2c2) /
+                           // +0.7 % (multi-bit), and the two-level build spills: off (profiles/r03/si_kernel_experiments.txt)
+#endif
+// the half transforms of k_pbs64s: the one-transpose form where it exists (1,024 points), the two-transpose form otherwise
+template <typename F, int LOGH, typename TW, int PRIO, typename HOOK = NoHook>
+__device__ __forceinline__ void half_forward(double (&x)[1][Geo<LOGH>::E], double *xb, const TW &tw, int lane,
+                                             const HOOK &hook = HOOK())
+{
+    if constexpr (LOGH == 10 && HELM_SI_SWAP_NTT) ntt_forward_sw10<F, TW, PRIO, HOOK>(x, xb, tw, lane, hook);
+    else ntt_forward<F, LOGH, 1, TW, PRIO, HOOK>(x, xb, tw, lane, hook);
+}
+template <typename F, int LOGH, typename TW, int PRIO, bool CENTRE, typename HOOK = NoHook>
+__device__ __forceinline__ void half_inverse(double (&x)[Geo<LOGH>::E], double *xb, const TW &tw, int lane,
+                                             const HOOK &hook = HOOK())
+{
+    if constexpr (LOGH == 10 && HELM_SI_SWAP_NTT) ntt_inverse_sw10<F, TW, PRIO, CENTRE, HOOK>(x, xb, tw, lane, hook);
+    else ntt_inverse<F, LOGH, TW, PRIO, CENTRE, HOOK>(x, xb, tw, lane, hook);
 }
 
 template <int LOGN_, int L_ = 1>
@@ -702,9 +738,9 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
                 for (int u = 0; u < HC; u++) kw[1][u] = (bp_i + (size_t)(1 * L + lev) * 4 * part)[u * 64];
             };
 #if HELM_SI_KW1_EARLY
-            ntt_forward<F, LOGN - 1, 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane, fetch_kw1);
+            half_forward<F, LOGN - 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane, fetch_kw1);
 #else
-            ntt_forward<F, LOGN - 1, 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
+            half_forward<F, LOGN - 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
 #endif
             if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
             if (lev == 0) {
@@ -748,7 +784,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         STAMP(4) // flag 1, sum
         auto partner_has_read = [&]() { lds_flag_wait(flag_partner + C::NW, seq); };
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
-        ntt_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane, partner_has_read);
+        half_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane, partner_has_read);
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
 #else
         lds_block_sync();
@@ -758,7 +794,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         STAMP(4) // barrier 2, sum, barrier 3
         // ---- (3) half inverse, meet the other half, last stage -------------------------------
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
-        ntt_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane); // a_h[e * 64 + lane], centred
+        half_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane); // a_h[e * 64 + lane], centred
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
 #endif
         STAMP(5) // half inverse
@@ -895,7 +931,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
                 x[0][e] = h ? U - V : U + V;
             }
         }
-        ntt_forward<F, LOGN - 1, 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
+        half_forward<F, LOGN - 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
         // ---- the group's key in the transform domain: G[c] = sum_S M(e_S) .* K_S[p][c], then the products
         //      x .* G[c].  The spectrum positions of a lane are expo(lane, e) = c_lane + (2N/EH) rev(e)
@@ -976,7 +1012,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
         lds_block_sync(); // hand-over read: scratch free again
         // ---- (3) half inverse, meet the other half, last stage -----------------------------------
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
-        ntt_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane);
+        half_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane);
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int e = 0; e < EH; e++) xb[e * 64 + lane] = mine[e];

@@ -506,4 +506,133 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *x
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 1,024-point transforms (16 values per lane) with ONE LDS transpose instead of two.  Stride bits 9..6 are slot bits of
+// layout A, stride bits 3..0 slot bits of layout C; the two in between, 5 and 4, are LANE bits 5 and 4 and are done with
+// gfx950's row swaps: v_permlane32_swap / v_permlane16_swap exchange the upper (odd) 32- / 16-lane rows of one register
+// with the lower rows of another, so that after swapping the registers of slots e and e | 8 (e | 4) every lane holds
+// both ends (j, j ^ 32) (j, j ^ 16) of eight butterflies.  The swap is not undone: lane bit 5 (4) then stands for what
+// was slot bit 3 (2), and the transpose addresses absorb it.  Same butterflies, same twiddles, same stage order as
+// ntt_forward<F, 10> / ntt_inverse<F, 10>: identical results, 32 LDS operations fewer and 32 vector instructions more
+// per transform.  Holder of coefficient j after the swap stages: lane = (j9 j8 j3 j2 j1 j0), slot = (j5 j4 j7 j6).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void swap32_f64(double &a, double &b)
+{
+    const u32x2_t lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const u32x2_t hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi.x, (int)lo.x);
+    b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ void swap16_f64(double &a, double &b)
+{
+    const u32x2_t lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const u32x2_t hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi.x, (int)lo.x);
+    b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+
+struct GeoSw10 {
+    using G = Geo<10>;
+    // padded address of coefficient j: j + (j >> 4) (conflict-free for the 16-consecutive writes of the swapped layout and
+    // for layout C's stride-16 reads); writer (lane, slot e) holds j = (l5 l4 e1 e0 e3 e2 l3 l2 l1 l0)
+    __device__ static __forceinline__ int baseP(int lane) { return ((lane >> 4) << 8) + ((lane >> 4) << 4) + (lane & 15); }
+    static constexpr int offP(int e) { return ((e & 3) << 6) + ((e >> 2) << 4) + ((e & 3) << 2) + (e >> 2); }
+    __device__ static __forceinline__ int baseC(int lane) { return lane * 17; }
+    // twiddle table indices of the two swap stages for this lane: stride bit 5: 16 + (j >> 6), stride bit 4: 32 + (j >> 5)
+    __device__ static __forceinline__ int idx5(int lane, int e_lo) { return 16 + ((lane >> 5) << 3) + e_lo; }                       // e_lo < 8
+    __device__ static __forceinline__ int idx4(int lane, int e_c) { return 32 + ((lane >> 4) << 3) + ((e_c & 3) << 1) + (e_c >> 3); } // bit 2 of e_c clear
+};
+
+template <typename F, typename TW, int PRIO = 0, typename HOOK = NoHook>
+__device__ __forceinline__ void ntt_forward_sw10(double (&x)[1][16], double *xbuf, const TW &tw, int lane,
+                                                 const HOOK &before_last = HOOK())
+{
+    using G = Geo<10>;
+    static_assert(F::LAZY, "the swap-stage transform is written for the lazy 49-bit fields (no recentring on the way)");
+    fwd_block<F, 10, 1, 6, 9, 6, 0>(x, tw, G::jA(lane, 0)); // stride bits 9..6
+    if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);
+    // stride bit 5: slots e and e + 8 swap rows of 32 lanes
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        double u = x[0][e], v = x[0][e + 8];
+        swap32_f64(u, v);
+        const double w = tw.get(5, 0, 0, GeoSw10::idx5(lane, e), 0);
+        const double V = mulmod<F>(v, w);
+        x[0][e] = u + V;
+        x[0][e + 8] = u - V;
+    }
+    // stride bit 4: slots e and e + 4 (bit 2 clear) swap rows of 16 lanes
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int e = (q & 3) | ((q >> 2) << 3);
+        double u = x[0][e], v = x[0][e + 4];
+        swap16_f64(u, v);
+        const double w = tw.get(4, 0, 0, GeoSw10::idx4(lane, e), 0);
+        const double V = mulmod<F>(v, w);
+        x[0][e] = u + V;
+        x[0][e + 4] = u - V;
+    }
+    if constexpr (PRIO > 1) __builtin_amdgcn_s_setprio(PRIO - 2);
+    double *pP = xbuf + GeoSw10::baseP(lane), *pC = xbuf + GeoSw10::baseC(lane);
+#pragma unroll
+    for (int e = 0; e < 16; e++) pP[GeoSw10::offP(e)] = x[0][e];
+    lds_wave_sync();
+#pragma unroll
+    for (int e = 0; e < 16; e++) x[0][e] = pC[e];
+    lds_wave_sync();
+    before_last();
+    fwd_block<F, 10, 1, 0, 3, 0, 0>(x, tw, G::jC(lane, 0)); // stride bits 3..0
+}
+
+template <typename F, typename TW, int PRIO = 0, bool CENTRE = true, typename HOOK = NoHook>
+__device__ __forceinline__ void ntt_inverse_sw10(double (&x)[16], double *xbuf, const TW &tw, int lane,
+                                                 const HOOK &before_write = HOOK())
+{
+    using G = Geo<10>;
+    static_assert(F::LAZY, "the swap-stage transform is written for the lazy 49-bit fields");
+    inv_block<F, 10, 0, 0, 3, 0>(x, tw, G::jC(lane, 0)); // stride bits 0..3: four doublings from 0.5 p
+    before_write();
+    if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);
+    double *pP = xbuf + GeoSw10::baseP(lane), *pC = xbuf + GeoSw10::baseC(lane);
+#pragma unroll
+    for (int e = 0; e < 16; e++) pC[e] = reduce<F>(x[e]);
+    lds_wave_sync();
+#pragma unroll
+    for (int e = 0; e < 16; e++) x[e] = pP[GeoSw10::offP(e)];
+    lds_wave_sync();
+    // stride bit 4, then the rows of 16 lanes go back
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int e = (q & 3) | ((q >> 2) << 3);
+        const double U = x[e], V = x[e + 4];
+        const double w = tw.get(4, 0, 0, GeoSw10::idx4(lane, e), 0);
+        double s0 = U + V, s1 = mulmod<F>(TW::MIRROR ? V - U : U - V, w);
+        swap16_f64(s0, s1);
+        x[e] = s0;
+        x[e + 4] = s1;
+    }
+    // stride bit 5, rows of 32 lanes back
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const double U = x[e], V = x[e + 8];
+        const double w = tw.get(5, 0, 0, GeoSw10::idx5(lane, e), 0);
+        double s0 = U + V, s1 = mulmod<F>(TW::MIRROR ? V - U : U - V, w);
+        swap32_f64(s0, s1);
+        x[e] = s0;
+        x[e + 8] = s1;
+    }
+    if constexpr (PRIO > 1) __builtin_amdgcn_s_setprio(PRIO - 2);
+    // two doublings since the transpose (<= 2 p); four more follow: recentre here (where the second transpose did)
+#pragma unroll
+    for (int e = 0; e < 16; e++) x[e] = reduce<F>(x[e]);
+    inv_block<F, 10, 6, 6, 9, 0>(x, tw, G::jA(lane, 0)); // stride bits 6..9
+    if constexpr (CENTRE) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) x[e] = reduce<F>(x[e]);
+    } else {
+        x[0] = reduce<F>(x[0]); // the pure-sum slot reaches 8 p (see ntt_inverse)
+    }
+}
+
 } // namespace helm
