@@ -579,6 +579,9 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 2) void k_pbs64k(const Pbs64Job
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+#ifndef HELM_SI_MB_NESTED
+#define HELM_SI_MB_NESTED 1 // multi-bit: the group's key sum in nested form (2^g - 1 multiplications per position and column)
+#endif
 #ifndef HELM_SI_SWAP_NTT
 #define HELM_SI_SWAP_NTT 0 // N = 2048: half transforms with one LDS transpose (lane-bit stages through row swaps, ntt_fp64.h):
                            // bit-identical, 13 % fewer LDS instructions, +2.5 % vector instructions - measured -0.4 % (m2c2) /
@@ -895,7 +898,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
     const int quarter = f * 2 + h;
     const size_t part = (size_t)(GS::N / 2);
     const size_t bsk_step = (size_t)K1 * K1 * 4 * part; // one GGSW
-    const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * 4 + f * 2 + h) * part + lane;
+    [[maybe_unused]] const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * 4 + f * 2 + h) * part + lane;
     const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
     const int subsets = 1 << g;
     // exponent of this lane's first spectrum position (slot e = 0 of the key-word order)
@@ -903,6 +906,13 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
     // omega^k, k < EH (omega = psi^(2N/EH)), held by lane k: read with v_readlane by a uniform index
     const double om_tab = psi_pow[(lane & (EH - 1)) * (2 * N / EH)];
     const int om_lo = __double2loint(om_tab), om_hi = __double2hiint(om_tab);
+#if HELM_SI_MB_NESTED
+    // key words through buffer loads: descriptor in scalar registers, scalar byte offset per (group, subset, column)
+    const unsigned ggsw_bytes = (unsigned)(bsk_step * 16), col_bytes = (unsigned)(4 * part * 16);
+    const unsigned wave_off = (unsigned)(((size_t)p * K1 * 4 + f * 2 + h) * part * 16);
+    KeyBuf kbuf;
+    kbuf.init(bsk, (size_t)(n / g) * subsets * ggsw_bytes, lane);
+#endif
     for (int t = 0; t < n / g; t++) {
         int am[3];
 #pragma unroll
@@ -933,6 +943,71 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
         }
         half_forward<F, LOGN - 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
+#if HELM_SI_MB_NESTED
+        // ---- the group's key in the transform domain, G[c] = sum_S M(e_S) .* K_S[p][c], in NESTED form, and the products
+        //      x .* G[c].  M(e_S) is the product of its members' monomial vectors M_i = M(a~_i), so
+        //        G = (K_000 + M_0 K_001) + M_1 (K_010 + M_0 K_011) + M_2 [(K_100 + M_0 K_101) + M_1 (K_110 + M_0 K_111)]:
+        //      2^g - 1 modular multiplications per spectrum position and column instead of 2 (2^g - 1) (one per subset for
+        //      the monomial's own value, one with the key word), plus g per position for the M_i.  The spectrum positions
+        //      of a lane are expo(lane, e) = c_lane + (2N/EH) rev(e), so M_i[e] = psi^(c_lane a~_i) * omega^(a~_i rev(e)):
+        //      one gathered power per lane and member (bq, fetched at the top of the step) times a wave-uniform power of
+        //      omega read out of a lane-held table with v_readlane.  Walked slot pair by slot pair and column by column:
+        //      the 2^g key words of one (slot pair, column) are fetched one iteration ahead (buffer loads: scalar offsets).
+        static_assert(K1 == 2, "two key columns");
+        double mine[EH], oth[EH];
+        auto key_products = [&](auto g_const) {
+            constexpr int GG = decltype(g_const)::value, SUB = 1 << GG; // compile-time group size: no branches in the walk
+            const unsigned so_t = (unsigned)t * (unsigned)SUB * ggsw_bytes + wave_off;
+            double2 kq[2][SUB];
+            auto fetch = [&](int it, double2 (&dst)[SUB]) { // it = 2 u + c
+                const int u = it >> 1, c = it & 1;
+#pragma unroll
+                for (int S = 0; S < SUB; S++)
+                    dst[S] = kbuf.load(so_t + (unsigned)S * ggsw_bytes + (unsigned)c * col_bytes + (unsigned)(u >> 2) * 4096u, (u & 3) * 1024);
+            };
+            fetch(0, kq[0]);
+            double m[GG][2];
+#pragma unroll
+            for (int it = 0; it < 2 * HC; it++) {
+                const int u = it >> 1, c = it & 1;
+                if (it + 1 < 2 * HC) fetch(it + 1, kq[(it + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c == 0) { // the members' monomial values at the two positions of this slot pair
+#pragma unroll
+                    for (int q = 0; q < GG; q++)
+#pragma unroll
+                        for (int z = 0; z < 2; z++) {
+                            const int k = (am[q] * bitrev_c(2 * u + z, GS::LOGE)) & (EH - 1);
+                            const double om = __hiloint2double(__builtin_amdgcn_readlane(om_hi, k), __builtin_amdgcn_readlane(om_lo, k));
+                            m[q][z] = mulmod<F>(bq[q], om);
+                        }
+                }
+                // |K| <= 0.5 p, |M| <= 0.56 p: 1.1 p, 1.8 p, 2.4 p after the three levels - far below 2^53 = 14.2 p
+                double2(&v)[SUB] = kq[it & 1];
+#pragma unroll
+                for (int q = 0; q < GG; q++)
+#pragma unroll
+                    for (int S = 0; S < SUB; S++)
+                        if (!(S & ((2 << q) - 1))) {
+                            v[S].x += mulmod<F>(v[S | (1 << q)].x, m[q][0]);
+                            v[S].y += mulmod<F>(v[S | (1 << q)].y, m[q][1]);
+                        }
+                const double c0 = mulmod<F>(x[0][2 * u], reduce<F>(v[0].x)), c1 = mulmod<F>(x[0][2 * u + 1], reduce<F>(v[0].y)); // <= 1.5 p
+                if (c == p) {
+                    mine[2 * u] = c0;
+                    mine[2 * u + 1] = c1;
+                } else {
+                    oth[2 * u] = c0;
+                    oth[2 * u + 1] = c1;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (g == 3) key_products(std::integral_constant<int, 3>());
+        else key_products(std::integral_constant<int, 2>());
+#pragma unroll
+        for (int e = 0; e < EH; e++) xb[e * 64 + lane] = oth[e];
+#else
         // ---- the group's key in the transform domain: G[c] = sum_S M(e_S) .* K_S[p][c], then the products
         //      x .* G[c].  The spectrum positions of a lane are expo(lane, e) = c_lane + (2N/EH) rev(e)
         //      (verified when the table is probed), so M(e_S)[e] = psi^(c_lane e_S) * omega^(e_S rev(e)) with
@@ -1006,6 +1081,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
             xb[e * 64 + lane] = p == 0 ? col[1][e] : col[0][e];
             mine[e] = p == 0 ? col[0][e] : col[1][e];
         }
+#endif
         lds_block_sync();
 #pragma unroll
         for (int e = 0; e < EH; e++) mine[e] = reduce<F>(mine[e] + x_poly[e * 64 + lane]); // <= 11.4 p before
