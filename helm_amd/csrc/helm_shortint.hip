@@ -579,6 +579,10 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 2) void k_pbs64k(const Pbs64Job
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+#ifndef HELM_SI_KEYBUF
+#define HELM_SI_KEYBUF 0 // classical k_pbs64s: key words through buffer loads (scalar offset + immediate) instead of pointers:
+                         // 7 vector instructions fewer per wave-step, measured +0.2 % (slower): off
+#endif
 #ifndef HELM_SI_MB_NESTED
 #define HELM_SI_MB_NESTED 1 // multi-bit: the group's key sum in nested form (2^g - 1 multiplications per position and column)
 #endif
@@ -675,13 +679,27 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
     const size_t bsk_step = (size_t)K1 * K1 * L * 4 * part;
     const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * L * 4 + f * 2 + h) * part + lane;
     const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+#if HELM_SI_KEYBUF
+    const unsigned step_bytes = (unsigned)(bsk_step * 16), col_bytes = (unsigned)(4 * part * 16);
+    const unsigned wave_off = (unsigned)(((size_t)p * K1 * L * 4 + f * 2 + h) * part * 16);
+    KeyBuf kbuf;
+    kbuf.init(bsk, (size_t)n * step_bytes, lane);
+#endif
 
     STAMP_DECL
     for (int i = 0; i < n; i++) {
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
         if (a == 0) continue; // uniform over the workgroup
         STAMP_BEGIN
-        const double2 *bp_i = bsk_w + (size_t)i * bsk_step;
+        [[maybe_unused]] const double2 *bp_i = bsk_w + (size_t)i * bsk_step;
+#if HELM_SI_KEYBUF
+        const unsigned so_i = (unsigned)i * step_bytes + wave_off;
+        auto key = [&](int col_lev, int u) { // double2 u of key polynomial (column, level) of this wave's row / field / half
+            return kbuf.load(so_i + (unsigned)col_lev * col_bytes + (unsigned)(u >> 2) * 4096u, (u & 3) * 1024);
+        };
+#else
+        auto key = [&](int col_lev, int u) { return (bp_i + (size_t)col_lev * 4 * part)[u * 64]; };
+#endif
         // ---- (1) digits of this wave's quarter of polynomial p -------------------------------
 #pragma unroll
         for (int u = 0; u < Q; u++) {
@@ -708,7 +726,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         // first key column of this wave's half (E/4 double2 per column)
         double2 kw[K1][HC];
 #pragma unroll
-        for (int u = 0; u < HC; u++) kw[0][u] = (bp_i + (size_t)0 * L * 4 * part)[u * 64];
+        for (int u = 0; u < HC; u++) kw[0][u] = key(0 * L, u);
         STAMP(0) // quarter decomposition
         lds_block_sync(); // digits published
         STAMP(1) // barrier 1
@@ -721,7 +739,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         for (int lev = 0; lev < L; lev++) {
             if (lev > 0) {
 #pragma unroll
-                for (int u = 0; u < HC; u++) kw[0][u] = (bp_i + (size_t)(0 * L + lev) * 4 * part)[u * 64];
+                for (int u = 0; u < HC; u++) kw[0][u] = key(0 * L + lev, u);
             }
             if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
             double x[1][EH];
@@ -738,7 +756,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
             // profiles/r02/si_kernel_experiments.txt), with a block of arithmetic to cover the latency
             auto fetch_kw1 = [&]() {
 #pragma unroll
-                for (int u = 0; u < HC; u++) kw[1][u] = (bp_i + (size_t)(1 * L + lev) * 4 * part)[u * 64];
+                for (int u = 0; u < HC; u++) kw[1][u] = key(1 * L + lev, u);
             };
 #if HELM_SI_KW1_EARLY
             half_forward<F, LOGN - 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane, fetch_kw1);
