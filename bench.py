@@ -56,6 +56,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the LUT-mode / arithmetic-mode side measurements")
     ap.add_argument("--no-side-legs", action="store_true", help="N > 1: only the headline run")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N > 1, sharded runs: launches cut to one lockstep round per rank, each launch's all-gather + scatter on "
+                         "a side stream while the next launch's bootstraps run (off until a SCALE run has measured it)")
     ap.add_argument("--side-steps", type=int, default=3, help="N > 1: timed steps of the runs that are not the headline")
     ap.add_argument("--leg-timeout", type=float, default=900.0,
                     help="N > 1: seconds one run may take before it counts as hung (the line is printed with the error, rc 3)")
@@ -163,15 +166,21 @@ def build_program_arrays(circuit, wire_names, blocks):
     return cat(opsT), cat(T(i0)), cat(T(i1)), cat(T(i2)), cat(T(out)), new_off, index
 
 
-def make_program(sk, circuit, wire_names, blocks, quantum, pack=True):
-    """-> (Program, launches, levels): the batch's level schedule, launch-packed to `quantum` bootstraps."""
+def make_program(sk, circuit, wire_names, blocks, quantum, pack=True, overlap_split=0):
+    """-> (Program, launches, levels, depends_on): the batch's level schedule, launch-packed to `quantum` bootstraps.
+    overlap_split > 0: every launch cut into sub-launches of at most that many bootstraps and the launch dependencies
+    computed, for the overlapped sharded schedule (helm_amd/distributed.py); depends_on is None otherwise."""
     import helm_amd
-    from helm_amd.distributed import pack_levels
+    from helm_amd.distributed import launch_dependencies, pack_levels, split_launches
     ops, i0, i1, i2, out, off, _ = build_program_arrays(circuit, wire_names, blocks)
     levels = len(off) - 1
     if pack:
         ops, i0, i1, i2, out, off, _ = pack_levels(ops, i0, i1, i2, out, off, quantum)
-    return helm_amd.Program(sk, ops, i0, i1, i2, out, off), len(off) - 1, levels
+    deps = None
+    if overlap_split > 0:
+        off = split_launches(ops, off, overlap_split)
+        deps = launch_dependencies(i0, i1, i2, out, off, len(wire_names) * blocks)
+    return helm_amd.Program(sk, ops, i0, i1, i2, out, off), len(off) - 1, levels, deps
 
 
 def upload_inputs(ck, wires, index, nw, keys_pt, first_block=0):
@@ -255,8 +264,9 @@ class Bench:
         a, np, torch, dist = self.args, self.np, self.torch, self.dist
         sharded = kind != "weak" and self.world > 1
         blocks = a.blocks * (self.world if kind == "sharded_weak" else 1)   # blocks in this rank's wire table
-        prog, launches, levels = make_program(self.sk, self.circuit, self.wire_names, blocks,
-                                              self.quantum * (self.world if sharded else 1), pack=not a.no_pack)
+        prog, launches, levels, deps = make_program(self.sk, self.circuit, self.wire_names, blocks,
+                                                    self.quantum * (self.world if sharded else 1), pack=not a.no_pack,
+                                                    overlap_split=self.quantum * self.world if (sharded and a.overlap) else 0)
         rng = np.random.default_rng(0x48454C4D + (0 if sharded else self.rank))
         keys_pt = [(bytes(rng.integers(0, 256, 16, dtype=np.uint8)), bytes(rng.integers(0, 256, 16, dtype=np.uint8)))
                    for _ in range(blocks)]
@@ -266,7 +276,7 @@ class Bench:
         wires = self.sk.wires(self.nw * blocks)
         upload_inputs(self.ck, wires, self.index, self.nw, keys_pt)
         runner = ShardedRunner(GpuLevelExecutor(prog, wires), self.rank, self.world if sharded else 1,
-                               dist if sharded else None, time_collective=sharded)
+                               dist if sharded else None, time_collective=sharded, depends_on=deps)
         for _ in range(warmup):
             runner.run()
         self.sync_all()
@@ -295,6 +305,7 @@ class Bench:
              "launches": launches, "levels": levels, "sharded_launches": len(runner.sharded_levels),
              "exchanged_MB_per_step": runner.exchanged_bytes_per_pass() / 1e6,
              "collective_ms_per_step": runner.collective_ms(reset=True) / steps if sharded else 0.0,
+             "overlapped": bool(deps is not None),
              "tm": tm, "clock_ghz": clock_ghz}
         if keep:
             r.update(prog=prog, wires=wires, keys_pt=keys_pt)
@@ -318,6 +329,7 @@ class Bench:
                 "launches_per_step": r["launches"], "sharded_launches": r["sharded_launches"],
                 "exchanged_MB_per_step": round(r["exchanged_MB_per_step"], 2),
                 "collective_ms_per_step": round(r["collective_ms_per_step"], 3),
+                "exchange_overlapped_with_next_launch": r["overlapped"],
                 "decrypt_check": "all blocks == software AES on every rank"}
 
 
@@ -511,7 +523,7 @@ def fill_result(bench, result):
     # ---- wall-clock of ONE AES-128 evaluation (latency; levels are 80-256 gates wide, so the
     #      GPU is far from full: this is the n-step blind-rotation chain, 207 levels deep) ------
     if world == 1:
-        prog1, _, _ = make_program(bench.sk, bench.circuit, bench.wire_names, 1, quantum)
+        prog1, _, _, _ = make_program(bench.sk, bench.circuit, bench.wire_names, 1, quantum)
         prog1.run(head["wires"])
         bench.sync_all()
         t0 = time.perf_counter()

@@ -50,6 +50,22 @@ class GpuLevelExecutor:
     def new_events(self):
         return self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
 
+    # ---- what the overlapped runner needs: a side stream, plain events, the engine put on a given stream -------------
+    def new_stream(self):
+        return self.torch.cuda.Stream(device=self.device)
+
+    def new_event(self):
+        return self.torch.cuda.Event()
+
+    def current_stream(self):
+        return self.torch.cuda.current_stream(self.device)
+
+    def stream(self, s):
+        return self.torch.cuda.stream(s)
+
+    def engine_on(self, s):
+        self.program.sk.set_stream(s.cuda_stream)
+
     def run_level_shard(self, level, rank, world, staging):
         self.program.run_level_shard(self.wires, level, rank, world, staging.data_ptr())
 
@@ -63,9 +79,15 @@ class ShardedRunner:
     `dist` is torch.distributed (backend "nccl" = RCCL on GPUs; "gloo" in the CPU
     tests); with world == 1 nothing is imported and nothing is exchanged."""
 
-    def __init__(self, executor, rank=0, world=1, dist=None, replicate_below=256, time_collective=False):
+    def __init__(self, executor, rank=0, world=1, dist=None, replicate_below=256, time_collective=False, depends_on=None,
+                 ring=3):
+        """depends_on (optional, one entry per launch: the last EARLIER launch whose outputs this one reads, -1 for
+        none; `launch_dependencies`) switches the overlapped schedule on: a sharded launch's all-gather and scatter go
+        to a side stream and the next launches run meanwhile, each waiting only for the launch it depends on."""
         self.ex, self.rank, self.world, self.dist = executor, rank, world, dist
         self.replicate_below = replicate_below
+        self.depends_on = None if depends_on is None or world <= 1 else [int(d) for d in depends_on]
+        self._ring_size = max(2, int(ring))
         self.time_collective = time_collective and world > 1 and hasattr(executor, "new_events")
         self._events = []
         self.sharded_levels = []
@@ -82,9 +104,16 @@ class ShardedRunner:
             if rows:
                 self._stage = executor.new_buffer(rows)
                 self._gather = executor.new_buffer(rows * world)
+            if self.depends_on is not None and rows:
+                assert len(self.depends_on) == executor.n_levels
+                self._side = executor.new_stream()
+                self._ring = [(executor.new_buffer(rows), executor.new_buffer(rows * world), executor.new_event())
+                              for _ in range(self._ring_size)]
         self._sharded = set(self.sharded_levels)
 
     def run(self):
+        if self.depends_on is not None and self.sharded_levels:
+            return self._run_overlapped()
         ex = self.ex
         for l in range(ex.n_levels):
             if l not in self._sharded:
@@ -103,6 +132,58 @@ class ShardedRunner:
             else:
                 self.dist.all_gather_into_tensor(gathered, stage)
             ex.scatter_level(l, self.world, gathered)
+
+    def _run_overlapped(self):
+        """Launch l's chunk is computed on the main stream; its all-gather and the scatter into the wire table follow on
+        the side stream while the main stream goes on with launch l + 1.  A launch waits for the scatter of the launch it
+        depends on (the side stream runs in order, so everything before that one is in the table as well); a staging
+        pair of the ring is reused once the side stream is through with it.  Replicated launches run on the main stream
+        as before.  Needs every wire written once per pass (checked by the caller: `launch_dependencies`)."""
+        ex = self.ex
+        main, side = ex.current_stream(), self._side
+        import bisect
+        done, done_at = [], []   # sharded launches in order, and the event recorded on the side stream after each scatter
+        k = 0
+        last = None
+        for l in range(ex.n_levels):
+            d = self.depends_on[l]
+            if d >= 0 and done:
+                w = bisect.bisect_right(done, d) - 1  # the latest sharded launch at or before d
+                if w >= 0:
+                    main.wait_event(done_at[w])
+            if l not in self._sharded:
+                ex.run_level(l)
+                continue
+            rows = -(-ex.level_count(l) // self.world)
+            stage_full, gather_full, free = self._ring[k % self._ring_size]
+            if k >= self._ring_size:
+                main.wait_event(free)  # the side stream has finished with this pair
+            k += 1
+            stage, gathered = stage_full[:rows], gather_full[:rows * self.world]
+            ex.run_level_shard(l, self.rank, self.world, stage)
+            computed = ex.new_event()
+            computed.record(main)
+            side.wait_event(computed)
+            with ex.stream(side):
+                if self.time_collective:
+                    a, b = ex.new_events()
+                    a.record(side)
+                    self.dist.all_gather_into_tensor(gathered, stage)
+                    b.record(side)
+                    self._events.append((a, b))
+                else:
+                    self.dist.all_gather_into_tensor(gathered, stage)
+                ex.engine_on(side)
+                ex.scatter_level(l, self.world, gathered)
+                ex.engine_on(main)
+                free.record(side)
+                ev = ex.new_event()
+                ev.record(side)
+            done.append(l)
+            done_at.append(ev)
+            last = l
+        if last is not None:
+            main.wait_event(done_at[-1])
 
     def collective_ms(self, reset=False):
         """GPU time between the records around every all-gather since the last reset (time_collective=True);
@@ -153,3 +234,50 @@ def pack_levels(opcode, in0, in1, in2, out, level_offsets, quantum):
     if rc < 0:
         raise H.Panic(H.host.helm_host_last_error().decode())
     return tuple(a[order] for a in arrs) + (new_off[:n.value + 1].copy(), rc == 0)
+
+
+def gate_pbs(opcode):
+    """Bootstraps of each gate: MUX 2, NOT / BUF / DFF / constants 0, every other gate 1 (helm_hip_program_level_pbs)."""
+    op = np.asarray(opcode)
+    w = np.ones(len(op), dtype=np.int64)
+    w[op == 3] = 2                                   # HELM_GATE_MUX
+    w[np.isin(op, (1, 6, 10, 11, 12))] = 0           # DFF, NOT, BUF, constants
+    return w
+
+
+def split_launches(opcode, launch_offsets, max_pbs):
+    """Cut every launch into sub-launches of at most `max_pbs` bootstraps (the gates of a launch are independent of
+    each other, so any cut is valid): consecutive sub-launches of one launch can then overlap - the exchange of one with
+    the bootstraps of the next.  -> new launch_offsets"""
+    w = gate_pbs(opcode)
+    off = [0]
+    for l in range(len(launch_offsets) - 1):
+        a, b = int(launch_offsets[l]), int(launch_offsets[l + 1])
+        c = np.cumsum(w[a:b])
+        parts = int(-(-int(c[-1]) // max_pbs)) if b > a else 1
+        if parts > 1:  # cut where the running count passes each multiple of max_pbs (a MUX may put one part 1 over)
+            cuts = a + np.searchsorted(c, np.arange(1, parts) * max_pbs, side="right")
+            off.extend(int(x) for x in np.unique(cuts) if a < x < b)
+        off.append(b)
+    return np.array(off, dtype=np.int64)
+
+
+def launch_dependencies(in0, in1, in2, out, launch_offsets, n_rows):
+    """For every launch the last EARLIER launch that writes one of its input rows (-1: none).  Raises if a row is written
+    twice in the pass (state-writing gates): the overlapped schedule needs every wire written once."""
+    out = np.asarray(out)
+    if len(np.unique(out)) != len(out):
+        raise ValueError("a wire is written more than once per pass: the overlapped schedule does not apply")
+    producer = np.full(int(n_rows), -1, dtype=np.int64)
+    deps = []
+    for l in range(len(launch_offsets) - 1):
+        a, b = int(launch_offsets[l]), int(launch_offsets[l + 1])
+        d = -1
+        for arr in (in0, in1, in2):
+            rows = np.asarray(arr[a:b])
+            rows = rows[rows >= 0]
+            if len(rows):
+                d = max(d, int(producer[rows].max()))
+        deps.append(d)
+        producer[out[a:b]] = l
+    return deps

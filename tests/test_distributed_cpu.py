@@ -125,3 +125,28 @@ def test_sharded_runner_matches_single_process(world, replicate_below):
         else:
             # levels with <= 2 bootstraps are computed redundantly, the others sharded
             assert 0 < n_sharded < len(arrays[5]) - 1
+
+
+def test_split_launches_and_dependencies():
+    """The two host helpers of the overlapped sharded schedule: sub-launches never exceed the cap by more than one MUX,
+    keep every gate in order, and a launch's dependency is the last earlier launch that writes one of its inputs."""
+    from helm_amd.distributed import gate_pbs, launch_dependencies, split_launches
+    rng = np.random.default_rng(5)
+    n = 5000
+    op = rng.choice([0, 3, 4, 6, 9], size=n).astype(np.int32)        # AND, MUX, NAND, NOT, XOR
+    off = np.array([0, 1200, 1300, 4000, n], dtype=np.int64)
+    new = split_launches(op, off, 256)
+    assert new[0] == 0 and new[-1] == n and np.all(np.diff(new) > 0) and set(off) <= set(new.tolist())
+    w = gate_pbs(op)
+    assert max(int(w[a:b].sum()) for a, b in zip(new[:-1], new[1:])) <= 257
+    # a chain: gate g reads the output of gate g - 700 (if any): dependency = the launch holding that gate
+    out = np.arange(100, 100 + n)
+    i0 = np.where(np.arange(n) >= 700, out - 700, np.arange(n) % 100).astype(np.int64)
+    none = np.full(n, -1)
+    deps = launch_dependencies(i0, none, none, out, new, 100 + n)
+    launch_of = np.searchsorted(new, np.arange(n), side="right") - 1
+    for l, (a, b) in enumerate(zip(new[:-1], new[1:])):
+        want = max([int(launch_of[g - 700]) for g in range(a, b) if g >= 700], default=-1)
+        assert deps[l] == want and deps[l] < l
+    with pytest.raises(ValueError, match="written more than once"):
+        launch_dependencies(i0, none, none, np.zeros(n, dtype=np.int64), new, 100 + n)

@@ -17,10 +17,10 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, blocks, result_dir, backend="gloo"):
+def _worker(rank, world, port, blocks, result_dir, backend="gloo", overlap=False):
     import helm_amd
     from helm_amd import Circuit, verilog_parser
-    from helm_amd.distributed import GpuLevelExecutor, ShardedRunner, level_arrays
+    from helm_amd.distributed import GpuLevelExecutor, ShardedRunner, launch_dependencies, level_arrays, split_launches
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dev = rank if backend == "nccl" else 0  # RCCL needs one GPU per rank; gloo shares cuda:0
     torch.cuda.set_device(dev)
@@ -48,14 +48,25 @@ def _worker(rank, world, port, blocks, result_dir, backend="gloo"):
                                                      for b in range(blocks)]) for l in range(nl)]).astype(np.int32)
     opsT = np.concatenate([np.tile(ops[off[l]:off[l + 1]], blocks) for l in range(nl)]).astype(np.int32)
     offT = (off * blocks).astype(np.int64)
-    prog = helm_amd.Program(sk, opsT, tile(i0), tile(i1), tile(i2), tile(out), offT)
+    deps = None
+    t0, t1, t2, tout = tile(i0), tile(i1), tile(i2), tile(out)
+    if overlap:
+        # the overlapped schedule: levels cut into sub-launches of <= 300 bootstraps, each launch's all-gather and scatter
+        # on a side stream while the next sub-launch's bootstraps run; a launch waits only for the launch it depends on
+        offT = split_launches(opsT, offT, 300)
+        deps = launch_dependencies(t0, t1, t2, tout, offT, nw * blocks)
+        assert len(offT) - 1 > nl and max(deps) >= 0
+    prog = helm_amd.Program(sk, opsT, t0, t1, t2, tout, offT)
     rng = np.random.default_rng(3)
     bits = rng.integers(0, 2, size=(blocks, len(inputs))).astype(bool)
     wires = sk.wires(nw * blocks)
     rows = np.concatenate([b * nw + np.arange(len(inputs)) for b in range(blocks)]).astype(np.int32)
     wires.upload(rows, ck.encrypt(bits.reshape(-1)))
-    runner = ShardedRunner(GpuLevelExecutor(prog, wires), rank, world, dist)
+    runner = ShardedRunner(GpuLevelExecutor(prog, wires), rank, world, dist, depends_on=deps,
+                           replicate_below=64 if overlap else 256)
     runner.run()
+    if overlap:
+        runner.run()  # a second pass right behind the first: the ring of staging pairs and the events are reused
     torch.cuda.synchronize()
     dist.barrier()
     got = wires.download()
@@ -79,6 +90,21 @@ def test_two_ranks_on_one_gpu(tmp_path):
         same, sharded, nl = np.load(tmp_path / f"rank{r}.npy")
         assert same == 1, f"rank {r}: sharded evaluation differs from the single-process one"
         assert 0 < sharded <= nl
+
+
+def test_two_ranks_overlapped_exchange(tmp_path):
+    """The overlapped schedule (ShardedRunner(depends_on=...)): all-gather + scatter of a launch on a side stream while
+    the next launch computes, launches waiting only for the launch they depend on - the same wire table, bit for bit, as
+    the single-process evaluation (two passes back to back)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, 4, str(tmp_path), "gloo", True), nprocs=2, join=True)
+    for r in range(2):
+        same, sharded, nl = np.load(tmp_path / f"rank{r}.npy")
+        assert same == 1, f"rank {r}: overlapped sharded evaluation differs from the single-process one"
+        assert sharded > nl  # sub-launches: more sharded launches than levels
 
 
 def test_two_ranks_over_rccl(tmp_path):
