@@ -1587,6 +1587,7 @@ struct helm_si_ctx {
     helm_si_params P{};
     int logN = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    bool high_priority = false; // own_stream was created at the device's highest priority (helm_si_set_priority)
     double *tw[2] = {nullptr, nullptr};
     double n_inv[2] = {0, 0}, two32[2] = {0, 0};
     double p0inv_mod_p1 = 0;
@@ -2303,6 +2304,23 @@ int helm_si_set_stream(helm_si_ctx *ctx, void *hip_stream)
     // switched streams - NOT "back to the context's own stream": collectives the caller orders on that
     // stream must see the engine's kernels on it
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return 0;
+}
+
+int helm_si_set_priority(helm_si_ctx *ctx, int high)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");
+    if (ctx->stream != ctx->own_stream) return 0; // the caller's stream: its priority is the caller's business
+    if ((high != 0) == ctx->high_priority) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamSynchronize(ctx->own_stream));
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high ? greatest : least));
+    (void)hipStreamDestroy(ctx->own_stream);
+    ctx->own_stream = ctx->stream = s;
+    ctx->high_priority = high != 0;
     return 0;
 }
 

@@ -1412,6 +1412,36 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
             load[lane] += oc.first;
             for (int id : comps[oc.second]) lane_plan[lane][where[(size_t)id].first].push_back(plan[where[(size_t)id].first][where[(size_t)id].second]);
         }
+        // the lane with the longest chain of bootstrap rounds is the critical path: its launches go first when both
+        // lanes have some ready (helm_si_set_priority: dispatch priority of the context's own stream)
+        {
+            auto rounds = [&](const RadixOp &op) -> int {
+                int lg = 0;
+                while ((1 << lg) < nb - 1) lg++;
+                const int prop = 2 + lg; // carry states, prefix rounds, messages
+                const bool cs = op.a2 >= 0 || op.b2 >= 0;
+                switch (op.kind) {
+                case RadixOp::Mul: return 5 + (op.out2 >= 0 ? 0 : prop);
+                case RadixOp::Add: case RadixOp::Sub: return prop + (cs ? 1 : 0);
+                case RadixOp::AddScalar: case RadixOp::SubScalar: return prop;
+                case RadixOp::MulScalar: return (op.scalar && !(op.scalar & (op.scalar - 1))) ? 1 : prop + 2;
+                case RadixOp::ShlScalar: case RadixOp::ShrScalar: return 1;
+                case RadixOp::Shl: case RadixOp::Shr: return 2 * (lg + 2);
+                case RadixOp::Div: case RadixOp::DivScalar: return 2 * nb * (prop + 2);
+                default: return 0;
+                }
+            };
+            std::vector<int64_t> chain(n_ctx, 0);
+            for (size_t lane = 0; lane < n_ctx; lane++)
+                for (auto &ops : lane_plan[lane]) {
+                    int m = 0;
+                    for (auto &op : ops) m = std::max(m, rounds(op));
+                    chain[lane] += m;
+                }
+            const size_t crit = (size_t)(std::max_element(chain.begin(), chain.end()) - chain.begin());
+            for (size_t lane = 0; lane < n_ctx; lane++)
+                si_ok(helm_si_set_priority(lane == 0 ? server_key_ : lanes[lane - 1], lane == crit ? 1 : 0), "set_priority");
+        }
         std::vector<std::unique_ptr<RadixEngine>> engines;
         std::vector<int64_t> lane_scratch(n_ctx, 0);
         int64_t total_scratch = 0;

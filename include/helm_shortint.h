@@ -81,6 +81,11 @@ int helm_si_ctx_fork(helm_si_ctx *primary, helm_si_ctx **lane_out);
 int helm_si_get_params(const helm_si_ctx *ctx, helm_si_params *out);
 int helm_si_set_stream(helm_si_ctx *ctx, void *hip_stream);
 int helm_si_sync(helm_si_ctx *ctx);
+/* Dispatch priority of the context's OWN stream (no effect after helm_si_set_stream): high != 0 = the device's highest
+ * stream priority, 0 = its lowest.  When two lanes have launches ready at the same time the workgroups of the
+ * high-priority one are placed first - the host library gives it to the lane with the longest chain of bootstrap rounds.
+ * Synchronises the stream it replaces. */
+int helm_si_set_priority(helm_si_ctx *ctx, int high);
 int helm_si_load_bootstrap_key(helm_si_ctx *ctx, const uint64_t *bsk_std, size_t n_words);
 int helm_si_load_keyswitch_key(helm_si_ctx *ctx, const uint64_t *ksk, size_t n_words);
 
