@@ -76,6 +76,7 @@ i32p = C.POINTER(C.c_int32)
 i64p = C.POINTER(C.c_int64)
 u8p = C.POINTER(C.c_uint8)
 vp = C.c_void_p
+HIP_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp, C.c_int64)  # helm_hip_exchange_fn
 
 
 def _load(name):
@@ -111,6 +112,7 @@ HIP_API = {
     "helm_hip_wires_download": (C.c_int, [vp, vp, i32p, u32p, C.c_int64]),
     "helm_hip_wires_set_trivial": (C.c_int, [vp, vp, i32p, u8p, C.c_int64]),
     "helm_hip_wires_copy": (C.c_int, [vp, vp, i32p, vp, i32p, C.c_int64]),
+    "helm_hip_program_run_sharded": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp, vp, C.c_int64, HIP_EXCHANGE_FN, vp]),
     "helm_hip_wires_device_ptr": (C.c_int, [vp, vp, C.POINTER(vp), i64p]),
     "helm_hip_eval_gate_level": (C.c_int, [vp, vp, i32p, i32p, i32p, i32p, i32p, C.c_int64]),
     "helm_hip_program_create": (C.c_int, [vp, i32p, i32p, i32p, i32p, i32p, i64p, C.c_int64, C.POINTER(vp)]),

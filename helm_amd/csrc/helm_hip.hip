@@ -2269,6 +2269,31 @@ int helm_hip_program_scatter_level(helm_hip_ctx *ctx, helm_hip_program *prog, he
     return 0;
 }
 
+int helm_hip_program_run_sharded(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, int rank, int world,
+                                 int64_t replicate_below, void *stage_dev, void *gather_dev, int64_t capacity_rows,
+                                 helm_hip_exchange_fn fn, void *user)
+{
+    if (int rc = check_program(ctx, prog, w)) return rc;
+    if (world <= 0 || rank < 0 || rank >= world) return fail(HELM_ERR_INVALID, "bad shard arguments");
+    if (world > 1 && (!stage_dev || !gather_dev || !fn || capacity_rows <= 0))
+        return fail(HELM_ERR_INVALID, "run_sharded: staging buffers and the exchange callback are needed for world > 1");
+    for (int64_t l = 0; l < prog->n_levels; l++) {
+        if (world == 1 || helm_hip_program_level_pbs(prog, l) <= replicate_below) { // one wave of workgroups absorbs it
+            if (int rc = helm_hip_program_run(ctx, prog, w, l, l + 1)) return rc;
+            continue;
+        }
+        const int64_t rows = helm_hip_program_chunk_rows(prog, l, world);
+        if (rows > capacity_rows)
+            return fail(HELM_ERR_INVALID, "run_sharded: a launch's chunk has " + std::to_string(rows) + " rows, the staging buffer " +
+                                              std::to_string(capacity_rows));
+        if (int rc = helm_hip_program_run_level_shard(ctx, prog, w, l, rank, world, stage_dev)) return rc;
+        if (int rc = fn(user, stage_dev, gather_dev, rows))
+            return fail(HELM_ERR_STATE, "run_sharded: the exchange callback failed (" + std::to_string(rc) + ")");
+        if (int rc = helm_hip_program_scatter_level(ctx, prog, w, l, world, gather_dev)) return rc;
+    }
+    return 0;
+}
+
 int helm_hip_pbs_batch(helm_hip_ctx *ctx, const uint32_t *lwe_in, const uint32_t *test_vectors, int64_t n_tv,
                        const int32_t *tv_index, uint32_t *out_big, int64_t count)
 {

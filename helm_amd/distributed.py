@@ -72,6 +72,10 @@ class GpuLevelExecutor:
     def scatter_level(self, level, world, gathered):
         self.program.scatter_level(self.wires, level, world, gathered.data_ptr())
 
+    def run_sharded(self, rank, world, stage, gather, capacity_rows, exchange, replicate_below):
+        self.program.run_sharded(self.wires, rank, world, stage.data_ptr(), gather.data_ptr(), capacity_rows, exchange,
+                                 replicate_below)
+
 
 class ShardedRunner:
     """Drives one evaluation pass over all levels on `world` ranks.
@@ -80,13 +84,16 @@ class ShardedRunner:
     tests); with world == 1 nothing is imported and nothing is exchanged."""
 
     def __init__(self, executor, rank=0, world=1, dist=None, replicate_below=256, time_collective=False, depends_on=None,
-                 ring=3):
+                 ring=3, in_library=False):
         """depends_on (optional, one entry per launch: the last EARLIER launch whose outputs this one reads, -1 for
         none; `launch_dependencies`) switches the overlapped schedule on: a sharded launch's all-gather and scatter go
         to a side stream and the next launches run meanwhile, each waiting only for the launch it depends on."""
         self.ex, self.rank, self.world, self.dist = executor, rank, world, dist
         self.replicate_below = replicate_below
         self.depends_on = None if depends_on is None or world <= 1 else [int(d) for d in depends_on]
+        # in_library: the launch loop runs inside libhelm_hip.so (helm_hip_program_run_sharded) and calls back for the
+        # all-gather only - the path a Rust host takes (INTEGRATION.md, Multi-GPU)
+        self.in_library = bool(in_library) and world > 1 and hasattr(executor, "run_sharded")
         self._ring_size = max(2, int(ring))
         self.time_collective = time_collective and world > 1 and hasattr(executor, "new_events")
         self._events = []
@@ -112,6 +119,13 @@ class ShardedRunner:
         self._sharded = set(self.sharded_levels)
 
     def run(self):
+        if self.in_library and self.sharded_levels:
+            rows_cap = self._stage.shape[0]
+
+            def exchange(_stage_ptr, _gather_ptr, rows):
+                self.dist.all_gather_into_tensor(self._gather[:rows * self.world], self._stage[:rows])
+                return 0
+            return self.ex.run_sharded(self.rank, self.world, self._stage, self._gather, rows_cap, exchange, self.replicate_below)
         if self.depends_on is not None and self.sharded_levels:
             return self._run_overlapped()
         ex = self.ex

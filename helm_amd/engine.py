@@ -273,6 +273,20 @@ class Program:
         hip_check(hip.helm_hip_program_run_level_shard(self.sk._h, self._h, wires._h, level, rank, world,
                                                        nv.vp(staging_ptr)))
 
+    def run_sharded(self, wires, rank, world, stage_ptr, gather_ptr, capacity_rows, exchange, replicate_below=256):
+        """The whole sharded pass inside the library (helm_hip_program_run_sharded): `exchange(stage_ptr, gather_ptr,
+        rows_per_rank) -> 0` all-gathers on the engine's stream.  The callback object must outlive the call."""
+        def _cb(_user, stage, gather, rows):
+            try:
+                return int(exchange(stage, gather, rows) or 0)
+            except Exception:  # an exception cannot cross the C frames
+                import traceback
+                traceback.print_exc()
+                return -1
+        fn = nv.HIP_EXCHANGE_FN(_cb)
+        hip_check(hip.helm_hip_program_run_sharded(self.sk._h, self._h, wires._h, int(rank), int(world), int(replicate_below),
+                                                   nv.vp(stage_ptr), nv.vp(gather_ptr), int(capacity_rows), fn, None))
+
     def scatter_level(self, wires, level, world, gathered_ptr):
         hip_check(hip.helm_hip_program_scatter_level(self.sk._h, self._h, wires._h, level, world,
                                                      nv.vp(gathered_ptr)))

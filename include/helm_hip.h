@@ -179,6 +179,17 @@ int helm_hip_program_run_level_shard(helm_hip_ctx *ctx, helm_hip_program *prog, 
                                      int64_t level, int rank, int world, void *staging_dev);
 int helm_hip_program_scatter_level(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w,
                                    int64_t level, int world, const void *gathered_dev);
+/* The whole sharded pass in one call - what a Rust host runs per evaluation: for every launch in order either
+ * helm_hip_program_run() (launches of at most replicate_below bootstraps: one wave of workgroups absorbs them, every rank
+ * computes them) or run_level_shard -> fn -> scatter_level.  fn(user, stage_dev, gather_dev, rows_per_rank) must all-gather
+ * rows_per_rank rows of n+1 words of stage_dev from every rank into gather_dev in rank order ON THE CONTEXT'S STREAM
+ * (ncclAllGather over RCCL/xGMI with the stream given to helm_hip_set_stream) and return 0.  stage_dev holds capacity_rows
+ * rows, gather_dev capacity_rows * world.  Every rank issues the same call; identical wire tables on every rank, identical
+ * to helm_hip_program_run() on one GPU.  The level is the sharded unit (reference src/circuit.rs:531). */
+typedef int (*helm_hip_exchange_fn)(void *user, void *stage_dev, void *gather_dev, int64_t rows_per_rank);
+int helm_hip_program_run_sharded(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, int rank, int world,
+                                 int64_t replicate_below, void *stage_dev, void *gather_dev, int64_t capacity_rows,
+                                 helm_hip_exchange_fn fn, void *user);
 /* Number of programmable bootstraps a level costs (binary gate 1, MUX 2, others 0). */
 int64_t helm_hip_program_level_pbs(helm_hip_program *prog, int64_t level);
 

@@ -105,6 +105,12 @@ extern "C" {
     pub fn helm_hip_program_run(ctx: *mut helm_hip_ctx, prog: *mut helm_hip_program, w: *mut helm_hip_wires, level_begin: i64, level_end: i64) -> c_int;
     pub fn helm_hip_program_destroy(ctx: *mut helm_hip_ctx, prog: *mut helm_hip_program) -> c_int;
     pub fn helm_hip_program_level_pbs(prog: *mut helm_hip_program, level: i64) -> i64;
+    // the whole sharded pass; `exchange` = ncclAllGather(stage, gather, rows * (n + 1) * 4 bytes) on the context's stream
+    pub fn helm_hip_program_run_sharded(ctx: *mut helm_hip_ctx, prog: *mut helm_hip_program, w: *mut helm_hip_wires, rank: c_int,
+                                        world: c_int, replicate_below: i64, stage_dev: *mut c_void, gather_dev: *mut c_void,
+                                        capacity_rows: i64,
+                                        exchange: extern "C" fn(*mut c_void, *mut c_void, *mut c_void, i64) -> c_int,
+                                        user: *mut c_void) -> c_int;
 
     // ---- include/helm_host.h: launch packing of the level map -------------------------------
     pub fn helm_host_pack_levels(opcode: *const i32, in0: *const i32, in1: *const i32, in2: *const i32, out: *const i32,

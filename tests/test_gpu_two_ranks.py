@@ -50,6 +50,8 @@ def _worker(rank, world, port, blocks, result_dir, backend="gloo", overlap=False
     offT = (off * blocks).astype(np.int64)
     deps = None
     t0, t1, t2, tout = tile(i0), tile(i1), tile(i2), tile(out)
+    in_library = overlap == "library"
+    overlap = overlap is True
     if overlap:
         # the overlapped schedule: levels cut into sub-launches of <= 300 bootstraps, each launch's all-gather and scatter
         # on a side stream while the next sub-launch's bootstraps run; a launch waits only for the launch it depends on
@@ -63,7 +65,8 @@ def _worker(rank, world, port, blocks, result_dir, backend="gloo", overlap=False
     rows = np.concatenate([b * nw + np.arange(len(inputs)) for b in range(blocks)]).astype(np.int32)
     wires.upload(rows, ck.encrypt(bits.reshape(-1)))
     runner = ShardedRunner(GpuLevelExecutor(prog, wires), rank, world, dist, depends_on=deps,
-                           replicate_below=64 if overlap else 256)
+                           replicate_below=64 if overlap else 256, in_library=in_library)
+    assert runner.in_library == in_library
     runner.run()
     if overlap:
         runner.run()  # a second pass right behind the first: the ring of staging pairs and the events are reused
@@ -105,6 +108,20 @@ def test_two_ranks_overlapped_exchange(tmp_path):
         same, sharded, nl = np.load(tmp_path / f"rank{r}.npy")
         assert same == 1, f"rank {r}: overlapped sharded evaluation differs from the single-process one"
         assert sharded > nl  # sub-launches: more sharded launches than levels
+
+
+def test_two_ranks_through_the_c_abi_pass(tmp_path):
+    """helm_hip_program_run_sharded: the launch loop of the sharded pass inside libhelm_hip.so, calling back for the
+    all-gather only (what a Rust host binds: INTEGRATION.md, Multi-GPU) - the same wire table as one process."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, 4, str(tmp_path), "gloo", "library"), nprocs=2, join=True)
+    for r in range(2):
+        same, sharded, nl = np.load(tmp_path / f"rank{r}.npy")
+        assert same == 1, f"rank {r}: the in-library sharded pass differs from the single-process one"
+        assert 0 < sharded <= nl
 
 
 def test_two_ranks_over_rccl(tmp_path):
