@@ -670,12 +670,12 @@ def other_modes(device):
 
 
 def _lut_m1c1_leg(device):
-    """LUT mode as the reference BINARY configures it (helm.rs:301: PARAM_MESSAGE_1_CARRY_1_KS_PBS, k = 3, N = 512): 1,024
-    independent 2-input LUT gates (XOR), the bivariate form of gates::lut() (gates.rs:761-764), on k_pbs64k."""
+    """LUT mode as the reference BINARY configures it (helm.rs:301: PARAM_MESSAGE_1_CARRY_1_KS_PBS, k = 3, N = 512): 2,048
+    independent 2-input LUT gates (XOR; four rounds of two ciphertexts per CU, as the 1,024 of the m2c2 leg are four of one), the bivariate form of gates::lut() (gates.rs:761-764), on k_pbs64k."""
     import helm_amd
     import torch
     ck, sk = helm_amd.gen_keys_shortint("shortint_m1c1", seed=1, device=device)
-    B = 1024
+    B = 2048
     bits = np.random.default_rng(0).integers(0, 2, size=2 * B).astype(np.uint64)
     w = sk.wires(3 * B)
     w.upload(np.arange(2 * B), ck.encrypt(bits))

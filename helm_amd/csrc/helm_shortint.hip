@@ -368,6 +368,9 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
 // exact integers below 2^53, so the sum does not depend on the order the waves arrive in.  Four
 // workgroup barriers per step; 64 KB of LDS and at most 128 registers: TWO ciphertexts per CU.
 // ------------------------------------------------------------------------------------
+#ifndef HELM_SI_K_GATHER
+#define HELM_SI_K_GATHER 1 // k_pbs64k: column sums gathered by the owner of the column instead of scattered with ds_add_f64
+#endif
 template <int LOGN_, int K_>
 struct Pbs64kCfg {
     static constexpr int LOGN = LOGN_, L = 1, K = K_, K1 = K_ + 1, NW = 2 * K1;
@@ -406,7 +409,7 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
     const unsigned poly_bytes = (unsigned)(N / 2) * 16u;      // one key polynomial in one field
     const unsigned col_bytes = 2u * poly_bytes;               // both fields
     const unsigned step_bytes = (unsigned)(K1 * K1) * col_bytes;
-    const unsigned row_off = (unsigned)(p * K1) * col_bytes + (unsigned)f * poly_bytes;
+    const unsigned row_off = (HELM_SI_K_GATHER ? (unsigned)p : (unsigned)(p * K1)) * col_bytes + (unsigned)f * poly_bytes;
     KeyBuf kb;
     kb.init(bsk, (size_t)n * step_bytes, lane);
     const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
@@ -414,6 +417,60 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
         if (a == 0) continue; // uniform over the workgroup
         const unsigned so_i = (unsigned)i * step_bytes + row_off;
+#if HELM_SI_K_GATHER
+        // Gather form of the hand-over: wave (p, f) owns OUTPUT column p.  Every wave publishes the spectrum of its digit
+        // polynomial in its scratch; after the barrier each wave reads all K1 spectra and multiplies them with the key
+        // words of column p (rows 0..k): the column sum stays in registers - no LDS atomics, no clear, no data-dependent
+        // branch, and the own spectrum's registers are free during the products.
+        double2 kw[H][K1];
+        auto fetch = [&](int u) {
+#pragma unroll
+            for (int r = 0; r < K1; r++) kw[u][r] = kb.load(so_i + (unsigned)(r * K1) * col_bytes, u * 1024);
+        };
+#pragma unroll
+        for (int u = 0; u < H / 2; u++) fetch(u);
+        double mine[E];
+        {
+            double x[1][E];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int j = G::jA(lane, e);
+                const int src = (j - a) & (2 * N - 1);
+                uint64_t v = acc_p[src & (N - 1)];
+                if (src >= N) v = 0ull - v;
+                v -= acc_p[j];
+                const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
+                x[0][e] = (double)((int)st - (int)(((st + half_m1) >> logB) << logB));
+            }
+            ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+#pragma unroll
+            for (int e = 0; e < E; e++) xb[e * 64 + lane] = x[0][e];
+        }
+        lds_block_sync(); // every spectrum published
+        const double *xs = X + (size_t)f * G::XPAD + lane; // spectrum of polynomial r: xs + r * 2 * XPAD
+        auto products = [&](int u) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < K1; r++) { // |t| <= 1.5 p each: the sum of K1 <= 4 stays below 6 p < 2^53, exact
+                const double *xr = xs + (size_t)r * 2 * G::XPAD;
+                const double t0 = mulmod<F>(xr[(2 * u) * 64], kw[u][r].x), t1 = mulmod<F>(xr[(2 * u + 1) * 64], kw[u][r].y);
+                s0 = r == 0 ? t0 : s0 + t0;
+                s1 = r == 0 ? t1 : s1 + t1;
+            }
+            mine[2 * u] = reduce<F>(s0);
+            mine[2 * u + 1] = reduce<F>(s1);
+        };
+#pragma unroll
+        for (int u = 0; u < H; u++) {
+            if (u + H / 2 < H) {
+                fetch(u + H / 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            products(u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_block_sync(); // every wave has read: the scratches are free for the inverse transforms
+#else
         // key words: all K1 columns of the first half of the spectrum slots at the top (the transform covers them), the
         // second half slot pair by slot pair around the products (at most three quarters of the words live at once:
         // the kernel must stay within 128 registers for two ciphertexts per CU)
@@ -469,6 +526,7 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
         lds_block_sync(); // every foreign product is in
 #pragma unroll
         for (int e = 0; e < E; e++) mine[e] = reduce<F>(mine[e] + xb[e * 64 + lane]);
+#endif
         ntt_inverse<F, LOGN>(mine, xb, twi, lane);
         // ---- CRT: field-f wave lifts slots [f*H, f*H+H) of its polynomial ---------------------
 #pragma unroll

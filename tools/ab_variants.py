@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-box A/B of builds of libhelm_hip.so: runs a micro-benchmark in a fresh process per build (HELM_HIP_LIB selects
 the library, helm_amd/_native.py), alternating the builds over several rounds.
-usage: ab_variants.py [--rounds R] [--bench lut|wop|chi] variant [variant ...]
+usage: ab_variants.py [--rounds R] [--bench lut|wop|m1c1] variant [variant ...]
 A variant is a file name under helm_amd/csrc/ (e.g. variants/libhelm_hip_base.so) or `default` (the Makefile's)."""
 import argparse
 import json
@@ -34,6 +34,29 @@ for name, B in (("shortint_m2c2", 1024), ("shortint_m2c2", 64), ("shortint_m2c2_
 print(json.dumps(res))
 '''
 
+M1C1 = r'''
+import json, time, numpy as np, sys
+sys.path.insert(0, %r)
+import helm_amd
+res = {}
+for name, B in (("shortint_m1c1", 2048), ("shortint_m1c1", 512), ("si_toy_512_k2", 2048)):
+    ck, sk = helm_amd.gen_keys_shortint(name, seed=1)
+    bits = np.random.default_rng(0).integers(0, 2, size=2 * B).astype(np.uint64)
+    w = sk.wires(3 * B)
+    w.upload(np.arange(2 * B), ck.encrypt(bits))
+    in_idx = np.arange(2 * B, dtype=np.int32).reshape(2, B).T.copy()
+    ar, tb, out = np.full(B, 2, np.int32), np.full(B, 0x8, np.uint64), np.arange(2 * B, 3 * B, dtype=np.int32)
+    w.eval_lut_level(ar, in_idx, tb, out); sk.sync()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter(); w.eval_lut_level(ar, in_idx, tb, out); sk.sync(); ts.append(time.perf_counter() - t0)
+    ok = bool(np.array_equal(ck.decrypt(w.download(out)), (bits[:B] + bits[B:]) >= 2))
+    res[f"{name}:{B}"] = {"ms": round(min(ts) * 1e3, 3), "luts_per_s": round(B / min(ts), 1), "ok": ok,
+                          "sha": __import__("hashlib").sha256(w.download(out).tobytes()).hexdigest()[:12]}
+    sk.close()
+print(json.dumps(res))
+'''
+
 WOP = r'''
 import json, subprocess, sys
 out = subprocess.run([sys.executable, %r + "/tools/wop_bench.py", "256", "6", "1"], capture_output=True, text=True).stdout
@@ -47,7 +70,7 @@ def main():
     ap.add_argument("--bench", default="lut")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
-    code = {"lut": LUT, "wop": WOP}[a.bench] % ROOT
+    code = {"lut": LUT, "wop": WOP, "m1c1": M1C1}[a.bench] % ROOT
     for r in range(a.rounds):
         for v in a.variants:
             env = dict(os.environ)
