@@ -687,7 +687,7 @@ struct Pbs64sCfg {
 #ifndef HELM_SI_LAZY_INV
 #define HELM_SI_LAZY_INV 1 // the half inverse leaves its outputs uncentred: the last stage recentres anyway
 #endif
-    static constexpr bool PRIO = HELM_SI_PRIO != 0;
+    static constexpr bool PRIO = HELM_SI_PRIO == 1; // 2: the waves of polynomial 1 above their SIMD partners throughout
     static constexpr int TW_IDX = GS::N >> GS::BC, TW_PART = TW_IDX + GS::TWC * 64; // per (field, half)
     static constexpr size_t X_OFF = 0;                                              // double [NW][GS::XPAD]
     static constexpr size_t TW_OFF = X_OFF + sizeof(double) * NW * GS::XPAD;        // double [2][2][TW_PART]
@@ -1266,6 +1266,9 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64s(const Pbs64Job *__rest
     __syncthreads();
     // psi^(N/2): entry 1 of the full forward table of this wave's field
     const double w1 = f == 0 ? tw0[1] : tw1[1], w1o = f == 0 ? tw1[1] : tw0[1];
+#if HELM_SI_PRIO == 2
+    if (p) __builtin_amdgcn_s_setprio(2);
+#endif
     // one specialisation per (field, transform half): both are uniform over the wave
     if constexpr (MB) {
         if (f == 0) {
