@@ -157,6 +157,7 @@ SI_API = {
     "helm_si_set_exchange": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_int64, SI_EXCHANGE_FN, vp]),
     "helm_si_exchange_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "helm_si_exchange_world": (C.c_int, [vp]),
+    "helm_si_round_capacity": (C.c_int64, [vp]),
     "helm_si_set_priority": (C.c_int, [vp, C.c_int]),
     "helm_si_keyswitch_batch": (C.c_int, [vp, u64p, u64p, C.c_int64]),
     "helm_si_pbs_batch": (C.c_int, [vp, u64p, u64p, C.c_int64, i32p, u64p, C.c_int64]),

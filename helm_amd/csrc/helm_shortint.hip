@@ -1668,6 +1668,7 @@ struct helm_si_ctx {
     bool have_bsk = false, have_ksk = false;
     uint64_t delta = 0;
     int n_cus = 256;
+    int64_t round_capacity = 0; // bootstraps resident at once (CUs x workgroups per CU of the set's kernel), probed on first need
     // per-call scratch
     DevBuf<Pbs64Job> d_pbs;
     DevBuf<Ks64Job> d_ks;
@@ -1743,7 +1744,7 @@ bool si_supported(const helm_si_params &P)
 
 template <typename C>
 hipError_t launch_pbs64k_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
-                           const uint64_t *luts, uint64_t *out)
+                           const uint64_t *luts, uint64_t *out, int *per_cu = nullptr)
 {
     static bool attr_done[64] = {false};
     auto kern = k_pbs64k<C>;
@@ -1753,6 +1754,7 @@ hipError_t launch_pbs64k_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count
         if (e != hipSuccess) return e;
         attr_done[ctx->device & 63] = true;
     }
+    if (per_cu) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, 64 * C::NW, C::BYTES);
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, small, luts, ctx->bsk,
                        ctx->tw[0], ctx->tw[1], out, ctx->P.n, ctx->P.pbs_logB, ctx->p0inv_mod_p1);
     return hipGetLastError();
@@ -1761,7 +1763,7 @@ hipError_t launch_pbs64k_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count
 template <typename C, int MODE = 0>
 hipError_t launch_pbs64_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
                           const uint64_t *luts, uint64_t *out, const double *key = nullptr, int n_steps = -1,
-                          int logB = 0, size_t key_stride = 0, int key_first = 0)
+                          int logB = 0, size_t key_stride = 0, int key_first = 0, int *per_cu = nullptr)
 {
     static bool attr_done[64] = {false};
     auto kern = k_pbs64<C, MODE>;
@@ -1771,6 +1773,7 @@ hipError_t launch_pbs64_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count,
         if (e != hipSuccess) return e;
         attr_done[ctx->device & 63] = true;
     }
+    if (per_cu) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, 64 * C::NW, C::BYTES);
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, small, luts,
                        key ? key : ctx->bsk, ctx->tw[0], ctx->tw[1], out, n_steps >= 0 ? n_steps : ctx->P.n,
                        logB ? logB : ctx->P.pbs_logB, ctx->p0inv_mod_p1, key_stride, key_first);
@@ -1790,7 +1793,7 @@ hipError_t launch_pbs64_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count,
 
 template <typename C, bool MB>
 hipError_t launch_pbs64s_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
-                           const uint64_t *luts, uint64_t *out)
+                           const uint64_t *luts, uint64_t *out, int *per_cu = nullptr)
 {
     static bool attr_done[64] = {false};
     auto kern = k_pbs64s<C, MB>;
@@ -1800,6 +1803,7 @@ hipError_t launch_pbs64s_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count
         if (e != hipSuccess) return e;
         attr_done[ctx->device & 63] = true;
     }
+    if (per_cu) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, 64 * C::NW, C::BYTES);
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, small, luts,
                        ctx->bsk_split, ctx->tw_sub, ctx->tw[0], ctx->tw[1], out, ctx->P.n, ctx->P.pbs_logB,
                        ctx->p0inv_mod_p1, ctx->group, ctx->expo, ctx->psi_pow);
@@ -1819,26 +1823,26 @@ hipError_t launch_pbs64s_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count
 }
 
 hipError_t launch_pbs64(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
-                        const uint64_t *luts, uint64_t *out)
+                        const uint64_t *luts, uint64_t *out, int *per_cu = nullptr)
 {
     const helm_si_params &P = ctx->P;
-    if (P.k == 3) return launch_pbs64k_c<Pbs64kCfg<9, 3>>(ctx, jobs, count, small, luts, out);
-    if (P.k == 2) return launch_pbs64k_c<Pbs64kCfg<9, 2>>(ctx, jobs, count, small, luts, out);
+    if (P.k == 3) return launch_pbs64k_c<Pbs64kCfg<9, 3>>(ctx, jobs, count, small, luts, out, per_cu);
+    if (P.k == 2) return launch_pbs64k_c<Pbs64kCfg<9, 2>>(ctx, jobs, count, small, luts, out, per_cu);
     if (ctx->use_split) {
         if (ctx->group > 1) {
-            if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10>, true>(ctx, jobs, count, small, luts, out);
-            if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11>, true>(ctx, jobs, count, small, luts, out);
+            if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10>, true>(ctx, jobs, count, small, luts, out, per_cu);
+            if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11>, true>(ctx, jobs, count, small, luts, out, per_cu);
         }
         if (P.pbs_l == 1) {
-            if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10>, false>(ctx, jobs, count, small, luts, out);
-            if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11>, false>(ctx, jobs, count, small, luts, out);
+            if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10>, false>(ctx, jobs, count, small, luts, out, per_cu);
+            if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11>, false>(ctx, jobs, count, small, luts, out, per_cu);
         } else {
-            if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10, 2>, false>(ctx, jobs, count, small, luts, out);
-            if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11, 2>, false>(ctx, jobs, count, small, luts, out);
+            if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10, 2>, false>(ctx, jobs, count, small, luts, out, per_cu);
+            if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11, 2>, false>(ctx, jobs, count, small, luts, out, per_cu);
         }
     }
 #define PBS64_CASE(LN, LV) \
-    if (ctx->logN == LN && P.pbs_l == LV) return launch_pbs64_c<Pbs64Cfg<LN, LV>>(ctx, jobs, count, small, luts, out);
+    if (ctx->logN == LN && P.pbs_l == LV) return launch_pbs64_c<Pbs64Cfg<LN, LV>>(ctx, jobs, count, small, luts, out, nullptr, -1, 0, 0, 0, per_cu);
     PBS64_CASE(9, 1) PBS64_CASE(9, 2) PBS64_CASE(10, 1) PBS64_CASE(10, 2) PBS64_CASE(11, 1) PBS64_CASE(11, 2)
 #undef PBS64_CASE
     return hipErrorInvalidValue;
@@ -2705,6 +2709,18 @@ int helm_si_set_exchange(helm_si_ctx *ctx, int32_t rank, int32_t world, int64_t 
 }
 
 int helm_si_exchange_world(const helm_si_ctx *ctx) { return ctx ? ctx->x_world : 1; }
+
+int64_t helm_si_round_capacity(helm_si_ctx *ctx)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null context");
+    if (ctx->round_capacity <= 0) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        int per_cu = 0;
+        HIP_TRY(launch_pbs64(ctx, nullptr, 0, nullptr, nullptr, nullptr, &per_cu));
+        ctx->round_capacity = (int64_t)std::max(per_cu, 1) * ctx->n_cus;
+    }
+    return ctx->round_capacity;
+}
 
 int helm_si_exchange_stats(const helm_si_ctx *ctx, int64_t *batches, int64_t *rows)
 {

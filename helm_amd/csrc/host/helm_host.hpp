@@ -12,7 +12,9 @@
 // code throws helm::Panic carrying the same message.
 #pragma once
 #include <cstdint>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <optional>
 #include <set>
@@ -346,9 +348,49 @@ struct RadixOp {
 
 // Level-batched FheUintN operators (add, sub, mul and their scalar forms, copy) over the two
 // device primitives helm_si_lincomb / helm_si_apply_luts.
+// Round merger: operator chains that share no wire run on one host thread each and meet here with every look-up round.
+// When each running chain has handed in its next round, the rounds are merged into launches of at most `capacity`
+// ciphertexts (helm_si_round_capacity: what the device bootstraps at once - a launch of that size takes one bootstrap's
+// time whatever it holds) on ONE context and stream: the chain with the most rounds left is served first, a round that does
+// not fit is continued in the next launch next to the other chains' NEXT rounds.  The reference's unit is the level
+// (src/circuit.rs:1321: every operator of a level, then a join); this is the same evaluation with the join per look-up
+// round instead of per level - identical ciphertexts, the device never waits for a launch slot.
+class RoundMerger {
+  public:
+    RoundMerger(helm_si_ctx *ctx, int chains, int64_t capacity);
+    void set_remaining(int chain, int64_t rounds) { remaining_[(size_t)chain] = rounds; }
+    // the chain's next round; returns once all of it is ENQUEUED (stream order does the rest)
+    void submit(int chain, helm_si_wires *w, const std::vector<int32_t> &in, const std::vector<int32_t> &lut,
+                const std::vector<int32_t> &out, const uint64_t *luts, int64_t n_luts);
+    void finish(int chain); // no more rounds from this chain (also on error)
+    std::mutex &device() { return mu_; } // every other device call of a chain holds it: one context, several threads
+    int64_t launches() const { return launches_; }
+
+  private:
+    struct Sub {
+        helm_si_wires *w = nullptr;
+        const std::vector<int32_t> *in = nullptr, *lut = nullptr, *out = nullptr;
+        const uint64_t *luts = nullptr;
+        int64_t n_luts = 0;
+        size_t taken = 0;
+        bool present = false;
+    };
+    void issue_locked();
+    helm_si_ctx *ctx_;
+    int64_t capacity_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<Sub> subs_;
+    std::vector<int64_t> remaining_;
+    std::vector<char> active_;
+    std::string error_;
+    int64_t launches_ = 0;
+};
+
 class RadixEngine {
   public:
     RadixEngine(helm_si_ctx *ctx, int blocks);
+    void attach(RoundMerger *merger, int chain) { merger_ = merger, chain_ = chain; }
     int64_t scratch_rows(const std::vector<RadixOp> &ops) const;
     void run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in, int scratch);
     void propagate(helm_si_wires *w, const std::vector<int32_t> &bases, int scratch, int width,
@@ -361,6 +403,13 @@ class RadixEngine {
                  const std::vector<int64_t> &cadd, const std::vector<int32_t> &out, int terms);
     void apply(helm_si_wires *w, const std::vector<int32_t> &in, const std::vector<int32_t> &lut,
                const std::vector<int32_t> &out);
+    struct Carries {
+        std::vector<int32_t> row; // [integer * (need + 1) + item]
+        bool bit = true;          // 0 / 4, else c form (4 c: carry <=> c >= 2)
+    };
+    Carries carries(helm_si_wires *w, const std::vector<int32_t> &states, int G, int n, int need, bool add_const, int &sp,
+                    bool want_bit);
+    static int prop_rows(int W); // scratch rows of propagate() per integer
     void shift_scalar(helm_si_wires *w, const std::vector<RadixOp> &ops);
     void shift_encrypted(helm_si_wires *w, const std::vector<RadixOp> &ops, int &scratch_pos);
     void divide(helm_si_wires *w, const std::vector<RadixOp> &ops, int &scratch_pos);
@@ -368,10 +417,15 @@ class RadixEngine {
     int nb_;
     helm_si_params P_{};
     std::vector<uint64_t> luts_;
-    int lut_msg_ = 0, lut_carry_ = 0, lut_state_ = 0, lut_state0_ = 0, lut_comb_ = 0, lut_mul_lo_ = 0, lut_mul_hi_ = 0;
+    int lut_msg_ = 0, lut_carry_ = 0, lut_mul_lo_ = 0, lut_mul_hi_ = 0;
+    int lut_t_[4] = {}, lut_s_[4] = {}, lut_q_[3] = {}, lut_gc_[3] = {}, lut_q3_ = 0, lut_gc3_ = 0, lut_resolve_ = 0, lut_final_ = 0,
+        lut_cout_ = 0; // carry propagation, see propagate()
     int lut_bit0_ = 0, lut_bit1_ = 0, lut_shl1_ = 0, lut_shr1_ = 0, lut_sel_ = 0;
     int64_t pbs_count_ = 0, pbs_rounds_ = 0;
     std::vector<int32_t> pend_in_, pend_lut_, pend_out_; // look-ups waiting for the level's next batch
+    RoundMerger *merger_ = nullptr; // set: look-up rounds go through the merger, other device calls under its lock
+    int chain_ = 0;
+    std::unique_lock<std::mutex> device_lock() { return merger_ ? std::unique_lock<std::mutex>(merger_->device()) : std::unique_lock<std::mutex>(); }
 };
 
 // reference src/circuit.rs:81-85, 1112-1500

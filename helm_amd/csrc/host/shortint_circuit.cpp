@@ -411,11 +411,21 @@ RadixEngine::RadixEngine(helm_si_ctx *ctx, int nb) : ctx_(ctx), nb_(nb)
     };
     lut_msg_ = add_lut([](int v) { return v & 3; });
     lut_carry_ = add_lut([](int v) { return v >> 2; });
-    // carry state of a block sum x <= 7: 0 none, 1 generates, 2 propagates an incoming carry
-    lut_state_ = add_lut([](int v) { return v >= 4 ? 1 : v == 3 ? 2 : 0; });
-    lut_state0_ = add_lut([](int v) { return v >= 4 ? 1 : 0; }); // block 0: nothing comes in
-    // prefix combine, packed hi * 4 + lo: a propagating block takes the state below it
-    lut_comb_ = add_lut([](int v) { return (v >> 2) == 2 ? (v & 3) : (v >> 2); });
+    // carry propagation (see propagate()): values are taken mod 32 - 16 is the padding bit, 32 - x is -x
+    for (int p = 0; p < 4; p++) { // carry state of a block sum x <= 7 (0 absorbs, 1 propagates, 2 generates), weighted 2^p
+        lut_t_[p] = add_lut([p](int v) { return (v >= 4 ? 2 : v == 3 ? 1 : 0) << p; });
+        // state of a whole group from V_3 = t_0 + 2 t_1 + 4 t_2 + 8 t_3 <= 30, negacyclic: -2^p (+ 2^p) below 15, 0 at 15
+        lut_s_[p] = add_lut([p](int v) { return v == 15 ? 0 : 32 - (1 << p); });
+    }
+    for (int i = 0; i < 3; i++) { // prefix 0..i of a group from V_i: state x 4, and the bare carry (x 4)
+        lut_q_[i] = add_lut([i](int v) { return v >= (2 << i) ? 8 : v == (2 << i) - 1 ? 4 : 0; });
+        lut_gc_[i] = add_lut([i](int v) { return v >= (2 << i) ? 4 : 0; });
+    }
+    lut_q3_ = add_lut([](int v) { return v == 15 ? 0 : 32 - 4; }); // + 4 afterwards: 0 / 4 / 8
+    lut_gc3_ = add_lut([](int) { return 32 - 2; });                // + 2 afterwards: 0 below 16, 4 from 16 on
+    lut_resolve_ = add_lut([](int v) { return v >= 8 ? 4 : 0; });  // c form (4 c) -> bit form
+    lut_final_ = add_lut([](int v) { return ((v & 3) + ((v >> 2) >= 2 ? 1 : 0)) & 3; });
+    lut_cout_ = add_lut([](int v) { return v >= 8 ? 1 : 0; });
     // products of two 2-bit messages, packed a * 4 + b
     lut_mul_lo_ = add_lut([](int v) { return ((v >> 2) * (v & 3)) & 3; });
     lut_mul_hi_ = add_lut([](int v) { return ((v >> 2) * (v & 3)) >> 2; });
@@ -427,10 +437,96 @@ RadixEngine::RadixEngine(helm_si_ctx *ctx, int nb) : ctx_(ctx), nb_(nb)
     lut_sel_ = add_lut([](int v) { return (v >> 2) ? (v & 3) : 0; }); // 4 * c + x -> c ? x : 0
 }
 
+// ---------------------------------------------------------------------------------------
+// RoundMerger
+// ---------------------------------------------------------------------------------------
+RoundMerger::RoundMerger(helm_si_ctx *ctx, int chains, int64_t capacity)
+    : ctx_(ctx), capacity_(std::max<int64_t>(capacity, 1)), subs_((size_t)chains), remaining_((size_t)chains, 0),
+      active_((size_t)chains, 1)
+{
+}
+
+// mu_ held.  Launches while every running chain waits with a round; returns as soon as one of them has been released.
+void RoundMerger::issue_locked()
+{
+    for (;;) {
+        size_t running = 0, present = 0;
+        int64_t total = 0;
+        for (size_t c = 0; c < subs_.size(); c++) {
+            running += active_[c] ? 1 : 0;
+            if (subs_[c].present) {
+                present++;
+                total += (int64_t)(subs_[c].in->size() - subs_[c].taken);
+            }
+        }
+        if (present == 0 || present != running) return;
+        std::vector<size_t> order;
+        for (size_t c = 0; c < subs_.size(); c++)
+            if (subs_[c].present) order.push_back(c);
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return remaining_[x] > remaining_[y]; });
+        // a single chain left, or everything fits: one launch; otherwise fill the device once, most urgent chain first
+        const int64_t cap = (present == 1 || total <= capacity_) ? total : capacity_;
+        std::vector<int32_t> in, lut, out;
+        in.reserve((size_t)cap), lut.reserve((size_t)cap), out.reserve((size_t)cap);
+        const Sub &first = subs_[order[0]];
+        for (size_t c : order) {
+            Sub &s = subs_[c];
+            if (s.w != first.w || s.n_luts != first.n_luts) {
+                error_ = "round merger: chains on different wire tables or look-up tables";
+                break;
+            }
+            const size_t n = (size_t)std::min<int64_t>((int64_t)(s.in->size() - s.taken), cap - (int64_t)in.size());
+            in.insert(in.end(), s.in->begin() + (long)s.taken, s.in->begin() + (long)(s.taken + n));
+            lut.insert(lut.end(), s.lut->begin() + (long)s.taken, s.lut->begin() + (long)(s.taken + n));
+            out.insert(out.end(), s.out->begin() + (long)s.taken, s.out->begin() + (long)(s.taken + n));
+            s.taken += n;
+        }
+        if (error_.empty() && !in.empty()) {
+            if (helm_si_apply_luts(ctx_, first.w, in.data(), lut.data(), out.data(), (int64_t)in.size(), first.luts, first.n_luts) != 0)
+                error_ = std::string("apply_luts: ") + helm_hip_last_error();
+            launches_++;
+        }
+        bool released = false;
+        for (size_t c : order) {
+            Sub &s = subs_[c];
+            if (!error_.empty() || s.taken == s.in->size()) {
+                s.present = false;
+                if (remaining_[c] > 0) remaining_[c]--;
+                released = true;
+            }
+        }
+        if (released) {
+            cv_.notify_all();
+            return;
+        }
+    }
+}
+
+void RoundMerger::submit(int chain, helm_si_wires *w, const std::vector<int32_t> &in, const std::vector<int32_t> &lut,
+                         const std::vector<int32_t> &out, const uint64_t *luts, int64_t n_luts)
+{
+    std::unique_lock<std::mutex> lk(mu_);
+    if (!error_.empty()) throw Panic(error_);
+    Sub &s = subs_[(size_t)chain];
+    s.w = w, s.in = &in, s.lut = &lut, s.out = &out, s.luts = luts, s.n_luts = n_luts, s.taken = 0, s.present = true;
+    issue_locked();
+    cv_.wait(lk, [&] { return !s.present; });
+    if (!error_.empty()) throw Panic(error_);
+}
+
+void RoundMerger::finish(int chain)
+{
+    std::unique_lock<std::mutex> lk(mu_);
+    active_[(size_t)chain] = 0;
+    subs_[(size_t)chain].present = false;
+    issue_locked(); // the others may all be waiting now
+}
+
 void RadixEngine::lincomb(helm_si_wires *w, const std::vector<int32_t> &in_idx, const std::vector<int64_t> &coef,
                           const std::vector<int64_t> &cadd, const std::vector<int32_t> &out, int terms)
 {
     if (out.empty()) return;
+    auto guard = device_lock();
     si_ok(helm_si_lincomb(ctx_, w, in_idx.data(), coef.data(), cadd.empty() ? nullptr : cadd.data(), out.data(), terms,
                           (int64_t)out.size()),
           "lincomb");
@@ -452,84 +548,191 @@ void RadixEngine::apply(helm_si_wires *w, const std::vector<int32_t> &in, const 
         return;
     }
     if (in.empty()) return;
-    si_ok(helm_si_apply_luts(ctx_, w, in.data(), lut.data(), out.data(), (int64_t)in.size(), luts_.data(),
-                             (int64_t)(luts_.size() / (size_t)P_.N)),
-          "apply_luts");
+    if (merger_)
+        merger_->submit(chain_, w, in, lut, out, luts_.data(), (int64_t)(luts_.size() / (size_t)P_.N));
+    else
+        si_ok(helm_si_apply_luts(ctx_, w, in.data(), lut.data(), out.data(), (int64_t)in.size(), luts_.data(),
+                                 (int64_t)(luts_.size() / (size_t)P_.N)),
+              "apply_luts");
     pbs_count_ += (int64_t)in.size();
     pbs_rounds_++;
 }
 
-// Full carry propagation of integers of `W` blocks whose block sums are <= 6 (block 0: <= 7):
-// carry states, Hillis-Steele prefix over them (log2 W rounds of one bootstrap per block), final
-// message extraction.  `scratch` needs 2 * W rows per integer.  With `flags` (one row per
-// integer) the carry OUT of the top block is kept there (0 / 1) instead of being dropped.
+// Full carry propagation of integers of `W` blocks whose block sums are <= 6 (block 0: <= 7), in
+//     2 + ceil(log4 W) rounds of look-ups (+1 per level beyond two: W > 16)
+// instead of the 2 + log2 W of a Hillis-Steele prefix over the carry states - four rounds instead of six for a u32.
+// A block's carry state t is 0 (absorbs), 1 (propagates an incoming carry: sum == 3) or 2 (generates: sum >= 4).  The
+// states of a group of four blocks, weighted 1, 2, 4, 8 BY THEIR LOOK-UP TABLES (a bootstrap's output noise does not
+// depend on the table, so the weights cost nothing), add up like the operands of a binary adder:
+//     V_i = sum_{j <= i} t_j 2^j   carries out of bit i  <=>  blocks 0..i generate,   V_i == 2^(i+1) - 1  <=>  they propagate
+// so ONE look-up on V_i gives the state of the prefix 0..i of the group (Q_i), for every position of the group in the same
+// round.  V_3 needs five bits: its table uses the padding bit (negacyclic look-up: f(v + 16) = -f(v); f = -x below 15,
+// 0 at 15, and a plaintext + x afterwards gives 0 / x / 2x for absorb / propagate / generate; V_3 <= 30).  The group
+// states S_k, again weighted by their tables, go through the same step one level up (recursively for more than 16
+// blocks), which yields the carry gc_k into every group; the carry into block i of group k is then c = Q_(i-1) + gc_k >= 2,
+// and the last round computes (message + [c >= 2]) & 3 from the packed value message + 4 c.  Every look-up input is a sum
+// of at most four fresh ciphertexts.  (tfhe's own radix propagation lives in the absent crate; results mod 2^bits are what
+// the reference's tests pin: tests/gates_test.rs:127-310.)
+// `scratch` needs prop_rows(W) rows per integer.  With `flags` (one row per integer) the carry OUT of the top block is
+// kept there (0 / 1) instead of being dropped.
+int RadixEngine::prop_rows(int W) { return 5 * W + 16; }
+
+// Carries INTO items 1..need of `n` items per integer (G integers) whose states sit in st[g * n + m], weighted 2^(m % 4);
+// add_const: the states still lack the plaintext + 2^(m % 4) of the negacyclic table (group states).  Returns rows
+// [g * (need + 1) + m]; bit form (0 / 4) if `bit`, else c form (4 c, carry <=> c >= 2).
+RadixEngine::Carries RadixEngine::carries(helm_si_wires *w, const std::vector<int32_t> &st, int G, int n, int need,
+                                         bool add_const, int &sp, bool want_bit)
+{
+    auto take = [&](int rows) { const int b = sp; sp += rows; return b; };
+    Carries R;
+    R.bit = true;
+    R.row.assign((size_t)G * (size_t)(need + 1), -1);
+    if (need <= 0) return R;
+    std::vector<int32_t> li, lo, in, lut, out, fix_rows;
+    std::vector<int64_t> lc, ca, fix_c;
+    auto sum_into = [&](int g, int first, int count, int dst) { // dst = sum of items first..first+count-1 (count <= 4)
+        int64_t c = 0;
+        for (int j = 0; j < 4; j++) {
+            li.push_back(j < count ? st[(size_t)g * n + first + j] : -1);
+            lc.push_back(j < count ? 1 : 0);
+            if (j < count && add_const) c += (int64_t)1 << ((first + j) % 4);
+        }
+        lo.push_back(dst);
+        ca.push_back(c);
+    };
+    if (n <= 4) {
+        const int base = take(G * need);
+        for (int g = 0; g < G; g++)
+            for (int m = 1; m <= need; m++) {
+                const int r = base + g * need + (m - 1);
+                sum_into(g, 0, m, r);
+                in.push_back(r), out.push_back(r), lut.push_back(m - 1 < 3 ? lut_gc_[m - 1] : lut_gc3_);
+                if (m - 1 == 3) fix_rows.push_back(r), fix_c.push_back(2);
+                R.row[(size_t)g * (need + 1) + m] = r;
+            }
+        lincomb(w, li, lc, ca, lo, 4);
+        apply(w, in, lut, out);
+        R.bit = true;
+    } else {
+        const int ng = (n + 3) / 4;
+        // one round: prefix states inside every group, group states of the full groups that are not the last
+        const int vbase = take(G * n), sbase = take(G * ng);
+        std::vector<int32_t> s_items((size_t)G * ng, -1), in_q, lut_q, out_q;
+        for (int g = 0; g < G; g++)
+            for (int k = 0; k < ng; k++) {
+                const int cnt = std::min(4, n - 4 * k);
+                for (int i = 0; i < cnt; i++) {
+                    const int m = 4 * k + i + 1; // the item this prefix carries into
+                    const bool want_q = m <= need && (m % 4 != 0 || m == n);
+                    const bool want_s = i == 3 && k < ng - 1;
+                    if (!want_q && !want_s) continue;
+                    const int v = vbase + g * n + 4 * k + i;
+                    sum_into(g, 4 * k, i + 1, v);
+                    if (want_s) { // reads v before the in-place look-up below may overwrite it: listed first
+                        const int srow = sbase + g * ng + k;
+                        in.push_back(v), out.push_back(srow), lut.push_back(lut_s_[k % 4]);
+                        s_items[(size_t)g * ng + k] = srow;
+                    }
+                    if (want_q) {
+                        in_q.push_back(v), out_q.push_back(v), lut_q.push_back(i < 3 ? lut_q_[i] : lut_q3_);
+                        if (i == 3) fix_rows.push_back(v), fix_c.push_back(4);
+                    }
+                }
+            }
+        lincomb(w, li, lc, ca, lo, 4);
+        in.insert(in.end(), in_q.begin(), in_q.end());
+        lut.insert(lut.end(), lut_q.begin(), lut_q.end());
+        out.insert(out.end(), out_q.begin(), out_q.end());
+        apply(w, in, lut, out);
+        if (!fix_rows.empty()) { // the plaintext halves of the negacyclic tables
+            std::vector<int64_t> fc(fix_rows.size(), 1);
+            lincomb(w, fix_rows, fc, fix_c, fix_rows, 1);
+            fix_rows.clear(), fix_c.clear();
+        }
+        // carries into the groups, one level up (bit form: they are added to the prefix states)
+        const int gneed = (need == n && n % 4 == 0) ? n / 4 - 1 : need / 4; // the last group a needed item sits in
+        Carries GC = carries(w, s_items, G, ng, gneed, true, sp, true);
+        // c form of every item: prefix state of the blocks below it in its group + the carry into the group
+        li.clear(), lc.clear(), lo.clear(), ca.clear();
+        const int cbase = take(G * need);
+        for (int g = 0; g < G; g++)
+            for (int m = 1; m <= need; m++) {
+                const int k = (m == n && m % 4 == 0) ? m / 4 - 1 : m / 4; // the virtual item behind a full last group
+                const int gc = k >= 1 ? GC.row[(size_t)g * (gneed + 1) + k] : -1;
+                const bool pos0 = m % 4 == 0 && m != n;
+                const int q = pos0 ? -1 : vbase + g * n + (m - 1);
+                const int r = cbase + g * need + (m - 1);
+                li.push_back(q), lc.push_back(q >= 0 ? 1 : 0);
+                li.push_back(gc), lc.push_back(gc >= 0 ? 1 : 0);
+                lo.push_back(r);
+                ca.push_back(pos0 ? 4 : 0); // first block of a group: c = 1 + gc
+                R.row[(size_t)g * (need + 1) + m] = r;
+            }
+        lincomb(w, li, lc, ca, lo, 2);
+        R.bit = false;
+        if (want_bit) {
+            in.clear(), lut.clear(), out.clear();
+            for (int g = 0; g < G; g++)
+                for (int m = 1; m <= need; m++) {
+                    const int r = R.row[(size_t)g * (need + 1) + m];
+                    in.push_back(r), out.push_back(r), lut.push_back(lut_resolve_);
+                }
+            apply(w, in, lut, out);
+            R.bit = true;
+        }
+    }
+    if (!fix_rows.empty()) {
+        std::vector<int64_t> fc(fix_rows.size(), 1);
+        lincomb(w, fix_rows, fc, fix_c, fix_rows, 1);
+    }
+    return R;
+}
+
 void RadixEngine::propagate(helm_si_wires *w, const std::vector<int32_t> &bases, int scratch, int W,
                             const std::vector<int32_t> *flags)
 {
     const int G = (int)bases.size();
     if (G == 0) return;
     if (W <= 0) W = nb_;
-    const int NS = flags ? W : W - 1; // blocks whose carry state matters
-    auto S = [&](int g, int buf, int i) { return scratch + (g * 2 + buf) * W + i; };
-    std::vector<int32_t> in, lut, out;
+    int sp = scratch;
+    auto take = [&](int rows) { const int b = sp; sp += rows; return b; };
+    const int need = flags ? W : W - 1; // carries into blocks 1..W-1, and out of the top block
+    // round 1: weighted carry states, and the messages (in place)
+    const int tbase = take(G * W);
+    std::vector<int32_t> st((size_t)G * W), in, lut, out, in2, lut2, out2;
     for (int g = 0; g < G; g++)
-        for (int i = 0; i < NS; i++) {
-            in.push_back(bases[(size_t)g] + i);
-            lut.push_back(i == 0 ? lut_state0_ : lut_state_);
-            out.push_back(S(g, 0, i));
-        }
-    apply(w, in, lut, out);
-    int cur = 0;
-    for (int d = 1; d < NS; d <<= 1) {
-        // s'[i] = comb(s[i], s[i-d]) for i >= d (packed 4 * s[i] + s[i-d]); s'[i] = s[i] below
-        std::vector<int32_t> li, lo;
-        std::vector<int64_t> lc;
-        in.clear();
-        lut.clear();
-        out.clear();
-        for (int g = 0; g < G; g++)
-            for (int i = 0; i < NS; i++) {
-                li.push_back(S(g, cur, i));
-                lc.push_back(i >= d ? 4 : 1);
-                li.push_back(i >= d ? S(g, cur, i - d) : -1);
-                lc.push_back(i >= d ? 1 : 0);
-                lo.push_back(S(g, cur ^ 1, i));
-                if (i >= d) {
-                    in.push_back(S(g, cur ^ 1, i));
-                    lut.push_back(lut_comb_);
-                    out.push_back(S(g, cur ^ 1, i));
-                }
-            }
-        lincomb(w, li, lc, {}, lo, 2);
-        apply(w, in, lut, out);
-        cur ^= 1;
-    }
-    // block i += carry out of block i-1 (state == 1), then keep the message
-    std::vector<int32_t> li, lo;
-    std::vector<int64_t> lc;
-    in.clear();
-    lut.clear();
-    out.clear();
-    for (int g = 0; g < G; g++) {
         for (int i = 0; i < W; i++) {
-            li.push_back(bases[(size_t)g] + i);
-            lc.push_back(1);
-            li.push_back(i > 0 ? S(g, cur, i - 1) : -1);
-            lc.push_back(i > 0 ? 1 : 0);
-            lo.push_back(bases[(size_t)g] + i);
-            in.push_back(bases[(size_t)g] + i);
-            lut.push_back(lut_msg_);
-            out.push_back(bases[(size_t)g] + i);
+            st[(size_t)g * W + i] = tbase + g * W + i;
+            if (i < need) in.push_back(bases[(size_t)g] + i), lut.push_back(lut_t_[i % 4]), out.push_back(tbase + g * W + i);
+            in2.push_back(bases[(size_t)g] + i), lut2.push_back(lut_msg_), out2.push_back(bases[(size_t)g] + i);
         }
-        if (flags) { // the prefix state of the top block is 0 or 1: the carry out
-            li.push_back(S(g, cur, W - 1));
-            lc.push_back(1);
-            li.push_back(-1);
-            lc.push_back(0);
-            lo.push_back((*flags)[(size_t)g]);
+    in.insert(in.end(), in2.begin(), in2.end());
+    lut.insert(lut.end(), lut2.begin(), lut2.end());
+    out.insert(out.end(), out2.begin(), out2.end());
+    apply(w, in, lut, out);
+    if (need == 0) return;
+    Carries C = carries(w, st, G, W, need, false, sp, false);
+    // last round: message + 4 c -> (message + [c >= 2]) & 3; bit-form carries are c = 1 + bit
+    std::vector<int32_t> li, lo;
+    std::vector<int64_t> lc, ca;
+    in.clear(), lut.clear(), out.clear();
+    for (int g = 0; g < G; g++) {
+        for (int i = 1; i < W; i++) {
+            const int b = bases[(size_t)g] + i;
+            li.push_back(b), lc.push_back(1);
+            li.push_back(C.row[(size_t)g * (need + 1) + i]), lc.push_back(1);
+            lo.push_back(b), ca.push_back(C.bit ? 4 : 0);
+            in.push_back(b), lut.push_back(lut_final_), out.push_back(b);
+        }
+        if (flags) {
+            const int c = C.row[(size_t)g * (need + 1) + W];
+            li.push_back(c), lc.push_back(1);
+            li.push_back(-1), lc.push_back(0);
+            lo.push_back(c), ca.push_back(C.bit ? 4 : 0);
+            in.push_back(c), lut.push_back(lut_cout_), out.push_back((*flags)[(size_t)g]);
         }
     }
-    lincomb(w, li, lc, {}, lo, 2);
+    lincomb(w, li, lc, ca, lo, 2);
     apply(w, in, lut, out);
 }
 
@@ -669,7 +872,7 @@ void RadixEngine::divide(helm_si_wires *w, const std::vector<RadixOp> &ops, int 
     const int G = (int)dv.size(), W = nb_ + 1, bits = 2 * nb_;
     auto take = [&](int rows) { const int b = sp; sp += rows; return b; };
     const int abit0 = take(G * bits), qbit0 = take(G * bits), B0 = take(G * W), R0 = take(G * W), D0 = take(G * W),
-              selA0 = take(G * W), selB0 = take(G * W), st0 = take(2 * W * G);
+              selA0 = take(G * W), selB0 = take(G * W), st0 = take(prop_rows(W) * G);
     std::vector<int32_t> li, lo, in, lut, out, idx;
     std::vector<int64_t> lc, ca;
     std::vector<uint64_t> val;
@@ -688,7 +891,10 @@ void RadixEngine::divide(helm_si_wires *w, const std::vector<RadixOp> &ops, int 
             val.push_back(0);
         }
     lincomb(w, li, lc, {}, lo, 2);
-    si_ok(helm_si_wires_set_trivial(ctx_, w, idx.data(), val.data(), (int64_t)idx.size()), "set_trivial");
+    {
+        auto guard = device_lock();
+        si_ok(helm_si_wires_set_trivial(ctx_, w, idx.data(), val.data(), (int64_t)idx.size()), "set_trivial");
+    }
     // bits of the numerators
     for (int g = 0; g < G; g++)
         for (int t = 0; t < bits; t++) {
@@ -766,14 +972,14 @@ int64_t RadixEngine::scratch_rows(const std::vector<RadixOp> &ops) const
 {
     int64_t rows = 0;
     for (auto &op : ops) {
-        rows += 2 * nb_; // propagate states
+        rows += prop_rows(nb_); // propagate scratch
         // partial-product vectors (2 nb - 1) plus the message / carry vectors of the reduction
         // rounds (about 1.5 nb): 4 nb + 4 vectors of nb rows bound both
         if (op.kind == RadixOp::Mul || op.kind == RadixOp::MulScalar) rows += (int64_t)(4 * nb_ + 4) * nb_;
         if (op.kind == RadixOp::AddScalar || op.kind == RadixOp::SubScalar) rows += nb_;
         if (op.a2 >= 0 || op.b2 >= 0) rows += 6 * nb_; // complemented terms and one reduction round of a carry-save sum
         if (op.kind == RadixOp::Shl || op.kind == RadixOp::Shr) rows += 4 * nb_ + 8;
-        if (op.kind == RadixOp::Div || op.kind == RadixOp::DivScalar) rows += 4 * 2 * nb_ + 7 * (nb_ + 1);
+        if (op.kind == RadixOp::Div || op.kind == RadixOp::DivScalar) rows += 4 * 2 * nb_ + 5 * (nb_ + 1) + prop_rows(nb_ + 1);
     }
     return rows;
 }
@@ -905,6 +1111,7 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
         }
         if (!zero_rows.empty()) {
             std::vector<uint64_t> z(zero_rows.size(), 0);
+            auto guard = device_lock();
             si_ok(helm_si_wires_set_trivial(ctx_, w, zero_rows.data(), z.data(), (int64_t)zero_rows.size()), "set_trivial");
         }
         // one batch: the keyswitch of every ciphertext of a call finishes before any bootstrap writes,
@@ -1000,6 +1207,7 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
         lincomb(w, li, lc, {}, lo, T);
         if (!zero_rows.empty()) {
             std::vector<uint64_t> z(zero_rows.size(), 0);
+            auto guard = device_lock();
             si_ok(helm_si_wires_set_trivial(ctx_, w, zero_rows.data(), z.data(), (int64_t)zero_rows.size()), "set_trivial");
         }
         // carries and (in place) messages of every summed row in one batch (see above)
@@ -1038,7 +1246,7 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
         lincomb(w, li, lc, {}, lo, 2);
     }
     // ---- carry propagation of everything that needs it -------------------------------------------
-    propagate(w, prop_bases, take(2 * nb_ * (int)prop_bases.size()), nb_, nullptr);
+    propagate(w, prop_bases, take(prop_rows(nb_) * (int)prop_bases.size()), nb_, nullptr);
     // ---- shifts by an encrypted amount and divisions (own round structure) ------------------------
     shift_encrypted(w, ops, sp);
     divide(w, ops, sp);
@@ -1362,11 +1570,12 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
     // and ONE lane forked from it (identical ciphertexts, the rounds of the longest component in a row instead of the sum
     // over the levels).  add_lane() / clear_lanes() override: explicit lanes, or none.
     std::vector<helm_si_ctx *> lanes = lanes_;
-    if (lanes.empty() && auto_lanes_ && helm_si_exchange_world(server_key_) <= 1 && component_count(plan) >= 2) {
-        if (!own_lane_) si_ok(helm_si_ctx_fork(server_key_, &own_lane_), "ctx_fork");
-        lanes.push_back(own_lane_);
-    }
-    if (!lanes.empty()) {
+    // Default (no explicit lanes): the components become chains on ONE context whose look-up rounds a RoundMerger joins
+    // into launches of at most the device's capacity - no launch of one chain ever waits for compute units another
+    // chain's launch holds (a bootstrap occupies its CU for the whole 8 ms, and a keyswitch + bootstrap pair that comes
+    // 1 ms late loses two full rounds; measured: profiles/r03/arith_round_merger.txt).
+    const bool merged = lanes.empty() && auto_lanes_ && helm_si_exchange_world(server_key_) <= 1 && component_count(plan) >= 2;
+    if (!lanes.empty() || merged) {
         // ---- lanes: connected components of the operator graph (wires produced by an operator connect it to its
         //      consumers; primary inputs and scalars connect nothing), each component's levels compacted, components
         //      spread over the contexts by their bootstrap estimate, one host thread per context.
@@ -1404,7 +1613,8 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
             order.push_back({w, c.first});
         }
         std::sort(order.begin(), order.end(), [](auto &x, auto &y) { return x.first > y.first; });
-        const size_t n_ctx = 1 + lanes.size();
+        const size_t n_ctx = merged ? std::min<size_t>(comps.size(), 8) : 1 + lanes.size();
+        auto ctx_of = [&](size_t lane) { return merged || lane == 0 ? server_key_ : lanes[lane - 1]; };
         std::vector<int64_t> load(n_ctx, 0);
         std::vector<std::vector<std::vector<RadixOp>>> lane_plan(n_ctx, std::vector<std::vector<RadixOp>>(plan.size()));
         for (auto &oc : order) {
@@ -1412,13 +1622,19 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
             load[lane] += oc.first;
             for (int id : comps[oc.second]) lane_plan[lane][where[(size_t)id].first].push_back(plan[where[(size_t)id].first][where[(size_t)id].second]);
         }
-        // the lane with the longest chain of bootstrap rounds is the critical path: its launches go first when both
-        // lanes have some ready (helm_si_set_priority: dispatch priority of the context's own stream)
+        // the lane with the longest chain of bootstrap rounds is the critical path: its look-ups go first (merger: served
+        // first in every launch; explicit lanes: helm_si_set_priority, dispatch priority of the context's own stream)
+        std::unique_ptr<RoundMerger> merger;
         {
             auto rounds = [&](const RadixOp &op) -> int {
                 int lg = 0;
                 while ((1 << lg) < nb - 1) lg++;
-                const int prop = 2 + lg; // carry states, prefix rounds, messages
+                // propagate(): states + messages, the grouped carries (one round per level of groups of four, one more
+                // per level beyond the first to turn c form into a bit), final messages
+                std::function<int(int, bool)> carry_rounds = [&](int n, bool bit) {
+                    return n <= 4 ? 1 : 1 + carry_rounds((n + 3) / 4, true) + (bit ? 1 : 0);
+                };
+                const int prop = nb <= 1 ? 1 : 2 + carry_rounds(nb, false);
                 const bool cs = op.a2 >= 0 || op.b2 >= 0;
                 switch (op.kind) {
                 case RadixOp::Mul: return 5 + (op.out2 >= 0 ? 0 : prop);
@@ -1439,14 +1655,19 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
                     chain[lane] += m;
                 }
             const size_t crit = (size_t)(std::max_element(chain.begin(), chain.end()) - chain.begin());
-            for (size_t lane = 0; lane < n_ctx; lane++)
-                si_ok(helm_si_set_priority(lane == 0 ? server_key_ : lanes[lane - 1], lane == crit ? 1 : 0), "set_priority");
+            if (merged) {
+                merger.reset(new RoundMerger(server_key_, (int)n_ctx, helm_si_round_capacity(server_key_)));
+                for (size_t lane = 0; lane < n_ctx; lane++) merger->set_remaining((int)lane, chain[lane]);
+            } else {
+                for (size_t lane = 0; lane < n_ctx; lane++) si_ok(helm_si_set_priority(ctx_of(lane), lane == crit ? 1 : 0), "set_priority");
+            }
         }
         std::vector<std::unique_ptr<RadixEngine>> engines;
         std::vector<int64_t> lane_scratch(n_ctx, 0);
         int64_t total_scratch = 0;
         for (size_t lane = 0; lane < n_ctx; lane++) {
-            engines.emplace_back(new RadixEngine(lane == 0 ? server_key_ : lanes[lane - 1], nb));
+            engines.emplace_back(new RadixEngine(ctx_of(lane), nb));
+            if (merger) engines.back()->attach(merger.get(), (int)lane);
             for (auto &ops : lane_plan[lane]) lane_scratch[lane] = std::max(lane_scratch[lane], engines[lane]->scratch_rows(ops));
             total_scratch += lane_scratch[lane];
         }
@@ -1462,15 +1683,17 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
             try {
                 for (auto &ops : lane_plan[lane])
                     if (!ops.empty()) engines[lane]->run_level(eval_values->table(), ops, lane_base[lane]);
-                si_ok(helm_si_sync(lane == 0 ? server_key_ : lanes[lane - 1]), "sync");
+                if (!merger) si_ok(helm_si_sync(ctx_of(lane)), "sync");
             } catch (const std::exception &e) {
                 errors[lane] = e.what();
             }
+            if (merger) merger->finish((int)lane);
         };
         std::vector<std::thread> threads;
         for (size_t lane = 1; lane < n_ctx; lane++) threads.emplace_back(run_lane, lane);
         run_lane(0);
         for (auto &t : threads) t.join();
+        if (merger) si_ok(helm_si_sync(server_key_), "sync");
         for (auto &e : errors)
             if (!e.empty()) throw Panic(e);
         pbs_count_ = 0;
@@ -1479,9 +1702,10 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
             pbs_count_ += e->pbs_count();
             pbs_rounds_ = std::max(pbs_rounds_, e->pbs_rounds()); // rounds in a row: the longest lane
         }
+        if (merger) pbs_rounds_ = merger->launches(); // what the device ran one after the other
         std::ostringstream os;
         os << "  Evaluated " << comps.size() << " independent sub-circuit(s) of " << total_levels << " level(s) on " << n_ctx
-           << " lane(s)\n";
+           << (merger ? " chain(s), look-up rounds merged\n" : " lane(s)\n");
         log_ += os.str();
         remember(*eval_values);
         return eval_values;

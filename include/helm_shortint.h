@@ -150,6 +150,11 @@ int helm_si_exchange_stats(const helm_si_ctx *ctx, int64_t *batches, int64_t *ro
  * that shard keep to the primary context (the host library's ArithCircuit does not fork its default lane then). */
 int helm_si_exchange_world(const helm_si_ctx *ctx);
 
+/* Programmable bootstraps the device holds at once under this parameter set: CUs x workgroups of the set's bootstrap kernel
+ * per CU (1 at N = 2048, 2 for k_pbs64k).  A batch of at most this many ciphertexts takes one bootstrap's time whatever its
+ * size; the host library merges the look-up rounds of concurrent operators into launches of at most this size. */
+int64_t helm_si_round_capacity(helm_si_ctx *ctx);
+
 /* Primitive forms on host buffers (tests).  small: count x (n+1); big: count x (k*N+1). */
 int helm_si_keyswitch_batch(helm_si_ctx *ctx, const uint64_t *in_big, uint64_t *out_small, int64_t count);
 int helm_si_pbs_batch(helm_si_ctx *ctx, const uint64_t *in_small, const uint64_t *luts, int64_t n_luts,

@@ -145,6 +145,7 @@ extern "C" {
                                   table: *const u64, out_idx: *const i32, count: i64) -> c_int;
     pub fn helm_si_sync(ctx: *mut helm_si_ctx) -> c_int;
     pub fn helm_si_set_priority(ctx: *mut helm_si_ctx, high: c_int) -> c_int;
+    pub fn helm_si_round_capacity(ctx: *mut helm_si_ctx) -> i64;
 
     // ---- include/helm_wopbs.h (WoP-PBS wide-LUT path) ------------------------------------------
     pub fn helm_wop_ctx_create(pbs_side: *mut helm_si_ctx, params: *const helm_wop_params, out: *mut *mut helm_wop_ctx) -> c_int;

@@ -163,8 +163,9 @@ def test_chi_squared_u32(keys):  # circuit_test.rs:313-370, inputs K-5 (2, 7, 9)
 def test_chi_squared_on_lanes_is_bit_identical_and_shorter(keys):
     """Lanes (helm_si_ctx_fork): the two sub-circuits of chi-squared that share no wire (alpha's and the betas') run
     concurrently instead of meeting at every level boundary: the same ciphertexts on every wire, fewer rounds in a row
-    (33 level-synchronous rounds -> the longer sub-circuit's 23).  Lanes are the DEFAULT when the operator graph has two or
-    more components; set_lanes(1) is the reference's level-by-level evaluation."""
+    (27 level-synchronous rounds -> the longer sub-circuit's 19).  The DEFAULT when the operator graph has two or more
+    components: the sub-circuits as chains on one context whose look-up rounds are merged into launches of at most the
+    device's capacity (RoundMerger); set_lanes(1) is the reference's level-by-level evaluation."""
     import time
     client_key, server_key = keys
     circuit, wire_set, _, _ = _circuit(f"{NET}/chi_squared_arith.v", is_arith=True)
@@ -185,16 +186,19 @@ def test_chi_squared_on_lanes_is_bit_identical_and_shorter(keys):
     for wire in one.keys():
         assert np.array_equal(one[wire], two[wire]), wire
     assert {k: v.value for k, v in ac.decrypt_outputs(two, True).items()} == {"alpha": 529, "beta1": 242, "beta2": 275, "beta3": 1250}
-    # mult by 2 is one round (a shift): the betas' chain is 1 + 6 + 11 + 1 = 19 rounds; alpha's products hand their terms
-    # to the subtraction in carry-save form: 5 + 0 + 7 + 11 = 23 (round 2: 29; level by level 5 + 6 + 11 + 11 = 33, was 39)
-    assert ac.pbs_per_cycle() == pbs_one and rounds_one == 33 and ac.pbs_rounds_per_cycle() == 23
+    # a carry propagation over 16 blocks is 4 rounds (grouped by four; round 2: 6).  mult by 2 is one round (a shift): the
+    # betas' chain is 1 + 4 + 9 + 1 = 15 rounds; alpha's products hand their terms to the subtraction in carry-save form:
+    # 5 + 0 + 5 + 9 = 19 (round 2: 29; level by level 5 + 4 + 9 + 9 = 27, was 39)
+    assert ac.pbs_per_cycle() == pbs_one and rounds_one == 27 and ac.pbs_rounds_per_cycle() == 19
     assert "2 independent sub-circuit(s)" in ac.log()
     print(f"chi-squared u32: {t_one:.3f} s level by level, {t_two:.3f} s on two lanes")
     assert t_two < t_one
-    # the default: a fresh circuit forks its own lane when there are two components
+    # the default: a fresh circuit runs its two components as chains and merges their rounds: 22 launches in a row, none
+    # above the device's capacity while both chains run (19 would need both chains to fit next to each other every round)
     ac2 = ArithCircuit(client_key, server_key, circuit)
     dflt = ac2.evaluate_encrypted(enc_in, 1, "u32")
-    assert ac2.pbs_rounds_per_cycle() == 23 and "2 independent sub-circuit(s)" in ac2.log()
+    log = ac2.log()
+    assert 19 <= ac2.pbs_rounds_per_cycle() <= 23 and "2 independent sub-circuit(s)" in log and "rounds merged" in log
     for wire in one.keys():
         assert np.array_equal(one[wire], dflt[wire]), wire
 
@@ -238,9 +242,10 @@ mult g7(t3, t3, W);
         got = {w: _decrypt_int(client_key, out[w]) for w in want}
         assert got == want, (lazy, got)
         results[lazy] = (ac.pbs_rounds_per_cycle(), ac.pbs_per_cycle())
-    # here level 1 also holds a product that must propagate (t3 feeds a product), so the level costs its 9 rounds either
-    # way and the carry-save sums add one reduction round: 24 against 23 - the saving shows where the products are alone:
-    assert results == {True: (24, results[True][1]), False: (23, results[False][1])}, results
+    # here level 1 also holds a product that must propagate (t3 feeds a product), so the level costs its 8 rounds either
+    # way and the carry-save sums add one reduction round: 21 against 20 - the saving shows where the products are alone
+    # (a carry propagation over 8 blocks is 4 rounds; round 2's Hillis-Steele form: 5, and 24 against 23 here):
+    assert results == {True: (21, results[True][1]), False: (20, results[False][1])}, results
     small, ws, _, _ = _circuit("input [15:0] A, B, C, D;\noutput [15:0] X;\nmult g0(A, B, t0);\nmult g1(C, D, t1);\nsub g2(t0, t1, X);\n",
                                is_arith=True, is_text=True)
     rounds = {}
@@ -251,9 +256,9 @@ mult g7(t3, t3, W);
         out = ac.evaluate_encrypted(enc, 1, "u16")
         assert {w: _decrypt_int(client_key, out[w]) for w in ("t0", "t1", "X")} == {"t0": want["t0"], "t1": want["t1"], "X": want["X"]}
         rounds[lazy] = ac.pbs_rounds_per_cycle()
-    # a * b - c * d on FheUint16: products 1 + 3 rounds, then 1 + 5 for the subtraction = 10; with every operator
-    # propagating: 9 + 5 = 14
-    assert rounds == {True: 10, False: 14}, rounds
+    # a * b - c * d on FheUint16: products 1 + 3 rounds, then 1 + 4 for the subtraction = 9; with every operator
+    # propagating: 8 + 4 = 12
+    assert rounds == {True: 9, False: 12}, rounds
     # on lanes (the default) the same ciphertexts as level by level
     ac = ArithCircuit(client_key, server_key, circuit)
     enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U16(a), "B": PtxtType.U16(b), "C": PtxtType.U16(c), "D": PtxtType.U16(d)})
