@@ -417,7 +417,7 @@ class RadixEngine {
     int nb_;
     helm_si_params P_{};
     std::vector<uint64_t> luts_;
-    int lut_msg_ = 0, lut_carry_ = 0, lut_mul_lo_ = 0, lut_mul_hi_ = 0;
+    int lut_msg_ = 0, lut_carry_ = 0, lut_mul_lo_ = 0, lut_mul_hi_ = 0, lut_mul2_lo_ = 0, lut_mul2_hi_ = 0;
     int lut_t_[4] = {}, lut_s_[4] = {}, lut_q_[3] = {}, lut_gc_[3] = {}, lut_q3_ = 0, lut_gc3_ = 0, lut_resolve_ = 0, lut_final_ = 0,
         lut_cout_ = 0; // carry propagation, see propagate()
     int lut_bit0_ = 0, lut_bit1_ = 0, lut_shl1_ = 0, lut_shr1_ = 0, lut_sel_ = 0;

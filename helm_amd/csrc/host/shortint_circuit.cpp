@@ -429,6 +429,9 @@ RadixEngine::RadixEngine(helm_si_ctx *ctx, int nb) : ctx_(ctx), nb_(nb)
     // products of two 2-bit messages, packed a * 4 + b
     lut_mul_lo_ = add_lut([](int v) { return ((v >> 2) * (v & 3)) & 3; });
     lut_mul_hi_ = add_lut([](int v) { return ((v >> 2) * (v & 3)) >> 2; });
+    // both cross products of a square at once: 2 * a_j * a_k
+    lut_mul2_lo_ = add_lut([](int v) { return (2 * (v >> 2) * (v & 3)) & 3; });
+    lut_mul2_hi_ = add_lut([](int v) { return (2 * (v >> 2) * (v & 3)) >> 2; });
     lut_bit0_ = add_lut([](int v) { return v & 1; });
     lut_bit1_ = add_lut([](int v) { return (v >> 1) & 1; });
     // one-bit shifts of a block x with its neighbour y, packed 4 * x + y
@@ -1002,7 +1005,7 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
     shift_scalar(w, ops);
     // ---- stage 1: block sums of add / sub, operand rows of the multiplications --------------
     struct Term { int base; int low; int maxv; }; // blocks below `low` are zero; block values <= maxv
-    struct MulState { std::vector<Term> terms; int out; int out2 = -1; };
+    struct MulState { std::vector<Term> terms; int out; int out2 = -1; bool square = false; };
     std::vector<MulState> muls;
     std::vector<int32_t> prop_bases; // integers waiting for the final propagation
     int sp = scratch;
@@ -1075,6 +1078,28 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
                 MulState ms;
                 ms.out = op.out;
                 ms.out2 = op.out2;
+                if (op.a == op.b) {
+                    // a square: a_j a_k and a_k a_j are the same product - one look-up on the pair gives lo / hi of
+                    // 2 a_j a_k (<= 18: lo <= 3, hi <= 4).  Term L_j: block j + k = lo, term H_j: block j + k + 1 = hi,
+                    // k >= j: (nb + 1) / 2 term pairs instead of nb, about half the look-ups, one reduction round fewer
+                    ms.square = true;
+                    for (int j = 0; 2 * j < nb_; j++) {
+                        const int Lb = take(nb_), Hb = 2 * j + 1 < nb_ ? take(nb_) : -1;
+                        for (int c = 0; c < nb_; c++) {
+                            if (c >= 2 * j) { // packed operand 4 * a_k + a_j, k = c - j
+                                li.push_back(op.a + (c - j)); lc.push_back(4);
+                                li.push_back(op.a + j); lc.push_back(1);
+                                lo.push_back(Lb + c);
+                            } else
+                                zero_rows.push_back(Lb + c);
+                            if (Hb >= 0 && c <= 2 * j) zero_rows.push_back(Hb + c);
+                        }
+                        ms.terms.push_back(Term{Lb, 2 * j, 3});
+                        if (Hb >= 0) ms.terms.push_back(Term{Hb, 2 * j + 1, 4});
+                    }
+                    muls.push_back(std::move(ms));
+                    continue;
+                }
                 for (int j = 0; j < nb_; j++) {
                     const int Lb = take(nb_), Hb = j + 1 < nb_ ? take(nb_) : -1;
                     for (int k = 0; k < nb_; k++) {
@@ -1101,6 +1126,17 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
             if (op.kind != RadixOp::Mul) continue;
             MulState &ms = muls[mi++];
             size_t ti = 0;
+            if (ms.square) {
+                for (int j = 0; 2 * j < nb_; j++) {
+                    const int Lb = ms.terms[ti++].base, Hb = 2 * j + 1 < nb_ ? ms.terms[ti++].base : -1;
+                    for (int c = 2 * j; c < nb_; c++) {
+                        const bool diag = c == 2 * j;
+                        if (Hb >= 0 && c + 1 < nb_) { in.push_back(Lb + c); lut.push_back(diag ? lut_mul_hi_ : lut_mul2_hi_); out.push_back(Hb + c + 1); }
+                        in2.push_back(Lb + c); lut2.push_back(diag ? lut_mul_lo_ : lut_mul2_lo_); out2.push_back(Lb + c);
+                    }
+                }
+                continue;
+            }
             for (int j = 0; j < nb_; j++) {
                 const int Lb = ms.terms[ti++].base, Hb = j + 1 < nb_ ? ms.terms[ti++].base : -1;
                 for (int k = j; k < nb_; k++) {

@@ -163,7 +163,7 @@ def test_chi_squared_u32(keys):  # circuit_test.rs:313-370, inputs K-5 (2, 7, 9)
 def test_chi_squared_on_lanes_is_bit_identical_and_shorter(keys):
     """Lanes (helm_si_ctx_fork): the two sub-circuits of chi-squared that share no wire (alpha's and the betas') run
     concurrently instead of meeting at every level boundary: the same ciphertexts on every wire, fewer rounds in a row
-    (27 level-synchronous rounds -> the longer sub-circuit's 19).  The DEFAULT when the operator graph has two or more
+    (26 level-synchronous rounds -> the longer sub-circuit's 18).  The DEFAULT when the operator graph has two or more
     components: the sub-circuits as chains on one context whose look-up rounds are merged into launches of at most the
     device's capacity (RoundMerger); set_lanes(1) is the reference's level-by-level evaluation."""
     import time
@@ -188,17 +188,18 @@ def test_chi_squared_on_lanes_is_bit_identical_and_shorter(keys):
     assert {k: v.value for k, v in ac.decrypt_outputs(two, True).items()} == {"alpha": 529, "beta1": 242, "beta2": 275, "beta3": 1250}
     # a carry propagation over 16 blocks is 4 rounds (grouped by four; round 2: 6).  mult by 2 is one round (a shift): the
     # betas' chain is 1 + 4 + 9 + 1 = 15 rounds; alpha's products hand their terms to the subtraction in carry-save form:
-    # 5 + 0 + 5 + 9 = 19 (round 2: 29; level by level 5 + 4 + 9 + 9 = 27, was 39)
-    assert ac.pbs_per_cycle() == pbs_one and rounds_one == 27 and ac.pbs_rounds_per_cycle() == 19
+    # 5 + 0 + 5 + 8 = 18 (the last product is a square: one reduction round fewer; round 2: 29); level by level
+    # 5 + 4 + 9 + 8 = 26 (was 39)
+    assert ac.pbs_per_cycle() == pbs_one and rounds_one == 26 and ac.pbs_rounds_per_cycle() == 18
     assert "2 independent sub-circuit(s)" in ac.log()
     print(f"chi-squared u32: {t_one:.3f} s level by level, {t_two:.3f} s on two lanes")
     assert t_two < t_one
-    # the default: a fresh circuit runs its two components as chains and merges their rounds: 22 launches in a row, none
-    # above the device's capacity while both chains run (19 would need both chains to fit next to each other every round)
+    # the default: a fresh circuit runs its two components as chains and merges their rounds: 20 launches in a row, none
+    # above the device's capacity while both chains run (18 would need both chains to fit next to each other every round)
     ac2 = ArithCircuit(client_key, server_key, circuit)
     dflt = ac2.evaluate_encrypted(enc_in, 1, "u32")
     log = ac2.log()
-    assert 19 <= ac2.pbs_rounds_per_cycle() <= 23 and "2 independent sub-circuit(s)" in log and "rounds merged" in log
+    assert 18 <= ac2.pbs_rounds_per_cycle() <= 22 and "2 independent sub-circuit(s)" in log and "rounds merged" in log
     for wire in one.keys():
         assert np.array_equal(one[wire], dflt[wire]), wire
 
@@ -243,9 +244,10 @@ mult g7(t3, t3, W);
         assert got == want, (lazy, got)
         results[lazy] = (ac.pbs_rounds_per_cycle(), ac.pbs_per_cycle())
     # here level 1 also holds a product that must propagate (t3 feeds a product), so the level costs its 8 rounds either
-    # way and the carry-save sums add one reduction round: 21 against 20 - the saving shows where the products are alone
-    # (a carry propagation over 8 blocks is 4 rounds; round 2's Hillis-Steele form: 5, and 24 against 23 here):
-    assert results == {True: (21, results[True][1]), False: (20, results[False][1])}, results
+    # way and the carry-save sums add one reduction round: 20 against 19 - the saving shows where the products are alone
+    # (a carry propagation over 8 blocks is 4 rounds, round 2's Hillis-Steele form: 5; the square t3 * t3 needs one
+    # reduction round fewer than a general product; 24 against 23 before both):
+    assert results == {True: (20, results[True][1]), False: (19, results[False][1])}, results
     small, ws, _, _ = _circuit("input [15:0] A, B, C, D;\noutput [15:0] X;\nmult g0(A, B, t0);\nmult g1(C, D, t1);\nsub g2(t0, t1, X);\n",
                                is_arith=True, is_text=True)
     rounds = {}
@@ -373,6 +375,31 @@ def test_wide_integers_add_sub_mul(keys, width, kind):
     assert out["S"].value == (a + b) % M and out["D"].value == (a - b) % M
     assert out["P"].value == (a * b) % M and out["M"].value == (a * 1000003) % M
     assert all(v.kind == kind.upper() for v in out.values())
+
+
+@pytest.mark.parametrize("width,kind", [(8, "u8"), (16, "u16"), (32, "u32"), (64, "u64")])
+def test_squares_share_their_cross_products(keys, width, kind):
+    """mult(x, x): a_j a_k and a_k a_j are one look-up on 2 a_j a_k - the same value mod 2^bits as the general product
+    (gates.rs:331-385: `*` on FheUintN), about half the bootstraps, never more rounds.  Extreme operands included: all
+    blocks 3 makes every doubled cross product 18 (lo 2, hi 4)."""
+    client_key, server_key = keys
+    text = "input A, B;\noutput S, T, P;\nmult g0(A, A, S);\nmult g1(B, B, T);\n"
+    sq, ws, _, _ = _circuit(text + "add g2(S, T, P);\n", is_arith=True, is_text=True)
+    gen, wg, _, _ = _circuit("input A, B;\noutput S;\nmult g0(A, B, S);\n", is_arith=True, is_text=True)
+    mk = {8: PtxtType.U8, 16: PtxtType.U16, 32: PtxtType.U32, 64: PtxtType.U64}[width]
+    M = 1 << width
+    rng = np.random.default_rng(width + 1)
+    for a, b in ((M - 1, int.from_bytes(rng.bytes(width // 8), "little")), (int.from_bytes(rng.bytes(width // 8), "little"), 0x55 % M)):
+        ac = ArithCircuit(client_key, server_key, sq)
+        ac.set_lanes(1)
+        out = ac.decrypt_outputs(ac.evaluate_encrypted(ac.encrypt_inputs(ws, {"A": mk(a), "B": mk(b)}), 1, kind), True)
+        assert (out["S"].value, out["T"].value, out["P"].value) == (a * a % M, b * b % M, (a * a + b * b) % M)
+        pbs_sq, rounds_sq = ac.pbs_per_cycle(), ac.pbs_rounds_per_cycle()
+    ag = ArithCircuit(client_key, server_key, gen)
+    out = ag.decrypt_outputs(ag.evaluate_encrypted(ag.encrypt_inputs(wg, {"A": mk(a), "B": mk(a)}), 1, kind), True)
+    assert out["S"].value == a * a % M
+    print(f"{kind}: two squares + their sum {pbs_sq} bootstraps in {rounds_sq} rounds; one general product {ag.pbs_per_cycle()} in {ag.pbs_rounds_per_cycle()}")
+    assert pbs_sq < 2 * ag.pbs_per_cycle()
 
 
 @pytest.mark.parametrize("width,kind", [(32, "u32"), (64, "u64")])
