@@ -810,7 +810,7 @@ def _other_modes_set(device, set_name, tfhe_name):
     decl = {k: int(v.value) for k, v in ac.decrypt_outputs(outl, True).items()}
     res["arith_mode"] = {"workload": "chi_squared_arith.v, u32 (16 radix blocks per integer), " + tfhe_name, "wall_s": round(dtl, 4),
                          "bootstraps": ac.pbs_per_cycle(), "rounds_in_a_row": ac.pbs_rounds_per_cycle(),
-                         "evaluation": "two independent sub-circuits on two lanes (the default)", "decrypt_ok": decl == want}
+                         "evaluation": "the default: two independent sub-circuits as chains on one context, their look-up rounds merged into launches of at most one ciphertext per CU (rounds_in_a_row = launches)", "decrypt_ok": decl == want}
     # level by level, as the reference joins every level (circuit.rs:1321): identical ciphertexts, more rounds in a row
     ac.set_lanes(1)
     ac.evaluate_encrypted(enc, 3, "u32")
