@@ -8,9 +8,12 @@ BENCH="--steps 1 --warmup 1 --no-cpu-baseline --no-other-modes"
 SMALL="--steps 1 --warmup 0 --blocks 4 --no-cpu-baseline --no-other-modes"
 echo "== 1 kernel-trace stats, gates mode (bench.py $BENCH)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 bench.py $BENCH > $O/bench.log 2>&1 || { tail -5 $O/bench.log; exit 1; }
-echo "== 2 kernel-trace stats, LUT mode (1,024 three-input LUTs x 3; classical and multi-bit sets)"
+echo "== 2 kernel-trace stats, LUT mode (1,024 three-input LUTs x 3; classical and multi-bit sets; 2,048 two-input LUTs x 3 on the binary's set)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lut -o lut -- python3 tools/prof_luts.py 1024 3 > $O/lut.log 2>&1 || { tail -5 $O/lut.log; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lutmb -o lutmb -- python3 tools/prof_luts.py 1024 3 shortint_m2c2_multibit3 > $O/lutmb.log 2>&1 || { tail -5 $O/lutmb.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lutm1 -o lutm1 -- python3 tools/prof_luts.py 2048 3 shortint_m1c1 2 > $O/lutm1.log 2>&1 || { tail -5 $O/lutm1.log; exit 1; }
+echo "== 2b kernel-trace stats, arithmetic mode (chi-squared u32, default evaluation, classical set)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/chi -o chi -- python3 tools/prof_chi.py > $O/chi.log 2>&1 || { tail -5 $O/chi.log; exit 1; }
 echo "== 3 kernel-trace stats, WoP-PBS wide gates (256 six-input gates, two bits per block, x 3)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/wop -o wop -- python3 tools/wop_bench.py 256 6 2 > $O/wop.log 2>&1 || { tail -5 $O/wop.log; exit 1; }
 echo "== 4 matrix-core counters: k_ks_mfma (gates mode), k_ks64_mfma (LUT mode and the WoP packing keyswitch)"
@@ -24,6 +27,7 @@ SQ2="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_I
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc $SQ1 -d $O/sq1_lut -o a -- python3 tools/prof_luts.py 256 2 > $O/sq1_lut.log 2>&1 || tail -5 $O/sq1_lut.log
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc $SQ2 -d $O/sq2_lut -o b -- python3 tools/prof_luts.py 256 2 > $O/sq2_lut.log 2>&1 || tail -5 $O/sq2_lut.log
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc $SQ1 -d $O/sq1_lutmb -o a -- python3 tools/prof_luts.py 256 2 shortint_m2c2_multibit3 > $O/sq1_lutmb.log 2>&1 || tail -5 $O/sq1_lutmb.log
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc $SQ1 -d $O/sq1_lutm1 -o a -- python3 tools/prof_luts.py 512 2 shortint_m1c1 2 > $O/sq1_lutm1.log 2>&1 || tail -5 $O/sq1_lutm1.log
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv --pmc $SQ1 -d $O/sq1_gates -o a -- python3 bench.py $SMALL > $O/sq1_gates.log 2>&1 || tail -5 $O/sq1_gates.log
 echo "== 6 fabric traffic of the lockstep k_pbs launches at the bench's launch sizes"
 B="--steps 1 --warmup 0 --no-cpu-baseline --no-other-modes"
