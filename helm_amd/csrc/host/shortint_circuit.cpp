@@ -980,7 +980,8 @@ int64_t RadixEngine::scratch_rows(const std::vector<RadixOp> &ops) const
         // rounds (about 1.5 nb): 4 nb + 4 vectors of nb rows bound both
         if (op.kind == RadixOp::Mul || op.kind == RadixOp::MulScalar) rows += (int64_t)(4 * nb_ + 4) * nb_;
         if (op.kind == RadixOp::AddScalar || op.kind == RadixOp::SubScalar) rows += nb_;
-        if (op.a2 >= 0 || op.b2 >= 0) rows += 6 * nb_; // complemented terms and one reduction round of a carry-save sum
+        if (op.a2 >= 0 || op.b2 >= 0 || ((op.kind == RadixOp::Add || op.kind == RadixOp::Sub) && op.out2 >= 0))
+            rows += 6 * nb_; // complemented terms and one reduction round of a carry-save sum
         if (op.kind == RadixOp::Shl || op.kind == RadixOp::Shr) rows += 4 * nb_ + 8;
         if (op.kind == RadixOp::Div || op.kind == RadixOp::DivScalar) rows += 4 * 2 * nb_ + 5 * (nb_ + 1) + prop_rows(nb_ + 1);
     }
@@ -1023,7 +1024,7 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
                 }
                 break;
             case RadixOp::Add: case RadixOp::Sub: case RadixOp::AddScalar: case RadixOp::SubScalar: {
-                if (op.a2 >= 0 || op.b2 >= 0) break; // an operand in carry-save form: summed with the term reduction below
+                if (op.a2 >= 0 || op.b2 >= 0 || op.out2 >= 0) break; // carry-save operands or result: through the term reduction below
                 // a + b, or a + ~b + 1 with ~b digit = 3 - b_i (two's complement, mod 2^bits)
                 const bool sub = op.kind == RadixOp::Sub || op.kind == RadixOp::SubScalar;
                 const bool scalar = op.kind == RadixOp::AddScalar || op.kind == RadixOp::SubScalar;
@@ -1165,7 +1166,7 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
         std::vector<int32_t> li, lo;
         std::vector<int64_t> lc, ca;
         for (auto &op : ops) {
-            if (!((op.kind == RadixOp::Add || op.kind == RadixOp::Sub) && (op.a2 >= 0 || op.b2 >= 0))) continue;
+            if (!((op.kind == RadixOp::Add || op.kind == RadixOp::Sub) && (op.a2 >= 0 || op.b2 >= 0 || op.out2 >= 0))) continue;
             MulState ms;
             ms.out = op.out;
             ms.out2 = op.out2;
@@ -1556,7 +1557,9 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
                 // operands first: terms of carry-save wires
                 auto ia = op.a >= 0 ? aux.find(op.a) : aux.end(), ib = op.b >= 0 ? aux.find(op.b) : aux.end();
                 const bool from_cs = ia != aux.end() && block_shift(op);
-                const bool make = lazy_ok[op.out] && (op.kind == RadixOp::Mul || from_cs);
+                // products, block shifts of carry-save wires, and (round 3) sums / differences themselves: a chain of
+                // additions propagates carries once, at its end
+                const bool make = lazy_ok[op.out] && (op.kind == RadixOp::Mul || from_cs || op.kind == RadixOp::Add || op.kind == RadixOp::Sub);
                 if (make) {
                     const int base = aux_base + (int)aux_total;
                     aux_total += 2 * nb;
@@ -1576,14 +1579,15 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
                     op.out2 = x.b;
                 }
             }
-        // the propagated value of every carry-save wire, in the level of its first adding consumer (reached through
-        // block shifts if need be)
+        // the propagated value of every carry-save wire, in the level of the first consumer that propagates carries
+        // anyway (reached through block shifts and carry-save sums if need be)
         std::function<size_t(int)> first_adder = [&](int wire) -> size_t {
             size_t best = plan.size();
             for (auto &u : uses[wire]) {
                 const RadixOp &c = plan[u.level][u.index];
-                if (c.kind == RadixOp::Add || c.kind == RadixOp::Sub) best = std::min(best, u.level);
-                else if (c.out2 >= 0) // a block shift in carry-save form: its wire is the key of the entry holding these rows
+                if ((c.kind == RadixOp::Add || c.kind == RadixOp::Sub) && c.out2 < 0) best = std::min(best, u.level);
+                else if (c.out2 >= 0) // a block shift or a sum in carry-save form: the level where ITS terms are first added
+                                      // up and propagated (its wire is the key of the entry holding these rows)
                     for (auto &kv : aux)
                         if (kv.second.a == c.out) best = std::min(best, first_adder(kv.first));
             }
@@ -1674,7 +1678,7 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
                 const bool cs = op.a2 >= 0 || op.b2 >= 0;
                 switch (op.kind) {
                 case RadixOp::Mul: return 5 + (op.out2 >= 0 ? 0 : prop);
-                case RadixOp::Add: case RadixOp::Sub: return prop + (cs ? 1 : 0);
+                case RadixOp::Add: case RadixOp::Sub: return (op.out2 >= 0 ? 0 : prop) + (cs || op.out2 >= 0 ? 1 : 0);
                 case RadixOp::AddScalar: case RadixOp::SubScalar: return prop;
                 case RadixOp::MulScalar: return (op.scalar && !(op.scalar & (op.scalar - 1))) ? 1 : prop + 2;
                 case RadixOp::ShlScalar: case RadixOp::ShrScalar: return 1;

@@ -271,6 +271,57 @@ mult g7(t3, t3, W);
         assert np.array_equal(lanes[w], flat[w]), w
 
 
+def test_chains_of_additions_propagate_once(keys):
+    """Sums and differences whose consumers are all additions / subtractions stay in carry-save form too (two terms, no
+    propagation): a chain of additions propagates carries once, at its end.  Every wire of the returned map - the inner
+    sums too - holds the reference's value (src/gates.rs:331-385, 453-487), in fewer rounds in a row."""
+    client_key, server_key = keys
+    text = """input [15:0] A, B, C, D, E;
+output [15:0] S, T;
+mult g0(A, B, p0);
+mult g1(C, D, p1);
+add g2(p0, p1, s0);
+add g3(s0, E, s1);
+sub g4(s1, A, s2);
+add g5(s2, s0, S);
+add g6(A, B, q0);
+sub g7(q0, C, q1);
+add g8(q1, D, q2);
+add g9(q2, q2, T);
+"""
+    circuit, wire_set, _, _ = _circuit(text, is_arith=True, is_text=True)
+    a, b, c, d, e = 51234, 60567, 65535, 4321, 65000
+    m = 1 << 16
+    want = {"p0": a * b % m, "p1": c * d % m}
+    want["s0"] = (want["p0"] + want["p1"]) % m
+    want["s1"] = (want["s0"] + e) % m
+    want["s2"] = (want["s1"] - a) % m
+    want["S"] = (want["s2"] + want["s0"]) % m
+    want["q0"] = (a + b) % m
+    want["q1"] = (want["q0"] - c) % m
+    want["q2"] = (want["q1"] + d) % m
+    want["T"] = (2 * want["q2"]) % m
+    results, maps = {}, {}
+    for lazy in (True, False):
+        ac = ArithCircuit(client_key, server_key, circuit)
+        ac.set_lanes(1)
+        ac.set_lazy_carries(lazy)
+        enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U16(a), "B": PtxtType.U16(b), "C": PtxtType.U16(c), "D": PtxtType.U16(d),
+                                           "E": PtxtType.U16(e)})
+        out = ac.evaluate_encrypted(enc, 1, "u16")
+        got = {w: _decrypt_int(client_key, out[w]) for w in want}
+        assert got == want, (lazy, got, want)
+        results[lazy] = ac.pbs_rounds_per_cycle()
+    print("chained additions, rounds in a row:", results)
+    assert results[True] < results[False]
+    # the default evaluation (two chains, merged rounds): the same values
+    ac = ArithCircuit(client_key, server_key, circuit)
+    enc = ac.encrypt_inputs(wire_set, {"A": PtxtType.U16(a), "B": PtxtType.U16(b), "C": PtxtType.U16(c), "D": PtxtType.U16(d),
+                                       "E": PtxtType.U16(e)})
+    out = ac.evaluate_encrypted(enc, 1, "u16")
+    assert {w: _decrypt_int(client_key, out[w]) for w in want} == want
+
+
 def test_shifts_and_division_u8(keys):  # gates.rs:386-452, 488-700 (div, shl, shr and their plain forms)
     client_key, server_key = keys
     text = """input [7:0] A, B;
