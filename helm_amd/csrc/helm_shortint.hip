@@ -684,6 +684,9 @@ struct Pbs64sCfg {
 #define HELM_SI_PAIR_FLAG 0 // hand-over between the two waves of a SIMD through LDS flags instead of two workgroup barriers:
                             // measured 2.2 % SLOWER (profiles/r03/si_kernel_experiments.txt), kept as a switch
 #endif
+#ifndef HELM_SI_STATIC_P
+#define HELM_SI_STATIC_P 1 // k_pbs64s: one inlined body per polynomial as well (the wave's polynomial is a literal inside)
+#endif
 #ifndef HELM_SI_LAZY_INV
 #define HELM_SI_LAZY_INV 1 // the half inverse leaves its outputs uncentred: the last stage recentres anyway
 #endif
@@ -1270,21 +1273,30 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64s(const Pbs64Job *__rest
     if (p) __builtin_amdgcn_s_setprio(2);
 #endif
     // one specialisation per (field, transform half): both are uniform over the wave
+    // (the polynomial as a literal too where HELM_SI_STATIC_P: the bodies are inlined, so `c == p` in the products and the
+    // row offsets fold - 66 v_cndmask per wave-step gone from the classical kernel)
+#define HELM_SI_BODY(FN, FT, HH, FF, ...)                                                      \
+    do {                                                                                       \
+        if (HELM_SI_STATIC_P && p == 0) FN<C, FT, HH>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, 0, FF, lane, ##__VA_ARGS__); \
+        else if (HELM_SI_STATIC_P) FN<C, FT, HH>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, 1, FF, lane, ##__VA_ARGS__);      \
+        else FN<C, FT, HH>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, FF, lane, ##__VA_ARGS__);                            \
+    } while (0)
     if constexpr (MB) {
         if (f == 0) {
-            if (h == 0) pbs64s_mb_body<C, F0, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 0, lane, g, expo, psi_pow);
-            else pbs64s_mb_body<C, F0, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 0, lane, g, expo, psi_pow);
+            if (h == 0) HELM_SI_BODY(pbs64s_mb_body, F0, 0, 0, g, expo, psi_pow);
+            else HELM_SI_BODY(pbs64s_mb_body, F0, 1, 0, g, expo, psi_pow);
         } else {
-            if (h == 0) pbs64s_mb_body<C, F1, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 1, lane, g, expo, psi_pow + 2 * N);
-            else pbs64s_mb_body<C, F1, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 1, lane, g, expo, psi_pow + 2 * N);
+            if (h == 0) HELM_SI_BODY(pbs64s_mb_body, F1, 0, 1, g, expo, psi_pow + 2 * N);
+            else HELM_SI_BODY(pbs64s_mb_body, F1, 1, 1, g, expo, psi_pow + 2 * N);
         }
     } else if (f == 0) {
-        if (h == 0) pbs64s_body<C, F0, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 0, lane);
-        else pbs64s_body<C, F0, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 0, lane);
+        if (h == 0) HELM_SI_BODY(pbs64s_body, F0, 0, 0);
+        else HELM_SI_BODY(pbs64s_body, F0, 1, 0);
     } else {
-        if (h == 0) pbs64s_body<C, F1, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 1, lane);
-        else pbs64s_body<C, F1, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, 1, lane);
+        if (h == 0) HELM_SI_BODY(pbs64s_body, F1, 0, 1);
+        else HELM_SI_BODY(pbs64s_body, F1, 1, 1);
     }
+#undef HELM_SI_BODY
 
     uint64_t *ob = out + (size_t)job.out_row * ((size_t)K * N + 1);
     const uint64_t *acc_p = ACC + (size_t)p * N;
