@@ -684,6 +684,9 @@ struct Pbs64sCfg {
 #define HELM_SI_PAIR_FLAG 0 // hand-over between the two waves of a SIMD through LDS flags instead of two workgroup barriers:
                             // measured 2.2 % SLOWER (profiles/r03/si_kernel_experiments.txt), kept as a switch
 #endif
+#ifndef HELM_SI_MIX_HALVES
+#define HELM_SI_MIX_HALVES 1 // k_pbs64s: one wave of either transform half per SIMD (the halves' last stages differ in cost)
+#endif
 #ifndef HELM_SI_STATIC_P
 #define HELM_SI_STATIC_P 1 // k_pbs64s: one inlined body per polynomial as well (the wave's polynomial is a literal inside)
 #endif
@@ -1240,7 +1243,9 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64s(const Pbs64Job *__rest
     double *TW = reinterpret_cast<double *>(smem + C::TW_OFF);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p = w >> 2, f = (w >> 1) & 1, h = w & 1;
+    // the waves of polynomial 1 take the halves the other way round: each SIMD (wave index mod 4) then holds one wave of
+    // either half - the last inverse stage costs the h = 1 waves sixteen modular multiplications more than the h = 0 waves
+    const int p = w >> 2, f = (w >> 1) & 1, h = HELM_SI_MIX_HALVES ? ((w & 1) ^ p) : (w & 1);
     const Pbs64Job job = jobs[blockIdx.x];
     const uint64_t *lwe = small + (size_t)job.in_row * ((size_t)n + 1);
     for (int i = tid; i <= n; i += 64 * C::NW) MS[i] = (uint16_t)modswitch64(lwe[i], LOGN + 1);
