@@ -684,6 +684,10 @@ struct Pbs64sCfg {
 #define HELM_SI_PAIR_FLAG 0 // hand-over between the two waves of a SIMD through LDS flags instead of two workgroup barriers:
                             // measured 2.2 % SLOWER (profiles/r03/si_kernel_experiments.txt), kept as a switch
 #endif
+#ifndef HELM_SI_PRIO_SKEW
+#define HELM_SI_PRIO_SKEW 0 // k_pbs64s: the waves of polynomial 0 (the older wave of each SIMD pair) enter the transforms one
+                            // priority level below their partners
+#endif
 #ifndef HELM_SI_MIX_HALVES
 #define HELM_SI_MIX_HALVES 1 // k_pbs64s: one wave of either transform half per SIMD (the halves' last stages differ in cost)
 #endif
@@ -707,7 +711,7 @@ struct Pbs64sCfg {
     static constexpr size_t BYTES = FLAG_OFF + sizeof(uint32_t) * 2 * NW;
 };
 
-template <typename C, typename F, int h>
+template <typename C, typename F, int h, int P = -1>
 __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *__restrict__ bsk, int n, int logB,
                                             double p0inv_mod_p1, double w1, double w1o, int p, int f, int lane)
 {
@@ -715,6 +719,8 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
     using G = typename C::G;
     using GS = typename C::GS;
     constexpr int N = G::N, E = G::E, EH = GS::E, Q = E / 4, HC = EH / 2;
+    // entry priority of the transforms (stepped down block by block inside them)
+    constexpr int PH = !C::PRIO ? 0 : (HELM_SI_PRIO_SKEW && P == 0) ? 2 : 3;
     double *X = reinterpret_cast<double *>(smem + C::X_OFF);
     uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
     using dig_t = typename C::dig_t;
@@ -805,7 +811,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
 #pragma unroll
                 for (int u = 0; u < HC; u++) kw[0][u] = key(0 * L + lev, u);
             }
-            if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
+            if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(PH);
             double x[1][EH];
             {
                 const dig_t *dg = dig_p + lev * N + lane;
@@ -823,9 +829,9 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
                 for (int u = 0; u < HC; u++) kw[1][u] = key(1 * L + lev, u);
             };
 #if HELM_SI_KW1_EARLY
-            half_forward<F, LOGN - 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane, fetch_kw1);
+            half_forward<F, LOGN - 1, decltype(twf), PH>(x, xb, twf, lane, fetch_kw1);
 #else
-            half_forward<F, LOGN - 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
+            half_forward<F, LOGN - 1, decltype(twf), PH>(x, xb, twf, lane);
 #endif
             if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
             if (lev == 0) {
@@ -868,8 +874,8 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         lds_flag_set(flag_mine + C::NW, seq);
         STAMP(4) // flag 1, sum
         auto partner_has_read = [&]() { lds_flag_wait(flag_partner + C::NW, seq); };
-        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
-        half_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane, partner_has_read);
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(PH);
+        half_inverse<F, LOGN - 1, decltype(twi), PH, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane, partner_has_read);
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
 #else
         lds_block_sync();
@@ -878,8 +884,8 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         lds_block_sync(); // hand-over read: scratch free again
         STAMP(4) // barrier 2, sum, barrier 3
         // ---- (3) half inverse, meet the other half, last stage -------------------------------
-        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
-        half_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane); // a_h[e * 64 + lane], centred
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(PH);
+        half_inverse<F, LOGN - 1, decltype(twi), PH, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane); // a_h[e * 64 + lane], centred
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
 #endif
         STAMP(5) // half inverse
@@ -952,7 +958,7 @@ __host__ __device__ constexpr int bitrev_c(int v, int bits)
 // point of spectrum position j (probed once per context through the key-conversion kernel) and psi_pow the 2N
 // powers of psi.  Same wave roles, transforms, hand-over and CRT as pbs64s_body; n/g steps instead of n, the
 // accumulator is replaced instead of added to.
-template <typename C, typename F, int h>
+template <typename C, typename F, int h, int P = -1>
 __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double *__restrict__ bsk, int n, int logB,
                                                double p0inv_mod_p1, double w1, double w1o, int p, int f, int lane, int g,
                                                const uint16_t *__restrict__ expo, const double *__restrict__ psi_pow)
@@ -960,6 +966,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
     constexpr int LOGN = C::LOGN, K1 = C::K1;
     using G = typename C::G;
     using GS = typename C::GS;
+    constexpr int PH = !C::PRIO ? 0 : (HELM_SI_PRIO_SKEW && P == 0) ? 2 : 3;
     constexpr int N = G::N, E = G::E, EH = GS::E, Q = E / 4, HC = EH / 2;
     double *X = reinterpret_cast<double *>(smem + C::X_OFF);
     uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
@@ -1013,7 +1020,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
         }
         lds_block_sync(); // digits published
         // ---- (2) stage 1 of the full transform, half transform ----------------------------------
-        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(PH);
         double x[1][EH];
         {
             const dig_t *dg = dig_p + lane;
@@ -1023,7 +1030,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
                 x[0][e] = h ? U - V : U + V;
             }
         }
-        half_forward<F, LOGN - 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
+        half_forward<F, LOGN - 1, decltype(twf), PH>(x, xb, twf, lane);
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
 #if HELM_SI_MB_NESTED
         // ---- the group's key in the transform domain, G[c] = sum_S M(e_S) .* K_S[p][c], in NESTED form, and the products
@@ -1169,8 +1176,8 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
         for (int e = 0; e < EH; e++) mine[e] = reduce<F>(mine[e] + x_poly[e * 64 + lane]); // <= 11.4 p before
         lds_block_sync(); // hand-over read: scratch free again
         // ---- (3) half inverse, meet the other half, last stage -----------------------------------
-        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(3);
-        half_inverse<F, LOGN - 1, decltype(twi), C::PRIO ? 3 : 0, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane);
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(PH);
+        half_inverse<F, LOGN - 1, decltype(twi), PH, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane);
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int e = 0; e < EH; e++) xb[e * 64 + lane] = mine[e];
@@ -1282,8 +1289,8 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64s(const Pbs64Job *__rest
     // row offsets fold - 66 v_cndmask per wave-step gone from the classical kernel)
 #define HELM_SI_BODY(FN, FT, HH, FF, ...)                                                      \
     do {                                                                                       \
-        if (HELM_SI_STATIC_P && p == 0) FN<C, FT, HH>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, 0, FF, lane, ##__VA_ARGS__); \
-        else if (HELM_SI_STATIC_P) FN<C, FT, HH>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, 1, FF, lane, ##__VA_ARGS__);      \
+        if (HELM_SI_STATIC_P && p == 0) FN<C, FT, HH, 0>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, 0, FF, lane, ##__VA_ARGS__); \
+        else if (HELM_SI_STATIC_P) FN<C, FT, HH, 1>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, 1, FF, lane, ##__VA_ARGS__);      \
         else FN<C, FT, HH>(smem, bsk, n, logB, p0inv_mod_p1, w1, w1o, p, FF, lane, ##__VA_ARGS__);                            \
     } while (0)
     if constexpr (MB) {
