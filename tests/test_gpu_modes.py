@@ -322,6 +322,43 @@ add g9(q2, q2, T);
     assert {w: _decrypt_int(client_key, out[w]) for w in want} == want
 
 
+def test_many_independent_sub_circuits_merge_their_rounds(keys):
+    """Six sub-circuits that share no wire (a product, a square behind a sum, a difference, a shift by a plaintext, a shift
+    by a ciphertext, a division) run as chains whose look-up rounds are merged: the same ciphertext on every wire as level by
+    level, in fewer launches than the level-by-level rounds."""
+    client_key, server_key = keys
+    text = """input [15:0] A, B, C, D, E, F, G, H, I, J, K;
+output [15:0] X, Y, Z, W, V, U;
+mult g0(A, B, X);
+add g1(C, D, t0);
+mult g2(t0, t0, Y);
+sub g3(E, F, Z);
+shl g4(G, 5, W);
+shr g5(H, I, V);
+div g6(J, K, U);
+"""
+    circuit, wire_set, _, _ = _circuit(text, is_arith=True, is_text=True)
+    vals = dict(A=40000, B=51111, C=65535, D=12345, E=7, F=65000, G=0xBEEF, H=0xF00D, I=9, J=54321, K=123)
+    m = 1 << 16
+    want = {"X": vals["A"] * vals["B"] % m, "t0": (vals["C"] + vals["D"]) % m, "Z": (vals["E"] - vals["F"]) % m,
+            "W": (vals["G"] << 5) % m, "V": vals["H"] >> 9, "U": vals["J"] // vals["K"]}
+    want["Y"] = want["t0"] ** 2 % m
+    enc_in = {k: PtxtType.U16(v) for k, v in vals.items()}
+    ac = ArithCircuit(client_key, server_key, circuit)
+    enc = ac.encrypt_inputs(wire_set, enc_in)
+    merged = ac.evaluate_encrypted(enc, 1, "u16")
+    log, launches = ac.log(), ac.pbs_rounds_per_cycle()
+    assert "6 independent sub-circuit(s)" in log and "rounds merged" in log, log
+    assert {w: _decrypt_int(client_key, merged[w]) for w in want} == want
+    ac.set_lanes(1)
+    flat = ac.evaluate_encrypted(enc, 2, "u16")
+    assert {w: _decrypt_int(client_key, flat[w]) for w in want} == want
+    for w in want:  # batching and launch boundaries do not change a single bit
+        assert np.array_equal(merged[w], flat[w]), w
+    print(f"six sub-circuits: {launches} merged launches, {ac.pbs_rounds_per_cycle()} rounds level by level")
+    assert launches <= ac.pbs_rounds_per_cycle()
+
+
 def test_shifts_and_division_u8(keys):  # gates.rs:386-452, 488-700 (div, shl, shr and their plain forms)
     client_key, server_key = keys
     text = """input [7:0] A, B;
