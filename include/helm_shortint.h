@@ -23,8 +23,9 @@
  * and helm_si_eval_lut_level() is gates::lut() for a whole netlist level.
  *
  * Conventions as in helm_hip.h: 0 / negative helm_status, helm_hip_last_error(),
- * caller owns host buffers, one context per device + host thread, stream-asynchronous
- * with helm_si_sync(), no CPU fallback.
+ * caller owns host buffers, one context per device + host thread (several threads may share a
+ * context if they serialise their calls - the host library's round merger does, under one lock),
+ * stream-asynchronous with helm_si_sync(), no CPU fallback.
  *
  * Layouts (all words uint64_t, arithmetic mod 2^64)
  *   big LWE / wire row   k*N mask words + body
