@@ -684,6 +684,9 @@ struct Pbs64sCfg {
 #define HELM_SI_PAIR_FLAG 0 // hand-over between the two waves of a SIMD through LDS flags instead of two workgroup barriers:
                             // measured 2.2 % SLOWER (profiles/r03/si_kernel_experiments.txt), kept as a switch
 #endif
+#ifndef HELM_SI_PAIR_LIFT
+#define HELM_SI_PAIR_LIFT 1 // k_pbs64s: a wave lifts both outputs j and j + N/2 of a quarter of the slots (lift_pairs)
+#endif
 #ifndef HELM_SI_PRIO_SKEW
 #define HELM_SI_PRIO_SKEW 0 // k_pbs64s: the waves of polynomial 0 (the older wave of each SIMD pair) enter the transforms one
                             // priority level below their partners
@@ -710,6 +713,39 @@ struct Pbs64sCfg {
     static constexpr size_t FLAG_OFF = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16; // u32 [2][NW]
     static constexpr size_t BYTES = FLAG_OFF + sizeof(uint32_t) * 2 * NW;
 };
+
+// The last inverse stage and the CRT of k_pbs64s, lifted in PAIRS (HELM_SI_PAIR_LIFT): wave (f, h) owns slots
+// [(2 f + h) E/4, + E/4) of BOTH halves of its polynomial - from its own value of the slot and the three others' (other
+// half, other field, other field's other half) it computes the last stage of both outputs j and j + N/2 in both fields and
+// lifts both.  Against "every wave lifts the slots of its own half": 12 LDS reads per wave instead of 24 (and 12 values
+// published instead of 16) in the phase that is bound by the LDS pipe, and the sixteen modular multiplications of the
+// (a1 - a0) psi^(N/2) outputs spread evenly over the waves instead of sitting on the h = 1 ones.  Same values.
+template <typename C, typename F, int h, bool ADD>
+__device__ __forceinline__ void lift_pairs(const double (&mine)[C::GS::E], const double *x_half, const double *x_field,
+                                           const double *x_fh, uint64_t *acc_p, int f, double w1, double w1o,
+                                           double p0inv_mod_p1, int lane)
+{
+    using FO = std::conditional_t<std::is_same<F, F0>::value, F1, F0>;
+    constexpr int EH = C::GS::E, QS = EH / 4, N = C::G::N;
+    const int s0 = (f * 2 + h) * QS;
+#pragma unroll
+    for (int e = 0; e < QS; e++) {
+        const int s = s0 + e;
+        const double a = mine[s], o = x_half[s * 64 + lane], a2 = x_field[s * 64 + lane], o2 = x_fh[s * 64 + lane];
+        const double e0 = h ? o : a, e1 = h ? a : o, g0 = h ? o2 : a2, g1 = h ? a2 : o2; // halves 0 and 1, own / other field
+        // y[j] = a0 + a1 ; y[j + N/2] = (a1 - a0) * psi^(N/2)
+        const double own[2] = {reduce<F>(e0 + e1), reduce<F>(mulmod<F>(e1 - e0, w1))};
+        const double oth[2] = {reduce<FO>(g0 + g1), reduce<FO>(mulmod<FO>(g1 - g0, w1o))};
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const double r0 = f == 0 ? own[u] : oth[u], r1 = f == 0 ? oth[u] : own[u];
+            const double t = mulmod<F1>(r1 - r0, p0inv_mod_p1);
+            const uint64_t xv = (uint64_t)to_int64(r0) + F0::P_U64 * (uint64_t)to_int64(t);
+            uint64_t *dst = acc_p + u * (N / 2) + s * 64 + lane;
+            *dst = ADD ? *dst + xv : xv;
+        }
+    }
+}
 
 template <typename C, typename F, int h, int P = -1>
 __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *__restrict__ bsk, int n, int logB,
@@ -890,9 +926,14 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
 #endif
         STAMP(5) // half inverse
 #pragma unroll
-        for (int e = 0; e < EH; e++) xb[e * 64 + lane] = mine[e];
+        for (int e = 0; e < EH; e++)
+            if (!(HELM_SI_PAIR_LIFT && HELM_SI_FUSED_XCHG) || e / (EH / 4) != f * 2 + h) xb[e * 64 + lane] = mine[e]; // own slots stay
         lds_block_sync();
-#if HELM_SI_FUSED_XCHG
+#if HELM_SI_FUSED_XCHG && HELM_SI_PAIR_LIFT
+        lift_pairs<C, F, h, true>(mine, x_half, x_field, X + (size_t)wave_of(p, 1 - f, 1 - h) * GS::XPAD, acc_p, f, w1, w1o,
+                                  p0inv_mod_p1, lane);
+        lds_block_sync(); // accumulator complete, scratch free again
+#elif HELM_SI_FUSED_XCHG
         // ---- (3b, 4) one exchange: every wave publishes its half inverse; the wave that lifts a slot computes the
         //      last inverse stage of that slot in BOTH fields (its own from registers + the other half, the other
         //      field's from the two waves that hold it) and the CRT.  Same values as the two-exchange form.
@@ -1180,9 +1221,14 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
         half_inverse<F, LOGN - 1, decltype(twi), PH, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane);
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-        for (int e = 0; e < EH; e++) xb[e * 64 + lane] = mine[e];
+        for (int e = 0; e < EH; e++)
+            if (!(HELM_SI_PAIR_LIFT && HELM_SI_FUSED_XCHG) || e / (EH / 4) != f * 2 + h) xb[e * 64 + lane] = mine[e]; // own slots stay
         lds_block_sync();
 #if HELM_SI_FUSED_XCHG
+#if HELM_SI_PAIR_LIFT
+        lift_pairs<C, F, h, false>(mine, x_half, x_field, X + (size_t)wave_of(p, 1 - f, 1 - h) * GS::XPAD, acc_p, f, w1, w1o,
+                                   p0inv_mod_p1, lane);
+#else
         // ---- (3b, 4) one exchange: every wave publishes its half inverse; the wave that lifts a slot computes the
         //      last inverse stage of that slot in BOTH fields (its own from registers + the other half, the other
         //      field's from the two waves that hold it) and the CRT.  Same values as the two-exchange form.
@@ -1203,6 +1249,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
                 acc_p[h * (N / 2) + s * 64 + lane] = xv;
             }
         }
+#endif
         lds_block_sync(); // accumulator complete, scratch free again
 #else
 #pragma unroll
