@@ -684,6 +684,13 @@ struct Pbs64sCfg {
 #define HELM_SI_PAIR_FLAG 0 // hand-over between the two waves of a SIMD through LDS flags instead of two workgroup barriers:
                             // measured 2.2 % SLOWER (profiles/r03/si_kernel_experiments.txt), kept as a switch
 #endif
+#ifndef HELM_SI_STAGE1_SRC
+#define HELM_SI_STAGE1_SRC 1 // k_pbs64s, one level: stage 1 of the full transform done by the wave that makes the digits
+#endif
+#ifndef HELM_SI_STAGE1_SRC_MB
+#define HELM_SI_STAGE1_SRC_MB 0 // the same in the multi-bit body: measured -0.3 % (its digit phase has no rotated reads to hide
+                                // the extra LDS writes behind): off
+#endif
 #ifndef HELM_SI_PAIR_LIFT
 #define HELM_SI_PAIR_LIFT 1 // k_pbs64s: a wave lifts both outputs j and j + N/2 of a quarter of the slots (lift_pairs)
 #endif
@@ -757,6 +764,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
     constexpr int N = G::N, E = G::E, EH = GS::E, Q = E / 4, HC = EH / 2;
     // entry priority of the transforms (stepped down block by block inside them)
     constexpr int PH = !C::PRIO ? 0 : (HELM_SI_PRIO_SKEW && P == 0) ? 2 : 3;
+    constexpr bool SRC1 = HELM_SI_STAGE1_SRC && L == 1; // stage 1 where the digits are made
     double *X = reinterpret_cast<double *>(smem + C::X_OFF);
     uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
     using dig_t = typename C::dig_t;
@@ -807,6 +815,33 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         auto key = [&](int col_lev, int u) { return (bp_i + (size_t)col_lev * 4 * part)[u * 64]; };
 #endif
         // ---- (1) digits of this wave's quarter of polynomial p -------------------------------
+        if constexpr (SRC1) {
+            // L = 1: the quarter is Q/2 PAIRS (j, j + N/2); stage 1 of the full transform is done here, once per pair
+            // and field (U + V psi^(N/2) for half 0, U - V psi^(N/2) for half 1), and the four results go straight
+            // into the transform scratches of the four waves that transform them - no digit buffer, no conversions and
+            // no stage-1 product on the consumers' side (they used to compute all sixteen, each half redundantly)
+            using FO = std::conditional_t<std::is_same<F, F0>::value, F1, F0>;
+            double *x_f0 = X + (size_t)wave_of(p, f, 0) * GS::XPAD + lane, *x_f1 = X + (size_t)wave_of(p, f, 1) * GS::XPAD + lane;
+            double *x_o0 = X + (size_t)wave_of(p, 1 - f, 0) * GS::XPAD + lane, *x_o1 = X + (size_t)wave_of(p, 1 - f, 1) * GS::XPAD + lane;
+            auto digit = [&](int j) {
+                const int src = (j - a) & (2 * N - 1);
+                uint64_t v = acc_p[src & (N - 1)];
+                if (src >= N) v = 0ull - v;
+                v -= acc_p[j];
+                const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
+                return (double)((int)st - (int)(((st + half_m1) >> logB) << logB));
+            };
+#pragma unroll
+            for (int u = 0; u < Q / 2; u++) {
+                const int e = quarter * (Q / 2) + u;
+                const double U = digit(G::jA(lane, e)), D1 = digit(G::jA(lane, e + EH));
+                const double Vf = mulmod<F>(D1, w1), Vo = mulmod<FO>(D1, w1o);
+                x_f0[e * 64] = U + Vf;
+                x_f1[e * 64] = U - Vf;
+                x_o0[e * 64] = U + Vo;
+                x_o1[e * 64] = U - Vo;
+            }
+        } else
 #pragma unroll
         for (int u = 0; u < Q; u++) {
             const int j = G::jA(lane, quarter * Q + u);
@@ -849,7 +884,10 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
             }
             if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(PH);
             double x[1][EH];
-            {
+            if constexpr (SRC1) {
+#pragma unroll
+                for (int e = 0; e < EH; e++) x[0][e] = xb[e * 64 + lane];
+            } else {
                 const dig_t *dg = dig_p + lev * N + lane;
 #pragma unroll
                 for (int e = 0; e < EH; e++) {
@@ -1020,7 +1058,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
     const double *x_half = X + (size_t)wave_of(p, f, 1 - h) * GS::XPAD;
     const double *x_field = X + (size_t)wave_of(p, 1 - f, h) * GS::XPAD;
     uint64_t *acc_p = ACC + (size_t)p * N;
-    dig_t *dig_p = DIG + (size_t)p * N;
+    [[maybe_unused]] dig_t *dig_p = DIG + (size_t)p * N;
     const double *twt = reinterpret_cast<const double *>(smem + C::TW_OFF);
     const double *tw_own = twt + (size_t)(f * 2 + h) * C::TW_PART, *tw_oth = twt + (size_t)(f * 2 + (1 - h)) * C::TW_PART;
     TwHybrid<LOGN - 1, false> twf{tw_own, tw_own + C::TW_IDX + lane};
@@ -1052,6 +1090,34 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
 #pragma unroll
         for (int q = 0; q < 3; q++) bq[q] = psi_pow[(c_lane * am[q]) & (2 * N - 1)];
         // ---- (1) digits of this wave's quarter of polynomial p ----------------------------------
+#if HELM_SI_STAGE1_SRC_MB
+        { // pairs (j, j + N/2), stage 1 in both fields, results into the consumers' scratches (see pbs64s_body)
+            using FO = std::conditional_t<std::is_same<F, F0>::value, F1, F0>;
+            double *x_f0 = X + (size_t)wave_of(p, f, 0) * GS::XPAD + lane, *x_f1 = X + (size_t)wave_of(p, f, 1) * GS::XPAD + lane;
+            double *x_o0 = X + (size_t)wave_of(p, 1 - f, 0) * GS::XPAD + lane, *x_o1 = X + (size_t)wave_of(p, 1 - f, 1) * GS::XPAD + lane;
+            auto digit = [&](int j) {
+                const uint64_t v = acc_p[j];
+                const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
+                return (double)((int)st - (int)(((st + half_m1) >> logB) << logB));
+            };
+#pragma unroll
+            for (int u = 0; u < Q / 2; u++) {
+                const int e = quarter * (Q / 2) + u;
+                const double U = digit(G::jA(lane, e)), D1 = digit(G::jA(lane, e + EH));
+                const double Vf = mulmod<F>(D1, w1), Vo = mulmod<FO>(D1, w1o);
+                x_f0[e * 64] = U + Vf;
+                x_f1[e * 64] = U - Vf;
+                x_o0[e * 64] = U + Vo;
+                x_o1[e * 64] = U - Vo;
+            }
+        }
+        lds_block_sync(); // stage-1 outputs published
+        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(PH);
+        double x[1][EH];
+#pragma unroll
+        for (int e = 0; e < EH; e++) x[0][e] = xb[e * 64 + lane];
+#else
+        // ---- (1) digits of this wave's quarter of polynomial p ----------------------------------
 #pragma unroll
         for (int u = 0; u < Q; u++) {
             const int j = G::jA(lane, quarter * Q + u);
@@ -1071,6 +1137,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
                 x[0][e] = h ? U - V : U + V;
             }
         }
+#endif
         half_forward<F, LOGN - 1, decltype(twf), PH>(x, xb, twf, lane);
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
 #if HELM_SI_MB_NESTED
