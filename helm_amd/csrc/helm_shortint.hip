@@ -687,6 +687,9 @@ struct Pbs64sCfg {
 #ifndef HELM_SI_STAGE1_SRC
 #define HELM_SI_STAGE1_SRC 1 // k_pbs64s, one level: stage 1 of the full transform done by the wave that makes the digits
 #endif
+#ifndef HELM_SI_TWC_REGS
+#define HELM_SI_TWC_REGS 1 // classical k_pbs64s, one level: the lane's block-C twiddles of both half transforms in registers
+#endif
 #ifndef HELM_SI_STAGE1_SRC_MB
 #define HELM_SI_STAGE1_SRC_MB 0 // the same in the multi-bit body: measured -0.3 % (its digit phase has no rotated reads to hide
                                 // the extra LDS writes behind): off
@@ -779,8 +782,18 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
     dig_t *dig_p = DIG + (size_t)p * L * N; // [level][N]
     const double *twt = reinterpret_cast<const double *>(smem + C::TW_OFF);
     const double *tw_own = twt + (size_t)(f * 2 + h) * C::TW_PART, *tw_oth = twt + (size_t)(f * 2 + (1 - h)) * C::TW_PART;
-    TwHybrid<LOGN - 1, false> twf{tw_own, tw_own + C::TW_IDX + lane};
-    TwHybrid<LOGN - 1, true> twi{tw_oth, tw_oth + C::TW_IDX + (63 - lane)};
+    // block-C twiddles of both transforms in registers where the kernel has them to spare (one level, classical: 176 + 60)
+    constexpr bool TWC_REGS = HELM_SI_TWC_REGS && L == 1;
+    std::conditional_t<TWC_REGS, TwHybridC<LOGN - 1, false>, TwHybrid<LOGN - 1, false>> twf;
+    std::conditional_t<TWC_REGS, TwHybridC<LOGN - 1, true>, TwHybrid<LOGN - 1, true>> twi;
+    twf.t = tw_own, twi.t = tw_oth;
+    if constexpr (TWC_REGS) {
+        twf.load(tw_own + C::TW_IDX + lane);
+        twi.load(tw_oth + C::TW_IDX + (63 - lane));
+    } else {
+        twf.base = tw_own + C::TW_IDX + lane;
+        twi.base = tw_oth + C::TW_IDX + (63 - lane);
+    }
     const int quarter = f * 2 + h; // which E/4 slots of the polynomial this wave decomposes
 #if HELM_SI_PAIR_FLAG
     uint32_t *flags = reinterpret_cast<uint32_t *>(smem + C::FLAG_OFF); // zeroed by the kernel before the first barrier

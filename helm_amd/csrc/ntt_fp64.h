@@ -325,6 +325,26 @@ struct TwHybrid {
     }
 };
 
+// TwHybrid with the block-C twiddles of the lane held in registers (they do not change from step to step): TWC fewer LDS
+// reads per transform, for kernels that have the registers.
+template <int LOGN, bool MIRROR_>
+struct TwHybridC {
+    static constexpr bool MIRROR = MIRROR_;
+    using G = Geo<LOGN>;
+    const double *t; // LDS index table, entries [0, N >> BC)
+    double c[G::TWC];
+    __device__ __forceinline__ void load(const double *base) // base as TwHybrid's
+    {
+#pragma unroll
+        for (int r = 0; r < G::TWC; r++) c[r] = base[r * 64];
+    }
+    __device__ __forceinline__ double get(int sb, int hi, int cnt, int idx, int) const
+    {
+        if (sb < G::BC) return c[tw_fwd_slot<LOGN>(sb, MIRROR ? cnt - 1 - hi : hi) - G::TWA - G::TWB];
+        return t[MIRROR ? 3 * (G::N >> (sb + 1)) - 1 - idx : idx];
+    }
+};
+
 // Enumerate (in consumption order) the table indices of a block's twiddles.
 template <int LOGN, int SHIFT, int SB_FIRST, int SB_LAST, int SLOT0, int NT>
 __device__ __forceinline__ void tw_fill_block(TwReg<NT> &r, const double *__restrict__ table, int jbase)
