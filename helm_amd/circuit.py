@@ -198,7 +198,9 @@ class _SiCircuit(EvalCircuit):
 
     def __init__(self, client_key, server_key, circuit):
         h = H.vp()
-        H.check(H.host.helm_host_si_circuit_new(self.MODE, client_key._h, server_key._h, circuit._h, C.byref(h)))
+        # client_key None: evaluation only (the caller encrypts / decrypts and moves rows through SiEncWireMap)
+        H.check(H.host.helm_host_si_circuit_new(self.MODE, client_key._h if client_key is not None else None, server_key._h,
+                                               circuit._h, C.byref(h)))
         self._h = h
         self._ck, self._sk, self.circuit = client_key, server_key, circuit  # keep alive
 

@@ -245,7 +245,7 @@ int helm_host_gate_circuit_new(helm_client_key *client_key, helm_hip_ctx *server
                                helm_gate_circuit **out)
 {
     return guard([&] {
-        if (!client_key || !server_key || !circuit) throw Panic("null argument");
+        if (!server_key || !circuit) throw Panic("null argument"); // client_key = NULL: evaluation only (see helm_host.h)
         *out = new helm_gate_circuit{std::make_unique<GateCircuit>(client_key, server_key, circuit->c)};
     });
 }
@@ -304,7 +304,9 @@ int helm_host_si_circuit_new(int mode, helm_si_client_key *client_key, helm_si_c
                              const helm_circuit *circuit, helm_si_circuit **out)
 {
     return guard([&] {
-        if (!client_key || !server_key || !circuit) throw Panic("null argument");
+        // client_key = NULL: an evaluation-only circuit - the caller encrypts and decrypts with its own keys (tfhe's, in the
+        // Rust shim) and moves ciphertext words through helm_host_si_enc_map_insert / _get
+        if (!server_key || !circuit) throw Panic("null argument");
         auto *c = new helm_si_circuit();
         try {
             if (mode == 0) c->lut = std::make_unique<LutCircuit>(client_key, server_key, circuit->c);

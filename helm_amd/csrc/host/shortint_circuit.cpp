@@ -194,7 +194,7 @@ std::unique_ptr<SiEncWireMap> LutCircuit::encrypt_inputs(const std::set<std::str
     if (!idx.empty()) {
         const size_t row = (size_t)P_.k * P_.N + 1;
         std::vector<uint64_t> cts(idx.size() * row);
-        if (helm_si_client_encrypt(client_key_, vals.data(), (int64_t)vals.size(), cts.data())) throw Panic("encrypt failed");
+        if (helm_si_client_encrypt(client_key_, vals.data(), (int64_t)vals.size(), cts.data())) throw Panic(client_key_ ? "encrypt failed" : "evaluation-only circuit (no client key): encrypt with the caller's keys and insert the ciphertext words");
         si_ok(helm_si_wires_upload(server_key_, m->table(), idx.data(), cts.data(), (int64_t)idx.size()), "wires_upload");
     }
     return m;
@@ -372,7 +372,7 @@ std::map<std::string, PtxtType> LutCircuit::decrypt_outputs(const SiEncWireMap &
     for (auto &w : circuit_.output_wires()) {
         auto ct = enc_wire_map.get(w);
         uint64_t v = 0;
-        if (helm_si_client_decrypt(client_key_, ct.data(), 1, &v)) throw Panic("decrypt failed");
+        if (helm_si_client_decrypt(client_key_, ct.data(), 1, &v)) throw Panic(client_key_ ? "decrypt failed" : "evaluation-only circuit (no client key): read the ciphertext words and decrypt with the caller's keys");
         PtxtType p;
         p.kind = PtxtType::U64;
         p.value = v % (uint64_t)P_.message_modulus; // ClientKey::decrypt: the message part
@@ -1361,7 +1361,7 @@ void ArithCircuit::encrypt_value(SiEncWireMap &m, const std::string &wire, unsig
     std::vector<uint64_t> digits((size_t)nb);
     for (int i = 0; i < nb; i++) digits[(size_t)i] = (uint64_t)((value >> (2 * i)) & 3);
     std::vector<uint64_t> cts((size_t)nb * ((size_t)P_.k * P_.N + 1));
-    if (helm_si_client_encrypt(client_key_, digits.data(), nb, cts.data())) throw Panic("encrypt failed");
+    if (helm_si_client_encrypt(client_key_, digits.data(), nb, cts.data())) throw Panic(client_key_ ? "encrypt failed" : "evaluation-only circuit (no client key): encrypt with the caller's keys and insert the ciphertext words");
     m.insert(wire, cts.data());
 }
 
@@ -1778,7 +1778,7 @@ std::map<std::string, PtxtType> ArithCircuit::decrypt_outputs(const SiEncWireMap
     for (auto &w : circuit_.output_wires()) {
         auto ct = enc_wire_map.get(w);
         std::vector<uint64_t> vals((size_t)nb);
-        if (helm_si_client_decrypt(client_key_, ct.data(), nb, vals.data())) throw Panic("decrypt failed");
+        if (helm_si_client_decrypt(client_key_, ct.data(), nb, vals.data())) throw Panic(client_key_ ? "decrypt failed" : "evaluation-only circuit (no client key): read the ciphertext words and decrypt with the caller's keys");
         unsigned __int128 v = 0;
         for (int i = nb - 1; i >= 0; i--) v = (v << 2) + vals[(size_t)i]; // carries included, wrapping
         if (bits < 128) v &= (((unsigned __int128)1 << bits) - 1);

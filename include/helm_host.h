@@ -110,6 +110,11 @@ int64_t helm_host_gate_circuit_memo_hits(const helm_gate_circuit *gc);
  * 1 = arithmetic.  Encrypted maps hold `blocks` big-LWE rows per wire (1 for LUT mode). */
 typedef struct helm_si_circuit helm_si_circuit;
 typedef struct helm_si_enc_map helm_si_enc_map;
+/* client_key may be NULL: an evaluation-only circuit for hosts that encrypt and decrypt with their own keys (tfhe's, in
+ * the Rust shim) - inputs go in through helm_host_si_enc_map_new / _insert, results come out through _get, and
+ * evaluate_encrypted brings everything this library adds to a whole circuit (merged rounds of independent
+ * sub-circuits, carry-save products and sums: DESIGN.md section 5) that the level-wise helm_host_radix_level cannot.
+ * encrypt_inputs / decrypt_outputs then fail with a message. */
 int helm_host_si_circuit_new(int mode, helm_si_client_key *client_key, helm_si_ctx *server_key,
                              const helm_circuit *circuit, helm_si_circuit **out);
 void helm_host_si_circuit_free(helm_si_circuit *c);

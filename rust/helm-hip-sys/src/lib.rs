@@ -81,6 +81,11 @@ pub struct helm_radix_op {
     pub scalar_hi: u64,
 }
 
+#[repr(C)] pub struct helm_netlist { _p: [u8; 0] }
+#[repr(C)] pub struct helm_circuit { _p: [u8; 0] }
+#[repr(C)] pub struct helm_si_circuit { _p: [u8; 0] }
+#[repr(C)] pub struct helm_si_enc_map { _p: [u8; 0] }
+
 extern "C" {
     // ---- include/helm_hip.h ---------------------------------------------------------------
     pub fn helm_hip_last_error() -> *const c_char;
@@ -122,6 +127,28 @@ extern "C" {
     pub fn helm_host_radix_scratch_rows(ctx: *mut helm_si_ctx, blocks: i32, ops: *const helm_radix_op, count: i64) -> i64;
     pub fn helm_host_radix_level(ctx: *mut helm_si_ctx, wires: *mut helm_si_wires, blocks: i32, ops: *const helm_radix_op,
                                  count: i64, scratch_first_row: i32, pbs_out: *mut i64, rounds_out: *mut i64) -> c_int;
+
+    // whole-circuit arithmetic / LUT evaluation inside the host library (merged rounds, carry-save planning): the netlist is
+    // parsed by the library from the same file; client_key = NULL makes an evaluation-only circuit
+    pub fn helm_host_read_verilog_file(file_name: *const c_char, is_arith: c_int, out: *mut *mut helm_netlist) -> c_int;
+    pub fn helm_host_netlist_free(nl: *mut helm_netlist);
+    pub fn helm_host_netlist_list(nl: *const helm_netlist, which: c_int) -> *mut c_char; // 2 inputs, 3 outputs, 4 dff outputs
+    pub fn helm_host_circuit_new(gates_from: *const helm_netlist, input_wires: *const c_char, output_wires: *const c_char,
+                                 dff_outputs: *const c_char, out: *mut *mut helm_circuit) -> c_int;
+    pub fn helm_host_circuit_free(c: *mut helm_circuit);
+    pub fn helm_host_circuit_sort_circuit(c: *mut helm_circuit) -> c_int;
+    pub fn helm_host_circuit_compute_levels(c: *mut helm_circuit) -> c_int;
+    pub fn helm_host_si_circuit_new(mode: c_int, client_key: *mut c_void, server_key: *mut helm_si_ctx, circuit: *const helm_circuit,
+                                    out: *mut *mut helm_si_circuit) -> c_int;
+    pub fn helm_host_si_circuit_free(c: *mut helm_si_circuit);
+    pub fn helm_host_si_circuit_evaluate_encrypted(c: *mut helm_si_circuit, enc_wire_map: *const helm_si_enc_map,
+                                                   current_cycle: i64, ptxt_type: *const c_char,
+                                                   out: *mut *mut helm_si_enc_map) -> c_int;
+    pub fn helm_host_si_enc_map_new(server_key: *mut helm_si_ctx, blocks: c_int, out: *mut *mut helm_si_enc_map) -> c_int;
+    pub fn helm_host_si_enc_map_free(m: *mut helm_si_enc_map);
+    pub fn helm_host_si_enc_map_insert(m: *mut helm_si_enc_map, wire: *const c_char, lwe: *const u64) -> c_int;
+    pub fn helm_host_si_enc_map_get(m: *const helm_si_enc_map, wire: *const c_char, lwe_out: *mut u64) -> c_int;
+    pub fn helm_host_free(text: *mut c_char); // strings the library returns
 
     // ---- include/helm_client.h: key import ---------------------------------------------------
     pub fn helm_keys_last_error() -> *const c_char;

@@ -6,6 +6,7 @@
 //! NOT COMPILED in this repository's image (no rustc); tests/c/shim_sequence.c issues the same calls in the
 //! same order from C and is run on the GPU by tests/test_shim_sequence.py.
 pub mod arith;
+pub mod arith_whole;
 pub mod keys;
 pub mod lut;
 pub mod wopbs;

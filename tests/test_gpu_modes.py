@@ -359,6 +359,31 @@ div g6(J, K, U);
     assert launches <= ac.pbs_rounds_per_cycle()
 
 
+def test_evaluation_only_circuit_without_a_client_key(keys):
+    """helm_host_si_circuit_new(client_key = NULL): the host encrypts and decrypts with its own keys (what the Rust shim
+    does with tfhe's) and moves ciphertext words through the encrypted map; evaluate_encrypted is the whole-circuit
+    evaluation (merged rounds, carry-save) - the same values as with the library's client key."""
+    from helm_amd.circuit import SiEncWireMap
+    client_key, server_key = keys
+    text = "input [15:0] A, B, C;\noutput [15:0] X, Y;\nmult g0(A, B, t0);\nadd g1(t0, C, X);\nsub g2(A, C, Y);\n"
+    circuit, wire_set, _, _ = _circuit(text, is_arith=True, is_text=True)
+    vals = {"A": 40321, "B": 777, "C": 65000}
+    ac = ArithCircuit(None, server_key, circuit)
+    enc = SiEncWireMap(server_key, blocks=8)
+    for name in sorted(wire_set):  # as the reference's encrypt_inputs: every wire is in the map (circuit.rs:970-1000),
+        enc[name] = np.zeros((8, enc.row_words), dtype=np.uint64)  # non-inputs as trivial encryptions of zero
+    for name, v in vals.items():
+        digits = np.array([(v >> (2 * i)) & 3 for i in range(8)], dtype=np.uint64)
+        enc[name] = client_key.encrypt(digits)
+    out = ac.evaluate_encrypted(enc, 1, "u16")
+    m = 1 << 16
+    assert _decrypt_int(client_key, out["X"]) == (vals["A"] * vals["B"] + vals["C"]) % m
+    assert _decrypt_int(client_key, out["Y"]) == (vals["A"] - vals["C"]) % m
+    assert "rounds merged" in ac.log()
+    with pytest.raises(Exception, match="evaluation-only"):
+        ac.decrypt_outputs(out, False)
+
+
 def test_shifts_and_division_u8(keys):  # gates.rs:386-452, 488-700 (div, shl, shr and their plain forms)
     client_key, server_key = keys
     text = """input [7:0] A, B;
