@@ -24,6 +24,12 @@
 #include <type_traits>
 #include <vector>
 
+#ifndef HELM_HIP_TU
+#define HELM_HIP_TU 0 // 1: the translation unit that holds k_pbs_wide alone (default scheduling strategy, Makefile)
+#endif
+#ifndef HELM_HIP_SPLIT_TU
+#define HELM_HIP_SPLIT_TU 0
+#endif
 using namespace helm;
 struct helm_hip_wires;
 struct helm_hip_program;
@@ -38,7 +44,9 @@ static int fail(int code, const std::string &msg)
     return code;
 }
 // shared with helm_shortint.hip (same library, same helm_hip_last_error())
+#if HELM_HIP_TU == 0
 int helm_hip_fail_(int code, const std::string &msg) { return fail(code, msg); }
+#endif
 #define HIP_TRY(expr)                                                                               \
     do {                                                                                            \
         hipError_t e__ = (expr);                                                                    \
@@ -124,10 +132,10 @@ __device__ __forceinline__ void decompose(uint32_t x, int logB, int (&dig)[L])
 // Diagnostic clock stamps (HELM_HIP_CLOCK_PROBE=1): workgroup 0 records s_memtime (shader
 // clock) and s_memrealtime (100 MHz) around its blind rotation; the ratio is the clock the
 // chip actually holds under this kernel's load.  Written to a buffer nothing else reads.
-__device__ unsigned long long g_clock_probe[4];
+static __device__ unsigned long long g_clock_probe[4];
 #ifdef HELM_WIDE_STAMPS
 // per-phase cycle totals (diagnostic build only): [workgroup 0 | last workgroup][wave][phase]
-__device__ unsigned long long g_wide_stamps[2 * 16 * 6];
+static __device__ unsigned long long g_wide_stamps[2 * 16 * 6];
 #define STAMP_DECL unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1;
 #define STAMP_BEGIN                        \
     t0 = __builtin_amdgcn_s_memtime();     \
@@ -803,6 +811,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
     }
 }
 
+#if HELM_HIP_TU == 0 // the keyswitch, linear and table kernels: main translation unit only (see launch_pbs_wide)
 // ------------------------------------------------------------------------------------
 // k_keyswitch: grid (ceil(jobs / 4), column chunks); 256 threads; one output column per
 // thread, FOUR gates per workgroup so that every key word fetched (from L2 / Infinity
@@ -1118,6 +1127,8 @@ __global__ __launch_bounds__(64) void k_ntt_roundtrip(const uint32_t *__restrict
     for (int e = 0; e < E; e++) dst[(size_t)blockIdx.x * N + G::jA(lane, e)] = to_torus32(x[0][e]);
 }
 
+#endif // HELM_HIP_TU == 0
+
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
@@ -1411,6 +1422,39 @@ static hipError_t launch_pbs_wide(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t
     return hipGetLastError();
 }
 
+// Two translation units from this one source (Makefile): the whole file is compiled under the compiler's max-ILP scheduling
+// strategy (-mllvm -amdgpu-sched-strategy=max-ilp: +1.9 % on the lockstep k_pbs, same box, alternating, identical
+// ciphertexts), except k_pbs_wide, which that strategy slows down by 0.9 % and which is therefore compiled a second time
+// with -DHELM_HIP_TU=1 under the default strategy - that unit holds this launcher and nothing else of the host side.
+__attribute__((visibility("hidden"))) hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int field, int logn, int k, int l,
+                                                                        const PbsJob *jobs, int64_t count, const uint32_t *wires,
+                                                                        const uint32_t *raw, const uint32_t *tvs,
+                                                                        uint32_t *out_big);
+#if HELM_HIP_TU == 1
+hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int field, int logn, int k, int l, const PbsJob *jobs, int64_t count,
+                                    const uint32_t *wires, const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
+{
+#define WIDE_CASE(FB, LN, KK, LL) \
+    if (field == FB && logn == LN && k == KK && l == LL) \
+        return launch_pbs_wide<WideCfg<Fp<FB>, LN, KK, LL>>(ctx, jobs, count, wires, raw, tvs, out_big);
+    WIDE_CASE(49, 9, 2, 3) WIDE_CASE(49, 9, 1, 3) WIDE_CASE(49, 9, 1, 2)
+    WIDE_CASE(51, 9, 2, 3) WIDE_CASE(51, 9, 1, 3) WIDE_CASE(51, 9, 1, 2) WIDE_CASE(51, 10, 1, 3) WIDE_CASE(51, 10, 1, 2)
+#undef WIDE_CASE
+    return hipErrorInvalidValue;
+}
+#endif
+#if HELM_HIP_TU == 0 // ==== everything below: the main unit only ===============================================
+template <typename F, int LOGN, int K, int L>
+static hipError_t wide_launch(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires, const uint32_t *raw,
+                              const uint32_t *tvs, uint32_t *out_big)
+{
+#if HELM_HIP_SPLIT_TU
+    return helm_hip_tu1_launch_wide(ctx, std::is_same<F, Fp<49>>::value ? 49 : 51, LOGN, K, L, jobs, count, wires, raw, tvs, out_big);
+#else
+    return launch_pbs_wide<WideCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
+#endif
+}
+
 // Build choice.  Measured on MI355X, boolean_default (profiles/r01/microbench_*): one launch of B
 // bootstraps takes
 //   wide       3.7 - 4.0 ms per round of <= 256 ((k+1) L = 9 waves per bootstrap: k_pbs_wide)
@@ -1452,7 +1496,7 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
             }
             v = count <= ctx->n_cus ? ctx->narrow_variant : 3;
         }
-        if (v == 4) return launch_pbs_wide<WideCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if (v == 4) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (v == 1) return launch_pbs_v<Lat>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (v == 2) return launch_pbs_v<Bal>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (v == 5) return launch_pbs_v<Lock>(ctx, jobs, count, wires, raw, tvs, out_big);
@@ -1469,7 +1513,7 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
         // bootstrap - 2.6 ms instead of 5.6 ms per bootstrap on helm_cuda (HELM_HIP_PBS_VARIANT=4 forces it,
         // HELM_HIP_NARROW=1 keeps the two-wave build)
         if (ctx->pbs_variant == 4 || (ctx->pbs_variant == 0 && count <= ctx->n_cus && ctx->narrow_variant == 4))
-            return launch_pbs_wide<WideCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
+            return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (ctx->pbs_variant != 1) {
             const int64_t round = 4 * (int64_t)ctx->n_cus;
             int64_t full = ctx->pbs_variant == 5 ? count : count / round * round;
@@ -1489,7 +1533,7 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
             }
         }
         if (ctx->pbs_variant == 0 && count <= ctx->n_cus && ctx->narrow_variant == 4)
-            return launch_pbs_wide<WideCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
+            return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
         return launch_pbs_v<Big>(ctx, jobs, count, wires, raw, tvs, out_big);
     }
 }
@@ -2426,3 +2470,4 @@ int helm_hip_get_timing(helm_hip_ctx *ctx, helm_hip_timing *out, int reset)
 }
 
 } // extern "C"
+#endif // HELM_HIP_TU == 0

@@ -28,6 +28,12 @@
 #include <type_traits>
 #include <vector>
 
+#ifndef HELM_SI_TU
+#define HELM_SI_TU 0 // 1: the max-ILP translation unit (two launchers only)
+#endif
+#ifndef HELM_SI_SPLIT_TU
+#define HELM_SI_SPLIT_TU 0
+#endif
 using namespace helm;
 
 int helm_hip_fail_(int code, const std::string &msg); // helm_hip.hip: sets helm_hip_last_error()
@@ -1973,10 +1979,42 @@ hipError_t launch_pbs64s_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count
     return hipGetLastError();
 }
 
+// Two translation units from this one source (Makefile).  The compiler's max-ILP scheduling strategy
+// (-mllvm -amdgpu-sched-strategy=max-ilp; there is no per-function switch) is worth +3.7 % on k_pbs64k and +2.0 % on the
+// multi-bit k_pbs64s, and costs the classical k_pbs64s 0.8 % and its two-level build 1.8 % (same box, alternating,
+// identical ciphertexts: profiles/r03/si_kernel_experiments.txt (15)).  So the launchers of the first two are compiled a
+// second time with -DHELM_SI_TU=1 under that strategy - nothing else of the file is - and the main unit
+// (-DHELM_SI_SPLIT_TU=1) calls them through this one function.  Without the two macros the file is a single unit as before.
+} // namespace
+__attribute__((visibility("hidden"))) hipError_t helm_si_tu1_launch_pbs64(helm_si_ctx *ctx, const void *jobs, int64_t count,
+                                                                        const uint64_t *small, const uint64_t *luts,
+                                                                        uint64_t *out, int *per_cu);
+#if HELM_SI_TU == 1
+hipError_t helm_si_tu1_launch_pbs64(helm_si_ctx *ctx, const void *jobs_v, int64_t count, const uint64_t *small,
+                                    const uint64_t *luts, uint64_t *out, int *per_cu)
+{
+    const Pbs64Job *jobs = static_cast<const Pbs64Job *>(jobs_v);
+    const helm_si_params &P = ctx->P;
+    if (P.k == 3) return launch_pbs64k_c<Pbs64kCfg<9, 3>>(ctx, jobs, count, small, luts, out, per_cu);
+    if (P.k == 2) return launch_pbs64k_c<Pbs64kCfg<9, 2>>(ctx, jobs, count, small, luts, out, per_cu);
+    if (ctx->use_split && ctx->group > 1) {
+        if (ctx->logN == 10) return launch_pbs64s_c<Pbs64sCfg<10>, true>(ctx, jobs, count, small, luts, out, per_cu);
+        if (ctx->logN == 11) return launch_pbs64s_c<Pbs64sCfg<11>, true>(ctx, jobs, count, small, luts, out, per_cu);
+    }
+    return hipErrorInvalidValue;
+}
+#endif
+#if HELM_SI_TU == 0 // ==== everything below: the main unit only ===============================================
+namespace {
+
 hipError_t launch_pbs64(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
                         const uint64_t *luts, uint64_t *out, int *per_cu = nullptr)
 {
     const helm_si_params &P = ctx->P;
+#if HELM_SI_SPLIT_TU
+    if (P.k == 3 || P.k == 2 || (ctx->use_split && ctx->group > 1))
+        return helm_si_tu1_launch_pbs64(ctx, jobs, count, small, luts, out, per_cu);
+#endif
     if (P.k == 3) return launch_pbs64k_c<Pbs64kCfg<9, 3>>(ctx, jobs, count, small, luts, out, per_cu);
     if (P.k == 2) return launch_pbs64k_c<Pbs64kCfg<9, 2>>(ctx, jobs, count, small, luts, out, per_cu);
     if (ctx->use_split) {
@@ -3061,3 +3099,4 @@ int helm_si_get_timing(helm_si_ctx *ctx, helm_si_timing *out, int reset)
 // the WoP-PBS wide-LUT path (include/helm_wopbs.h): same translation unit, it is built from the kernels and launch
 // helpers above
 #include "helm_wopbs.inc"
+#endif // HELM_SI_TU == 0
