@@ -374,6 +374,9 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
 // exact integers below 2^53, so the sum does not depend on the order the waves arrive in.  Four
 // workgroup barriers per step; 64 KB of LDS and at most 128 registers: TWO ciphertexts per CU.
 // ------------------------------------------------------------------------------------
+#ifndef HELM_SI_K_ACC2
+#define HELM_SI_K_ACC2 1 // k_pbs64k: the accumulator polynomials stored with their negated copies behind them
+#endif
 #ifndef HELM_SI_K_GATHER
 #define HELM_SI_K_GATHER 1 // k_pbs64k: column sums gathered by the owner of the column instead of scattered with ds_add_f64
 #endif
@@ -387,7 +390,10 @@ struct Pbs64kCfg {
     static constexpr int TW_IDX = G::N >> G::BC, TW_FIELD = TW_IDX + G::TWC * 64;
     static constexpr size_t TW_OFF = X_OFF + sizeof(double) * NW * G::XPAD;       // double [2][TW_FIELD]
     static constexpr size_t ACC_OFF = TW_OFF + sizeof(double) * 2 * TW_FIELD;     // u64 [K1][N]
-    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint64_t) * K1 * G::N;      // u16 [n+1]
+    // HELM_SI_K_ACC2: every polynomial is stored as [acc | -acc] (2N words): a rotated read X^a acc is then ONE indexed read,
+    // no sign logic (5 vector instructions per coefficient in a kernel that is bound by its instruction stream)
+    static constexpr int ACC_LEN = HELM_SI_K_ACC2 ? 2 * G::N : G::N;
+    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint64_t) * K1 * ACC_LEN;   // u16 [n+1]
     static constexpr size_t BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
     static_assert(NW <= 16, "a workgroup holds at most 16 waves");
     static_assert(2 * BYTES <= 160 * 1024, "two ciphertexts per CU");
@@ -405,7 +411,7 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
     const uint16_t *MS = reinterpret_cast<const uint16_t *>(smem + C::MS_OFF);
     double *xb = X + (size_t)(p * 2 + f) * G::XPAD;                          // own scratch
     const double *x_field = X + (size_t)(p * 2 + (1 - f)) * G::XPAD;         // same polynomial, other field
-    uint64_t *acc_p = ACC + (size_t)p * N;
+    uint64_t *acc_p = ACC + (size_t)p * C::ACC_LEN;
     const double *twt = reinterpret_cast<const double *>(smem + C::TW_OFF) + (size_t)f * C::TW_FIELD;
     TwHybrid<LOGN, false> twf{twt, twt + C::TW_IDX + lane};
     TwHybrid<LOGN, true> twi{twt, twt + C::TW_IDX + (63 - lane)};
@@ -442,8 +448,12 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
             for (int e = 0; e < E; e++) {
                 const int j = G::jA(lane, e);
                 const int src = (j - a) & (2 * N - 1);
-                uint64_t v = acc_p[src & (N - 1)];
-                if (src >= N) v = 0ull - v;
+                uint64_t v;
+                if constexpr (HELM_SI_K_ACC2) v = acc_p[src];
+                else {
+                    v = acc_p[src & (N - 1)];
+                    if (src >= N) v = 0ull - v;
+                }
                 v -= acc_p[j];
                 const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
                 x[0][e] = (double)((int)st - (int)(((st + half_m1) >> logB) << logB));
@@ -493,8 +503,12 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
         for (int e = 0; e < E; e++) {
             const int j = G::jA(lane, e);
             const int src = (j - a) & (2 * N - 1);
-            uint64_t v = acc_p[src & (N - 1)];
-            if (src >= N) v = 0ull - v;
+            uint64_t v;
+            if constexpr (HELM_SI_K_ACC2) v = acc_p[src];
+            else {
+                v = acc_p[src & (N - 1)];
+                if (src >= N) v = 0ull - v;
+            }
             v -= acc_p[j];
             const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
             x[0][e] = (double)((int)st - (int)(((st + half_m1) >> logB) << logB));
@@ -544,7 +558,10 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
             const double r0 = f == 0 ? own : oth, r1 = f == 0 ? oth : own;
             const double t = mulmod<F1>(r1 - r0, p0inv_mod_p1);
             const uint64_t xv = (uint64_t)to_int64(r0) + F0::P_U64 * (uint64_t)to_int64(t);
-            acc_p[G::jA(lane, f * H + e)] += xv;
+            const int j = G::jA(lane, f * H + e);
+            const uint64_t nv = acc_p[j] + xv;
+            acc_p[j] = nv;
+            if constexpr (HELM_SI_K_ACC2) acc_p[j + N] = 0ull - nv;
         }
         lds_block_sync(); // accumulator complete before the next step's rotated reads; scratch free again
     }
@@ -592,14 +609,16 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 2) void k_pbs64k(const Pbs64Job
                 v = tv[idx & (N - 1)];
                 if (idx >= N) v = 0ull - v;
             }
-            ACC[j] = v;
+            const int pp = j / N, jj = j - pp * N;
+            ACC[(size_t)pp * C::ACC_LEN + jj] = v;
+            if constexpr (HELM_SI_K_ACC2) ACC[(size_t)pp * C::ACC_LEN + N + jj] = 0ull - v;
         }
     }
     __syncthreads();
     if (f == 0) pbs64k_body<C, F0>(smem, bsk, n, logB, p0inv_mod_p1, p, 0, lane);
     else pbs64k_body<C, F1>(smem, bsk, n, logB, p0inv_mod_p1, p, 1, lane);
     // ---- sample extract (coefficient 0); wave (p, f) writes its half of the slots ------
-    const uint64_t *acc_p = ACC + (size_t)p * N;
+    const uint64_t *acc_p = ACC + (size_t)p * C::ACC_LEN;
     uint64_t *ob = out + (size_t)job.out_row * ((size_t)K * N + 1);
     if (p < K) {
 #pragma unroll
