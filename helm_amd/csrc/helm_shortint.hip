@@ -177,6 +177,7 @@ __device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__
         }
         double mine[E], other[E];
         const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+    [[maybe_unused]] const uint32_t bmask = (1u << logB) - 1u;
 #pragma unroll
         for (int lev = L - 1; lev >= 0; lev--) {
             double x[1][E];
@@ -425,6 +426,7 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
     KeyBuf kb;
     kb.init(bsk, (size_t)n * step_bytes, lane);
     const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+    [[maybe_unused]] const uint32_t bmask = (1u << logB) - 1u;
     for (int i = 0; i < n; i++) {
         const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
         if (a == 0) continue; // uniform over the workgroup
@@ -456,7 +458,7 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
                 }
                 v -= acc_p[j];
                 const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
-                x[0][e] = (double)((int)st - (int)(((st + half_m1) >> logB) << logB));
+                x[0][e] = (double)((int)((st + half_m1) & bmask) - (int)half_m1); // st <= B/2 stays, above it st - B
             }
             ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
 #pragma unroll
@@ -511,7 +513,7 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
             }
             v -= acc_p[j];
             const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
-            x[0][e] = (double)((int)st - (int)(((st + half_m1) >> logB) << logB));
+            x[0][e] = (double)((int)((st + half_m1) & bmask) - (int)half_m1); // st <= B/2 stays, above it st - B
         }
         ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
         // the scratch becomes this wave's column sum: clear it, and wait until every wave is through its transform
@@ -831,6 +833,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
     const size_t bsk_step = (size_t)K1 * K1 * L * 4 * part;
     const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * L * 4 + f * 2 + h) * part + lane;
     const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+    [[maybe_unused]] const uint32_t bmask = (1u << logB) - 1u;
 #if HELM_SI_KEYBUF
     const unsigned step_bytes = (unsigned)(bsk_step * 16), col_bytes = (unsigned)(4 * part * 16);
     const unsigned wave_off = (unsigned)(((size_t)p * K1 * L * 4 + f * 2 + h) * part * 16);
@@ -867,7 +870,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
                 if (src >= N) v = 0ull - v;
                 v -= acc_p[j];
                 const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
-                return (double)((int)st - (int)(((st + half_m1) >> logB) << logB));
+                return (double)((int)((st + half_m1) & bmask) - (int)half_m1); // st <= B/2 stays, above it st - B
             };
 #pragma unroll
             for (int u = 0; u < Q / 2; u++) {
@@ -1106,6 +1109,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
     const size_t bsk_step = (size_t)K1 * K1 * 4 * part; // one GGSW
     [[maybe_unused]] const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * 4 + f * 2 + h) * part + lane;
     const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+    [[maybe_unused]] const uint32_t bmask = (1u << logB) - 1u;
     const int subsets = 1 << g;
     // exponent of this lane's first spectrum position (slot e = 0 of the key-word order)
     const int c_lane = (int)expo[((size_t)h * HC * 64 + lane) * 2];
@@ -1136,7 +1140,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
             auto digit = [&](int j) {
                 const uint64_t v = acc_p[j];
                 const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
-                return (double)((int)st - (int)(((st + half_m1) >> logB) << logB));
+                return (double)((int)((st + half_m1) & bmask) - (int)half_m1); // st <= B/2 stays, above it st - B
             };
 #pragma unroll
             for (int u = 0; u < Q / 2; u++) {
