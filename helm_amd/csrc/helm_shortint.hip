@@ -375,6 +375,9 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64(const Pbs64Job *__restr
 // exact integers below 2^53, so the sum does not depend on the order the waves arrive in.  Four
 // workgroup barriers per step; 64 KB of LDS and at most 128 registers: TWO ciphertexts per CU.
 // ------------------------------------------------------------------------------------
+#ifndef HELM_SI_K_SPLIT_DIGITS
+#define HELM_SI_K_SPLIT_DIGITS 1
+#endif
 #ifndef HELM_SI_K_ACC2
 #define HELM_SI_K_ACC2 1 // k_pbs64k: the accumulator polynomials stored with their negated copies behind them
 #endif
@@ -446,8 +449,7 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
         double mine[E];
         {
             double x[1][E];
-#pragma unroll
-            for (int e = 0; e < E; e++) {
+            auto digit = [&](int e) {
                 const int j = G::jA(lane, e);
                 const int src = (j - a) & (2 * N - 1);
                 uint64_t v;
@@ -458,8 +460,24 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
                 }
                 v -= acc_p[j];
                 const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
-                x[0][e] = (double)((int)((st + half_m1) & bmask) - (int)half_m1); // st <= B/2 stays, above it st - B
+                return (double)((int)((st + half_m1) & bmask) - (int)half_m1); // st <= B/2 stays, above it st - B
+            };
+#if HELM_SI_K_SPLIT_DIGITS
+            // the two field waves of a polynomial need the same digits: each makes half of them and hands them to the other
+            // through the other's (free) transform scratch - one more barrier, half the decomposition work
+            double *xb_field = X + (size_t)(p * 2 + (1 - f)) * G::XPAD;
+#pragma unroll
+            for (int e = 0; e < H; e++) {
+                x[0][f * H + e] = digit(f * H + e);
+                xb_field[(f * H + e) * 64 + lane] = x[0][f * H + e];
             }
+            lds_block_sync();
+#pragma unroll
+            for (int e = 0; e < H; e++) x[0][(1 - f) * H + e] = xb[((1 - f) * H + e) * 64 + lane];
+#else
+#pragma unroll
+            for (int e = 0; e < E; e++) x[0][e] = digit(e);
+#endif
             ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
 #pragma unroll
             for (int e = 0; e < E; e++) xb[e * 64 + lane] = x[0][e];
