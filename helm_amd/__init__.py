@@ -10,7 +10,7 @@ from ._native import HelmError, Params, SiParams  # noqa: F401
 from .shortint import SiClientKey, SiServerKey, SiWires, si_named_params  # noqa: F401
 from .wopbs import WopClientKey, WopServerKey, wop_named_params  # noqa: F401
 from ._native import WopParams  # noqa: F401
-from . import verilog_parser, circuit, gates, netlists  # noqa: F401,E402
+from . import verilog_parser, circuit, gates, netlists, comm  # noqa: F401,E402
 from .circuit import (Circuit, GateCircuit, EvalCircuit, EncWireMap, LutCircuit, ArithCircuit,  # noqa: F401,E402
                       SiEncWireMap)
 from .gates import PtxtType, GateType, Gate  # noqa: F401,E402

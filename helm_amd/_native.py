@@ -39,7 +39,8 @@ class Timing(C.Structure):
 
 class HipTiming(C.Structure):  # helm_hip_timing
     _fields_ = Timing._fields_ + [("pbs_main_ms", C.c_double), ("pbs_main_launches", C.c_int64),
-                                  ("pbs_main_count", C.c_int64)]
+                                  ("pbs_main_count", C.c_int64), ("exchange_ms", C.c_double),
+                                  ("exchange_count", C.c_int64), ("exchange_bytes", C.c_int64)]
 
 
 class SiParams(C.Structure):
@@ -113,6 +114,7 @@ HIP_API = {
     "helm_hip_wires_set_trivial": (C.c_int, [vp, vp, i32p, u8p, C.c_int64]),
     "helm_hip_wires_copy": (C.c_int, [vp, vp, i32p, vp, i32p, C.c_int64]),
     "helm_hip_program_run_sharded": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp, vp, C.c_int64, HIP_EXCHANGE_FN, vp]),
+    "helm_hip_program_run_sharded_comm": (C.c_int, [vp, vp, vp, vp, C.c_int64]),
     "helm_hip_wires_device_ptr": (C.c_int, [vp, vp, C.POINTER(vp), i64p]),
     "helm_hip_eval_gate_level": (C.c_int, [vp, vp, i32p, i32p, i32p, i32p, i32p, C.c_int64]),
     "helm_hip_program_create": (C.c_int, [vp, i32p, i32p, i32p, i32p, i32p, i64p, C.c_int64, C.POINTER(vp)]),
@@ -155,6 +157,7 @@ SI_API = {
     "helm_si_apply_luts": (C.c_int, [vp, vp, i32p, i32p, i32p, C.c_int64, u64p, C.c_int64]),
     "helm_si_eval_lut_level": (C.c_int, [vp, vp, i32p, i32p, C.c_int32, u64p, i32p, C.c_int64]),
     "helm_si_set_exchange": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_int64, SI_EXCHANGE_FN, vp]),
+    "helm_si_set_exchange_comm": (C.c_int, [vp, vp, C.c_int64, C.c_int64]),
     "helm_si_exchange_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "helm_si_exchange_world": (C.c_int, [vp]),
     "helm_si_round_capacity": (C.c_int64, [vp]),
@@ -163,6 +166,19 @@ SI_API = {
     "helm_si_pbs_batch": (C.c_int, [vp, u64p, u64p, C.c_int64, i32p, u64p, C.c_int64]),
     "helm_si_timing_enable": (C.c_int, [vp, C.c_int]),
     "helm_si_get_timing": (C.c_int, [vp, C.POINTER(Timing), C.c_int]),
+}
+
+# every symbol include/helm_comm.h declares (the library's own RCCL communicator)
+COMM_API = {
+    "helm_comm_available": (C.c_int, []),
+    "helm_comm_get_unique_id": (C.c_int, [u8p]),
+    "helm_comm_create": (C.c_int, [C.c_int, u8p, C.c_int, C.c_int, C.POINTER(vp)]),
+    "helm_comm_destroy": (C.c_int, [vp]),
+    "helm_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "helm_comm_stats": (C.c_int, [vp, i64p, i64p]),
+    "helm_comm_all_gather": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "helm_comm_all_reduce_f64": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int]),
+    "helm_comm_barrier": (C.c_int, [vp]),
 }
 
 WOP_CLIENT_API = {
@@ -235,7 +251,7 @@ KEYS_API = {
 }
 
 for _lib, _api in ((hip, HIP_API), (host, CLIENT_API), (hip, SI_API), (host, SI_CLIENT_API), (host, KEYS_API),
-                   (hip, WOP_API), (host, WOP_CLIENT_API)):
+                   (hip, WOP_API), (host, WOP_CLIENT_API), (hip, COMM_API)):
     for _name, (_res, _args) in _api.items():
         _fn = getattr(_lib, _name)  # AttributeError here = header/library mismatch
         _fn.restype = _res

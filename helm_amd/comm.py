@@ -1,0 +1,84 @@
+"""The library's own RCCL communicator (include/helm_comm.h): one per process, one process per GPU.
+
+The sharded unit is the level of reference src/circuit.rs:531 (the reference has no multi-GPU path);
+with a `Comm` the all-gather of a launch's output ciphertexts runs inside libhelm_hip.so
+(`Program.run_sharded_comm`, `SiServerKey.set_exchange_comm`) - no torch in the data path.
+
+The 128-byte unique id has to reach every rank by some control plane; `Comm.from_torch_dist`
+uses whatever torch.distributed backend the caller has initialised (gloo is enough), and
+`Comm.single` is the world-size-1 communicator (every collective still goes through RCCL).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nv
+from ._native import hip, hip_check
+
+ID_BYTES = 128
+
+
+def available():
+    """True when an RCCL library could be bound in this process (never touches a device)."""
+    return bool(hip.helm_comm_available())
+
+
+def unique_id():
+    buf = np.zeros(ID_BYTES, dtype=np.uint8)
+    hip_check(hip.helm_comm_get_unique_id(nv.as_u8p(buf)))
+    return buf
+
+
+class Comm:
+    def __init__(self, device, uid, rank, world):
+        uid = np.ascontiguousarray(uid, dtype=np.uint8)
+        assert uid.shape == (ID_BYTES,)
+        h = nv.vp()
+        hip_check(hip.helm_comm_create(int(device), nv.as_u8p(uid), int(rank), int(world), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    @classmethod
+    def single(cls, device=0):
+        return cls(device, unique_id(), 0, 1)
+
+    @classmethod
+    def from_torch_dist(cls, dist, device):
+        """Rank 0 draws the id, torch.distributed (any backend) carries it to the others."""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [unique_id().tobytes() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(device, np.frombuffer(box[0], dtype=np.uint8).copy(), rank, world)
+
+    def info(self):
+        """What RCCL reports: rank, world size, device, library version."""
+        r, w, d, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        hip_check(hip.helm_comm_info(self._h, C.byref(r), C.byref(w), C.byref(d), C.byref(v)))
+        return {"rank": r.value, "world_size": w.value, "device": d.value, "rccl_version": v.value}
+
+    def stats(self):
+        n, b = C.c_int64(), C.c_int64()
+        hip_check(hip.helm_comm_stats(self._h, C.byref(n), C.byref(b)))
+        return {"collectives": n.value, "bytes_sent": b.value}
+
+    def all_gather(self, send_ptr, recv_ptr, bytes_per_rank, stream_ptr):
+        hip_check(hip.helm_comm_all_gather(self._h, nv.vp(send_ptr), nv.vp(recv_ptr), int(bytes_per_rank), nv.vp(stream_ptr)))
+
+    def all_reduce(self, value, op="max"):
+        v = C.c_double(float(value))
+        hip_check(hip.helm_comm_all_reduce_f64(self._h, C.byref(v), {"sum": 0, "max": 1}[op]))
+        return v.value
+
+    def barrier(self):
+        hip_check(hip.helm_comm_barrier(self._h))
+
+    def destroy(self):
+        if getattr(self, "_h", None):
+            hip_check(hip.helm_comm_destroy(self._h))
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -1,0 +1,238 @@
+// helm_comm.cpp — the RCCL communicator behind include/helm_comm.h.
+//
+// The sharded unit is the level of reference src/circuit.rs:531 (gates mode), :1057 (LUT mode) and
+// :1321 (arithmetic mode); the reference itself has no multi-GPU path.  One process per GPU, keys and
+// wire tables replicated, the output LWE rows of a launch all-gathered over RCCL / xGMI.
+//
+// RCCL is bound with dlopen at first use: a process that already holds a librccl.so.1 (PyTorch ships
+// its own) must not get a second, different copy mapped over it, and a machine without RCCL must still
+// load libhelm_hip.so (single-GPU use).  Only entry points of the stable NCCL 2 ABI are used.
+#include "../../include/helm_comm.h"
+#include "../../include/helm_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+int helm_hip_fail_(int code, const std::string &msg); // helm_hip.hip: sets helm_hip_last_error()
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    std::string origin, error;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+Rccl g_rccl;
+std::once_flag g_once;
+
+template <typename T> bool sym(T &fn, const char *name)
+{
+    fn = reinterpret_cast<T>(dlsym(g_rccl.handle, name));
+    if (!fn) g_rccl.error = std::string("librccl: missing symbol ") + name;
+    return fn != nullptr;
+}
+
+void bind_rccl()
+{
+    // HELM_RCCL_LIB names a library explicitly; otherwise: the copy this process already holds, the loader's
+    // search path, the ROCm installation
+    struct Try {
+        const char *path;
+        int flags;
+        const char *what;
+    };
+    const char *forced = getenv("HELM_RCCL_LIB");
+    const Try tries[] = {
+        {forced, RTLD_NOW | RTLD_GLOBAL, "HELM_RCCL_LIB"},
+        {"librccl.so.1", RTLD_NOW | RTLD_NOLOAD, "already loaded by the process"},
+        {"librccl.so", RTLD_NOW | RTLD_NOLOAD, "already loaded by the process"},
+        {"librccl.so.1", RTLD_NOW | RTLD_GLOBAL, "loader search path"},
+        {"/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL, "/opt/rocm/lib"},
+    };
+    for (const Try &t : tries) {
+        if (!t.path || !*t.path) continue;
+        g_rccl.handle = dlopen(t.path, t.flags);
+        if (g_rccl.handle) {
+            g_rccl.origin = std::string(t.path) + " (" + t.what + ")";
+            break;
+        }
+    }
+    if (!g_rccl.handle) {
+        g_rccl.error = "no RCCL library could be loaded (librccl.so.1; set HELM_RCCL_LIB)";
+        return;
+    }
+    const bool ok = sym(g_rccl.GetVersion, "ncclGetVersion") && sym(g_rccl.GetUniqueId, "ncclGetUniqueId") &&
+                    sym(g_rccl.CommInitRank, "ncclCommInitRank") && sym(g_rccl.CommDestroy, "ncclCommDestroy") &&
+                    sym(g_rccl.CommCount, "ncclCommCount") && sym(g_rccl.CommCuDevice, "ncclCommCuDevice") &&
+                    sym(g_rccl.CommUserRank, "ncclCommUserRank") && sym(g_rccl.AllGather, "ncclAllGather") &&
+                    sym(g_rccl.AllReduce, "ncclAllReduce") && sym(g_rccl.GetErrorString, "ncclGetErrorString");
+    if (!ok) g_rccl.handle = nullptr; // the mapping stays (it may be the process's own copy); we just do not use it
+}
+
+int need_rccl()
+{
+    std::call_once(g_once, bind_rccl);
+    if (!g_rccl.handle) return helm_hip_fail_(HELM_ERR_STATE, g_rccl.error);
+    return 0;
+}
+
+#define NCCL_TRY(expr)                                                                                          \
+    do {                                                                                                        \
+        ncclResult_t r__ = (expr);                                                                              \
+        if (r__ != ncclSuccess)                                                                                 \
+            return helm_hip_fail_(HELM_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r__));        \
+    } while (0)
+#define HIPC_TRY(expr)                                                                                          \
+    do {                                                                                                        \
+        hipError_t e__ = (expr);                                                                                \
+        if (e__ != hipSuccess) return helm_hip_fail_(HELM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+} // namespace
+
+struct helm_comm {
+    ncclComm_t comm = nullptr;
+    int device = 0, rank = 0, world = 1;
+    hipStream_t side = nullptr; // the host-side helpers' own stream
+    double *scratch = nullptr;  // one double on the device for them
+    int64_t collectives = 0, bytes_sent = 0;
+};
+
+extern "C" {
+
+int helm_comm_available(void)
+{
+    std::call_once(g_once, bind_rccl);
+    return g_rccl.handle ? 1 : 0;
+}
+
+int helm_comm_get_unique_id(uint8_t id[HELM_COMM_ID_BYTES])
+{
+    if (!id) return helm_hip_fail_(HELM_ERR_INVALID, "null id");
+    if (int rc = need_rccl()) return rc;
+    static_assert(sizeof(ncclUniqueId) == HELM_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    NCCL_TRY(g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+int helm_comm_create(int device_id, const uint8_t id[HELM_COMM_ID_BYTES], int rank, int world, helm_comm **out)
+{
+    if (!id || !out) return helm_hip_fail_(HELM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return helm_hip_fail_(HELM_ERR_INVALID, "helm_comm_create: bad rank / world");
+    if (int rc = need_rccl()) return rc;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device_id < 0 || device_id >= n_dev)
+        return helm_hip_fail_(HELM_ERR_NO_DEVICE, "helm_comm_create: no such device");
+    HIPC_TRY(hipSetDevice(device_id));
+    helm_comm *c = new (std::nothrow) helm_comm();
+    if (!c) return helm_hip_fail_(HELM_ERR_OOM, "communicator");
+    c->device = device_id;
+    c->rank = rank;
+    c->world = world;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return helm_hip_fail_(HELM_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r) + " [" + g_rccl.origin + "]");
+    }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->scratch, sizeof(double)) != hipSuccess) {
+        helm_comm_destroy(c);
+        return helm_hip_fail_(HELM_ERR_HIP, "helm_comm_create: side stream / scratch");
+    }
+    *out = c;
+    return 0;
+}
+
+int helm_comm_destroy(helm_comm *c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+    }
+    (void)hipFree(c->scratch);
+    ncclResult_t r = ncclSuccess;
+    if (c->comm && g_rccl.handle) r = g_rccl.CommDestroy(c->comm);
+    delete c;
+    if (r != ncclSuccess) return helm_hip_fail_(HELM_ERR_HIP, std::string("ncclCommDestroy: ") + g_rccl.GetErrorString(r));
+    return 0;
+}
+
+int helm_comm_info(const helm_comm *c, int *rank, int *world, int *device, int *rccl_version)
+{
+    if (!c) return helm_hip_fail_(HELM_ERR_INVALID, "null communicator");
+    int v = 0;
+    if (rank) NCCL_TRY(g_rccl.CommUserRank(c->comm, rank));
+    if (world) NCCL_TRY(g_rccl.CommCount(c->comm, world));
+    if (device) NCCL_TRY(g_rccl.CommCuDevice(c->comm, device));
+    if (rccl_version) {
+        NCCL_TRY(g_rccl.GetVersion(&v));
+        *rccl_version = v;
+    }
+    return 0;
+}
+
+int helm_comm_stats(const helm_comm *c, int64_t *collectives, int64_t *bytes_sent)
+{
+    if (!c) return helm_hip_fail_(HELM_ERR_INVALID, "null communicator");
+    if (collectives) *collectives = c->collectives;
+    if (bytes_sent) *bytes_sent = c->bytes_sent;
+    return 0;
+}
+
+int helm_comm_all_gather(helm_comm *c, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *hip_stream)
+{
+    if (!c || !send_dev || !recv_dev) return helm_hip_fail_(HELM_ERR_INVALID, "helm_comm_all_gather: null argument");
+    if (bytes_per_rank == 0) return 0;
+    // words where the size allows it (rows of u32 / u64 always do), bytes otherwise
+    if (bytes_per_rank % 4 == 0)
+        NCCL_TRY(g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank / 4, ncclUint32, c->comm, static_cast<hipStream_t>(hip_stream)));
+    else
+        NCCL_TRY(g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, ncclUint8, c->comm, static_cast<hipStream_t>(hip_stream)));
+    c->collectives++;
+    c->bytes_sent += (int64_t)bytes_per_rank;
+    return 0;
+}
+
+int helm_comm_all_reduce_f64(helm_comm *c, double *value, int op)
+{
+    if (!c || !value || (op != 0 && op != 1)) return helm_hip_fail_(HELM_ERR_INVALID, "helm_comm_all_reduce_f64: bad argument");
+    HIPC_TRY(hipSetDevice(c->device));
+    HIPC_TRY(hipMemcpyAsync(c->scratch, value, sizeof(double), hipMemcpyHostToDevice, c->side));
+    NCCL_TRY(g_rccl.AllReduce(c->scratch, c->scratch, 1, ncclFloat64, op == 0 ? ncclSum : ncclMax, c->comm, c->side));
+    HIPC_TRY(hipMemcpyAsync(value, c->scratch, sizeof(double), hipMemcpyDeviceToHost, c->side));
+    HIPC_TRY(hipStreamSynchronize(c->side));
+    c->collectives++;
+    c->bytes_sent += (int64_t)sizeof(double);
+    return 0;
+}
+
+int helm_comm_barrier(helm_comm *c)
+{
+    double one = 1.0;
+    return helm_comm_all_reduce_f64(c, &one, 0);
+}
+
+} // extern "C"

@@ -12,6 +12,7 @@
 //
 // There is no CPU fallback in this file.
 #include "../../include/helm_hip.h"
+#include "../../include/helm_comm.h"
 #include "ntt_fp64.h"
 
 #include <hip/hip_runtime.h>
@@ -1236,7 +1237,7 @@ struct helm_hip_ctx {
     DevBuf<uint32_t> d_big;
     // timing
     bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pbs, ev_pbs_main, ev_ks, ev_lin;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pbs, ev_pbs_main, ev_ks, ev_lin, ev_xchg;
     helm_hip_timing tacc{};
     // wire tables and programs created from this context: released with it, so that a handle
     // freed after its context (host-language destructors run in any order) is harmless
@@ -1264,6 +1265,7 @@ struct helm_hip_program {
     DevBuf<LinJob> s_lin;
     DevBuf<int32_t> s_rows;
     std::vector<int64_t> sh_pbs_off, sh_ks_off, sh_lin_off, sh_rows_off;
+    DevBuf<uint32_t> x_gather; // helm_hip_program_run_sharded_comm: the launches' gather buffer (chunk rows x world)
 };
 
 static bool needs_pbs(int op)
@@ -1318,6 +1320,38 @@ static int plan_level(const int32_t *op, const int32_t *in0, const int32_t *in1,
                                               " can't be mixed with Boolean gates");
         }
     }
+    return 0;
+}
+
+// The gates of a level run concurrently (circuit.rs:531: par_iter over the level), and the reference gets its guarantee that
+// none of them reads what another one writes from Circuit::compute_levels (circuit.rs:174-239).  A host with a wrong level
+// map must not get silently non-deterministic ciphertexts: a level in which a gate reads a row ANOTHER gate of the level
+// writes (RAW), or in which two gates write one row (WAW), is refused.  A gate may update its own row in place (the READY
+// latch of circuit.rs:482-504: out = mux(READY, new, out)): every kernel reads a gate's operands before it writes its
+// result.  `owner` has one entry per row, -1 at the start; `base` = index of the level's first gate among all gates checked
+// with this `owner` (stale entries of earlier levels are below it, so nothing is cleared between levels).
+static int check_level_hazards(const int32_t *in0, const int32_t *in1, const int32_t *in2, const int32_t *out, int64_t count,
+                               int64_t base, std::vector<int64_t> &owner, int64_t level)
+{
+    for (int64_t g = 0; g < count; g++) {
+        int64_t &o = owner[(size_t)out[g]];
+        if (o >= base)
+            return fail(HELM_ERR_INVALID, "level " + std::to_string(level) + ": gates " + std::to_string(o - base) + " and " +
+                                              std::to_string(g) + " both write wire " + std::to_string(out[g]) +
+                                              " (write-after-write inside a level)");
+        o = base + g;
+    }
+    const int32_t *ins[3] = {in0, in1, in2};
+    for (int64_t g = 0; g < count; g++)
+        for (int q = 0; q < 3; q++) {
+            const int32_t r = ins[q][g];
+            if (r < 0) continue;
+            const int64_t o = owner[(size_t)r];
+            if (o >= base && o != base + g)
+                return fail(HELM_ERR_INVALID, "level " + std::to_string(level) + ": gate " + std::to_string(g) + " reads wire " +
+                                                  std::to_string(r) + ", which gate " + std::to_string(o - base) +
+                                                  " of the same level writes (read-after-write inside a level)");
+        }
     return 0;
 }
 
@@ -1773,6 +1807,7 @@ int helm_hip_ctx_destroy(helm_hip_ctx *ctx)
         pr->s_ks.release();
         pr->s_lin.release();
         pr->s_rows.release();
+        pr->x_gather.release();
         pr->owner = nullptr;
     }
     (void)hipFree(ctx->tw_fwd);
@@ -2054,6 +2089,39 @@ int helm_hip_eval_gate_level(helm_hip_ctx *ctx, helm_hip_wires *w, const int32_t
     if (int rc = check_idx(w, in1, count, true)) return rc;
     if (int rc = check_idx(w, in2, count, true)) return rc;
     if (int rc = check_idx(w, out, count, false)) return rc;
+    if ((int64_t)count * 16 >= w->n_wires) {
+        std::vector<int64_t> owner((size_t)w->n_wires, -1);
+        if (int rc = check_level_hazards(in0, in1, in2, out, count, 0, owner, 0)) return rc;
+    } else { // a narrow level on a large table: the same check over a compacted row numbering, O(count log count)
+        std::vector<int32_t> rows(out, out + count);
+        std::sort(rows.begin(), rows.end());
+        rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+        if ((int64_t)rows.size() != count)
+            return fail(HELM_ERR_INVALID, "two gates of the level write the same wire (write-after-write inside a level)");
+        auto compact = [&](const int32_t *src, std::vector<int32_t> &dst) {
+            dst.resize((size_t)count);
+            for (int64_t g = 0; g < count; g++) {
+                auto it = src[g] < 0 ? rows.end() : std::lower_bound(rows.begin(), rows.end(), src[g]);
+                dst[(size_t)g] = it != rows.end() && *it == src[g] ? (int32_t)(it - rows.begin()) : -1; // rows nobody writes: no hazard
+            }
+        };
+        std::vector<int32_t> c0, c1, c2, co;
+        compact(in0, c0); compact(in1, c1); compact(in2, c2); compact(out, co);
+        std::vector<int64_t> owner(rows.size(), -1);
+        if (int rc = check_level_hazards(c0.data(), c1.data(), c2.data(), co.data(), count, 0, owner, 0)) {
+            // name the caller's wire in the message, not the compacted index
+            for (int64_t g = 0; g < count; g++) {
+                const int32_t *ins[3] = {c0.data(), c1.data(), c2.data()};
+                const int32_t *raw[3] = {in0, in1, in2};
+                for (int q = 0; q < 3; q++)
+                    if (ins[q][g] >= 0 && owner[(size_t)ins[q][g]] >= 0 && owner[(size_t)ins[q][g]] != g)
+                        return fail(HELM_ERR_INVALID, "gate " + std::to_string(g) + " reads wire " + std::to_string(raw[q][g]) +
+                                                          ", which gate " + std::to_string(owner[(size_t)ins[q][g]]) +
+                                                          " of the same level writes (read-after-write inside a level)");
+            }
+            return rc;
+        }
+    }
     LevelPlan pl;
     if (int rc = plan_level(opcode, in0, in1, in2, count, [&](int64_t g) { return out[g]; }, pl)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -2103,6 +2171,16 @@ int helm_hip_program_create(helm_hip_ctx *ctx, const int32_t *opcode, const int3
                 return fail(HELM_ERR_INVALID, "gate " + std::to_string(i) + ": bad wire index " + std::to_string(v[q]));
             }
             pr->max_row = std::max<int64_t>(pr->max_row, v[q]);
+        }
+    }
+    {
+        std::vector<int64_t> owner((size_t)(pr->max_row + 1), -1);
+        for (int64_t l = 0; l < n_levels; l++) {
+            const int64_t b = pr->off[l], cnt = pr->off[l + 1] - b;
+            if (int rc = check_level_hazards(in0 + b, in1 + b, in2 + b, out + b, cnt, b, owner, l)) {
+                delete pr;
+                return rc;
+            }
         }
     }
     pr->plans.resize(n_levels);
@@ -2172,6 +2250,7 @@ int helm_hip_program_destroy(helm_hip_ctx *ctx, helm_hip_program *prog)
     prog->s_ks.release();
     prog->s_lin.release();
     prog->s_rows.release();
+    prog->x_gather.release();
     delete prog;
     return 0;
 }
@@ -2319,10 +2398,10 @@ int helm_hip_program_run_sharded(helm_hip_ctx *ctx, helm_hip_program *prog, helm
 {
     if (int rc = check_program(ctx, prog, w)) return rc;
     if (world <= 0 || rank < 0 || rank >= world) return fail(HELM_ERR_INVALID, "bad shard arguments");
-    if (world > 1 && (!stage_dev || !gather_dev || !fn || capacity_rows <= 0))
+    if ((world > 1 || fn) && (!stage_dev || !gather_dev || !fn || capacity_rows <= 0))
         return fail(HELM_ERR_INVALID, "run_sharded: staging buffers and the exchange callback are needed for world > 1");
     for (int64_t l = 0; l < prog->n_levels; l++) {
-        if (world == 1 || helm_hip_program_level_pbs(prog, l) <= replicate_below) { // one wave of workgroups absorbs it
+        if ((world == 1 && !fn) || helm_hip_program_level_pbs(prog, l) <= replicate_below) { // one wave of workgroups absorbs it
             if (int rc = helm_hip_program_run(ctx, prog, w, l, l + 1)) return rc;
             continue;
         }
@@ -2334,6 +2413,40 @@ int helm_hip_program_run_sharded(helm_hip_ctx *ctx, helm_hip_program *prog, helm
         if (int rc = fn(user, stage_dev, gather_dev, rows))
             return fail(HELM_ERR_STATE, "run_sharded: the exchange callback failed (" + std::to_string(rc) + ")");
         if (int rc = helm_hip_program_scatter_level(ctx, prog, w, l, world, gather_dev)) return rc;
+    }
+    return 0;
+}
+
+int helm_hip_program_run_sharded_comm(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, helm_comm *comm,
+                                      int64_t replicate_below)
+{
+    if (int rc = check_program(ctx, prog, w)) return rc;
+    if (!comm) return fail(HELM_ERR_INVALID, "run_sharded_comm: null communicator");
+    int rank = 0, world = 0, dev = -1;
+    if (int rc = helm_comm_info(comm, &rank, &world, &dev, nullptr)) return rc;
+    if (dev != ctx->device) return fail(HELM_ERR_STATE, "run_sharded_comm: the communicator lives on another device than the context");
+    if (int rc = shard_prepare(ctx, prog, rank, world)) return rc;
+    const size_t row = (size_t)ctx->P.n + 1;
+    int64_t cap = 0;
+    for (int64_t l = 0; l < prog->n_levels; l++)
+        if (helm_hip_program_level_pbs(prog, l) > replicate_below) cap = std::max(cap, helm_hip_program_chunk_rows(prog, l, world));
+    if (cap > 0 && prog->x_gather.ensure((size_t)cap * world * row)) return fail(HELM_ERR_OOM, "gather buffer");
+    for (int64_t l = 0; l < prog->n_levels; l++) {
+        if (helm_hip_program_level_pbs(prog, l) <= replicate_below) {
+            if (int rc = helm_hip_program_run(ctx, prog, w, l, l + 1)) return rc;
+            continue;
+        }
+        // this rank's chunk goes straight into its slot of the gather buffer: ncclAllGather in place
+        const int64_t rows = helm_hip_program_chunk_rows(prog, l, world);
+        uint32_t *slot = prog->x_gather.p + (size_t)rank * rows * row;
+        if (int rc = helm_hip_program_run_level_shard(ctx, prog, w, l, rank, world, slot)) return rc;
+        {
+            TimedScope t(ctx, &ctx->ev_xchg);
+            if (int rc = helm_comm_all_gather(comm, slot, prog->x_gather.p, (size_t)rows * row * sizeof(uint32_t), ctx->stream)) return rc;
+        }
+        ctx->tacc.exchange_count++;
+        ctx->tacc.exchange_bytes += rows * (int64_t)(row * sizeof(uint32_t));
+        if (int rc = helm_hip_program_scatter_level(ctx, prog, w, l, world, prog->x_gather.p)) return rc;
     }
     return 0;
 }
@@ -2464,6 +2577,7 @@ int helm_hip_get_timing(helm_hip_ctx *ctx, helm_hip_timing *out, int reset)
     drain(ctx->ev_pbs_main, ctx->tacc.pbs_main_ms);
     drain(ctx->ev_ks, ctx->tacc.ks_ms);
     drain(ctx->ev_lin, ctx->tacc.linear_ms);
+    drain(ctx->ev_xchg, ctx->tacc.exchange_ms);
     *out = ctx->tacc;
     if (reset) ctx->tacc = helm_hip_timing{};
     return 0;

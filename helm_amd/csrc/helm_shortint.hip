@@ -15,6 +15,7 @@
 //
 // There is no CPU fallback in this file.
 #include "../../include/helm_shortint.h"
+#include "../../include/helm_comm.h"
 #include "ntt_fp64.h"
 
 #include <hip/hip_runtime.h>
@@ -1899,7 +1900,17 @@ struct helm_si_ctx {
     uint64_t *x_stage = nullptr, *x_gather = nullptr;
     helm_si_exchange_fn x_fn = nullptr;
     void *x_user = nullptr;
+    // helm_si_set_exchange_comm: the collective is the library's own ncclAllGather through x_comm; the gather buffer is
+    // the context's (x_own), this rank's chunk is computed straight into its slot of it (all-gather in place)
+    helm_comm *x_comm = nullptr;
+    uint64_t *x_own = nullptr;
+    bool x_on = false; // sharding active (world = 1 with a collective installed counts: the single-GPU test of the path)
     int64_t x_batches = 0, x_rows = 0;
+    // where this rank's chunk of a sharded batch goes, and the exchange that follows it
+    uint64_t *x_slot(int64_t rows) const
+    {
+        return x_comm ? x_gather + (size_t)x_rank * (size_t)rows * ((size_t)P.k * P.N + 1) : x_stage;
+    }
 };
 
 namespace {
@@ -2355,6 +2366,17 @@ int probe_spectrum_positions(helm_si_ctx *ctx)
     return 0;
 }
 
+// all-gather of `rows` big-LWE rows per rank into x_gather, on the context's stream
+int si_exchange(helm_si_ctx *ctx, int64_t rows)
+{
+    if (ctx->x_comm)
+        return helm_comm_all_gather(ctx->x_comm, ctx->x_slot(rows), ctx->x_gather,
+                                    (size_t)rows * ((size_t)ctx->P.k * ctx->P.N + 1) * sizeof(uint64_t), ctx->stream);
+    if (int rc = ctx->x_fn(ctx->x_user, rows))
+        return fail(HELM_ERR_STATE, "exchange callback failed with " + std::to_string(rc));
+    return 0;
+}
+
 // helm_si_apply_luts with the batch sharded over the ranks of helm_si_set_exchange(): identical
 // ciphertexts to the unsharded call (every bootstrap is independent and deterministic)
 int apply_luts_sharded(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, const int32_t *lut_idx,
@@ -2372,11 +2394,10 @@ int apply_luts_sharded(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx
             ks[(size_t)(g - lo)] = Ks64Job{in_idx[g], (int32_t)(g - lo)};
             pbs[(size_t)(g - lo)] = Pbs64Job{(int32_t)(g - lo), lut_idx[g], (int32_t)(g - lo), 0};
         }
-        if (int rc = apply_luts_device(ctx, w->d, ctx->x_stage, ks, pbs, luts, n_luts)) return rc;
-        // the collective is the caller's (RCCL all-gather on this context's stream): every rank calls it,
-        // also one whose chunk is empty
-        if (int rc = ctx->x_fn(ctx->x_user, rows))
-            return fail(HELM_ERR_STATE, "exchange callback failed with " + std::to_string(rc));
+        if (int rc = apply_luts_device(ctx, w->d, ctx->x_slot(rows), ks, pbs, luts, n_luts)) return rc;
+        // the collective (the library's ncclAllGather, or the caller's callback) on this context's stream: every
+        // rank calls it, also one whose chunk is empty
+        if (int rc = si_exchange(ctx, rows)) return rc;
         if (int rc = drain(ctx)) return rc;
         if (int rc = upload(ctx, ctx->d_idx2, out_idx + base, (size_t)per)) return rc;
         // gathered row q * rows + i is gate base + q * rows + i: the chunks are contiguous
@@ -2559,6 +2580,7 @@ int helm_si_ctx_destroy(helm_si_ctx *ctx)
         (void)hipFree(ctx->bsk_split);
         (void)hipFree(ctx->tw_sub);
         (void)hipFree(ctx->expo);
+        (void)hipFree(ctx->x_own);
         (void)hipFree(ctx->psi_pow);
         (void)hipFree(ctx->ksk);
         (void)hipFree(ctx->ksk_planes);
@@ -2907,7 +2929,7 @@ int helm_si_apply_luts(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx
         ks[(size_t)g] = Ks64Job{in_idx[g], (int32_t)g};
         pbs[(size_t)g] = Pbs64Job{(int32_t)g, lut_idx[g], out_idx[g], 0};
     }
-    if (ctx->x_world > 1 && count >= ctx->x_min)
+    if (ctx->x_on && count >= ctx->x_min)
         return apply_luts_sharded(ctx, w, in_idx, lut_idx, out_idx, count, luts, n_luts);
     // every keyswitch finishes (kernel boundary) before any bootstrap writes its output row
     return apply_luts_device(ctx, w->d, w->d, ks, pbs, luts, n_luts);
@@ -2917,15 +2939,24 @@ int helm_si_set_exchange(helm_si_ctx *ctx, int32_t rank, int32_t world, int64_t 
                          void *gather_dev, int64_t capacity_rows, helm_si_exchange_fn fn, void *user)
 {
     if (!ctx) return fail(HELM_ERR_INVALID, "null context");
-    if (world <= 1) { // back to single-GPU evaluation
+    if (ctx->x_own) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->x_own);
+        ctx->x_own = nullptr;
+    }
+    ctx->x_comm = nullptr;
+    if (world < 1 || (world == 1 && !fn)) { // back to single-GPU evaluation
         ctx->x_world = 1;
         ctx->x_rank = 0;
         ctx->x_fn = nullptr;
+        ctx->x_on = false;
         ctx->x_stage = ctx->x_gather = nullptr;
         return 0;
     }
     if (rank < 0 || rank >= world || min_batch < 1 || capacity_rows < 1 || !stage_dev || !gather_dev || !fn)
         return fail(HELM_ERR_INVALID, "helm_si_set_exchange: bad argument");
+    ctx->x_on = true;
     ctx->x_rank = rank;
     ctx->x_world = world;
     ctx->x_min = min_batch;
@@ -2934,6 +2965,32 @@ int helm_si_set_exchange(helm_si_ctx *ctx, int32_t rank, int32_t world, int64_t 
     ctx->x_gather = static_cast<uint64_t *>(gather_dev);
     ctx->x_fn = fn;
     ctx->x_user = user;
+    ctx->x_batches = ctx->x_rows = 0;
+    return 0;
+}
+
+int helm_si_set_exchange_comm(helm_si_ctx *ctx, helm_comm *comm, int64_t min_batch, int64_t capacity_rows)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null context");
+    if (!comm) return helm_si_set_exchange(ctx, 0, 1, 1, nullptr, nullptr, 1, nullptr, nullptr);
+    if (min_batch < 1 || capacity_rows < 1) return fail(HELM_ERR_INVALID, "helm_si_set_exchange_comm: bad argument");
+    int rank = 0, world = 0, dev = -1;
+    if (int rc = helm_comm_info(comm, &rank, &world, &dev, nullptr)) return rc;
+    if (dev != ctx->device) return fail(HELM_ERR_STATE, "helm_si_set_exchange_comm: the communicator lives on another device than the context");
+    if (int rc = helm_si_set_exchange(ctx, 0, 1, 1, nullptr, nullptr, 1, nullptr, nullptr)) return rc; // releases an earlier buffer
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t brow = (size_t)ctx->P.k * ctx->P.N + 1;
+    HIP_TRY(hipMalloc(&ctx->x_own, (size_t)capacity_rows * (size_t)world * brow * sizeof(uint64_t)));
+    ctx->x_comm = comm;
+    ctx->x_gather = ctx->x_own;
+    ctx->x_stage = nullptr; // chunks go straight into the gather buffer (x_slot)
+    ctx->x_rank = rank;
+    ctx->x_world = world;
+    ctx->x_min = min_batch;
+    ctx->x_cap = capacity_rows;
+    ctx->x_fn = nullptr;
+    ctx->x_user = nullptr;
+    ctx->x_on = true;
     ctx->x_batches = ctx->x_rows = 0;
     return 0;
 }

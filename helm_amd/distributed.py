@@ -76,30 +76,49 @@ class GpuLevelExecutor:
         self.program.run_sharded(self.wires, rank, world, stage.data_ptr(), gather.data_ptr(), capacity_rows, exchange,
                                  replicate_below)
 
+    def run_sharded_comm(self, comm, replicate_below):
+        self.program.run_sharded_comm(self.wires, comm, replicate_below)
+
+    def exchange_ms(self, reset=False):
+        """Device time of the in-library all-gathers (helm_hip_timing.exchange_ms; needs timing_enable)."""
+        t = self.program.sk.timing(reset=False)
+        return t.exchange_ms
+
 
 class ShardedRunner:
     """Drives one evaluation pass over all levels on `world` ranks.
 
-    `dist` is torch.distributed (backend "nccl" = RCCL on GPUs; "gloo" in the CPU
-    tests); with world == 1 nothing is imported and nothing is exchanged."""
+    The collective is either the library's own (`comm`: helm_amd.comm.Comm, an RCCL communicator
+    inside libhelm_hip.so - launch loop and ncclAllGather both native, no torch in the data path;
+    what bench.py uses) or `dist`, torch.distributed (backend "nccl" = RCCL on GPUs; "gloo" in the
+    CPU tests).  With world == 1 nothing is exchanged unless `force` (or a `comm`) asks for the
+    sharded path anyway: every launch of more than `replicate_below` bootstraps then still goes
+    stage -> all-gather -> scatter (the single-GPU test of the path over real RCCL)."""
 
     def __init__(self, executor, rank=0, world=1, dist=None, replicate_below=256, time_collective=False, depends_on=None,
-                 ring=3, in_library=False):
+                 ring=3, in_library=False, comm=None, force=False):
         """depends_on (optional, one entry per launch: the last EARLIER launch whose outputs this one reads, -1 for
         none; `launch_dependencies`) switches the overlapped schedule on: a sharded launch's all-gather and scatter go
         to a side stream and the next launches run meanwhile, each waiting only for the launch it depends on."""
-        self.ex, self.rank, self.world, self.dist = executor, rank, world, dist
+        self.ex, self.rank, self.world, self.dist, self.comm = executor, rank, world, dist, comm
         self.replicate_below = replicate_below
-        self.depends_on = None if depends_on is None or world <= 1 else [int(d) for d in depends_on]
+        active = world > 1 or bool(force) or comm is not None
+        self.active = active
+        self.depends_on = None if depends_on is None or not active or comm is not None else [int(d) for d in depends_on]
         # in_library: the launch loop runs inside libhelm_hip.so (helm_hip_program_run_sharded) and calls back for the
-        # all-gather only - the path a Rust host takes (INTEGRATION.md, Multi-GPU)
-        self.in_library = bool(in_library) and world > 1 and hasattr(executor, "run_sharded")
+        # all-gather only - the path a Rust host takes when it brings its own collective (INTEGRATION.md, Multi-GPU)
+        self.in_library = bool(in_library) and active and comm is None and hasattr(executor, "run_sharded")
         self._ring_size = max(2, int(ring))
-        self.time_collective = time_collective and world > 1 and hasattr(executor, "new_events")
+        self.time_collective = time_collective and active and hasattr(executor, "new_events")
         self._events = []
         self.sharded_levels = []
         self._staging, self._gathered = {}, {}
-        if world > 1:
+        if active and comm is not None:
+            for l in range(executor.n_levels):
+                if executor.level_pbs(l) > replicate_below:
+                    self.sharded_levels.append(l)
+            executor.shard_prepare(rank, world)
+        elif active:
             if hasattr(executor, "bind_stream"):
                 executor.bind_stream()  # not left to the caller: an unordered all-gather silently corrupts wires
             for l in range(executor.n_levels):
@@ -119,6 +138,8 @@ class ShardedRunner:
         self._sharded = set(self.sharded_levels)
 
     def run(self):
+        if self.comm is not None:
+            return self.ex.run_sharded_comm(self.comm, self.replicate_below)
         if self.in_library and self.sharded_levels:
             rows_cap = self._stage.shape[0]
 
@@ -202,6 +223,10 @@ class ShardedRunner:
     def collective_ms(self, reset=False):
         """GPU time between the records around every all-gather since the last reset (time_collective=True);
         includes the wait for the slowest rank's chunk, which is what the exchange costs a launch."""
+        if self.comm is not None:
+            # the engine's own events around every ncclAllGather, accumulated since ITS last reset
+            # (ServerKey.timing_enable / timing(reset=True)); `reset` is the engine's business here
+            return self.ex.exchange_ms()
         if self._events:
             self._events[-1][1].synchronize()
         ms = sum(a.elapsed_time(b) for a, b in self._events)

@@ -287,6 +287,13 @@ class Program:
         hip_check(hip.helm_hip_program_run_sharded(self.sk._h, self._h, wires._h, int(rank), int(world), int(replicate_below),
                                                    nv.vp(stage_ptr), nv.vp(gather_ptr), int(capacity_rows), fn, None))
 
+    def run_sharded_comm(self, wires, comm, replicate_below=256):
+        """The whole sharded pass with the collective inside the library too (helm_hip_program_run_sharded_comm): every
+        launch of more than `replicate_below` bootstraps is computed into this rank's slot of the program's gather
+        buffer, all-gathered in place with ncclAllGather through `comm` (helm_amd.comm.Comm) on the engine's stream and
+        scattered into the replicated wire table."""
+        hip_check(hip.helm_hip_program_run_sharded_comm(self.sk._h, self._h, wires._h, comm._h, int(replicate_below)))
+
     def scatter_level(self, wires, level, world, gathered_ptr):
         hip_check(hip.helm_hip_program_scatter_level(self.sk._h, self._h, wires._h, level, world,
                                                      nv.vp(gathered_ptr)))

@@ -153,12 +153,29 @@ class SiServerKey:
     def set_stream(self, stream_ptr):
         hip_check(hip.helm_si_set_stream(self._h, nv.vp(stream_ptr)))
 
-    def set_exchange(self, dist, rank, world, min_batch=None, capacity_rows=4096):
+    def set_exchange_comm(self, comm, min_batch=None, capacity_rows=4096):
+        """Shard every bootstrap batch of at least `min_batch` ciphertexts over the ranks of `comm`
+        (helm_amd.comm.Comm: the library's own RCCL communicator; helm_si_set_exchange_comm) - the
+        all-gather is ncclAllGather inside libhelm_hip.so on the engine's stream, no torch in the data
+        path.  comm = None switches sharding off.  A world-size-1 communicator keeps every batch on the
+        stage -> all-gather -> scatter path."""
+        if comm is None:
+            hip_check(hip.helm_si_set_exchange_comm(self._h, None, 1, 1))
+            self._exchange = None
+            return
+        if min_batch is None:
+            # a batch that fits one wave of workgroups gains nothing from sharding
+            min_batch = int(hip.helm_si_round_capacity(self._h)) + 1
+        hip_check(hip.helm_si_set_exchange_comm(self._h, comm._h, int(min_batch), int(capacity_rows)))
+        self._exchange = (comm,)  # kept alive for the engine
+
+    def set_exchange(self, dist, rank, world, min_batch=None, capacity_rows=4096, force=False):
         """Shard every bootstrap batch of at least `min_batch` ciphertexts over the `world`
         ranks of torch.distributed `dist` (backend nccl = RCCL; helm_si_set_exchange).  The
         engine is put on torch's current stream so that the all-gather is ordered behind the
-        kernels that fill the staging rows.  world <= 1 switches sharding off."""
-        if world <= 1:
+        kernels that fill the staging rows.  world <= 1 switches sharding off, unless `force`
+        (world = 1 then still sends every batch through stage -> all-gather -> scatter)."""
+        if world <= 1 and not force:
             hip_check(hip.helm_si_set_exchange(self._h, 0, 1, 1, None, None, 1, nv.SI_EXCHANGE_FN(0), None))
             self._exchange = None
             return

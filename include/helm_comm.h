@@ -1,0 +1,65 @@
+/*
+ * helm_comm.h — C ABI of the multi-GPU exchange: an RCCL communicator owned by the library.
+ *
+ * The reference has no multi-GPU code; its unit of parallelism is the level
+ * (reference src/circuit.rs:531 `gates.par_iter_mut()` for gates mode, :1057 for LUT mode,
+ * :1321 for arithmetic mode).  BASELINE.json's north star shards that unit: the gates of a level
+ * (here: of a packed launch) are split over the GPUs of a node, keys and wire tables replicated,
+ * and only the small output LWE ciphertexts are all-gathered over RCCL / xGMI.
+ *
+ * With this header the collective lives INSIDE libhelm_hip.so: a host in any language creates one
+ * communicator per process (one process per GPU), hands it to helm_hip_program_run_sharded_comm()
+ * (include/helm_hip.h) or helm_si_set_exchange_comm() (include/helm_shortint.h), and needs neither
+ * a host framework nor its own RCCL binding for the data path.  The callback forms
+ * (helm_hip_program_run_sharded, helm_si_set_exchange) stay for hosts that bring their own collective.
+ *
+ * RCCL is bound at run time (dlopen of librccl.so.1: the copy the process has already loaded - e.g.
+ * a host framework's - is reused, otherwise the loader's search path, otherwise /opt/rocm/lib), so the library
+ * loads on machines without RCCL; helm_comm_create() is what fails there (HELM_ERR_STATE).
+ *
+ * Conventions as in helm_hip.h: 0 on success, negative helm_status otherwise, message through
+ * helm_hip_last_error().  A communicator is bound to one device; collectives are issued on the
+ * stream passed in (the engine contexts pass their own), never on a hidden one.
+ */
+#ifndef HELM_COMM_H
+#define HELM_COMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct helm_comm helm_comm;
+
+#define HELM_COMM_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+
+/* 1 when an RCCL library could be bound in this process, 0 otherwise (never touches a device). */
+int helm_comm_available(void);
+/* ncclGetUniqueId: rank 0 calls it and sends the 128 bytes to the other ranks by any means it has
+ * (a file, a socket, MPI, a host framework's key-value store). */
+int helm_comm_get_unique_id(uint8_t id[HELM_COMM_ID_BYTES]);
+/* ncclCommInitRank on `device_id`: collective over the `world` processes that share `id`
+ * (world = 1 is a valid communicator: every collective still goes through RCCL). */
+int helm_comm_create(int device_id, const uint8_t id[HELM_COMM_ID_BYTES], int rank, int world, helm_comm **out);
+/* ncclCommDestroy.  NULL is accepted. */
+int helm_comm_destroy(helm_comm *comm);
+/* What RCCL itself reports for the communicator (ncclCommUserRank / ncclCommCount / ncclCommCuDevice /
+ * ncclGetVersion); any out pointer may be NULL. */
+int helm_comm_info(const helm_comm *comm, int *rank, int *world, int *device, int *rccl_version);
+/* Collectives issued so far through this communicator and the bytes this rank contributed to them. */
+int helm_comm_stats(const helm_comm *comm, int64_t *collectives, int64_t *bytes_sent);
+
+/* ncclAllGather of bytes_per_rank bytes from every rank into recv_dev (rank order) on hip_stream.
+ * In place when send_dev == recv_dev + rank * bytes_per_rank. */
+int helm_comm_all_gather(helm_comm *comm, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *hip_stream);
+/* Host-side helpers for a host without another control plane: max / sum of one double over the ranks
+ * (ncclAllReduce on a private stream, synchronous), and a barrier (an all-reduce of one word). */
+int helm_comm_all_reduce_f64(helm_comm *comm, double *value, int op /* 0 = sum, 1 = max */);
+int helm_comm_barrier(helm_comm *comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HELM_COMM_H */

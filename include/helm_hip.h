@@ -181,7 +181,7 @@ int helm_hip_program_scatter_level(helm_hip_ctx *ctx, helm_hip_program *prog, he
                                    int64_t level, int world, const void *gathered_dev);
 /* The whole sharded pass in one call - what a Rust host runs per evaluation: for every launch in order either
  * helm_hip_program_run() (launches of at most replicate_below bootstraps: one wave of workgroups absorbs them, every rank
- * computes them) or run_level_shard -> fn -> scatter_level.  fn(user, stage_dev, gather_dev, rows_per_rank) must all-gather
+ * computes them; world = 1 without a callback: every launch) or run_level_shard -> fn -> scatter_level.  fn(user, stage_dev, gather_dev, rows_per_rank) must all-gather
  * rows_per_rank rows of n+1 words of stage_dev from every rank into gather_dev in rank order ON THE CONTEXT'S STREAM
  * (ncclAllGather over RCCL/xGMI with the stream given to helm_hip_set_stream) and return 0.  stage_dev holds capacity_rows
  * rows, gather_dev capacity_rows * world.  Every rank issues the same call; identical wire tables on every rank, identical
@@ -190,6 +190,15 @@ typedef int (*helm_hip_exchange_fn)(void *user, void *stage_dev, void *gather_de
 int helm_hip_program_run_sharded(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, int rank, int world,
                                  int64_t replicate_below, void *stage_dev, void *gather_dev, int64_t capacity_rows,
                                  helm_hip_exchange_fn fn, void *user);
+/* The same pass with the collective INSIDE the library: every sharded launch is computed straight into this rank's slot
+ * of a gather buffer the program owns, all-gathered in place with ncclAllGather on the context's stream through `comm`
+ * (include/helm_comm.h: an RCCL communicator created by the library; rank and world are the communicator's) and scattered
+ * into the replicated wire table.  No callback, no host framework: what a Rust host and bench.py call.  world = 1 is valid and still
+ * sends every launch of more than replicate_below bootstraps through stage -> ncclAllGather -> scatter (the path's
+ * single-GPU test).  With timing enabled the all-gathers are bracketed by events (helm_hip_timing.exchange_ms). */
+struct helm_comm;
+int helm_hip_program_run_sharded_comm(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, struct helm_comm *comm,
+                                      int64_t replicate_below);
 /* Number of programmable bootstraps a level costs (binary gate 1, MUX 2, others 0). */
 int64_t helm_hip_program_level_pbs(helm_hip_program *prog, int64_t level);
 
@@ -217,6 +226,10 @@ typedef struct {
      * dominant kernel of wide levels); also contained in pbs_ms */
     double pbs_main_ms;
     int64_t pbs_main_launches, pbs_main_count;
+    /* in-library exchanges (helm_hip_program_run_sharded_comm): device time between the events around every
+     * ncclAllGather - it includes the wait for the slowest rank's chunk - their number and this rank's bytes */
+    double exchange_ms;
+    int64_t exchange_count, exchange_bytes;
 } helm_hip_timing;
 /* When enabled, HIP events on the context's stream bracket each kernel launch
  * (adds a sync per get_timing call, not per launch). */

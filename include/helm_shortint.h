@@ -140,11 +140,20 @@ int helm_si_eval_lut_level(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *ar
  * scatters the gathered rows into the table.  Every rank must issue the same calls in the same
  * order; the ciphertexts are identical to a single-GPU evaluation.  stage_dev holds
  * capacity_rows rows, gather_dev capacity_rows * world (larger batches go in several rounds).
- * world <= 1 switches sharding off.  The reference has no multi-GPU path; its unit of
- * parallelism is the level (src/circuit.rs:1057 par_iter_mut over the gates of a level). */
+ * world < 1, or world = 1 without a callback, switches sharding off (world = 1 WITH a callback keeps
+ * every batch on the stage -> collective -> scatter path: the single-GPU test of it).  The reference
+ * has no multi-GPU path; its unit of parallelism is the level (src/circuit.rs:1057 par_iter_mut over
+ * the gates of a level). */
 typedef int (*helm_si_exchange_fn)(void *user, int64_t rows_per_rank);
 int helm_si_set_exchange(helm_si_ctx *ctx, int32_t rank, int32_t world, int64_t min_batch, void *stage_dev,
                          void *gather_dev, int64_t capacity_rows, helm_si_exchange_fn fn, void *user);
+/* The same with the collective INSIDE the library: the all-gather is ncclAllGather through `comm`
+ * (include/helm_comm.h; rank and world are the communicator's) on the context's stream, into a gather
+ * buffer of capacity_rows * world rows the context allocates; this rank's chunk is bootstrapped straight
+ * into its slot of that buffer (all-gather in place).  No callback, no host framework - what a Rust host calls.
+ * comm = NULL switches sharding off.  The communicator must outlive the setting. */
+struct helm_comm;
+int helm_si_set_exchange_comm(helm_si_ctx *ctx, struct helm_comm *comm, int64_t min_batch, int64_t capacity_rows);
 /* batches sharded so far and rows moved through gather_dev (per rank) */
 int helm_si_exchange_stats(const helm_si_ctx *ctx, int64_t *batches, int64_t *rows);
 /* the `world` of helm_si_set_exchange (1: sharding off).  A lane does not inherit the exchange of its primary: callers

@@ -31,6 +31,7 @@ def _declared(header, prefix, exclude=None):
     ("helm_client.h", "helm_keys_", nv.host, nv.KEYS_API, None),
     ("helm_wopbs.h", "helm_wop_", nv.hip, nv.WOP_API, "helm_wop_client_"),
     ("helm_wopbs.h", "helm_wop_client_", nv.host, nv.WOP_CLIENT_API, None),
+    ("helm_comm.h", "helm_comm_", nv.hip, nv.COMM_API, None),
 ])
 def test_every_declared_symbol_is_exported_and_bound(header, prefix, lib, table, exclude):
     names = _declared(header, prefix, exclude)
@@ -43,7 +44,7 @@ def test_every_declared_symbol_is_exported_and_bound(header, prefix, lib, table,
 
 
 def test_no_torch_types_in_the_abi():
-    for h in ("helm_hip.h", "helm_shortint.h", "helm_client.h", "helm_host.h", "helm_wopbs.h"):
+    for h in ("helm_hip.h", "helm_shortint.h", "helm_client.h", "helm_host.h", "helm_wopbs.h", "helm_comm.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
         assert "torch" not in text.lower() and "at::" not in text and "#include <hip" not in text
 
@@ -108,6 +109,25 @@ def test_shortint_client_roundtrip():
     # multi-bit key: 2^g GGSWs per group of g mask words (include/helm_shortint.h)
     ck = helm_amd.SiClientKey.generate("si_toy_2048_mb3", seed=4)
     assert ck.bsk.size == (ck.params.n // 3) * 8 * ck.params.pbs_l * 4 * ck.params.N
+
+
+def test_communicator_binds_rccl_lazily_and_validates_without_a_device(have_gpu):
+    """include/helm_comm.h: libhelm_hip.so has no link-time dependency on librccl (dlopen at first use: a process that
+    already holds PyTorch's copy keeps it), and argument validation needs no device."""
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", os.path.join(ROOT, "helm_amd", "csrc", "libhelm_hip.so")],
+                            capture_output=True, text=True).stdout
+    assert "librccl" not in needed
+    h = nv.vp()
+    ident = np.zeros(128, dtype=np.uint8)
+    assert nv.hip.helm_comm_create(0, None, 0, 1, C.byref(h)) == -1
+    assert nv.hip.helm_comm_create(0, nv.as_u8p(ident), 2, 2, C.byref(h)) == -1     # rank outside the world
+    assert b"rank" in nv.hip.helm_hip_last_error()
+    assert nv.hip.helm_comm_destroy(None) == 0
+    assert nv.hip.helm_comm_all_gather(None, None, None, 16, None) == -1
+    assert nv.hip.helm_comm_available() in (0, 1)
+    if not have_gpu and nv.hip.helm_comm_available():
+        assert nv.hip.helm_comm_create(0, nv.as_u8p(ident), 0, 1, C.byref(h)) == -2   # HELM_ERR_NO_DEVICE: no fallback
 
 
 def test_no_cpu_fallback(have_gpu):

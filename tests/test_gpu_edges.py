@@ -129,3 +129,46 @@ def test_circuit_without_a_bootstrap(toy):
     enc = gc.encrypt_inputs(wire_set, {"a": PtxtType.Bool(True), "b": PtxtType.Bool(True)})
     res = gc.decrypt_outputs(gc.evaluate_encrypted(enc, 1, "bool"), False)
     assert {k: bool(v.value) for k, v in res.items()} == {"y0": False, "y1": True}
+
+
+def test_levels_with_intra_level_hazards_are_refused(toy):
+    """The gates of a level run concurrently (reference src/circuit.rs:531); the reference gets its guarantee that none reads
+    what another writes from compute_levels (circuit.rs:174-239).  A host with a wrong level map gets HELM_ERR_INVALID - not
+    silently non-deterministic ciphertexts - from helm_hip_program_create and helm_hip_eval_gate_level; a gate that updates
+    its OWN row in place (the READY latch, circuit.rs:482-504) is legal."""
+    ck, sk = toy
+    A, X, N = oracle.AND, oracle.XOR, oracle.NOT
+    m1 = np.full(2, -1, np.int32)
+
+    def create(ops, i0, i1, out, off):
+        return helm_amd.Program(sk, np.array(ops, np.int32), np.array(i0, np.int32), np.array(i1, np.int32),
+                                np.full(len(ops), -1, np.int32), np.array(out, np.int32), np.array(off, np.int64))
+    # read-after-write: gate 1 reads wire 2, which gate 0 of the same level writes
+    with pytest.raises(helm_amd.HelmError, match="read-after-write"):
+        create([A, X], [0, 2], [1, 1], [2, 3], [0, 2])
+    # the same two gates in two levels are fine
+    create([A, X], [0, 2], [1, 1], [2, 3], [0, 1, 2]).destroy()
+    # write-after-write: both gates write wire 2
+    with pytest.raises(helm_amd.HelmError, match="write-after-write"):
+        create([A, X], [0, 0], [1, 1], [2, 2], [0, 2])
+    # a free gate reading a bootstrapped gate's output row inside the level
+    with pytest.raises(helm_amd.HelmError, match="read-after-write"):
+        create([A, N], [0, 2], [1, -1], [2, 3], [0, 2])
+    # the hazard is per level: level 1 may rewrite a row level 0 wrote, and read it
+    create([A, X], [0, 2], [1, 0], [2, 2], [0, 1, 2]).destroy()
+    w = sk.wires(6)
+    w.upload(np.arange(2, dtype=np.int32), ck.encrypt(np.array([True, False])))
+    for dense in (True, False):  # both forms of the per-level check (full row map / compacted rows of a narrow level)
+        ww = w if dense else sk.wires(4096)
+        with pytest.raises(helm_amd.HelmError, match="read-after-write"):
+            ww.eval_gate_level([A, X], [0, 2], [1, 1], m1, [2, 3])
+        with pytest.raises(helm_amd.HelmError, match="write-after-write"):
+            ww.eval_gate_level([A, X], [0, 0], [1, 1], m1, [2, 2])
+    # in place: out = AND(in0, out) reads and writes its own row - every kernel reads before it writes
+    w.set_trivial([2], [True])
+    w.eval_gate_level([A], [0], [2], [-1], [2])
+    sk.sync()
+    assert bool(ck.decrypt(w.download([2]))[0]) is True
+    w.eval_gate_level([A], [1], [2], [-1], [2])
+    sk.sync()
+    assert bool(ck.decrypt(w.download([2]))[0]) is False
