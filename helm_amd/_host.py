@@ -55,6 +55,10 @@ HOST_API = {
     "helm_host_si_circuit_set_wopbs": (C.c_int, [vp, vp, C.c_int]),
     "helm_host_si_circuit_add_lane": (C.c_int, [vp, vp]),
     "helm_host_si_circuit_set_lazy_carries": (C.c_int, [vp, C.c_int]),
+    "helm_host_si_circuit_set_round_capacity": (C.c_int, [vp, C.c_int64]),
+    "helm_host_si_circuit_set_memo": (C.c_int, [vp, C.c_int]),
+    "helm_host_si_circuit_reset_memo": (C.c_int, [vp]),
+    "helm_host_si_circuit_set_timing_lines": (C.c_int, [vp, C.c_int]),
     "helm_host_si_circuit_log": (vp, [vp]),
     "helm_host_radix_scratch_rows": (C.c_int64, [vp, C.c_int32, vp, C.c_int64]),
     "helm_host_radix_level": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

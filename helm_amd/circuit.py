@@ -259,10 +259,36 @@ class LutCircuit(_SiCircuit):
                                                       int(bits_per_block)))
         self._wop = wop_server_key  # keep alive
 
+    def set_timing_lines(self, on=True):
+        """The per-gate `PBS time: {} us` lines of reference src/gates.rs:293-302 (default on) cost one host
+        synchronisation per level; False drops the lines and the synchronisation."""
+        H.check(H.host.helm_host_si_circuit_set_timing_lines(self._h, int(bool(on))))
+
 
 class ArithCircuit(_SiCircuit):
-    """reference src/circuit.rs:81-85, 1112-1500"""
+    """reference src/circuit.rs:81-85, 1112-1500
+
+    SAME-CYCLE MEMO - read this before calling evaluate_encrypted twice.  As in the reference (src/gates.rs:307-312:
+    `if self.cycle == cycle { return cached }`, the operands are not looked at; tests/gates_test.rs:196-223 relies on
+    it, tests/circuit_test.rs:314-474 passes cycles 1..4 to defeat it), the memo is keyed on the cycle number ALONE:
+    evaluate_encrypted(other_inputs, same_cycle) returns the FIRST call's gate outputs and launches nothing.
+    GateCircuit and LutCircuit differ: they only answer from the memo for the very same, unmodified input map.  Pass a
+    new cycle for new inputs, or call reset_memo() / set_memo(False).  set_lanes, set_lazy_carries and
+    set_round_capacity reset the memo."""
     MODE = 1
+
+    def set_memo(self, on=True):
+        """Switch the same-cycle memo (class docstring) off or back on (helm_host_si_circuit_set_memo)."""
+        H.check(H.host.helm_host_si_circuit_set_memo(self._h, int(bool(on))))
+
+    def reset_memo(self):
+        """Forget the remembered cycle and release the device copy of its wire map."""
+        H.check(H.host.helm_host_si_circuit_reset_memo(self._h))
+
+    def set_round_capacity(self, capacity=0):
+        """Merged rounds: launches of at most `capacity` ciphertexts (0 = what the device bootstraps at once).  A round
+        is cut where it does not fit; every round is checked to list the readers of a row before its in-place writer."""
+        H.check(H.host.helm_host_si_circuit_set_round_capacity(self._h, int(capacity)))
 
     def set_lazy_carries(self, on=True):
         """Carry-save products feeding additions / subtractions (default on; helm_host_si_circuit_set_lazy_carries)."""

@@ -407,6 +407,42 @@ int helm_host_si_circuit_set_lazy_carries(helm_si_circuit *c, int on)
     c->arith->set_lazy_carries(on != 0);
     return 0;
 }
+int helm_host_si_circuit_set_round_capacity(helm_si_circuit *c, int64_t capacity)
+{
+    if (!c || !c->arith || capacity < 0) {
+        g_err = "set_round_capacity: not an arithmetic-mode circuit, or a negative capacity";
+        return -1;
+    }
+    c->arith->set_round_capacity(capacity);
+    return 0;
+}
+int helm_host_si_circuit_set_memo(helm_si_circuit *c, int on)
+{
+    if (!c || !c->arith) {
+        g_err = "set_memo: not an arithmetic-mode circuit";
+        return -1;
+    }
+    c->arith->set_memo(on != 0);
+    return 0;
+}
+int helm_host_si_circuit_reset_memo(helm_si_circuit *c)
+{
+    if (!c || !c->arith) {
+        g_err = "reset_memo: not an arithmetic-mode circuit";
+        return -1;
+    }
+    c->arith->reset_memo();
+    return 0;
+}
+int helm_host_si_circuit_set_timing_lines(helm_si_circuit *c, int on)
+{
+    if (!c || !c->lut) {
+        g_err = "set_timing_lines: not a LUT-mode circuit";
+        return -1;
+    }
+    c->lut->set_timing_lines(on != 0);
+    return 0;
+}
 char *helm_host_si_circuit_log(helm_si_circuit *c) { return dup(c->lut ? c->lut->log() : c->arith->log()); }
 int64_t helm_host_si_circuit_pbs_per_cycle(const helm_si_circuit *c)
 {

@@ -161,6 +161,14 @@ uint64_t next_map_id(); // process-wide counter behind EncWireMap::id() / SiEncW
 // Same-cycle memo of an evaluator (reference src/gates.rs:55-59: every Gate keeps `cycle` and its last encrypted
 // output, and gates.rs:288-292, 307-312 return it when called again in that cycle).  All gates of a circuit are
 // evaluated with the same cycle, so the memo lives once per circuit: the wire map the cycle produced.
+// The evaluators' progress text (what the reference prints) is kept until log() is read; a host that never reads it must
+// not grow without bound: beyond 1 MiB the older half is dropped.
+inline void append_log(std::string &log, const std::string &text)
+{
+    log += text;
+    if (log.size() > (1u << 20)) log = "[... older lines dropped ...]\n" + log.substr(log.size() - (1u << 19));
+}
+
 template <typename MapT> struct CycleMemo {
     bool valid = false;
     size_t cycle = 0;
@@ -316,12 +324,17 @@ class LutCircuit : public EvalCircuit<SiEncWireMap> {
     // Gate::evaluate_encrypted_high_precision_lut (gates.rs:721-742): LUT gates whose index does not fit one block
     // (more inputs than log2(message_modulus * carry_modulus)) go through the WoP-PBS path once a key is set
     void set_wide_lut_key(helm_wop_ctx *wop, int bits_per_block);
+    // The reference prints `PBS time: {} us` for every LUT gate (gates.rs:293-302); here that is one line per LUT gate
+    // carrying its level's time, which costs one host synchronisation per level.  set_timing_lines(false) drops the
+    // lines AND the per-level synchronisation: the host then prepares the next level while the GPU runs this one.
+    void set_timing_lines(bool on) { timing_lines_ = on; }
 
   private:
     helm_si_client_key *client_key_;
     helm_si_ctx *server_key_;
     helm_wop_ctx *wop_ = nullptr;
     int wop_bits_per_block_ = 1;
+    bool timing_lines_ = true;
     Circuit circuit_;
     helm_si_params P_{};
     int64_t pbs_count_ = 0;
@@ -357,7 +370,7 @@ struct RadixOp {
 // round instead of per level - identical ciphertexts, the device never waits for a launch slot.
 class RoundMerger {
   public:
-    RoundMerger(helm_si_ctx *ctx, int chains, int64_t capacity);
+    RoundMerger(helm_si_ctx *ctx, int chains, int64_t capacity, bool strict = false);
     void set_remaining(int chain, int64_t rounds) { remaining_[(size_t)chain] = rounds; }
     // the chain's next round; returns once all of it is ENQUEUED (stream order does the rest)
     void submit(int chain, helm_si_wires *w, const std::vector<int32_t> &in, const std::vector<int32_t> &lut,
@@ -378,6 +391,7 @@ class RoundMerger {
     void issue_locked();
     helm_si_ctx *ctx_;
     int64_t capacity_;
+    bool strict_;
     std::mutex mu_;
     std::condition_variable cv_;
     std::vector<Sub> subs_;
@@ -445,20 +459,31 @@ class ArithCircuit : public EvalCircuit<SiEncWireMap> {
     std::string log() { std::string s; s.swap(log_); return s; }
     // Lanes (helm_si_ctx_fork): sub-circuits that share no wire are evaluated concurrently, one lane each, instead of
     // meeting at every level boundary (circuit.rs:1321 joins the whole level).  Same ciphertexts, fewer rounds in a row.
-    // Default: with two or more independent sub-circuits the circuit forks ONE lane of its own.  add_lane() installs
-    // the caller's lanes instead; clear_lanes() switches lanes off altogether (level by level, as the reference).
-    void add_lane(helm_si_ctx *lane) { lanes_.push_back(lane); }
-    void clear_lanes() { lanes_.clear(); auto_lanes_ = false; }
-    void set_lazy_carries(bool on) { lazy_carries_ = on; }
+    // Default: with two or more independent sub-circuits they run as chains on the server key's own context, their look-up
+    // rounds merged (RoundMerger).  add_lane() installs the caller's lanes instead; clear_lanes() switches concurrency
+    // off altogether (level by level, as the reference).
+    // (every schedule switch also drops the same-cycle memo: a cycle evaluated under another schedule is not "the same call")
+    void add_lane(helm_si_ctx *lane) { lanes_.push_back(lane); reset_memo(); }
+    void clear_lanes() { lanes_.clear(); auto_lanes_ = false; reset_memo(); }
+    void set_lazy_carries(bool on) { lazy_carries_ = on; reset_memo(); }
+    // The same-cycle memo is keyed on the cycle ALONE, as the reference's (gates.rs:307-312): evaluate_encrypted with a
+    // cycle that was already evaluated returns that cycle's gate outputs WHATEVER the inputs.  reset_memo() forgets the
+    // remembered cycle (and releases the device copy of its wire map); set_memo(false) switches the memo off.
+    void reset_memo() { memo_.valid = false; memo_.out.reset(); }
+    void set_memo(bool on) { memo_on_ = on; if (!on) reset_memo(); }
+    // Merged rounds: launches of at most this many ciphertexts (0 = helm_si_round_capacity(), what the device
+    // bootstraps at once).  Tests force 1 to cut every round into single-ciphertext launches.
+    void set_round_capacity(int64_t capacity) { round_capacity_ = capacity; reset_memo(); }
 
   private:
     void encrypt_value(SiEncWireMap &m, const std::string &wire, unsigned __int128 value);
     helm_si_client_key *client_key_;
     helm_si_ctx *server_key_;
     std::vector<helm_si_ctx *> lanes_;
-    helm_si_ctx *own_lane_ = nullptr; // forked on first need when auto_lanes_
     bool auto_lanes_ = true;
-    bool lazy_carries_ = true; // carry-save products feeding additions / subtractions (HELM_LAZY_CARRIES=0: off)
+    bool lazy_carries_ = true; // carry-save products feeding additions / subtractions (set_lazy_carries)
+    bool memo_on_ = true;
+    int64_t round_capacity_ = 0;
     Circuit circuit_;
     helm_si_params P_{};
     std::string global_ptxt_type_;

@@ -13,6 +13,7 @@
 // reference's tests pin: tests/gates_test.rs:127-310, tests/circuit_test.rs:349-368).
 #include "helm_host.hpp"
 #include <functional>
+#include <unordered_set>
 #include <thread>
 
 #include <algorithm>
@@ -347,14 +348,16 @@ std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap 
                   "eval_lut_level");
         std::ostringstream os;
         // gates.rs:293-302 prints the time of every gate's lut() call; the gates of a level are one batched dispatch
-        // here, so each of them took the level's time (one synchronisation per level: microseconds next to the
-        // milliseconds of a bootstrap round)
-        si_ok(helm_si_sync(server_key_), "sync");
-        const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - level_start).count();
-        for (auto &g : gates)
-            if (g.get_gate_type() == GateType::Lut) os << "PBS time: " << us << " us\n";
+        // here, so each of them took the level's time.  That needs one host synchronisation per level, which also keeps
+        // the host from preparing the next level meanwhile: set_timing_lines(false) drops both.
+        if (timing_lines_) {
+            si_ok(helm_si_sync(server_key_), "sync");
+            const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - level_start).count();
+            for (auto &g : gates)
+                if (g.get_gate_type() == GateType::Lut) os << "PBS time: " << us << " us\n";
+        }
         os << "  Evaluated gates in level [" << kv.first << "/" << total_levels << "]\n";
-        log_ += os.str();
+        append_log(log_, os.str());
     }
     si_ok(helm_si_sync(server_key_), "sync");
     memo_.out = eval_values->clone(0);
@@ -443,8 +446,8 @@ RadixEngine::RadixEngine(helm_si_ctx *ctx, int nb) : ctx_(ctx), nb_(nb)
 // ---------------------------------------------------------------------------------------
 // RoundMerger
 // ---------------------------------------------------------------------------------------
-RoundMerger::RoundMerger(helm_si_ctx *ctx, int chains, int64_t capacity)
-    : ctx_(ctx), capacity_(std::max<int64_t>(capacity, 1)), subs_((size_t)chains), remaining_((size_t)chains, 0),
+RoundMerger::RoundMerger(helm_si_ctx *ctx, int chains, int64_t capacity, bool strict)
+    : ctx_(ctx), capacity_(std::max<int64_t>(capacity, 1)), strict_(strict), subs_((size_t)chains), remaining_((size_t)chains, 0),
       active_((size_t)chains, 1)
 {
 }
@@ -468,7 +471,8 @@ void RoundMerger::issue_locked()
             if (subs_[c].present) order.push_back(c);
         std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return remaining_[x] > remaining_[y]; });
         // a single chain left, or everything fits: one launch; otherwise fill the device once, most urgent chain first
-        const int64_t cap = (present == 1 || total <= capacity_) ? total : capacity_;
+        // (strict_: a capacity the caller set is honoured for a lone chain too - the tests' way to cut everywhere)
+        const int64_t cap = ((present == 1 && !strict_) || total <= capacity_) ? total : capacity_;
         std::vector<int32_t> in, lut, out;
         in.reserve((size_t)cap), lut.reserve((size_t)cap), out.reserve((size_t)cap);
         const Sub &first = subs_[order[0]];
@@ -508,6 +512,22 @@ void RoundMerger::issue_locked()
 void RoundMerger::submit(int chain, helm_si_wires *w, const std::vector<int32_t> &in, const std::vector<int32_t> &lut,
                          const std::vector<int32_t> &out, const uint64_t *luts, int64_t n_luts)
 {
+    // Ordering contract of a round (RadixEngine::apply): the merger may cut a round into several launches, so the
+    // guarantee of ONE helm_si_apply_luts call - every keyswitch reads its input before any bootstrap writes - only holds
+    // inside each part.  A round is therefore safe to cut anywhere iff no entry reads a row an EARLIER-listed entry writes
+    // (readers of a row come before its in-place writer; an entry may rewrite its own input row).  Checked here, for every
+    // round, whether or not this device's capacity happens to cut it: a batch that lists a writer first would otherwise
+    // return wrong ciphertexts on some devices only.
+    {
+        std::unordered_set<int32_t> written;
+        written.reserve(out.size() * 2);
+        for (size_t i = 0; i < in.size(); i++) {
+            if (written.count(in[i]))
+                throw Panic("round merger: entry " + std::to_string(i) + " of a look-up round reads row " + std::to_string(in[i]) +
+                            ", which an earlier entry of the same round writes - list the readers of a row before its in-place writer");
+            written.insert(out[i]);
+        }
+    }
     std::unique_lock<std::mutex> lk(mu_);
     if (!error_.empty()) throw Panic(error_);
     Sub &s = subs_[(size_t)chain];
@@ -995,6 +1015,11 @@ void RadixEngine::run_level(helm_si_wires *w, const std::vector<RadixOp> &ops_in
     // look-up per block, where the digit-wise product (block values up to 6) would need a full carry propagation
     // (x * 2: one round of bootstraps instead of six; same value mod 2^bits)
     std::vector<RadixOp> ops(ops_in);
+    // x * s = x * (s mod 2^bits) mod 2^bits: a scalar is reduced to the operand's width FIRST, so that 2^s with s >= bits is
+    // the product by zero it is and not a shift by s mod bits (helm_host_radix_level takes a raw 128-bit scalar)
+    const unsigned __int128 width_mask = 2 * nb_ >= 128 ? ~(unsigned __int128)0 : (((unsigned __int128)1 << (2 * nb_)) - 1);
+    for (auto &op : ops)
+        if (op.kind == RadixOp::MulScalar) op.scalar &= width_mask;
     for (auto &op : ops)
         if (op.kind == RadixOp::MulScalar && op.scalar >= 2 && (op.scalar & (op.scalar - 1)) == 0) {
             int s = 0;
@@ -1344,10 +1369,7 @@ static size_t component_count(const std::vector<std::vector<RadixOp>> &plan)
     return roots.size();
 }
 
-ArithCircuit::~ArithCircuit()
-{
-    if (own_lane_) helm_si_ctx_destroy(own_lane_); // before its primary, which the caller owns
-}
+ArithCircuit::~ArithCircuit() = default;
 
 ArithCircuit::ArithCircuit(helm_si_client_key *client_key, helm_si_ctx *server_key, Circuit circuit)
     : client_key_(client_key), server_key_(server_key), circuit_(std::move(circuit))
@@ -1433,7 +1455,7 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
     // Same-cycle memo, keyed on the cycle ALONE as in the reference (gates.rs:307-312 and every *_block method: `if
     // self.cycle == cycle { return cached }`, the operands are not looked at; tests/gates_test.rs:196-223).  Every gate
     // then hands back its cached output: the result is the given map with the gate outputs of that cycle, no launch.
-    if (memo_.hit(cycle) && memo_.out->blocks() == nb) {
+    if (memo_on_ && memo_.hit(cycle) && memo_.out->blocks() == nb) {
         memo_hits_++;
         auto cached = enc_wire_map.clone(0);
         std::vector<int32_t> src, dst;
@@ -1452,6 +1474,7 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
         return cached;
     }
     auto remember = [&](SiEncWireMap &values) {
+        if (!memo_on_) return;
         memo_.out = values.clone(0);
         memo_.cycle = cycle;
         memo_.in_id = enc_wire_map.id();
@@ -1696,7 +1719,13 @@ std::unique_ptr<SiEncWireMap> ArithCircuit::evaluate_encrypted(const SiEncWireMa
                 }
             const size_t crit = (size_t)(std::max_element(chain.begin(), chain.end()) - chain.begin());
             if (merged) {
-                merger.reset(new RoundMerger(server_key_, (int)n_ctx, helm_si_round_capacity(server_key_)));
+                int64_t capacity = round_capacity_;
+                if (capacity <= 0) {
+                    capacity = helm_si_round_capacity(server_key_);
+                    if (capacity <= 0) // a failed occupancy query must not turn into one-ciphertext launches
+                        throw Panic(std::string("helm_si_round_capacity: ") + helm_hip_last_error());
+                }
+                merger.reset(new RoundMerger(server_key_, (int)n_ctx, capacity, round_capacity_ > 0));
                 for (size_t lane = 0; lane < n_ctx; lane++) merger->set_remaining((int)lane, chain[lane]);
             } else {
                 for (size_t lane = 0; lane < n_ctx; lane++) si_ok(helm_si_set_priority(ctx_of(lane), lane == crit ? 1 : 0), "set_priority");

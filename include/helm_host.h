@@ -140,6 +140,19 @@ int helm_host_si_circuit_add_lane(helm_si_circuit *c, helm_si_ctx *lane);
  * sums the terms of both operands and propagates carries once - a * b - c * d costs 11 + 7 rounds of bootstraps in a row
  * instead of 11 + 6 + 6.  Same values mod 2^bits on every wire; 0 = every operator propagates (as round 2). */
 int helm_host_si_circuit_set_lazy_carries(helm_si_circuit *c, int on);
+/* Arithmetic mode, merged rounds: launches of at most `capacity` ciphertexts (0 = helm_si_round_capacity(), the default).
+ * A round that does not fit is cut; the cut is safe because every round lists the readers of a row before its in-place
+ * writer - checked for every round, a violation is an error whatever the capacity.  Tests force capacity 1. */
+int helm_host_si_circuit_set_round_capacity(helm_si_circuit *c, int64_t capacity);
+/* Arithmetic mode, same-cycle memo (see helm_host_si_circuit_memo_hits): on by default and keyed on the cycle ALONE as the
+ * reference's (src/gates.rs:307-312) - evaluate_encrypted with an already evaluated cycle returns that cycle's gate outputs
+ * WHATEVER the inputs.  set_memo(0) switches it off, reset_memo() forgets the remembered cycle; changing lanes, lazy carries
+ * or the round capacity resets it too. */
+int helm_host_si_circuit_set_memo(helm_si_circuit *c, int on);
+int helm_host_si_circuit_reset_memo(helm_si_circuit *c);
+/* LUT mode: the per-gate `PBS time: {} us` lines of src/gates.rs:293-302 (default on) cost one host synchronisation per
+ * level; 0 drops the lines and the synchronisation. */
+int helm_host_si_circuit_set_timing_lines(helm_si_circuit *c, int on);
 /* One level of arithmetic-mode operators as ONE batched call on a table of radix integers - what the reference does
  * gate by gate with the FheUintN operators (src/gates.rs:306-702: evaluate_encrypted_{copy,mul,div,add,sub,shift}_block
  * and their _plain forms; level loop src/circuit.rs:1320-1441).  An integer is `blocks` consecutive rows (2 message bits

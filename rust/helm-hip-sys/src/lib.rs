@@ -39,6 +39,10 @@ pub struct helm_si_params {
 #[repr(C)] pub struct helm_hip_program { _p: [u8; 0] }
 #[repr(C)] pub struct helm_si_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct helm_si_wires { _p: [u8; 0] }
+#[repr(C)] pub struct helm_comm { _p: [u8; 0] }
+
+/// include/helm_comm.h: bytes of an RCCL unique id (= NCCL_UNIQUE_ID_BYTES)
+pub const HELM_COMM_ID_BYTES: usize = 128;
 
 // include/helm_hip.h `helm_gate_op` (declaration order of GateType, reference src/gates.rs:23-45; the shim maps the
 // enum with an explicit match, helm-hip/src/lib.rs::gate_opcode)
@@ -85,6 +89,7 @@ pub struct helm_radix_op {
 #[repr(C)] pub struct helm_circuit { _p: [u8; 0] }
 #[repr(C)] pub struct helm_si_circuit { _p: [u8; 0] }
 #[repr(C)] pub struct helm_si_enc_map { _p: [u8; 0] }
+#[repr(C)] pub struct helm_si_client_key { _p: [u8; 0] } // include/helm_client.h: the library's own client key (tests, benches)
 
 extern "C" {
     // ---- include/helm_hip.h ---------------------------------------------------------------
@@ -117,6 +122,20 @@ extern "C" {
                                         exchange: extern "C" fn(*mut c_void, *mut c_void, *mut c_void, i64) -> c_int,
                                         user: *mut c_void) -> c_int;
 
+    // the same pass with the collective inside the library: ncclAllGather through a communicator of include/helm_comm.h
+    pub fn helm_hip_program_run_sharded_comm(ctx: *mut helm_hip_ctx, prog: *mut helm_hip_program, w: *mut helm_hip_wires,
+                                             comm: *mut helm_comm, replicate_below: i64) -> c_int;
+
+    // ---- include/helm_comm.h: the library's own RCCL communicator (one process per GPU) --------
+    pub fn helm_comm_available() -> c_int;
+    pub fn helm_comm_get_unique_id(id: *mut u8) -> c_int;
+    pub fn helm_comm_create(device_id: c_int, id: *const u8, rank: c_int, world: c_int, out: *mut *mut helm_comm) -> c_int;
+    pub fn helm_comm_destroy(comm: *mut helm_comm) -> c_int;
+    pub fn helm_comm_info(comm: *const helm_comm, rank: *mut c_int, world: *mut c_int, device: *mut c_int,
+                          rccl_version: *mut c_int) -> c_int;
+    pub fn helm_comm_all_reduce_f64(comm: *mut helm_comm, value: *mut f64, op: c_int) -> c_int;
+    pub fn helm_comm_barrier(comm: *mut helm_comm) -> c_int;
+
     // ---- include/helm_host.h: launch packing of the level map -------------------------------
     pub fn helm_host_pack_levels(opcode: *const i32, in0: *const i32, in1: *const i32, in2: *const i32, out: *const i32,
                                  level_offsets: *const i64, n_levels: i64, quantum: i64, order: *mut i64,
@@ -138,7 +157,7 @@ extern "C" {
     pub fn helm_host_circuit_free(c: *mut helm_circuit);
     pub fn helm_host_circuit_sort_circuit(c: *mut helm_circuit) -> c_int;
     pub fn helm_host_circuit_compute_levels(c: *mut helm_circuit) -> c_int;
-    pub fn helm_host_si_circuit_new(mode: c_int, client_key: *mut c_void, server_key: *mut helm_si_ctx, circuit: *const helm_circuit,
+    pub fn helm_host_si_circuit_new(mode: c_int, client_key: *mut helm_si_client_key, server_key: *mut helm_si_ctx, circuit: *const helm_circuit,
                                     out: *mut *mut helm_si_circuit) -> c_int;
     pub fn helm_host_si_circuit_free(c: *mut helm_si_circuit);
     pub fn helm_host_si_circuit_evaluate_encrypted(c: *mut helm_si_circuit, enc_wire_map: *const helm_si_enc_map,
@@ -173,6 +192,8 @@ extern "C" {
     pub fn helm_si_sync(ctx: *mut helm_si_ctx) -> c_int;
     pub fn helm_si_set_priority(ctx: *mut helm_si_ctx, high: c_int) -> c_int;
     pub fn helm_si_round_capacity(ctx: *mut helm_si_ctx) -> i64;
+    // multi-GPU: every bootstrap batch of at least min_batch ciphertexts sharded over the communicator's ranks
+    pub fn helm_si_set_exchange_comm(ctx: *mut helm_si_ctx, comm: *mut helm_comm, min_batch: i64, capacity_rows: i64) -> c_int;
 
     // ---- include/helm_wopbs.h (WoP-PBS wide-LUT path) ------------------------------------------
     pub fn helm_wop_ctx_create(pbs_side: *mut helm_si_ctx, params: *const helm_wop_params, out: *mut *mut helm_wop_ctx) -> c_int;

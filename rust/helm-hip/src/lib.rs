@@ -9,10 +9,12 @@ pub mod arith;
 pub mod arith_whole;
 pub mod keys;
 pub mod lut;
+pub mod multi_gpu;
 pub mod wopbs;
 
 pub use arith::HipArithCircuit;
 pub use lut::HipLutCircuit;
+pub use multi_gpu::HipComm;
 
 use helm::circuit::{Circuit, EvalCircuit};
 use helm::gates::GateType;
@@ -35,6 +37,9 @@ pub struct HipGateCircuit<'a> {
     row_of: HashMap<String, i32>,
     n_launches: i64,
     lwe_words: usize, // n + 1
+    // multi-GPU (multi_gpu.rs): a communicator of include/helm_comm.h, or null for one GPU
+    pub(crate) comm: *mut sys::helm_comm,
+    pub(crate) replicate_below: i64,
 }
 
 pub(crate) fn check(rc: i32) {
@@ -85,6 +90,7 @@ impl<'a> HipGateCircuit<'a> {
         HipGateCircuit {
             circuit, client_key, ctx, wires: std::ptr::null_mut(), prog: std::ptr::null_mut(),
             row_of: HashMap::new(), n_launches: 0, lwe_words: std_keys.params.n as usize + 1,
+            comm: std::ptr::null_mut(), replicate_below: 256,
         }
     }
 
@@ -168,7 +174,12 @@ impl<'a> EvalCircuit<DeviceWire> for HipGateCircuit<'a> {
     /// per-level progress lines of :542).
     fn evaluate_encrypted(&mut self, enc_wire_map: &HashMap<String, DeviceWire>, _current_cycle: usize, _ptxt_type: &str)
         -> HashMap<String, DeviceWire> {
-        check(unsafe { sys::helm_hip_program_run(self.ctx, self.prog, self.wires, 0, self.n_launches) });
+        if self.comm.is_null() {
+            check(unsafe { sys::helm_hip_program_run(self.ctx, self.prog, self.wires, 0, self.n_launches) });
+        } else {
+            // launches split over the ranks, outputs all-gathered with ncclAllGather inside the library (multi_gpu.rs)
+            check(unsafe { sys::helm_hip_program_run_sharded_comm(self.ctx, self.prog, self.wires, self.comm, self.replicate_below) });
+        }
         check(unsafe { sys::helm_hip_sync(self.ctx) });
         enc_wire_map.clone() // rows are stable; the values changed in HBM
     }

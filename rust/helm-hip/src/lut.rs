@@ -18,7 +18,7 @@ use tfhe::shortint::prelude::*;
 pub struct HipLutCircuit<'a> {
     circuit: Circuit<'a>,
     client_key: ClientKey,
-    ctx: *mut sys::helm_si_ctx,
+    pub(crate) ctx: *mut sys::helm_si_ctx,
     wires: *mut sys::helm_si_wires,
     row_of: HashMap<String, i32>,
     row_words: usize, // k N + 1

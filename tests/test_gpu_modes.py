@@ -571,3 +571,95 @@ endmodule
     enc = ac.encrypt_inputs(wire_set, {"N0": PtxtType.U32(2), "N1": PtxtType.U32(7), "N2": PtxtType.U32(9)})
     out = {k: v.value for k, v in ac.decrypt_outputs(ac.evaluate_encrypted(enc, 1, "u32"), True).items()}
     assert out == {"alpha": 529, "beta1": 242, "beta2": 275, "beta3": 1250}
+
+
+def test_merged_rounds_cut_at_capacity_one_are_bit_identical(keys):
+    """RoundMerger with the capacity forced to ONE ciphertext per launch: every look-up round of every chain is cut into
+    single-ciphertext launches, i.e. at every position a cut can fall.  The one-call guarantee (all keyswitches before any
+    bootstrap writes) then only holds inside each part, so a batch that listed an in-place writer before a reader of the same
+    row would return other ciphertexts here - the rounds' ordering contract (readers first), which the merger now checks for
+    every round whatever the device's capacity.  Same ciphertext on every wire as the level-by-level evaluation."""
+    client_key, server_key = keys
+    text = """input [7:0] A, B, C, D, E, F, G;
+output [7:0] X, Y, Z, W;
+mult g0(A, B, p0);
+mult g1(C, C, p1);
+add g2(p0, p1, X);
+sub g3(D, E, t0);
+shl g4(t0, 3, Y);
+add g5(F, 77, t1);
+mult g6(t1, 6, Z);
+shr g7(G, 1, W);
+"""
+    circuit, wire_set, _, _ = _circuit(text, is_arith=True, is_text=True)
+    vals = dict(A=201, B=77, C=254, D=3, E=200, F=250, G=0xB7)
+    m = 256
+    want = {"p0": vals["A"] * vals["B"] % m, "p1": vals["C"] ** 2 % m, "t0": (vals["D"] - vals["E"]) % m,
+            "t1": (vals["F"] + 77) % m, "W": vals["G"] >> 1}
+    want.update(X=(want["p0"] + want["p1"]) % m, Y=(want["t0"] << 3) % m, Z=want["t1"] * 6 % m)
+    ac = ArithCircuit(client_key, server_key, circuit)
+    enc = ac.encrypt_inputs(wire_set, {k: PtxtType.U8(v) for k, v in vals.items()})
+    ac.set_lanes(1)
+    flat = ac.evaluate_encrypted(enc, 1, "u8")
+    assert {w: _decrypt_int(client_key, flat[w]) for w in want} == want
+    ac2 = ArithCircuit(client_key, server_key, circuit)
+    default = ac2.evaluate_encrypted(enc, 1, "u8")
+    assert "rounds merged" in ac2.log()
+    launches_default = ac2.pbs_rounds_per_cycle()
+    ac2.set_round_capacity(1)
+    one = ac2.evaluate_encrypted(enc, 1, "u8")  # the capacity change reset the same-cycle memo: this is a real evaluation
+    assert ac2.memo_hits() == 0
+    assert ac2.pbs_rounds_per_cycle() == ac2.pbs_per_cycle() > launches_default  # one launch per look-up
+    for w in flat.keys():
+        assert np.array_equal(one[w], flat[w]), w
+        assert np.array_equal(default[w], flat[w]), w
+
+
+def test_arithmetic_memo_can_be_switched_off_and_reset(keys):
+    """The arithmetic-mode same-cycle memo follows the reference (gates.rs:307-312: keyed on the cycle alone); the opt-out
+    the other two evaluators do not need: set_memo(False) / reset_memo(), and a schedule switch resets it."""
+    client_key, server_key = keys
+    circuit, wire_set, _, _ = _circuit("input [7:0] A, B;\noutput [7:0] X;\nadd g0(A, B, X);\n", is_arith=True, is_text=True)
+    ac = ArithCircuit(client_key, server_key, circuit)
+    e1 = ac.encrypt_inputs(wire_set, {"A": PtxtType.U8(10), "B": PtxtType.U8(20)})
+    e2 = ac.encrypt_inputs(wire_set, {"A": PtxtType.U8(100), "B": PtxtType.U8(7)})
+    assert _decrypt_int(client_key, ac.evaluate_encrypted(e1, 1, "u8")["X"]) == 30
+    assert _decrypt_int(client_key, ac.evaluate_encrypted(e2, 1, "u8")["X"]) == 30 and ac.memo_hits() == 1  # the reference's behaviour
+    ac.reset_memo()
+    assert _decrypt_int(client_key, ac.evaluate_encrypted(e2, 1, "u8")["X"]) == 107 and ac.memo_hits() == 1
+    ac.set_memo(False)
+    assert _decrypt_int(client_key, ac.evaluate_encrypted(e1, 1, "u8")["X"]) == 30 and ac.memo_hits() == 1
+    ac.set_memo(True)
+    assert _decrypt_int(client_key, ac.evaluate_encrypted(e2, 5, "u8")["X"]) == 107
+    ac.set_lazy_carries(False)  # a schedule switch: the remembered cycle is gone
+    assert _decrypt_int(client_key, ac.evaluate_encrypted(e1, 5, "u8")["X"]) == 30 and ac.memo_hits() == 1
+
+
+def test_radix_level_scalar_power_of_two_beyond_the_width(keys):
+    """helm_host_radix_level takes a raw 128-bit scalar: x * 2^s with s >= bits is x * 0 = 0 mod 2^bits, not a shift by
+    s mod bits; x * (2^bits + 3) is x * 3 (gates.rs:560-600 multiplies mod 2^bits)."""
+    import ctypes as C
+    from helm_amd import _host as H
+    client_key, server_key = keys
+    nb = 4  # u8
+
+    class Op(C.Structure):
+        _fields_ = [("kind", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("out", C.c_int32),
+                    ("scalar_lo", C.c_uint64), ("scalar_hi", C.c_uint64)]
+    MUL_SCALAR = 9
+    scalars = [1 << 8, 1 << 9, (1 << 8) + 3, 1 << 7, 1 << 100]
+    ops = (Op * len(scalars))()
+    for i, sc in enumerate(scalars):
+        ops[i] = Op(MUL_SCALAR, 0, -1, nb * (1 + i), sc & (2**64 - 1), sc >> 64)
+    x = 0xB5
+    ints = 1 + len(scalars)
+    scratch = int(H.host.helm_host_radix_scratch_rows(server_key._h, nb, C.cast(ops, C.c_void_p), len(scalars)))
+    assert scratch >= 0
+    w = server_key.wires(ints * nb + scratch)
+    w.upload(np.arange(nb), client_key.encrypt(np.array([(x >> (2 * i)) & 3 for i in range(nb)], dtype=np.uint64)))
+    pbs, rounds = C.c_int64(), C.c_int64()
+    H.check(H.host.helm_host_radix_level(server_key._h, w._h, nb, C.cast(ops, C.c_void_p), len(scalars), ints * nb,
+                                         C.byref(pbs), C.byref(rounds)))
+    server_key.sync()
+    got = [_decrypt_int(client_key, w.download(np.arange(nb * (1 + i), nb * (2 + i)))) for i in range(len(scalars))]
+    assert got == [x * sc % 256 for sc in scalars] == [0, 0, x * 3 % 256, x * 128 % 256, 0]
