@@ -3025,6 +3025,29 @@ int helm_si_eval_lut_level(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *ar
     if (!owns(ctx, w)) return fail(HELM_ERR_STATE, "table belongs to another context");
     if (count == 0) return 0;
     if (int rc = check_rows(w, out_idx, count, false)) return rc;
+    // The gates of a level run concurrently (circuit.rs:1057: par_iter over the level; the reference's guarantee comes from
+    // compute_levels, circuit.rs:174-239): a level in which a gate reads a row ANOTHER gate of the level writes, or in which
+    // two gates write one row, is refused instead of evaluated in an unspecified order.  A gate may rewrite its own input row.
+    {
+        std::vector<std::pair<int32_t, int64_t>> writer((size_t)count);
+        for (int64_t g = 0; g < count; g++) writer[(size_t)g] = {out_idx[g], g};
+        std::sort(writer.begin(), writer.end());
+        for (int64_t g = 1; g < count; g++)
+            if (writer[(size_t)g].first == writer[(size_t)g - 1].first)
+                return fail(HELM_ERR_INVALID, "gates " + std::to_string(writer[(size_t)g - 1].second) + " and " +
+                                                  std::to_string(writer[(size_t)g].second) + " both write row " +
+                                                  std::to_string(writer[(size_t)g].first) + " (write-after-write inside a level)");
+        for (int64_t g = 0; g < count; g++) {
+            const int ar = arity[g] < 0 ? 0 : (arity[g] > max_in ? max_in : arity[g]);
+            for (int q = 0; q < std::max(ar, 1); q++) {
+                const int32_t r = in_idx[(size_t)g * max_in + q];
+                auto it = std::lower_bound(writer.begin(), writer.end(), std::make_pair(r, (int64_t)-1));
+                if (it != writer.end() && it->first == r && it->second != g)
+                    return fail(HELM_ERR_INVALID, "gate " + std::to_string(g) + " reads row " + std::to_string(r) + ", which gate " +
+                                                      std::to_string(it->second) + " of the same level writes (read-after-write inside a level)");
+            }
+        }
+    }
     const helm_si_params &P = ctx->P;
     const int t = P.message_modulus * P.carry_modulus;
     // ---- linear part of every gate: packed operand (LUT gates), copy or negation ---------

@@ -3,6 +3,7 @@
 // the per-gate ServerKey calls of gates.rs:254-275 become one helm_hip level per
 // netlist level.
 #include "helm_host.hpp"
+#include <unordered_set>
 
 #include <algorithm>
 #include <atomic>
@@ -265,7 +266,15 @@ std::unique_ptr<EncWireMap> GateCircuit::evaluate_encrypted(const EncWireMap &en
         prog_ = nullptr;
         std::vector<int32_t> op, i0, i1, i2, out;
         std::vector<int64_t> off = {0};
+        level_end_.clear();
         for (auto &kv : circuit_.level_map()) {
+            // compute_levels (circuit.rs:174-239) keeps the combinational gates of a level independent, but every DFF goes
+            // to ONE last level, and a flip-flop fed by another (`dff g1(d, q1); dff g2(q1, q2);`) reads a wire written in
+            // that same level.  The reference evaluates such a level with par_iter (circuit.rs:531: whichever gate comes
+            // first) and its plaintext evaluator gate by gate in order (circuit.rs:348-381: g2 latches the NEW q1).  The
+            // engine refuses a level in which a gate reads or rewrites what another gate of it writes, so the level is cut
+            // here, in order, wherever that would happen: the encrypted evaluation follows the plaintext evaluator.
+            std::unordered_set<int32_t> written, read;
             for (auto &gate : kv.second) {
                 const auto &ins = gate.get_input_wires();
                 auto in_row = [&](size_t i) -> int32_t { return i < ins.size() ? eval_values->row(ins[i]) : -1; };
@@ -275,13 +284,25 @@ std::unique_ptr<EncWireMap> GateCircuit::evaluate_encrypted(const EncWireMap &en
                       t == GateType::Xor || t == GateType::Xnor) && ins.size() < 2) ||
                     ((t == GateType::Not || t == GateType::Buf || t == GateType::Dff) && ins.empty()))
                     throw Panic("index out of bounds: gate " + gate.get_gate_name() + " has too few inputs");
+                const int32_t rows_in[3] = {in_row(0), in_row(1), in_row(2)}, row_out = eval_values->row(gate.get_output_wire());
+                bool clash = written.count(row_out) != 0 || read.count(row_out) != 0; // (its own operands are added below)
+                for (int32_t r : rows_in) clash = clash || (r >= 0 && written.count(r) != 0);
+                if (clash) {
+                    off.push_back((int64_t)op.size());
+                    written.clear();
+                    read.clear();
+                }
                 op.push_back((int32_t)t);
-                i0.push_back(in_row(0));
-                i1.push_back(in_row(1));
-                i2.push_back(in_row(2));
-                out.push_back(eval_values->row(gate.get_output_wire()));
+                i0.push_back(rows_in[0]);
+                i1.push_back(rows_in[1]);
+                i2.push_back(rows_in[2]);
+                out.push_back(row_out);
+                written.insert(row_out);
+                for (int32_t r : rows_in)
+                    if (r >= 0) read.insert(r);
             }
             off.push_back((int64_t)op.size());
+            level_end_.push_back((int64_t)off.size() - 1);
         }
         // launch packing (level_pack.cpp): wide levels are re-timed into whole lockstep rounds; a netlist
         // whose levels are narrower than one round keeps its level schedule unchanged
@@ -320,10 +341,12 @@ std::unique_ptr<EncWireMap> GateCircuit::evaluate_encrypted(const EncWireMap &en
     std::ostringstream os;
     if (!packed_) {
         int64_t l = 0;
+        size_t li = 0;
         for (auto &kv : circuit_.level_map()) {
-            hip_ok(helm_hip_program_run(server_key_, prog_, eval_values->table(), l, l + 1), "program_run");
+            const int64_t end = level_end_[li++]; // a level of chained flip-flops spans several program levels
+            hip_ok(helm_hip_program_run(server_key_, prog_, eval_values->table(), l, end), "program_run");
             os << "  Evaluated gates in level [" << kv.first << "/" << total_levels << "]\n";
-            l++;
+            l = end;
         }
     } else {
         hip_ok(helm_hip_program_run(server_key_, prog_, eval_values->table(), 0, prog_launches_), "program_run");

@@ -256,6 +256,7 @@ class GateCircuit : public EvalCircuit<EncWireMap> {
     std::vector<int> prog_rows_;
     int64_t pbs_count_ = 0;
     int64_t prog_launches_ = 0;
+    std::vector<int64_t> level_end_; // program level at which each circuit level ends (unpacked schedule)
     bool packed_ = false; // the program's launches are packed rounds, not the circuit's levels
     std::string log_;
     // Same cycle AND the very input map (unmodified): the cached wire map is returned without a launch.  The

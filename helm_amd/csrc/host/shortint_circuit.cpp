@@ -284,7 +284,34 @@ std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap 
     pbs_count_ = 0;
     int capacity = 0; // index bits one block holds: gates::lut() packs sum in_i << (arity-1-i) into a single block
     while ((2 << capacity) <= P_.message_modulus * P_.carry_modulus) capacity++;
+    // A level is evaluated as one batched call - except where a gate reads or rewrites a wire another gate of the level
+    // writes (flip-flops fed by flip-flops: every DFF sits in the last level, circuit.rs:174-239): the level is then cut, in
+    // order, so that the encrypted evaluation follows the plaintext evaluator's gate-by-gate order (circuit.rs:348-381);
+    // the engine refuses such a level otherwise (helm_si_eval_lut_level).
+    std::vector<std::pair<size_t, std::vector<Gate>>> parts; // (circuit level, gates of one call)
+    std::vector<char> last_of_level;
     for (auto &kv : circuit_.level_map()) {
+        std::unordered_set<int32_t> written, read;
+        parts.push_back({kv.first, {}});
+        last_of_level.push_back(0);
+        for (auto &g : kv.second) {
+            const int32_t row_out = eval_values->row(g.get_output_wire());
+            bool clash = written.count(row_out) != 0 || read.count(row_out) != 0;
+            for (auto &w : g.get_input_wires()) clash = clash || written.count(eval_values->row(w)) != 0;
+            if (clash) {
+                parts.push_back({kv.first, {}});
+                last_of_level.push_back(0);
+                written.clear();
+                read.clear();
+            }
+            parts.back().second.push_back(g);
+            written.insert(row_out);
+            for (auto &w : g.get_input_wires()) read.insert(eval_values->row(w));
+        }
+        last_of_level.back() = 1;
+    }
+    for (size_t part = 0; part < parts.size(); part++) {
+        const std::pair<size_t, std::vector<Gate>> &kv = parts[part];
         const auto &gates = kv.second;
         int max_in = 1;
         for (auto &g : gates)
@@ -356,7 +383,7 @@ std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap 
             for (auto &g : gates)
                 if (g.get_gate_type() == GateType::Lut) os << "PBS time: " << us << " us\n";
         }
-        os << "  Evaluated gates in level [" << kv.first << "/" << total_levels << "]\n";
+        if (last_of_level[part]) os << "  Evaluated gates in level [" << kv.first << "/" << total_levels << "]\n";
         append_log(log_, os.str());
     }
     si_ok(helm_si_sync(server_key_), "sync");

@@ -306,3 +306,33 @@ def test_gate_circuit_packs_wide_levels():
     for wire, want in ptxt.items():
         assert client_key.decrypt(enc[wire]) == bool(want), wire
     server_key.close()
+
+
+@pytest.mark.parametrize("order", ["forward", "backward"])
+def test_flip_flops_fed_by_flip_flops_follow_the_plaintext_evaluator(keys, order):
+    """Every DFF sits in ONE last level (circuit.rs:174-239), so a flip-flop fed by another reads a wire written in its own
+    level.  The reference's encrypted evaluation of such a level is a race (par_iter, circuit.rs:531); its plaintext
+    evaluator goes gate by gate in order (circuit.rs:348-381).  Here the level is cut in that order (the engine refuses a
+    level with a read-after-write inside): on every wire, every cycle, encrypted == plaintext - for both orders of the
+    chain, including the swap of two registers."""
+    client_key, server_key = keys
+    chain = ["dff ga(d, q0);", "dff gb(q0, q1);", "dff gc(q1, q2);", "dff gd(s1, s0);", "dff ge(s0, s1);"]
+    if order == "backward":
+        chain = [c.replace("ga", "gz").replace("gb", "gy").replace("gc", "gx") for c in chain]  # sort_circuit orders by name
+    text = "input x;\noutput q2, s0, s1;\n" + "\n".join(chain) + "\nxor g9(x, q2, d);\n"
+    circuit, wire_set, input_wires, output_wires = _circuit(text, is_text=True)
+    names = [g.gate_name for g in circuit.level_map()[max(circuit.level_map())]]
+    assert len(names) == 5
+    gc = GateCircuit(client_key, server_key, circuit)
+    state = {"x": True, "q0": False, "q1": True, "q2": False, "s0": True, "s1": False}
+    enc = gc.encrypt_inputs(wire_set, {k: PtxtType.Bool(v) for k, v in state.items()})
+    # DFF outputs start at encrypt(false) (circuit.rs:474-476): put the test's initial state in
+    for w in ("q1", "s0"):
+        enc.insert(w, client_key.encrypt(True))
+    ptxt = {w: PtxtType.None_() for w in wire_set}
+    ptxt.update({k: PtxtType.Bool(v) for k, v in state.items()})
+    for cycle in range(4):
+        ptxt = circuit.evaluate(ptxt)
+        enc = gc.evaluate_encrypted(enc, cycle + 1, "bool")
+        for w in sorted(ptxt):
+            assert bool(client_key.decrypt(enc[w])) == bool(ptxt[w].value), (order, cycle, w, names)

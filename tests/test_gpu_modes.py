@@ -663,3 +663,46 @@ def test_radix_level_scalar_power_of_two_beyond_the_width(keys):
     server_key.sync()
     got = [_decrypt_int(client_key, w.download(np.arange(nb * (1 + i), nb * (2 + i)))) for i in range(len(scalars))]
     assert got == [x * sc % 256 for sc in scalars] == [0, 0, x * 3 % 256, x * 128 % 256, 0]
+
+
+def test_lut_mode_flip_flops_fed_by_flip_flops(keys):
+    """LUT mode's DFF level (circuit.rs:1063-1069 copies) with a chain and a swap of registers: the level is cut in the
+    plaintext evaluator's order (circuit.rs:348-381) where a flip-flop reads what another one of the level writes -
+    helm_si_eval_lut_level refuses such a level - and every wire equals the plaintext evaluation on every cycle; the
+    per-level timing lines can be switched off (no host synchronisation per level)."""
+    client_key, server_key = keys
+    text = """input x;
+output q2, s0, s1;
+dff ga(d, q0);
+dff gb(q0, q1);
+dff gc(q1, q2);
+dff gd(s1, s0);
+dff ge(s0, s1);
+lut g9(0x6, x, q2, d);
+"""
+    circuit, wire_set, _, _ = _circuit(text, is_text=True)
+    lc = LutCircuit(client_key, server_key, circuit)
+    lc.set_timing_lines(False)
+    state = {"x": 1, "q0": 0, "q1": 0, "q2": 0, "s0": 0, "s1": 0}
+    enc = lc.encrypt_inputs(wire_set, {k: PtxtType.Bool(bool(v)) for k, v in state.items()})
+    for w in ("q1", "s0"):
+        enc.insert(w, client_key.encrypt(1))
+        state[w] = 1
+    ptxt = {w: PtxtType.None_() for w in wire_set}
+    ptxt.update({k: PtxtType.Bool(bool(v)) for k, v in state.items()})
+    for cycle in range(4):
+        ptxt = circuit.evaluate(ptxt)
+        enc = lc.evaluate_encrypted(enc, cycle + 1, "bool")
+        for w in sorted(ptxt):
+            assert int(client_key.decrypt(enc[w])) == int(bool(ptxt[w].value)), (cycle, w)
+    assert "PBS time" not in lc.log()
+    # the engine itself refuses a level with a read-after-write / write-after-write inside
+    w = server_key.wires(8)
+    w.upload(np.arange(3), client_key.encrypt(np.array([1, 0, 1], dtype=np.uint64)))
+    with pytest.raises(helm_amd.HelmError, match="read-after-write"):
+        w.eval_lut_level([2, 0], [[0, 1], [3, -1]], [0x6, 0], [3, 4])      # the copy reads row 3, which the LUT writes
+    with pytest.raises(helm_amd.HelmError, match="write-after-write"):
+        w.eval_lut_level([2, 2], [[0, 1], [1, 2]], [0x6, 0x8], [3, 3])
+    w.eval_lut_level([2], [[0, 1]], [0x6], [0])                            # in place: row 0 <- XOR(row 0, row 1)
+    server_key.sync()
+    assert int(client_key.decrypt(w.download([0]))[0]) == 1
