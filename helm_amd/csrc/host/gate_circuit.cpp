@@ -3,7 +3,7 @@
 // the per-gate ServerKey calls of gates.rs:254-275 become one helm_hip level per
 // netlist level.
 #include "helm_host.hpp"
-#include <unordered_set>
+#include <unordered_map>
 
 #include <algorithm>
 #include <atomic>
@@ -70,6 +70,12 @@ void EncWireMap::grow(int64_t rows)
     }
     wires_ = nw;
     cap_ = want;
+}
+
+int EncWireMap::scratch(int64_t rows)
+{
+    grow((int64_t)index_.size() + rows);
+    return (int)index_.size();
 }
 
 void EncWireMap::reserve_keys(const std::vector<std::string> &names)
@@ -267,14 +273,19 @@ std::unique_ptr<EncWireMap> GateCircuit::evaluate_encrypted(const EncWireMap &en
         std::vector<int32_t> op, i0, i1, i2, out;
         std::vector<int64_t> off = {0};
         level_end_.clear();
+        n_scratch_ = 0;
+        const int32_t scratch_base = (int32_t)keys.size(); // scratch rows sit behind the named rows
         for (auto &kv : circuit_.level_map()) {
             // compute_levels (circuit.rs:174-239) keeps the combinational gates of a level independent, but every DFF goes
             // to ONE last level, and a flip-flop fed by another (`dff g1(d, q1); dff g2(q1, q2);`) reads a wire written in
-            // that same level.  The reference evaluates such a level with par_iter (circuit.rs:531: whichever gate comes
-            // first) and its plaintext evaluator gate by gate in order (circuit.rs:348-381: g2 latches the NEW q1).  The
-            // engine refuses a level in which a gate reads or rewrites what another gate of it writes, so the level is cut
-            // here, in order, wherever that would happen: the encrypted evaluation follows the plaintext evaluator.
-            std::unordered_set<int32_t> written, read;
+            // that same level.  The reference evaluates such a level with par_iter (circuit.rs:531, also in its plaintext
+            // evaluator, :348-381): whichever gate comes first.  This repository's plaintext evaluator gives the level
+            // snapshot semantics - every gate reads the values from before the level, as flip-flops on one clock edge do -
+            // and the encrypted evaluation follows it: rows that one gate of the level writes and ANOTHER reads are copied
+            // to scratch rows in a level of BUF gates put in front, and the readers read the copies (the engine refuses a
+            // level with a read-after-write inside; a gate that rewrites its own operand needs no copy).
+            const size_t first = op.size();
+            std::unordered_map<int32_t, size_t> writer; // row -> gate (index into op) that writes it in this level
             for (auto &gate : kv.second) {
                 const auto &ins = gate.get_input_wires();
                 auto in_row = [&](size_t i) -> int32_t { return i < ins.size() ? eval_values->row(ins[i]) : -1; };
@@ -284,22 +295,34 @@ std::unique_ptr<EncWireMap> GateCircuit::evaluate_encrypted(const EncWireMap &en
                       t == GateType::Xor || t == GateType::Xnor) && ins.size() < 2) ||
                     ((t == GateType::Not || t == GateType::Buf || t == GateType::Dff) && ins.empty()))
                     throw Panic("index out of bounds: gate " + gate.get_gate_name() + " has too few inputs");
-                const int32_t rows_in[3] = {in_row(0), in_row(1), in_row(2)}, row_out = eval_values->row(gate.get_output_wire());
-                bool clash = written.count(row_out) != 0 || read.count(row_out) != 0; // (its own operands are added below)
-                for (int32_t r : rows_in) clash = clash || (r >= 0 && written.count(r) != 0);
-                if (clash) {
-                    off.push_back((int64_t)op.size());
-                    written.clear();
-                    read.clear();
-                }
+                writer.emplace(eval_values->row(gate.get_output_wire()), op.size()); // (two writers: the engine refuses the level)
                 op.push_back((int32_t)t);
-                i0.push_back(rows_in[0]);
-                i1.push_back(rows_in[1]);
-                i2.push_back(rows_in[2]);
-                out.push_back(row_out);
-                written.insert(row_out);
-                for (int32_t r : rows_in)
-                    if (r >= 0) read.insert(r);
+                i0.push_back(in_row(0));
+                i1.push_back(in_row(1));
+                i2.push_back(in_row(2));
+                out.push_back(eval_values->row(gate.get_output_wire()));
+            }
+            std::map<int32_t, int32_t> copy_of; // hazard row -> scratch row
+            for (size_t g = first; g < op.size(); g++)
+                for (std::vector<int32_t> *in : {&i0, &i1, &i2}) {
+                    int32_t &r = (*in)[g];
+                    auto it = r >= 0 ? writer.find(r) : writer.end();
+                    if (it == writer.end() || it->second == g) continue;
+                    auto c = copy_of.find(r);
+                    if (c == copy_of.end()) c = copy_of.emplace(r, scratch_base + (int32_t)n_scratch_++).first;
+                    r = c->second;
+                }
+            if (!copy_of.empty()) { // the copies form a level of their own in front of the level
+                const size_t n = copy_of.size();
+                for (std::vector<int32_t> *v : {&op, &i0, &i1, &i2, &out}) v->insert(v->begin() + (long)first, n, -1);
+                size_t q = first;
+                for (auto &c : copy_of) {
+                    op[q] = (int32_t)GateType::Buf;
+                    i0[q] = c.first;
+                    out[q] = c.second;
+                    q++;
+                }
+                off.push_back((int64_t)(first + n));
             }
             off.push_back((int64_t)op.size());
             level_end_.push_back((int64_t)off.size() - 1);
@@ -337,6 +360,7 @@ std::unique_ptr<EncWireMap> GateCircuit::evaluate_encrypted(const EncWireMap &en
         pbs_count_ = 0;
         for (int64_t l = 0; l < prog_launches_; l++) pbs_count_ += helm_hip_program_level_pbs(prog_, l);
     }
+    if (n_scratch_ > 0) eval_values->scratch(n_scratch_); // the copies of rows a level both reads and rewrites
     const int64_t total_levels = (int64_t)circuit_.level_map().size();
     std::ostringstream os;
     if (!packed_) {

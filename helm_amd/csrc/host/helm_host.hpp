@@ -197,6 +197,7 @@ class EncWireMap {
     helm_hip_ctx *ctx() const { return ctx_; }
     // build with a fixed key set (rows in iteration order of `names`)
     void reserve_keys(const std::vector<std::string> &names);
+    int scratch(int64_t rows); // makes room for `rows` unnamed rows behind the named ones; their first row
     // identity of this map object and a counter of its host-side modifications: what the evaluators' same-cycle
     // memo (gates.rs:55-59) compares instead of the ciphertext rows themselves
     uint64_t id() const { return id_; }
@@ -257,6 +258,7 @@ class GateCircuit : public EvalCircuit<EncWireMap> {
     int64_t pbs_count_ = 0;
     int64_t prog_launches_ = 0;
     std::vector<int64_t> level_end_; // program level at which each circuit level ends (unpacked schedule)
+    int64_t n_scratch_ = 0;          // scratch rows the program uses behind the named rows (copies for flip-flop chains)
     bool packed_ = false; // the program's launches are packed rounds, not the circuit's levels
     std::string log_;
     // Same cycle AND the very input map (unmodified): the cached wire map is returned without a launch.  The

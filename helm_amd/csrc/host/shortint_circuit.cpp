@@ -13,6 +13,7 @@
 // reference's tests pin: tests/gates_test.rs:127-310, tests/circuit_test.rs:349-368).
 #include "helm_host.hpp"
 #include <functional>
+#include <unordered_map>
 #include <unordered_set>
 #include <thread>
 
@@ -284,35 +285,46 @@ std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap 
     pbs_count_ = 0;
     int capacity = 0; // index bits one block holds: gates::lut() packs sum in_i << (arity-1-i) into a single block
     while ((2 << capacity) <= P_.message_modulus * P_.carry_modulus) capacity++;
-    // A level is evaluated as one batched call - except where a gate reads or rewrites a wire another gate of the level
-    // writes (flip-flops fed by flip-flops: every DFF sits in the last level, circuit.rs:174-239): the level is then cut, in
-    // order, so that the encrypted evaluation follows the plaintext evaluator's gate-by-gate order (circuit.rs:348-381);
-    // the engine refuses such a level otherwise (helm_si_eval_lut_level).
+    // A level is one batched call.  Where a gate reads a wire ANOTHER gate of the level writes (flip-flops fed by
+    // flip-flops: every DFF sits in the last level, circuit.rs:174-239) the reference's par_iter is a race; this
+    // repository's plaintext evaluator gives a level snapshot semantics (every gate reads the values from before the level,
+    // as flip-flops on one clock edge do) and the encrypted evaluation follows it: such rows are copied to scratch rows by a
+    // call of copy gates in front and the readers read the copies (helm_si_eval_lut_level refuses a read-after-write inside
+    // a level).  `redirect`: wire row -> scratch row for the gates of the level at hand.
     std::vector<std::pair<size_t, std::vector<Gate>>> parts; // (circuit level, gates of one call)
-    std::vector<char> last_of_level;
-    for (auto &kv : circuit_.level_map()) {
-        std::unordered_set<int32_t> written, read;
-        parts.push_back({kv.first, {}});
-        last_of_level.push_back(0);
-        for (auto &g : kv.second) {
-            const int32_t row_out = eval_values->row(g.get_output_wire());
-            bool clash = written.count(row_out) != 0 || read.count(row_out) != 0;
-            for (auto &w : g.get_input_wires()) clash = clash || written.count(eval_values->row(w)) != 0;
-            if (clash) {
-                parts.push_back({kv.first, {}});
-                last_of_level.push_back(0);
-                written.clear();
-                read.clear();
-            }
-            parts.back().second.push_back(g);
-            written.insert(row_out);
-            for (auto &w : g.get_input_wires()) read.insert(eval_values->row(w));
-        }
-        last_of_level.back() = 1;
-    }
+    for (auto &kv : circuit_.level_map()) parts.push_back({kv.first, kv.second});
+    std::vector<char> last_of_level(parts.size(), 1);
+    std::map<int32_t, int32_t> redirect;
     for (size_t part = 0; part < parts.size(); part++) {
         const std::pair<size_t, std::vector<Gate>> &kv = parts[part];
         const auto &gates = kv.second;
+        redirect.clear();
+        {
+            std::unordered_map<int32_t, const Gate *> writer;
+            for (auto &g : gates) writer.emplace(eval_values->row(g.get_output_wire()), &g);
+            std::vector<int32_t> hazard;
+            for (auto &g : gates)
+                for (auto &w : g.get_input_wires()) {
+                    auto it = writer.find(eval_values->row(w));
+                    if (it != writer.end() && it->second != &g) hazard.push_back(it->first);
+                }
+            std::sort(hazard.begin(), hazard.end());
+            hazard.erase(std::unique(hazard.begin(), hazard.end()), hazard.end());
+            if (!hazard.empty()) {
+                const int32_t base = eval_values->scratch((int64_t)hazard.size());
+                std::vector<int32_t> car(hazard.size(), 0), cin(hazard), cout(hazard.size());
+                std::vector<uint64_t> ctab(hazard.size(), 0);
+                for (size_t q = 0; q < hazard.size(); q++) redirect[hazard[q]] = cout[q] = base + (int32_t)q;
+                si_ok(helm_si_eval_lut_level(server_key_, eval_values->table(), car.data(), cin.data(), 1, ctab.data(), cout.data(),
+                                             (int64_t)hazard.size()),
+                      "eval_lut_level");
+            }
+        }
+        auto in_row_of = [&](const std::string &w) {
+            const int32_t r = eval_values->row(w);
+            auto it = redirect.find(r);
+            return it == redirect.end() ? r : it->second;
+        };
         int max_in = 1;
         for (auto &g : gates)
             if (!(wop_ && g.get_gate_type() == GateType::Lut && (int)g.get_input_wires().size() > capacity))
@@ -335,7 +347,7 @@ std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap 
                     si_ok(helm_wop_get_params(wop_, &W), "wop_get_params");
                     const int m = (int)ins.size();
                     Wide &wg = wide[m];
-                    for (auto &w : ins) wg.in.push_back(eval_values->row(w));
+                    for (auto &w : ins) wg.in.push_back(in_row_of(w));
                     wg.out.push_back(eval_values->row(g.get_output_wire()));
                     const size_t words = helm_wop_table_words(&W, m * wop_bits_per_block_);
                     wg.tables.resize(wg.tables.size() + words);
@@ -360,7 +372,7 @@ std::unique_ptr<SiEncWireMap> LutCircuit::evaluate_encrypted(const SiEncWireMap 
             }
             const size_t slot = in_idx.size();
             in_idx.resize(slot + (size_t)max_in, -1);
-            for (size_t q = 0; q < ins.size(); q++) in_idx[slot + q] = eval_values->row(ins[q]);
+            for (size_t q = 0; q < ins.size(); q++) in_idx[slot + q] = in_row_of(ins[q]);
             out.push_back(eval_values->row(g.get_output_wire()));
         }
         const auto level_start = std::chrono::steady_clock::now();

@@ -311,10 +311,11 @@ def test_gate_circuit_packs_wide_levels():
 @pytest.mark.parametrize("order", ["forward", "backward"])
 def test_flip_flops_fed_by_flip_flops_follow_the_plaintext_evaluator(keys, order):
     """Every DFF sits in ONE last level (circuit.rs:174-239), so a flip-flop fed by another reads a wire written in its own
-    level.  The reference's encrypted evaluation of such a level is a race (par_iter, circuit.rs:531); its plaintext
-    evaluator goes gate by gate in order (circuit.rs:348-381).  Here the level is cut in that order (the engine refuses a
-    level with a read-after-write inside): on every wire, every cycle, encrypted == plaintext - for both orders of the
-    chain, including the swap of two registers."""
+    level.  The reference evaluates such a level as a race (par_iter, circuit.rs:531 and :348-381); this repository's
+    plaintext evaluator gives a level snapshot semantics (every gate reads the values from before the level: flip-flops on
+    one clock edge) and the encrypted evaluation follows it by copying the rows in question to scratch rows first (the
+    engine refuses a level with a read-after-write inside): on every wire, every cycle, encrypted == plaintext - a shift
+    register in either gate order, and the swap of two registers."""
     client_key, server_key = keys
     chain = ["dff ga(d, q0);", "dff gb(q0, q1);", "dff gc(q1, q2);", "dff gd(s1, s0);", "dff ge(s0, s1);"]
     if order == "backward":

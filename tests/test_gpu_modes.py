@@ -666,10 +666,10 @@ def test_radix_level_scalar_power_of_two_beyond_the_width(keys):
 
 
 def test_lut_mode_flip_flops_fed_by_flip_flops(keys):
-    """LUT mode's DFF level (circuit.rs:1063-1069 copies) with a chain and a swap of registers: the level is cut in the
-    plaintext evaluator's order (circuit.rs:348-381) where a flip-flop reads what another one of the level writes -
-    helm_si_eval_lut_level refuses such a level - and every wire equals the plaintext evaluation on every cycle; the
-    per-level timing lines can be switched off (no host synchronisation per level)."""
+    """LUT mode's DFF level (circuit.rs:1063-1069 copies) with a shift register and a swap of registers: rows that one
+    flip-flop of the level writes and another reads are copied to scratch rows first (snapshot semantics, as the plaintext
+    evaluator's; helm_si_eval_lut_level refuses a read-after-write inside a level) and every wire equals the plaintext
+    evaluation on every cycle; the per-level timing lines can be switched off (no host synchronisation per level)."""
     client_key, server_key = keys
     text = """input x;
 output q2, s0, s1;
