@@ -812,6 +812,252 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------
+// k_pbs_duo: the build for launches of MORE than one and at most TWO bootstraps per CU - each bootstrap on two SIMDs.
+// Round 3 had nothing between the wide build (one bootstrap per CU on all four SIMDs, 3.2 - 3.6 ms per round) and a
+// lockstep round (four per CU, one SIMD each, 8.5 ms): 257 - 512 bootstraps cost 7.4 ms on the throughput build, which is
+// what a rank's chunk of a sharded launch looks like at 8 GPUs (circuit.rs:531: the level is the sharded unit).
+//
+// 2 (k+1) waves per bootstrap = (polynomial r, part g), NB bootstraps per workgroup:
+//   g = 0 ("A")  the digits of levels 0 .. L-2 of polynomial r: per level one forward transform and k+1 products, summed
+//                over its levels in registers and added to the per-column accumulators in LDS (ds_add_f64: exact
+//                integer sums, any order)
+//   g = 1 ("B")  the digit of level L-1 (first out of the carry chain), its transform and products; after the first
+//                barrier the inverse transform of column r, the lift and the accumulator update of polynomial r, whose
+//                negacyclically unrolled u32 copy both waves of the polynomial rotate and decompose in the next step.
+// With NB = 2 the workgroup has 4 (k+1) = 12 waves, three per SIMD (the hardware deals a workgroup's waves round the four
+// SIMDs, tools/ubench_placement.hip): bootstrap b sits on SIMDs 2b and 2b + 1 as (A0, A1, B2 | B0, B1, A2), so both of
+// its SIMDs carry one and a half polynomials.  NB = 1 (six waves, two workgroups per CU) leaves the interleaving of two
+// bootstraps to the hardware.  Same arithmetic as every other build: identical ciphertexts.
+// ------------------------------------------------------------------------------------
+template <typename F_, int LOGN_, int K_, int L_, int NB_>
+struct DuoCfg {
+    using F = F_;
+    static constexpr int LOGN = LOGN_, K = K_, L = L_, K1 = K_ + 1, NB = NB_, NWB = 2 * (K_ + 1), NW = 2 * (K_ + 1) * NB_;
+    using G = Geo<LOGN>;
+    static constexpr int MAX_SMALL_N = 1024;
+    static constexpr int ACC3 = (3 * G::N - 64 + 1) / 2 * 2; // u32 entries per polynomial (see PbsCfg)
+    static constexpr int TW_ROWS = G::TWB + G::TWC;
+    static_assert(L >= 2, "part A needs at least one level");
+    // per bootstrap
+    static constexpr size_t X_OFF = 0;                                              // double [NWB][XPAD]
+    static constexpr size_t COL_OFF = X_OFF + sizeof(double) * NWB * G::XPAD;       // double [K1][N]
+    static constexpr size_t TW_OFF = COL_OFF + sizeof(double) * K1 * G::N;          // double [TW_ROWS][64]
+    static constexpr size_t ACC_OFF = TW_OFF + sizeof(double) * TW_ROWS * 64;       // u32 [K1][ACC3]
+    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint32_t) * K1 * ACC3;        // u16 [n+1]
+    static constexpr size_t BOOT_BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
+    static constexpr size_t BYTES = BOOT_BYTES * NB;
+};
+
+template <typename C>
+__global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restrict__ jobs, const uint32_t *__restrict__ wires,
+                                                           const uint32_t *__restrict__ raw_in, const uint32_t *__restrict__ tvs,
+                                                           const double *__restrict__ bsk, const double *__restrict__ tw_fwd,
+                                                           uint32_t *__restrict__ out_big, int n, int logB, int flags, int count)
+{
+    constexpr int LOGN = C::LOGN, K = C::K, L = C::L, K1 = C::K1, NB = C::NB, NWB = C::NWB;
+    using F = typename C::F;
+    using G = Geo<LOGN>;
+    constexpr int N = G::N, E = G::E;
+    extern __shared__ __align__(16) unsigned char smem_wg[];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // wave -> (bootstrap of the workgroup, polynomial, part)
+    int b, r, g;
+    if constexpr (NB == 2) {
+        const int s = w & 1, q = w >> 2; // SIMD of the pair, wave of that SIMD
+        b = (w & 3) >> 1;
+        r = q;
+        g = ((q == K1 - 1) ? 1 : 0) ^ s;
+    } else {
+        b = 0;
+        r = w % K1;
+        g = w / K1;
+    }
+    const int jix = (int)blockIdx.x * NB + b;
+    if (NB > 1 && jix >= count) return; // the hardware barrier counts the surviving waves only
+    unsigned char *smem = smem_wg + (size_t)b * C::BOOT_BYTES;
+    double *X = reinterpret_cast<double *>(smem + C::X_OFF);
+    double *COL = reinterpret_cast<double *>(smem + C::COL_OFF);
+    double *TW = reinterpret_cast<double *>(smem + C::TW_OFF);
+    uint32_t *ACC = reinterpret_cast<uint32_t *>(smem + C::ACC_OFF);
+    uint16_t *MS = reinterpret_cast<uint16_t *>(smem + C::MS_OFF);
+    const int wb = r * 2 + g;            // wave index within the bootstrap
+    const int tid = wb * 64 + lane;      // thread index within the bootstrap
+    const PbsJob job = jobs[jix];
+    const size_t row = (size_t)n + 1;
+    {
+        const uint32_t *a0 = nullptr, *a1 = nullptr, *a2 = nullptr;
+        if (job.op < 0) a0 = raw_in + row * (size_t)job.in0;
+        else {
+            if (job.in0 >= 0) a0 = wires + row * (size_t)job.in0;
+            if (job.in1 >= 0) a1 = wires + row * (size_t)job.in1;
+            if (job.in2 >= 0) a2 = wires + row * (size_t)job.in2;
+        }
+        for (int i = tid; i <= n; i += 64 * NWB) {
+            uint32_t v;
+            if (job.op < 0) v = a0[i];
+            else v = gate_lincomb(job.op, job.which, a0 ? a0[i] : 0u, a1 ? a1[i] : 0u, a2 ? a2[i] : 0u, i == n);
+            MS[i] = (uint16_t)modswitch(v, LOGN + 1);
+        }
+    }
+    for (int q = wb; q < C::TW_ROWS; q += NWB) TW[q * 64 + lane] = tw_fwd[tw_lane_index<LOGN>(q, lane)];
+    for (int j = tid; j < K1 * N; j += 64 * NWB) COL[j] = 0.0;
+    TwLane<LOGN, false> twf;
+    TwLane<LOGN, true> twi;
+    twf.base = TW + lane;
+    twi.base = TW + (63 - lane);
+    twf.fill_uniform(tw_fwd);
+    twi.fill_uniform(tw_fwd);
+    __syncthreads();
+
+    // accumulator (0, ..., 0, X^{-b~} tv): part B of polynomial r owns it (registers) and publishes the unrolled u32 copy
+    uint32_t *acc_r = ACC + (size_t)r * C::ACC3;
+    uint32_t accr[E];
+    auto acc_store = [&]() {
+        uint32_t *aw = acc_r + lane;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            aw[64 * e] = accr[e];
+            aw[64 * e + N] = 0u - accr[e];
+            if (e < E - 1) aw[64 * e + 2 * N] = accr[e];
+        }
+    };
+    if (g == 1) {
+        const int bt = (int)MS[n];
+        const uint32_t *tv = tvs + (size_t)job.tv * N;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            uint32_t v = 0;
+            if (r == K) {
+                const int idx = (G::jA(lane, e) + bt) & (2 * N - 1);
+                v = tv[idx & (N - 1)];
+                if (idx >= N) v = 0u - v;
+            }
+            accr[e] = v;
+        }
+        acc_store();
+    }
+    __syncthreads();
+
+    double *xb = X + (size_t)wb * G::XPAD;
+    const unsigned poly_bytes = (unsigned)(N / 2) * 16u;
+    const unsigned step_bytes = (unsigned)(K1 * K1 * L) * poly_bytes;
+    const unsigned row_off = (unsigned)(r * K1 * L) * poly_bytes; // + (c * L + lev) * poly_bytes
+    KeyBuf kb;
+    kb.init(bsk, (size_t)n * step_bytes, lane);
+    const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+    const int neg_B = -(1 << logB);
+    const int rep = logB * L;
+    const bool prio = (flags & 1) != 0;
+
+    // key words of one level of this wave's row: k+1 polynomials
+    double2 kw[K1][E / 2];
+    auto load_keys = [&](int ii, int lev) {
+        const unsigned so = (unsigned)ii * step_bytes + row_off + (unsigned)lev * poly_bytes;
+#pragma unroll
+        for (int c = 0; c < K1; c++)
+#pragma unroll
+            for (int e2 = 0; e2 < E / 2; e2++) kw[c][e2] = kb.load(so + (unsigned)(c * L) * poly_bytes, e2 * 1024);
+    };
+    // the level a wave transforms first in a step: its key words are fetched one step ahead - by part A during the inverse
+    // transforms (it idles there), by part B right after its accumulator update
+    const int first_lev = g == 1 ? L - 1 : L - 2;
+    int i = 0;
+    if constexpr (NB == 1)
+        while (i < n && __builtin_amdgcn_readfirstlane((int)MS[i]) == 0) i++; // a zero rotation adds nothing
+    if (i < n) load_keys(i, first_lev);
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    while (i < n) {
+        const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
+        uint32_t st[E];
+        {
+            const uint32_t *ar = acc_r + ((lane - a) & (2 * N - 1));
+            const uint32_t *ac = acc_r + lane;
+#pragma unroll
+            for (int e = 0; e < E; e++) st[e] = ((ar[64 * e] - ac[64 * e]) + (1u << (31 - rep))) >> (32 - rep);
+        }
+        double x[1][E];
+        if (g == 1) {
+#pragma unroll
+            for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(st[e], logB, half_m1, neg_B);
+            ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+            if (prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int c = 0; c < K1; c++) {
+                double *col = COL + (size_t)c * N + lane;
+#pragma unroll
+                for (int e2 = 0; e2 < E / 2; e2++) {
+                    lds_add_wg(col + (2 * e2) * 64, reduce_unless_lazy<F>(mulmod<F>(x[0][2 * e2], kw[c][e2].x)));
+                    lds_add_wg(col + (2 * e2 + 1) * 64, reduce_unless_lazy<F>(mulmod<F>(x[0][2 * e2 + 1], kw[c][e2].y)));
+                }
+            }
+        } else {
+            // the carry chain starts at the least significant level, which part B transforms
+#pragma unroll
+            for (int e = 0; e < E; e++) (void)decompose_step(st[e], logB, half_m1, neg_B);
+            // (summing the levels' products in registers first would halve the LDS additions, but (k+1) E more doubles next
+            // to the key words and the transform's temporaries do not fit three waves per SIMD: 49 spilled registers)
+#pragma unroll
+            for (int lev = L - 2; lev >= 0; lev--) {
+#pragma unroll
+                for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(st[e], logB, half_m1, neg_B);
+                if (lev != L - 2) load_keys(i, lev); // (the first level's words came a step ahead)
+                ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+                if (prio) {
+                    if (lev) __builtin_amdgcn_s_setprio(2);
+                    else __builtin_amdgcn_s_setprio(1);
+                }
+#pragma unroll
+                for (int c = 0; c < K1; c++) {
+                    double *col = COL + (size_t)c * N + lane;
+#pragma unroll
+                    for (int e2 = 0; e2 < E / 2; e2++) {
+                        lds_add_wg(col + (2 * e2) * 64, reduce_unless_lazy<F>(mulmod<F>(x[0][2 * e2], kw[c][e2].x)));
+                        lds_add_wg(col + (2 * e2 + 1) * 64, reduce_unless_lazy<F>(mulmod<F>(x[0][2 * e2 + 1], kw[c][e2].y)));
+                    }
+                }
+            }
+        }
+        int inext = i + 1;
+        if constexpr (NB == 1)
+            while (inext < n && __builtin_amdgcn_readfirstlane((int)MS[inext]) == 0) inext++;
+        lds_block_sync(); // every product of the step is in its column
+        if (prio) __builtin_amdgcn_s_setprio(3);
+        if (g == 1) {
+            double mine[E];
+            double *col = COL + (size_t)r * N + lane;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                mine[e] = reduce<F>(col[e * 64]);
+                col[e * 64] = 0.0;
+            }
+            ntt_inverse<F, LOGN>(mine, xb, twi, lane);
+#pragma unroll
+            for (int e = 0; e < E; e++) accr[e] += to_torus32(mine[e]);
+            acc_store();
+        }
+        if (inext < n) load_keys(inext, first_lev);
+        lds_block_sync(); // accumulator copies published, columns cleared
+        i = inext;
+    }
+
+    uint32_t *ob = out_big + (size_t)jix * ((size_t)K * N + 1);
+    if (g == 1) {
+        if (r < K) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const int j = G::jA(lane, e);
+                if (j == 0) ob[r * N] = accr[e];
+                else ob[r * N + (N - j)] = 0u - accr[e];
+            }
+        } else if (lane == 0) {
+            ob[K * N] = accr[0];
+        }
+    }
+}
+
 #if HELM_HIP_TU == 0 // the keyswitch, linear and table kernels: main translation unit only (see launch_pbs_wide)
 // ------------------------------------------------------------------------------------
 // k_keyswitch: grid (ceil(jobs / 4), column chunks); 256 threads; one output column per
@@ -1229,7 +1475,10 @@ struct helm_hip_ctx {
     int n_cus = 256;
     int narrow_variant = 4;  // build for launches of at most one workgroup per CU: 4 wide, 1 latency (HELM_HIP_NARROW)
     int clock_probe = 0;     // HELM_HIP_CLOCK_PROBE: print the in-kernel clock of every k_pbs launch
-    int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput, 4 wide, 5 lockstep (HELM_HIP_PBS_VARIANT)
+    int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput, 4 wide, 5 lockstep, 6 duo (two bootstraps
+                             // per workgroup), 7 duo (one per workgroup, two workgroups per CU) (HELM_HIP_PBS_VARIANT)
+    int duo_build = 1;       // the k_pbs_duo form the size dispatch uses: 1 = two per workgroup, 2 = one (HELM_HIP_DUO)
+    int duo_flags = 1;       // bit 0: issue-priority staging inside k_pbs_duo (HELM_HIP_DUO_FLAGS)
     // per-call scratch
     DevBuf<PbsJob> d_pbs;
     DevBuf<KsJob> d_ks;
@@ -1456,35 +1705,75 @@ static hipError_t launch_pbs_wide(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t
     return hipGetLastError();
 }
 
+template <typename C>
+static hipError_t launch_pbs_duo(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
+                                 const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
+{
+    static bool attr_done[64] = {false};
+    auto kern = k_pbs_duo<C>;
+    if (!attr_done[ctx->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
+        if (e != hipSuccess) return e;
+        attr_done[ctx->device & 63] = true;
+        if (getenv("HELM_HIP_VERBOSE")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 64 * C::NW, C::BYTES);
+            hipFuncAttributes fa{};
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
+            fprintf(stderr, "[helm_hip] k_pbs_duo NB=%d: %d waves, LDS %zu B, regs %d, scratch %zu B, max %d workgroups/CU\n", C::NB,
+                    C::NW, (size_t)C::BYTES, fa.numRegs, (size_t)fa.localSizeBytes, nb);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((count + C::NB - 1) / C::NB)), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, wires,
+                       raw, tvs, ctx->bsk, ctx->tw_fwd, out_big, ctx->P.n, ctx->P.pbs_logB, ctx->duo_flags, (int)count);
+    return hipGetLastError();
+}
+
 // Two translation units from this one source (Makefile): the whole file is compiled under the compiler's max-ILP scheduling
 // strategy (-mllvm -amdgpu-sched-strategy=max-ilp: +1.9 % on the lockstep k_pbs, same box, alternating, identical
 // ciphertexts), except k_pbs_wide, which that strategy slows down by 0.9 % and which is therefore compiled a second time
 // with -DHELM_HIP_TU=1 under the default strategy - that unit holds this launcher and nothing else of the host side.
-__attribute__((visibility("hidden"))) hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int field, int logn, int k, int l,
-                                                                        const PbsJob *jobs, int64_t count, const uint32_t *wires,
-                                                                        const uint32_t *raw, const uint32_t *tvs,
-                                                                        uint32_t *out_big);
+// build: 0 = k_pbs_wide, 1 = k_pbs_duo with two bootstraps per workgroup, 2 = k_pbs_duo with one
+__attribute__((visibility("hidden"))) hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int logn, int k,
+                                                                        int l, const PbsJob *jobs, int64_t count,
+                                                                        const uint32_t *wires, const uint32_t *raw,
+                                                                        const uint32_t *tvs, uint32_t *out_big);
 #if HELM_HIP_TU == 1
-hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int field, int logn, int k, int l, const PbsJob *jobs, int64_t count,
+hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int logn, int k, int l, const PbsJob *jobs, int64_t count,
                                     const uint32_t *wires, const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
 {
-#define WIDE_CASE(FB, LN, KK, LL) \
-    if (field == FB && logn == LN && k == KK && l == LL) \
-        return launch_pbs_wide<WideCfg<Fp<FB>, LN, KK, LL>>(ctx, jobs, count, wires, raw, tvs, out_big);
+#define WIDE_CASE(FB, LN, KK, LL)                                                                                        \
+    if (field == FB && logn == LN && k == KK && l == LL) {                                                               \
+        if (build == 1) return launch_pbs_duo<DuoCfg<Fp<FB>, LN, KK, LL, 2>>(ctx, jobs, count, wires, raw, tvs, out_big); \
+        if (build == 2) return launch_pbs_duo<DuoCfg<Fp<FB>, LN, KK, LL, 1>>(ctx, jobs, count, wires, raw, tvs, out_big); \
+        return launch_pbs_wide<WideCfg<Fp<FB>, LN, KK, LL>>(ctx, jobs, count, wires, raw, tvs, out_big);                  \
+    }
     WIDE_CASE(49, 9, 2, 3) WIDE_CASE(49, 9, 1, 3) WIDE_CASE(49, 9, 1, 2)
-    WIDE_CASE(51, 9, 2, 3) WIDE_CASE(51, 9, 1, 3) WIDE_CASE(51, 9, 1, 2) WIDE_CASE(51, 10, 1, 3) WIDE_CASE(51, 10, 1, 2)
+    WIDE_CASE(51, 9, 2, 3) WIDE_CASE(51, 9, 1, 3) WIDE_CASE(51, 9, 1, 2)
 #undef WIDE_CASE
+    // N = 1024: two bootstraps of k_pbs_duo do not fit a CU's LDS (91 KB each): the wide build only
+    if (build == 0 && field == 51 && logn == 10 && k == 1 && l == 3)
+        return launch_pbs_wide<WideCfg<Fp<51>, 10, 1, 3>>(ctx, jobs, count, wires, raw, tvs, out_big);
+    if (build == 0 && field == 51 && logn == 10 && k == 1 && l == 2)
+        return launch_pbs_wide<WideCfg<Fp<51>, 10, 1, 2>>(ctx, jobs, count, wires, raw, tvs, out_big);
     return hipErrorInvalidValue;
 }
 #endif
 #if HELM_HIP_TU == 0 // ==== everything below: the main unit only ===============================================
 template <typename F, int LOGN, int K, int L>
 static hipError_t wide_launch(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires, const uint32_t *raw,
-                              const uint32_t *tvs, uint32_t *out_big)
+                              const uint32_t *tvs, uint32_t *out_big, int build = 0)
 {
 #if HELM_HIP_SPLIT_TU
-    return helm_hip_tu1_launch_wide(ctx, std::is_same<F, Fp<49>>::value ? 49 : 51, LOGN, K, L, jobs, count, wires, raw, tvs, out_big);
+    return helm_hip_tu1_launch_wide(ctx, build, std::is_same<F, Fp<49>>::value ? 49 : 51, LOGN, K, L, jobs, count, wires, raw, tvs,
+                                    out_big);
 #else
+    if constexpr (LOGN == 9) {
+        if (build == 1) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, 2>>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if (build == 2) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, 1>>(ctx, jobs, count, wires, raw, tvs, out_big);
+    }
+    if (build) return hipErrorInvalidValue;
     return launch_pbs_wide<WideCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
 #endif
 }
@@ -1528,9 +1817,12 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
                 out_big += (size_t)full * ((size_t)K * (1 << LOGN) + 1);
                 count -= full;
             }
-            v = count <= ctx->n_cus ? ctx->narrow_variant : 3;
+            // the remainder: up to one per CU wide, up to two per CU duo (each bootstrap on two SIMDs; HELM_HIP_DUO=0: the
+            // throughput build as in round 3)
+            v = count <= ctx->n_cus ? ctx->narrow_variant : ctx->duo_build ? 5 + ctx->duo_build : 3;
         }
         if (v == 4) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if (v == 6 || v == 7) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big, v - 5);
         if (v == 1) return launch_pbs_v<Lat>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (v == 2) return launch_pbs_v<Bal>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (v == 5) return launch_pbs_v<Lock>(ctx, jobs, count, wires, raw, tvs, out_big);
@@ -1737,6 +2029,8 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         ctx->n_cus = prop.multiProcessorCount;
         if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) ctx->pbs_variant = atoi(v);
         if (const char *v = getenv("HELM_HIP_NARROW")) ctx->narrow_variant = atoi(v) == 4 ? 4 : 1;
+        if (const char *v = getenv("HELM_HIP_DUO")) ctx->duo_build = atoi(v) == 2 ? 2 : atoi(v) == 0 ? 0 : 1;
+        if (const char *v = getenv("HELM_HIP_DUO_FLAGS")) ctx->duo_flags = atoi(v);
         if (const char *v = getenv("HELM_HIP_CLOCK_PROBE")) ctx->clock_probe = atoi(v);
         if (const char *v = getenv("HELM_HIP_KS_MFMA")) ctx->ks_mfma = atoi(v);
         if (const char *v = getenv("HELM_HIP_WIDE_MAP")) ctx->wide_map = atoi(v);
