@@ -16,11 +16,13 @@ torch.distributed.run directly (RANK set), the process is a worker.
 One line, every result named:
   value / scaling "strong"   the north star's per-level shard: a FIXED job of `--blocks` blocks, every packed launch
                              split into N contiguous chunks, keys and wire table replicated, the launch's output
-                             ciphertexts all-gathered over RCCL (helm_amd/distributed.py); EXACTLY K timed steps
+                             ciphertexts all-gathered with ncclAllGather INSIDE libhelm_hip.so (include/helm_comm.h:
+                             helm_hip_program_run_sharded_comm - no torch in the data path); EXACTLY K timed steps
   weak                       independent blocks: every GPU evaluates its own `--blocks` blocks, no data-path collective
   sharded_weak               the sharded path at fixed work per GPU: ONE job of N x `--blocks` blocks, every launch
                              sharded and all-gathered (whole lockstep rounds per rank: what the exchange itself costs)
-  rccl_ranks                 dist.get_world_size() and the backend that carried the collectives
+  rccl_ranks                 what the library's own RCCL communicator reports (ncclCommCount / ncclCommUserRank), the RCCL
+                             version, and what carried the control plane (barrier, maximum over the ranks, the unique id)
 `--scaling weak` makes the independent-block run the headline instead (the strong run moves under "strong").
 
 A worker that fails - an exception, a wrong decryption, a collective that does not come back within
@@ -59,6 +61,9 @@ def parse_args(argv=None):
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1, sharded runs: launches cut to one lockstep round per rank, each launch's all-gather + scatter on "
                          "a side stream while the next launch's bootstraps run (off until a SCALE run has measured it)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="N = 1: run the headline through the sharded path anyway - a world-size-1 RCCL communicator inside the library, "
+                         "every launch stage -> ncclAllGather -> scatter (what the exchange machinery itself costs; rccl_ranks is filled)")
     ap.add_argument("--side-steps", type=int, default=3, help="N > 1: timed steps of the runs that are not the headline")
     ap.add_argument("--leg-timeout", type=float, default=900.0,
                     help="N > 1: seconds one run may take before it counts as hung (the line is printed with the error, rc 3)")
@@ -174,8 +179,8 @@ def make_program(sk, circuit, wire_names, blocks, quantum, pack=True, overlap_sp
     from helm_amd.distributed import launch_dependencies, pack_levels, split_launches
     ops, i0, i1, i2, out, off, _ = build_program_arrays(circuit, wire_names, blocks)
     levels = len(off) - 1
-    if pack:
-        ops, i0, i1, i2, out, off, _ = pack_levels(ops, i0, i1, i2, out, off, quantum)
+    if pack:  # cost-aware: launches narrower than a round take the engine's most efficient width (wide / duo / lockstep)
+        ops, i0, i1, i2, out, off, _ = pack_levels(ops, i0, i1, i2, out, off, quantum, quarter_cost=sk.launch_costs())
     deps = None
     if overlap_split > 0:
         off = split_launches(ops, off, overlap_split)
@@ -230,11 +235,35 @@ class Bench:
             local_rank = 0
         self.local_rank = local_rank
         torch.cuda.set_device(local_rank)
+        self.comm, self.comm_error = None, None
         if self.world > 1:
-            if self.rehearse:
+            # control plane (barrier, maximum over the ranks, the communicator's unique id): torch.distributed over gloo;
+            # --overlap drives the collectives from Python on torch's streams and needs torch's own nccl backend instead
+            if self.rehearse or not args.overlap:
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # data path: the library's own RCCL communicator, one rank per GPU (include/helm_comm.h)
+            if not self.rehearse and not args.overlap:
+                from helm_amd import comm as hc
+                ok = torch.tensor([1 if hc.available() else 0])
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank can bind RCCL, or nobody tries
+                if int(ok.item()):
+                    try:
+                        self.comm = hc.Comm.from_torch_dist(dist, local_rank)
+                    except Exception as e:                          # reported in the line; the data path falls back to gloo
+                        self.comm_error = repr(e)
+                else:
+                    self.comm_error = "librccl could not be loaded on every rank"
+                ok = torch.tensor([1 if self.comm is not None else 0])
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if not int(ok.item()) and self.comm is not None:
+                    self.comm.destroy()
+                    self.comm = None
+                    self.comm_error = self.comm_error or "another rank could not create its communicator"
+        elif args.force_comm:
+            from helm_amd import comm as hc
+            self.comm = hc.Comm.single(local_rank)
         # keys (identical on every rank: same deterministic benchmark seed) and engine
         t0 = time.time()
         self.ck = helm_amd.ClientKey.generate(args.params, seed=1)
@@ -262,7 +291,7 @@ class Bench:
         synchronize on both sides; the elapsed time is the maximum over the ranks."""
         from helm_amd.distributed import GpuLevelExecutor, ShardedRunner
         a, np, torch, dist = self.args, self.np, self.torch, self.dist
-        sharded = kind != "weak" and self.world > 1
+        sharded = kind != "weak" and (self.world > 1 or self.comm is not None)
         blocks = a.blocks * (self.world if kind == "sharded_weak" else 1)   # blocks in this rank's wire table
         prog, launches, levels, deps = make_program(self.sk, self.circuit, self.wire_names, blocks,
                                                     self.quantum * (self.world if sharded else 1), pack=not a.no_pack,
@@ -276,7 +305,8 @@ class Bench:
         wires = self.sk.wires(self.nw * blocks)
         upload_inputs(self.ck, wires, self.index, self.nw, keys_pt)
         runner = ShardedRunner(GpuLevelExecutor(prog, wires), self.rank, self.world if sharded else 1,
-                               dist if sharded else None, time_collective=sharded, depends_on=deps)
+                               dist if sharded else None, time_collective=sharded, depends_on=deps,
+                               comm=self.comm if sharded else None)
         for _ in range(warmup):
             runner.run()
         self.sync_all()
@@ -292,7 +322,7 @@ class Bench:
         self.sk.timing_enable(False)
         clock_ghz = self.sk.kernel_clock_ghz()
         if self.world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         # correctness of what was timed: every block of this rank's table decrypts to AES(key, pt)
@@ -304,7 +334,11 @@ class Bench:
              "blocks_per_table": blocks, "blocks_total": blocks * (self.world if kind == "weak" else 1),
              "launches": launches, "levels": levels, "sharded_launches": len(runner.sharded_levels),
              "exchanged_MB_per_step": runner.exchanged_bytes_per_pass() / 1e6,
-             "collective_ms_per_step": runner.collective_ms(reset=True) / steps if sharded else 0.0,
+             # in-library communicator: the engine's events around every ncclAllGather; torch path: events around the calls
+             "collective_ms_per_step": ((tm.exchange_ms if self.comm is not None else runner.collective_ms(reset=True)) / steps
+                                        if sharded else 0.0),
+             "collectives_per_step": (int(tm.exchange_count) // steps if (sharded and self.comm is not None)
+                                      else len(runner.sharded_levels) if sharded else 0),
              "overlapped": bool(deps is not None),
              "tm": tm, "clock_ghz": clock_ghz}
         if keep:
@@ -329,6 +363,7 @@ class Bench:
                 "launches_per_step": r["launches"], "sharded_launches": r["sharded_launches"],
                 "exchanged_MB_per_step": round(r["exchanged_MB_per_step"], 2),
                 "collective_ms_per_step": round(r["collective_ms_per_step"], 3),
+                "collectives_per_step": r["collectives_per_step"],
                 "exchange_overlapped_with_next_launch": r["overlapped"],
                 "decrypt_check": "all blocks == software AES on every rank"}
 
@@ -403,6 +438,8 @@ def worker(args):
     if rank == 0:
         emit(result)
     if bench is not None and bench.world > 1 and rc == 0:
+        if bench.comm is not None:
+            bench.comm.destroy()
         bench.dist.destroy_process_group()
     return rc
 
@@ -472,8 +509,10 @@ def fill_result(bench, result):
             "ks_l": p.ks_l, "ks_logB": p.ks_logB,
             "levels": head["levels"], "launches_per_step": head["launches"], "bootstraps_per_step": head["job_pbs"],
             "blocks_total": head["blocks_total"],
+            "value_is": f"a batch of {head['blocks_total']} independent AES-128 evaluations run together (the blocks share no wires, so launches "
+                        "hold whole lockstep rounds); ONE evaluation, what helm.rs:256-262 runs, is `single_block` with its own roofline",
             "parallelism": ("single GPU" if world == 1 else
-                            f"launch-shard x{world} + all-gather of launch outputs (RCCL), keys and wire table replicated" if sharded else
+                            f"launch-shard x{world} + ncclAllGather of launch outputs inside the library (RCCL), keys and wire table replicated" if sharded else
                             f"block-parallel x{world}: independent blocks per GPU, keys replicated, no data-path collective"),
             "sharded_launches": head["sharded_launches"],
             "exchanged_MB_per_step": round(head["exchanged_MB_per_step"], 2),
@@ -507,9 +546,22 @@ def fill_result(bench, result):
         },
         "setup_s": {"keygen_upload": round(bench.t_keys, 2)},
     })
-    if world > 1:
-        result["rccl_ranks"] = {"world_size": bench.dist.get_world_size(), "backend": bench.dist.get_backend(),
-                                "one_process_per_gpu": not bench.rehearse}
+    if world > 1 or bench.comm is not None:
+        if bench.comm is not None:
+            info = bench.comm.info()   # what RCCL itself reports for the library's communicator
+            result["rccl_ranks"] = {"world_size": info["world_size"], "rank_of_this_line": info["rank"], "rccl_version": info["rccl_version"],
+                                    "communicator": "helm_comm: ncclCommInitRank / ncclAllGather inside libhelm_hip.so (include/helm_comm.h)",
+                                    "collectives_issued_by_rank_0": bench.comm.stats()["collectives"],
+                                    "control_plane": (f"torch.distributed {bench.dist.get_backend()} (barrier, max over ranks, unique id)"
+                                                      if world > 1 else "none (one process)"),
+                                    "one_process_per_gpu": True}
+        else:
+            result["rccl_ranks"] = {"world_size": bench.dist.get_world_size(), "backend": bench.dist.get_backend(),
+                                    "communicator": "torch.distributed (" + ("rehearsal on one GPU" if bench.rehearse else
+                                                    "--overlap" if args.overlap else f"FALLBACK, RCCL not used: {bench.comm_error}") + ")",
+                                    "one_process_per_gpu": not bench.rehearse}
+            if bench.comm_error:
+                result["rccl_error"] = bench.comm_error
         result[head_kind] = bench.describe(head)   # the headline under its own name as well
     checkpoint(result)
 
@@ -523,15 +575,47 @@ def fill_result(bench, result):
     # ---- wall-clock of ONE AES-128 evaluation (latency; levels are 80-256 gates wide, so the
     #      GPU is far from full: this is the n-step blind-rotation chain, 207 levels deep) ------
     if world == 1:
-        prog1, _, _, _ = make_program(bench.sk, bench.circuit, bench.wire_names, 1, quantum)
+        prog1, launches1, _, _ = make_program(bench.sk, bench.circuit, bench.wire_names, 1, quantum)
         prog1.run(head["wires"])
         bench.sync_all()
         t0 = time.perf_counter()
         prog1.run(head["wires"])
         bench.sync_all()
         t1 = time.perf_counter() - t0
-        result["single_block"] = {"wall_s": round(t1, 4), "gate_bootstraps_per_s": round(prog1.total_pbs() / t1, 1),
-                                  "bootstraps": int(prog1.total_pbs())}
+        # once more with the engine's events on (outside wall_s): the launches of ONE circuit are 80 - 256 bootstraps wide, so
+        # the kernel is k_pbs_wide (one bootstrap per CU on all four SIMDs) and the figure of merit is the latency of the
+        # n-step chain, not the chip's throughput
+        bench.sk.timing_enable(True)
+        bench.sk.timing(reset=True)
+        prog1.run(head["wires"])
+        bench.sync_all()
+        tm1 = bench.sk.timing(reset=True)
+        bench.sk.timing_enable(False)
+        n_l = max(1, tm1.pbs_launches)
+        avg_ms, avg_w = tm1.pbs_ms / n_l, tm1.pbs_count / n_l
+        ach1 = algo_ops * tm1.pbs_count / (tm1.pbs_ms * 1e-3) / 1e12
+        occ = avg_w / n_cus
+        cyc = avg_ms * 1e-3 * (clock_ghz or PEAK_CLOCK_GHZ) * 1e9 / p.n
+        result["single_block"] = {
+            "wall_s": round(t1, 4), "gate_bootstraps_per_s": round(prog1.total_pbs() / t1, 1),
+            "bootstraps": int(prog1.total_pbs()), "launches": int(launches1),
+            "what": "ONE AES-128 evaluation - what the reference binary runs (helm.rs:256-262); `value` above is a batch of "
+                    f"{head['blocks_total']} such blocks evaluated together",
+            "roofline": {
+                "kernel": "k_pbs_wide<WideCfg<...>> ((k+1) l = 9 waves per bootstrap, one bootstrap per CU)" if p.N == 512 else "k_pbs_wide",
+                "bound": "fp64_valu (latency of the n-step chain: a launch of <= one bootstrap per CU costs one chain whatever its width)",
+                "achieved": round(ach1, 2), "peak": round(peak_tops, 2), "unit": "T fp64 lane-op/s (FMA = 1)",
+                "frac": round(ach1 / peak_tops, 4),
+                "occupancy": round(occ, 3),
+                "frac_of_the_busy_cus": round(ach1 / (peak_tops * max(occ, 1e-9)), 4),
+                "avg_launch_ms": round(avg_ms, 4), "avg_bootstraps_per_launch": round(avg_w, 1), "launches_timed": int(n_l),
+                "cycles_per_step": round(cyc), "cycles_per_step_if_the_four_simds_were_perfectly_packed": 8400,
+                "cycles_per_step_clock": "the clock k_pbs held in the timed region (k_pbs_wide has no probe of its own)" if clock_ghz else "nominal",
+                "algorithmic_lane_ops_per_bootstrap": int(algo_ops),
+                "issue_slot_fraction": "0.60 (VALU active 0.266 per wave x 2.25 waves per SIMD: profiles/r03/pmc_and_stats_summary.txt; "
+                                       "the kernel is unchanged since)",
+                "traffic": None,
+            }}
         prog1.destroy()
         checkpoint(result)
 

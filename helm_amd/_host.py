@@ -29,6 +29,8 @@ HOST_API = {
     "helm_host_preprocess": (C.c_int, [cp, C.c_int, C.POINTER(vp)]),
     "helm_host_pack_levels": (C.c_int, [C.POINTER(C.c_int32)] * 5 + [C.POINTER(C.c_int64), C.c_int64, C.c_int64] +
                               [C.POINTER(C.c_int64)] * 3),
+    "helm_host_pack_levels_costed": (C.c_int, [C.POINTER(C.c_int32)] * 5 + [C.POINTER(C.c_int64), C.c_int64, C.c_int64,
+                                                C.POINTER(C.c_double)] + [C.POINTER(C.c_int64)] * 3),
     "helm_host_enc_map_new": (C.c_int, [vp, C.POINTER(vp)]),
     "helm_host_enc_map_free": (None, [vp]),
     "helm_host_enc_map_insert": (C.c_int, [vp, cp, u32p]),

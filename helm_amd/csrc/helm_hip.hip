@@ -813,32 +813,39 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
 }
 
 // ------------------------------------------------------------------------------------
-// k_pbs_duo: the build for launches of MORE than one and at most TWO bootstraps per CU - each bootstrap on two SIMDs.
+// k_pbs_duo: the build for launches of MORE than one and at most TWO bootstraps per CU.
 // Round 3 had nothing between the wide build (one bootstrap per CU on all four SIMDs, 3.2 - 3.6 ms per round) and a
 // lockstep round (four per CU, one SIMD each, 8.5 ms): 257 - 512 bootstraps cost 7.4 ms on the throughput build, which is
 // what a rank's chunk of a sharded launch looks like at 8 GPUs (circuit.rs:531: the level is the sharded unit).
 //
-// 2 (k+1) waves per bootstrap = (polynomial r, part g), NB bootstraps per workgroup:
-//   g = 0 ("A")  the digits of levels 0 .. L-2 of polynomial r: per level one forward transform and k+1 products, summed
-//                over its levels in registers and added to the per-column accumulators in LDS (ds_add_f64: exact
-//                integer sums, any order)
-//   g = 1 ("B")  the digit of level L-1 (first out of the carry chain), its transform and products; after the first
-//                barrier the inverse transform of column r, the lift and the accumulator update of polynomial r, whose
-//                negacyclically unrolled u32 copy both waves of the polynomial rotate and decompose in the next step.
-// With NB = 2 the workgroup has 4 (k+1) = 12 waves, three per SIMD (the hardware deals a workgroup's waves round the four
-// SIMDs, tools/ubench_placement.hip): bootstrap b sits on SIMDs 2b and 2b + 1 as (A0, A1, B2 | B0, B1, A2), so both of
-// its SIMDs carry one and a half polynomials.  NB = 1 (six waves, two workgroups per CU) leaves the interleaving of two
-// bootstraps to the hardware.  Same arithmetic as every other build: identical ciphertexts.
+// Two bootstraps per workgroup, 2 (k+1) waves per bootstrap = (polynomial r, part g): 12 waves, three per SIMD.
+//   g = 0 ("A")  the digits of levels 0 .. L-2 of polynomial r: per level one forward transform and k+1 products, added to
+//                the per-column accumulators in LDS (ds_add_f64: exact integer sums, any order)
+//   g = 1 ("B")  the digit of level L-1 (first out of the carry chain), its transform and products; after the barrier the
+//                inverse transform of column r, the lift and the accumulator update of polynomial r, whose negacyclically
+//                unrolled u32 copy both waves of the polynomial rotate and decompose in the next step.
+// A step of a bootstrap is two intervals between workgroup barriers: the forward interval (rotation, digits, transforms,
+// products: issue-bound, 4.8 k wave-instructions) and the inverse interval (k+1 inverse transforms on k+1 waves: a
+// dependent chain of nine butterfly stages and four LDS round trips, 3.5 k cycles for a wave that runs alone while the
+// other waves of the bootstrap have nothing to do).
+//   STAG = false  both bootstraps in the same interval, bootstrap b on SIMDs 2b and 2b + 1 as (A0, A1, B2 | B0, B1, A2):
+//                 per-phase stamps (profiles/r04) show 11.4 k cycles of forward interval and 5.5 k of inverse interval in
+//                 which nine of twelve waves wait.
+//   STAG = true   bootstrap 1 runs ONE INTERVAL BEHIND bootstrap 0 and the two share all four SIMDs: while one bootstrap's
+//                 three inverse waves walk their latency chain (at high issue priority), the other's six waves fill the issue
+//                 slots with its forward interval.  Same barriers per step, same arithmetic: identical ciphertexts.
 // ------------------------------------------------------------------------------------
-template <typename F_, int LOGN_, int K_, int L_, int NB_>
+template <typename F_, int LOGN_, int K_, int L_, bool STAG_>
 struct DuoCfg {
     using F = F_;
-    static constexpr int LOGN = LOGN_, K = K_, L = L_, K1 = K_ + 1, NB = NB_, NWB = 2 * (K_ + 1), NW = 2 * (K_ + 1) * NB_;
+    static constexpr int LOGN = LOGN_, K = K_, L = L_, K1 = K_ + 1, NB = 2, NWB = 2 * (K_ + 1), NW = 4 * (K_ + 1);
+    static constexpr bool STAG = STAG_;
     using G = Geo<LOGN>;
     static constexpr int MAX_SMALL_N = 1024;
     static constexpr int ACC3 = (3 * G::N - 64 + 1) / 2 * 2; // u32 entries per polynomial (see PbsCfg)
     static constexpr int TW_ROWS = G::TWB + G::TWC;
     static_assert(L >= 2, "part A needs at least one level");
+    static_assert(K1 == 2 || K1 == 3, "wave maps are written for k = 1 and k = 2");
     // per bootstrap
     static constexpr size_t X_OFF = 0;                                              // double [NWB][XPAD]
     static constexpr size_t COL_OFF = X_OFF + sizeof(double) * NWB * G::XPAD;       // double [K1][N]
@@ -863,20 +870,31 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // wave -> (bootstrap of the workgroup, polynomial, part)
+    // wave -> (bootstrap of the workgroup, polynomial, part); wave w sits on SIMD w % 4
     int b, r, g;
-    if constexpr (NB == 2) {
-        const int s = w & 1, q = w >> 2; // SIMD of the pair, wave of that SIMD
+    if constexpr (!C::STAG) {
+        const int s = w & 1, q = w >> 2; // SIMD of the bootstrap's pair, wave of that SIMD
         b = (w & 3) >> 1;
         r = q;
         g = ((q == K1 - 1) ? 1 : 0) ^ s;
+    } else if constexpr (K1 == 3) {
+        // SIMD 0: A0 a0 B0   SIMD 1: A1 a1 B1   SIMD 2: A2 a2 b0   SIMD 3: B2 b1 b2   (capitals: bootstrap 0): in either kind of
+        // interval every SIMD carries close to a quarter of (forward interval of one bootstrap + inverses of the other)
+        // w:     0  1  2  3  4  5  6  7  8  9 10 11
+        // b:     0  0  0  0  1  1  1  1  0  0  1  1      r:  0 1 2 2 0 1 2 1 0 1 0 2      g:  0 0 0 1 0 0 0 1 1 1 1 1
+        constexpr unsigned BB = 0xCF0u, GG = 0xF88u;
+        constexpr unsigned RR = 0u | 1u << 2 | 2u << 4 | 2u << 6 | 0u << 8 | 1u << 10 | 2u << 12 | 1u << 14 | 0u << 16 | 1u << 18 | 0u << 20 | 2u << 22;
+        b = (int)((BB >> w) & 1u);
+        g = (int)((GG >> w) & 1u);
+        r = (int)((RR >> (2 * w)) & 3u);
     } else {
-        b = 0;
-        r = w % K1;
-        g = w / K1;
+        // eight waves, two per SIMD: SIMD 0: A0 a0   SIMD 1: A1 a1   SIMD 2: B0 b0   SIMD 3: B1 b1
+        b = w >> 2;
+        r = w & 1;
+        g = (w >> 1) & 1;
     }
     const int jix = (int)blockIdx.x * NB + b;
-    if (NB > 1 && jix >= count) return; // the hardware barrier counts the surviving waves only
+    if (jix >= count) return; // the hardware barrier counts the surviving waves only
     unsigned char *smem = smem_wg + (size_t)b * C::BOOT_BYTES;
     double *X = reinterpret_cast<double *>(smem + C::X_OFF);
     double *COL = reinterpret_cast<double *>(smem + C::COL_OFF);
@@ -961,54 +979,36 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
 #pragma unroll
             for (int e2 = 0; e2 < E / 2; e2++) kw[c][e2] = kb.load(so + (unsigned)(c * L) * poly_bytes, e2 * 1024);
     };
-    // the level a wave transforms first in a step: its key words are fetched one step ahead - by part A during the inverse
-    // transforms (it idles there), by part B right after its accumulator update
+    // the level a wave transforms first in a step: its key words are fetched in the inverse interval before - by part A
+    // while it has nothing else to do, by part B right after its accumulator update
     const int first_lev = g == 1 ? L - 1 : L - 2;
-    int i = 0;
-    if constexpr (NB == 1)
-        while (i < n && __builtin_amdgcn_readfirstlane((int)MS[i]) == 0) i++; // a zero rotation adds nothing
-    if (i < n) load_keys(i, first_lev);
-    if (prio) __builtin_amdgcn_s_setprio(3);
-    while (i < n) {
-        const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
-        uint32_t st[E];
-        {
-            const uint32_t *ar = acc_r + ((lane - a) & (2 * N - 1));
-            const uint32_t *ac = acc_r + lane;
+    // a zero rotation is not skipped: the two bootstraps of a workgroup meet at the same barriers (one step in 2N; its
+    // external product is exactly zero)
+    load_keys(0, first_lev);
+    const int lag = C::STAG ? b : 0;          // intervals this bootstrap runs behind bootstrap 0
+    const int T = 2 * n + (C::STAG ? 1 : 0);  // intervals of the workgroup
+    STAMP_DECL
+    for (int t = 0; t < T; t++) {
+        STAMP_BEGIN
+        const int tt = t - lag;
+        const int i = tt >> 1;
+        if (tt >= 0 && tt < 2 * n && !(tt & 1)) {
+            // ---- forward interval of step i --------------------------------------------------------------------------
+            if (prio) __builtin_amdgcn_s_setprio(3);
+            const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
+            uint32_t st[E];
+            {
+                const uint32_t *ar = acc_r + ((lane - a) & (2 * N - 1));
+                const uint32_t *ac = acc_r + lane;
 #pragma unroll
-            for (int e = 0; e < E; e++) st[e] = ((ar[64 * e] - ac[64 * e]) + (1u << (31 - rep))) >> (32 - rep);
-        }
-        double x[1][E];
-        if (g == 1) {
-#pragma unroll
-            for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(st[e], logB, half_m1, neg_B);
-            ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
-            if (prio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int c = 0; c < K1; c++) {
-                double *col = COL + (size_t)c * N + lane;
-#pragma unroll
-                for (int e2 = 0; e2 < E / 2; e2++) {
-                    lds_add_wg(col + (2 * e2) * 64, reduce_unless_lazy<F>(mulmod<F>(x[0][2 * e2], kw[c][e2].x)));
-                    lds_add_wg(col + (2 * e2 + 1) * 64, reduce_unless_lazy<F>(mulmod<F>(x[0][2 * e2 + 1], kw[c][e2].y)));
-                }
+                for (int e = 0; e < E; e++) st[e] = ((ar[64 * e] - ac[64 * e]) + (1u << (31 - rep))) >> (32 - rep);
             }
-        } else {
-            // the carry chain starts at the least significant level, which part B transforms
-#pragma unroll
-            for (int e = 0; e < E; e++) (void)decompose_step(st[e], logB, half_m1, neg_B);
-            // (summing the levels' products in registers first would halve the LDS additions, but (k+1) E more doubles next
-            // to the key words and the transform's temporaries do not fit three waves per SIMD: 49 spilled registers)
-#pragma unroll
-            for (int lev = L - 2; lev >= 0; lev--) {
+            double x[1][E];
+            if (g == 1) {
 #pragma unroll
                 for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(st[e], logB, half_m1, neg_B);
-                if (lev != L - 2) load_keys(i, lev); // (the first level's words came a step ahead)
                 ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
-                if (prio) {
-                    if (lev) __builtin_amdgcn_s_setprio(2);
-                    else __builtin_amdgcn_s_setprio(1);
-                }
+                if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int c = 0; c < K1; c++) {
                     double *col = COL + (size_t)c * N + lane;
@@ -1018,30 +1018,57 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
                         lds_add_wg(col + (2 * e2 + 1) * 64, reduce_unless_lazy<F>(mulmod<F>(x[0][2 * e2 + 1], kw[c][e2].y)));
                     }
                 }
-            }
-        }
-        int inext = i + 1;
-        if constexpr (NB == 1)
-            while (inext < n && __builtin_amdgcn_readfirstlane((int)MS[inext]) == 0) inext++;
-        lds_block_sync(); // every product of the step is in its column
-        if (prio) __builtin_amdgcn_s_setprio(3);
-        if (g == 1) {
-            double mine[E];
-            double *col = COL + (size_t)r * N + lane;
+            } else {
+                // the carry chain starts at the least significant level, which part B transforms
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                mine[e] = reduce<F>(col[e * 64]);
-                col[e * 64] = 0.0;
-            }
-            ntt_inverse<F, LOGN>(mine, xb, twi, lane);
+                for (int e = 0; e < E; e++) (void)decompose_step(st[e], logB, half_m1, neg_B);
+                // (summing the levels' products in registers first would halve the LDS additions, but (k+1) E more doubles
+                // next to the key words and the transform's temporaries do not fit three waves per SIMD: 49 spilled registers)
 #pragma unroll
-            for (int e = 0; e < E; e++) accr[e] += to_torus32(mine[e]);
-            acc_store();
+                for (int lev = L - 2; lev >= 0; lev--) {
+#pragma unroll
+                    for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(st[e], logB, half_m1, neg_B);
+                    if (lev != L - 2) load_keys(i, lev); // (the first level's words came an interval ahead)
+                    ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+                    if (prio) { // a wave steps its priority down as it advances: whoever is behind goes first (see k_pbs)
+                        if (lev) __builtin_amdgcn_s_setprio(2);
+                        else __builtin_amdgcn_s_setprio(1);
+                    }
+#pragma unroll
+                    for (int c = 0; c < K1; c++) {
+                        double *col = COL + (size_t)c * N + lane;
+#pragma unroll
+                        for (int e2 = 0; e2 < E / 2; e2++) {
+                            lds_add_wg(col + (2 * e2) * 64, reduce_unless_lazy<F>(mulmod<F>(x[0][2 * e2], kw[c][e2].x)));
+                            lds_add_wg(col + (2 * e2 + 1) * 64, reduce_unless_lazy<F>(mulmod<F>(x[0][2 * e2 + 1], kw[c][e2].y)));
+                        }
+                    }
+                }
+            }
+            STAMP(0) // rotation, digits, forward transforms, products
+        } else if (tt >= 0 && tt < 2 * n) {
+            // ---- inverse interval of step i: every product of the step is in its column ------------------------------
+            if (prio) __builtin_amdgcn_s_setprio(3); // (staggered: the latency chain goes first, the other bootstrap's forward waves fill in)
+            if (g == 1) {
+                double mine[E];
+                double *col = COL + (size_t)r * N + lane;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    mine[e] = reduce<F>(col[e * 64]);
+                    col[e * 64] = 0.0;
+                }
+                ntt_inverse<F, LOGN>(mine, xb, twi, lane);
+#pragma unroll
+                for (int e = 0; e < E; e++) accr[e] += to_torus32(mine[e]);
+                acc_store();
+            }
+            if (i + 1 < n) load_keys(i + 1, first_lev);
+            STAMP(2) // part B: inverse transform, lift, accumulator update; key words of the next step issued
         }
-        if (inext < n) load_keys(inext, first_lev);
-        lds_block_sync(); // accumulator copies published, columns cleared
-        i = inext;
+        lds_block_sync(); // forward interval: products in their columns; inverse interval: accumulator copies published
+        STAMP(1) // barrier
     }
+    STAMP_END(w)
 
     uint32_t *ob = out_big + (size_t)jix * ((size_t)K * N + 1);
     if (g == 1) {
@@ -1475,9 +1502,9 @@ struct helm_hip_ctx {
     int n_cus = 256;
     int narrow_variant = 4;  // build for launches of at most one workgroup per CU: 4 wide, 1 latency (HELM_HIP_NARROW)
     int clock_probe = 0;     // HELM_HIP_CLOCK_PROBE: print the in-kernel clock of every k_pbs launch
-    int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput, 4 wide, 5 lockstep, 6 duo (two bootstraps
-                             // per workgroup), 7 duo (one per workgroup, two workgroups per CU) (HELM_HIP_PBS_VARIANT)
-    int duo_build = 1;       // the k_pbs_duo form the size dispatch uses: 1 = two per workgroup, 2 = one (HELM_HIP_DUO)
+    int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput, 4 wide, 5 lockstep, 6 duo (the two
+                             // bootstraps of a workgroup in step), 7 duo staggered (HELM_HIP_PBS_VARIANT)
+    int duo_build = 1;       // the k_pbs_duo form the size dispatch uses: 1 in step, 2 staggered, 0 none (HELM_HIP_DUO)
     int duo_flags = 1;       // bit 0: issue-priority staging inside k_pbs_duo (HELM_HIP_DUO_FLAGS)
     // per-call scratch
     DevBuf<PbsJob> d_pbs;
@@ -1721,12 +1748,13 @@ static hipError_t launch_pbs_duo(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t 
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 64 * C::NW, C::BYTES);
             hipFuncAttributes fa{};
             (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
-            fprintf(stderr, "[helm_hip] k_pbs_duo NB=%d: %d waves, LDS %zu B, regs %d, scratch %zu B, max %d workgroups/CU\n", C::NB,
-                    C::NW, (size_t)C::BYTES, fa.numRegs, (size_t)fa.localSizeBytes, nb);
+            fprintf(stderr, "[helm_hip] k_pbs_duo%s: %d waves, LDS %zu B, regs %d, scratch %zu B, max %d workgroups/CU\n",
+                    C::STAG ? " (staggered)" : "", C::NW, (size_t)C::BYTES, fa.numRegs, (size_t)fa.localSizeBytes, nb);
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((count + C::NB - 1) / C::NB)), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, wires,
                        raw, tvs, ctx->bsk, ctx->tw_fwd, out_big, ctx->P.n, ctx->P.pbs_logB, ctx->duo_flags, (int)count);
+    print_stamps(ctx, C::NW, "duo: forward | barriers | inverse | - | - | -");
     return hipGetLastError();
 }
 
@@ -1734,7 +1762,7 @@ static hipError_t launch_pbs_duo(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t 
 // strategy (-mllvm -amdgpu-sched-strategy=max-ilp: +1.9 % on the lockstep k_pbs, same box, alternating, identical
 // ciphertexts), except k_pbs_wide, which that strategy slows down by 0.9 % and which is therefore compiled a second time
 // with -DHELM_HIP_TU=1 under the default strategy - that unit holds this launcher and nothing else of the host side.
-// build: 0 = k_pbs_wide, 1 = k_pbs_duo with two bootstraps per workgroup, 2 = k_pbs_duo with one
+// build: 0 = k_pbs_wide, 1 = k_pbs_duo with the two bootstraps of a workgroup in step, 2 = k_pbs_duo staggered
 __attribute__((visibility("hidden"))) hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int logn, int k,
                                                                         int l, const PbsJob *jobs, int64_t count,
                                                                         const uint32_t *wires, const uint32_t *raw,
@@ -1745,8 +1773,8 @@ hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int
 {
 #define WIDE_CASE(FB, LN, KK, LL)                                                                                        \
     if (field == FB && logn == LN && k == KK && l == LL) {                                                               \
-        if (build == 1) return launch_pbs_duo<DuoCfg<Fp<FB>, LN, KK, LL, 2>>(ctx, jobs, count, wires, raw, tvs, out_big); \
-        if (build == 2) return launch_pbs_duo<DuoCfg<Fp<FB>, LN, KK, LL, 1>>(ctx, jobs, count, wires, raw, tvs, out_big); \
+        if (build == 1) return launch_pbs_duo<DuoCfg<Fp<FB>, LN, KK, LL, false>>(ctx, jobs, count, wires, raw, tvs, out_big); \
+        if (build == 2) return launch_pbs_duo<DuoCfg<Fp<FB>, LN, KK, LL, true>>(ctx, jobs, count, wires, raw, tvs, out_big); \
         return launch_pbs_wide<WideCfg<Fp<FB>, LN, KK, LL>>(ctx, jobs, count, wires, raw, tvs, out_big);                  \
     }
     WIDE_CASE(49, 9, 2, 3) WIDE_CASE(49, 9, 1, 3) WIDE_CASE(49, 9, 1, 2)
@@ -1770,8 +1798,8 @@ static hipError_t wide_launch(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t cou
                                     out_big);
 #else
     if constexpr (LOGN == 9) {
-        if (build == 1) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, 2>>(ctx, jobs, count, wires, raw, tvs, out_big);
-        if (build == 2) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, 1>>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if (build == 1) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, false>>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if (build == 2) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, true>>(ctx, jobs, count, wires, raw, tvs, out_big);
     }
     if (build) return hipErrorInvalidValue;
     return launch_pbs_wide<WideCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
@@ -2151,6 +2179,24 @@ int64_t helm_hip_launch_quantum(const helm_hip_ctx *ctx)
 {
     if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");
     return 4 * (int64_t)ctx->n_cus; // PbsCfg::NB bootstraps per workgroup, one workgroup per CU
+}
+
+int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4])
+{
+    if (!ctx || !cost) return fail(HELM_ERR_INVALID, "null argument");
+    // launch_pbs_f's dispatch, measured (profiles/r04/microbench.jsonl, boolean_default: 3.55 / 5.3 / 7.5 / 8.5 ms for
+    // <= 256 / 512 / 768 / 1,024 bootstraps; without k_pbs_duo the throughput build takes 6.7 ms for <= 512)
+    if (ctx->P.N == 512) {
+        cost[0] = ctx->narrow_variant == 4 ? 0.42 : 0.50;
+        cost[1] = ctx->duo_build ? 0.62 : 0.80;
+        cost[2] = 0.88;
+    } else { // N = 1024: the wide build for <= one per CU (3.9 of 8.8 ms), whole lockstep rounds above it
+        cost[0] = ctx->narrow_variant == 4 ? 0.46 : 0.64;
+        cost[1] = 1.0;
+        cost[2] = 1.0;
+    }
+    cost[3] = 1.0;
+    return 0;
 }
 
 int helm_hip_load_bootstrap_key(helm_hip_ctx *ctx, const uint32_t *bsk_std, size_t n_words)

@@ -232,6 +232,33 @@ int helm_host_pack_levels(const int32_t *opcode, const int32_t *in0, const int32
     }
 }
 
+int helm_host_pack_levels_costed(const int32_t *opcode, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                                 const int32_t *out, const int64_t *level_offsets, int64_t n_levels, int64_t quantum,
+                                 const double *quarter_cost, int64_t *order, int64_t *new_offsets, int64_t *n_launches)
+{
+    if (!opcode || !in0 || !in1 || !in2 || !out || !level_offsets || !order || !new_offsets || !n_launches || n_levels < 0) {
+        g_err = "null argument";
+        return -1;
+    }
+    if (quarter_cost)
+        for (int q = 0; q < 4; q++)
+            if (!(quarter_cost[q] > 0.0)) {
+                g_err = "pack_levels: quarter costs must be positive";
+                return -1;
+            }
+    try {
+        std::vector<int64_t> ord, off;
+        const int rc = pack_levels(opcode, in0, in1, in2, out, level_offsets, n_levels, quantum, ord, off, quarter_cost);
+        std::copy(ord.begin(), ord.end(), order);
+        std::copy(off.begin(), off.end(), new_offsets);
+        *n_launches = (int64_t)off.size() - 1;
+        return rc;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
 int helm_host_enc_map_new(helm_hip_ctx *server_key, helm_enc_map **out)
 {
     return guard([&] {

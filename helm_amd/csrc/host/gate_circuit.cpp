@@ -331,10 +331,12 @@ std::unique_ptr<EncWireMap> GateCircuit::evaluate_encrypted(const EncWireMap &en
         // whose levels are narrower than one round keeps its level schedule unchanged
         {
             const int64_t quantum = helm_hip_launch_quantum(server_key_);
+            double quarter_cost[4]; // the engine's cost per launch width: launches narrower than a round take its best width
+            const bool costed = helm_hip_launch_costs(server_key_, quarter_cost) == 0;
             std::vector<int64_t> order, poff;
             if (quantum > 0 &&
                 pack_levels(op.data(), i0.data(), i1.data(), i2.data(), out.data(), off.data(), (int64_t)off.size() - 1,
-                            quantum, order, poff) == 0 &&
+                            quantum, order, poff, costed ? quarter_cost : nullptr) == 0 &&
                 poff != off) {
                 auto permute = [&](std::vector<int32_t> &v) {
                     std::vector<int32_t> t(v.size());

@@ -152,9 +152,11 @@ std::string preprocess(const std::string &text, bool arithmetic);
 // Launch packing (level_pack.cpp): the level map of circuit.rs:174-239 as index arrays -> `order`
 // (new position -> gate) and `new_off` (launch boundaries) such that every launch but the last few
 // holds a whole number of `quantum` bootstraps.  Returns 0, or 1 when the schedule was kept as it is.
+// quarter_cost (optional, 4 entries: helm_hip_launch_costs()): launches narrower than a round take the width with the best
+// bootstraps-per-cost and leave the rest to the next launch.
 int pack_levels(const int32_t *op, const int32_t *in0, const int32_t *in1, const int32_t *in2, const int32_t *out,
                 const int64_t *off, int64_t n_levels, int64_t quantum, std::vector<int64_t> &order,
-                std::vector<int64_t> &new_off);
+                std::vector<int64_t> &new_off, const double *quarter_cost = nullptr);
 
 uint64_t next_map_id(); // process-wide counter behind EncWireMap::id() / SiEncWireMap::id()
 

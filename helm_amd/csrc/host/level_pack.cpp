@@ -34,7 +34,7 @@ static int pbs_cost(int op)
 
 int pack_levels(const int32_t *op, const int32_t *in0, const int32_t *in1, const int32_t *in2, const int32_t *out,
                 const int64_t *off, int64_t n_levels, int64_t quantum, std::vector<int64_t> &order,
-                std::vector<int64_t> &new_off)
+                std::vector<int64_t> &new_off, const double *quarter_cost)
 {
     const int64_t total = n_levels > 0 ? off[n_levels] : 0;
     order.clear();
@@ -112,8 +112,35 @@ int pack_levels(const int32_t *op, const int32_t *in0, const int32_t *in1, const
     };
     for (int64_t g = 0; g < total; g++)
         if (!tail[(size_t)g] && indeg[(size_t)g] == 0) make_ready(g);
+    // quarter_cost (optional): what a launch of at most 1/4, 2/4, 3/4, 4/4 of a round costs relative to a full round
+    // (helm_hip_launch_costs(): the engine has a build per width - wide, duo, partial and full lockstep rounds).  A launch
+    // narrower than a round then takes the width with the best bootstraps-per-cost among {everything that is ready, the
+    // quarter steps below it} and leaves the rest for the next launch - as long as gates are still waiting for their
+    // producers (at the drain nothing new will join the leftover: everything goes).  With 8 ranks a packed launch of a
+    // 32-block AES batch is ~630 bootstraps per rank: 512 of them on the two-per-CU build (0.62 of a round's time) and 118
+    // riding along with the next launch beat 630 in a 3/4-filled lockstep round (0.88).
+    int64_t unreleased = 0; // bootstrapped gates not yet ready
+    for (int64_t g = 0; g < total; g++)
+        if (!tail[(size_t)g]) unreleased += pbs_cost(op[g]);
+    auto pick_target = [&](int64_t ready, int64_t waiting) -> int64_t {
+        if (ready >= quantum) return ready / quantum * quantum;
+        if (!quarter_cost || quantum < 4 || waiting < quantum) return ready;
+        auto cost = [&](int64_t w) { return quarter_cost[std::min<int64_t>(3, (4 * w - 1) / quantum)]; };
+        int64_t best = ready;
+        double best_rate = (double)ready / cost(ready);
+        for (int q = 3; q >= 1; q--) {
+            const int64_t w = quantum * q / 4;
+            if (w >= ready) continue;
+            const double rate = (double)w / cost(w);
+            if (rate > best_rate * 1.02) { // (a leftover costs launches later: only for a clear gain)
+                best = w;
+                best_rate = rate;
+            }
+        }
+        return best;
+    };
     while (!heap.empty() || !linear.empty()) {
-        const int64_t target = ready_pbs >= quantum ? ready_pbs / quantum * quantum : ready_pbs;
+        const int64_t target = pick_target(ready_pbs, unreleased - ready_pbs);
         int64_t taken = 0;
         launch.clear();
         skipped.clear();
@@ -129,6 +156,7 @@ int pack_levels(const int32_t *op, const int32_t *in0, const int32_t *in1, const
         }
         for (int64_t g : skipped) heap.push(g);
         ready_pbs -= taken;
+        unreleased -= taken;
         launch.insert(launch.end(), linear.begin(), linear.end());
         linear.clear();
         if (launch.empty()) throw Panic("pack_levels: no progress"); // cannot happen: target >= one ready gate's cost

@@ -255,10 +255,12 @@ def level_arrays(circuit, index):
             np.array(out, np.int32), np.array(off, np.int64))
 
 
-def pack_levels(opcode, in0, in1, in2, out, level_offsets, quantum):
+def pack_levels(opcode, in0, in1, in2, out, level_offsets, quantum, quarter_cost=None):
     """Launch packing (helm_host_pack_levels, helm_amd/csrc/host/level_pack.cpp): the level schedule re-timed so
     that a launch holds a whole number of `quantum` bootstraps while that many gates are ready; dependency order
-    kept, outputs bit-identical.  -> (opcode, in0, in1, in2, out, launch_offsets, packed: bool)"""
+    kept, outputs bit-identical.  quarter_cost (ServerKey.launch_costs(): relative cost of a launch of at most 1/4,
+    2/4, 3/4, 4/4 of a round) lets launches narrower than a round take the engine's most efficient width and leave
+    the rest to the next launch.  -> (opcode, in0, in1, in2, out, launch_offsets, packed: bool)"""
     import ctypes as C
     from . import _host as H
     arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (opcode, in0, in1, in2, out)]
@@ -268,8 +270,14 @@ def pack_levels(opcode, in0, in1, in2, out, level_offsets, quantum):
     new_off = np.zeros(total + 1, dtype=np.int64)
     n = C.c_int64()
     i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
-    rc = H.host.helm_host_pack_levels(*[a.ctypes.data_as(i32p) for a in arrs], off.ctypes.data_as(i64p), len(off) - 1,
-                                      int(quantum), order.ctypes.data_as(i64p), new_off.ctypes.data_as(i64p), C.byref(n))
+    if quarter_cost is None:
+        rc = H.host.helm_host_pack_levels(*[a.ctypes.data_as(i32p) for a in arrs], off.ctypes.data_as(i64p), len(off) - 1,
+                                          int(quantum), order.ctypes.data_as(i64p), new_off.ctypes.data_as(i64p), C.byref(n))
+    else:
+        qc = (C.c_double * 4)(*[float(x) for x in quarter_cost])
+        rc = H.host.helm_host_pack_levels_costed(*[a.ctypes.data_as(i32p) for a in arrs], off.ctypes.data_as(i64p), len(off) - 1,
+                                                 int(quantum), qc, order.ctypes.data_as(i64p), new_off.ctypes.data_as(i64p),
+                                                 C.byref(n))
     if rc < 0:
         raise H.Panic(H.host.helm_host_last_error().decode())
     return tuple(a[order] for a in arrs) + (new_off[:n.value + 1].copy(), rc == 0)

@@ -165,6 +165,13 @@ class ServerKey:
         hip_check(hip.helm_hip_ntt_roundtrip(self._h, nv.as_u32p(polys), nv.as_u32p(out), len(polys)))
         return out
 
+    def launch_costs(self):
+        """Relative cost of a launch of at most 1/4, 2/4, 3/4, 4/4 of launch_quantum() bootstraps (helm_hip_launch_costs):
+        what pack_levels(..., quarter_cost=) sizes launches narrower than a round with."""
+        c = (C.c_double * 4)()
+        hip_check(hip.helm_hip_launch_costs(self._h, c))
+        return [float(x) for x in c]
+
     def kernel_clock_ghz(self):
         """Shader clock held during the most recent k_pbs launch (None before the first one)."""
         g, ms = C.c_double(), C.c_double()

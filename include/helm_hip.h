@@ -113,6 +113,13 @@ int helm_hip_sync(helm_hip_ctx *ctx);
  * (helm_host_pack_levels) sizes launches with it.  Negative on error. */
 int64_t helm_hip_launch_quantum(const helm_hip_ctx *ctx);
 
+/* What a launch of at most 1/4, 2/4, 3/4 and 4/4 of helm_hip_launch_quantum() bootstraps costs on this context, relative to
+ * a full round (cost[3] = 1): the engine runs a different build of the blind-rotate kernel per width (k_pbs_wide: one
+ * bootstrap per CU on four SIMDs, k_pbs_duo: two per CU on two SIMDs each, partial and full lockstep rounds).  Measured on
+ * MI355X (profiles/r04/microbench.jsonl); the host's launch packing (helm_host_pack_levels_costed) sizes launches that are
+ * narrower than a round with it. */
+int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4]);
+
 /* -- keys ------------------------------------------------------------------ */
 /* Replaces convert_lwe_bootstrap_key / convert_lwe_keyswitch_key (reference
  * src/bin/helm.rs:187-192): standard-domain keys from the host are uploaded and

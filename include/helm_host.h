@@ -75,6 +75,16 @@ int helm_host_pack_levels(const int32_t *opcode, const int32_t *in0, const int32
                           const int32_t *out, const int64_t *level_offsets, int64_t n_levels, int64_t quantum,
                           int64_t *order, int64_t *new_offsets, int64_t *n_launches);
 
+/* The same with the engine's cost table: quarter_cost[q] = cost of a launch of at most (q + 1) / 4 of `quantum`
+ * bootstraps relative to a full round (helm_hip_launch_costs(); NULL = helm_host_pack_levels).  A launch narrower than
+ * a round then takes the width with the best bootstraps-per-cost among {everything ready, the quarter steps below it}
+ * and leaves the rest for the next launch while gates are still waiting for their producers.  Same dependency order,
+ * same ciphertexts; what changes is where the launch boundaries fall - this is what keeps per-rank chunks of a
+ * launch sharded over N GPUs (quantum = N x helm_hip_launch_quantum()) on the engine's efficient widths. */
+int helm_host_pack_levels_costed(const int32_t *opcode, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                                 const int32_t *out, const int64_t *level_offsets, int64_t n_levels, int64_t quantum,
+                                 const double *quarter_cost, int64_t *order, int64_t *new_offsets, int64_t *n_launches);
+
 /* encrypted wire maps */
 int helm_host_enc_map_new(helm_hip_ctx *server_key, helm_enc_map **out);
 void helm_host_enc_map_free(helm_enc_map *m);

@@ -100,6 +100,7 @@ extern "C" {
     pub fn helm_hip_set_stream(ctx: *mut helm_hip_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn helm_hip_sync(ctx: *mut helm_hip_ctx) -> c_int;
     pub fn helm_hip_launch_quantum(ctx: *const helm_hip_ctx) -> i64;
+    pub fn helm_hip_launch_costs(ctx: *const helm_hip_ctx, cost: *mut f64) -> c_int;
     pub fn helm_hip_load_bootstrap_key(ctx: *mut helm_hip_ctx, bsk_std: *const u32, n_words: usize) -> c_int;
     pub fn helm_hip_load_keyswitch_key(ctx: *mut helm_hip_ctx, ksk: *const u32, n_words: usize) -> c_int;
     pub fn helm_hip_wires_alloc(ctx: *mut helm_hip_ctx, n_wires: i64, out: *mut *mut helm_hip_wires) -> c_int;
@@ -140,6 +141,10 @@ extern "C" {
     pub fn helm_host_pack_levels(opcode: *const i32, in0: *const i32, in1: *const i32, in2: *const i32, out: *const i32,
                                  level_offsets: *const i64, n_levels: i64, quantum: i64, order: *mut i64,
                                  new_offsets: *mut i64, n_launches: *mut i64) -> c_int;
+
+    pub fn helm_host_pack_levels_costed(opcode: *const i32, in0: *const i32, in1: *const i32, in2: *const i32, out: *const i32,
+                                        level_offsets: *const i64, n_levels: i64, quantum: i64, quarter_cost: *const f64,
+                                        order: *mut i64, new_offsets: *mut i64, n_launches: *mut i64) -> c_int;
 
     pub fn helm_host_last_error() -> *const c_char;
     // one level of arithmetic-mode operators (FheUintN + - * / << >> and their scalar forms, copy) as one batched call

@@ -39,6 +39,7 @@ pub struct HipGateCircuit<'a> {
     lwe_words: usize, // n + 1
     // multi-GPU (multi_gpu.rs): a communicator of include/helm_comm.h, or null for one GPU
     pub(crate) comm: *mut sys::helm_comm,
+    pub(crate) world: i32,
     pub(crate) replicate_below: i64,
 }
 
@@ -90,7 +91,7 @@ impl<'a> HipGateCircuit<'a> {
         HipGateCircuit {
             circuit, client_key, ctx, wires: std::ptr::null_mut(), prog: std::ptr::null_mut(),
             row_of: HashMap::new(), n_launches: 0, lwe_words: std_keys.params.n as usize + 1,
-            comm: std::ptr::null_mut(), replicate_below: 256,
+            comm: std::ptr::null_mut(), world: 1, replicate_below: 256,
         }
     }
 
@@ -115,9 +116,14 @@ impl<'a> HipGateCircuit<'a> {
         let total = op.len();
         let (mut order, mut poff, mut n_launch) = (vec![0i64; total], vec![0i64; total + 1], 0i64);
         let q = unsafe { sys::helm_hip_launch_quantum(self.ctx) };
-        let rc = unsafe { sys::helm_host_pack_levels(op.as_ptr(), i0.as_ptr(), i1.as_ptr(), i2.as_ptr(), out.as_ptr(),
-                                                     off.as_ptr(), off.len() as i64 - 1, q, order.as_mut_ptr(),
-                                                     poff.as_mut_ptr(), &mut n_launch) };
+        // the engine's cost per launch width (wide / duo / partial / full lockstep round): launches narrower than a round
+        // take its most efficient width; sharded over N ranks the quantum is N rounds (multi_gpu.rs)
+        let mut quarter_cost = [1.0f64; 4];
+        check(unsafe { sys::helm_hip_launch_costs(self.ctx, quarter_cost.as_mut_ptr()) });
+        let world = if self.comm.is_null() { 1 } else { self.world as i64 };
+        let rc = unsafe { sys::helm_host_pack_levels_costed(op.as_ptr(), i0.as_ptr(), i1.as_ptr(), i2.as_ptr(), out.as_ptr(),
+                                                            off.as_ptr(), off.len() as i64 - 1, q * world, quarter_cost.as_ptr(),
+                                                            order.as_mut_ptr(), poff.as_mut_ptr(), &mut n_launch) };
         assert!(rc >= 0, "pack_levels failed");
         let pick = |v: &Vec<i32>| order.iter().map(|&g| v[g as usize]).collect::<Vec<i32>>();
         let (op, i0, i1, i2, out) = (pick(&op), pick(&i0), pick(&i1), pick(&i2), pick(&out));

@@ -61,8 +61,10 @@ impl<'a> crate::HipGateCircuit<'a> {
     /// instead: 256 = one bootstrap per CU is the usual value).  Every rank must hold the same circuit, keys and
     /// input ciphertexts and make the same calls; every rank ends with the wire table of a one-GPU evaluation.
     /// The communicator must outlive the circuit's evaluations.
+    /// Call before `encrypt_inputs` (which packs the launches for `world` ranks and uploads the program).
     pub fn shard_over(&mut self, comm: &HipComm, replicate_below: i64) {
         self.comm = comm.raw;
+        self.world = comm.rank_and_world().1;
         self.replicate_below = replicate_below;
     }
 }
