@@ -214,6 +214,21 @@ def check_outputs(ck, wires, index, nw, keys_pt, what):
             raise WrongResult(f"{what}: decrypted AES output of block {b} is WRONG")
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; stdout carries the ONE JSON line only."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 class Bench:
     """State shared by the runs of one worker."""
 
@@ -250,7 +265,8 @@ class Bench:
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank can bind RCCL, or nobody tries
                 if int(ok.item()):
                     try:
-                        self.comm = hc.Comm.from_torch_dist(dist, local_rank)
+                        with _StdoutToStderr():
+                            self.comm = hc.Comm.from_torch_dist(dist, local_rank)
                     except Exception as e:                          # reported in the line; the data path falls back to gloo
                         self.comm_error = repr(e)
                 else:
@@ -263,7 +279,8 @@ class Bench:
                     self.comm_error = self.comm_error or "another rank could not create its communicator"
         elif args.force_comm:
             from helm_amd import comm as hc
-            self.comm = hc.Comm.single(local_rank)
+            with _StdoutToStderr():
+                self.comm = hc.Comm.single(local_rank)
         # keys (identical on every rank: same deterministic benchmark seed) and engine
         t0 = time.time()
         self.ck = helm_amd.ClientKey.generate(args.params, seed=1)
