@@ -84,7 +84,10 @@ def _worker(rank, world, port, replicate_below, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ck, orc, arrays, wires, index, bits = _setup()
     ex = OracleExecutor(orc, arrays, wires)
-    runner = ShardedRunner(ex, rank, world, dist, replicate_below=replicate_below)
+    # world 1 shards only when asked to (force): every launch then still goes stage -> all-gather -> scatter - what
+    # tests/test_gpu_rccl_world1.py runs over real RCCL on the one-GPU box
+    runner = ShardedRunner(ex, rank, world, dist, replicate_below=replicate_below, force=world == 1)
+    assert runner.active
     runner.run()
     q.put((rank, wires.copy(), len(runner.sharded_levels), runner.exchanged_bytes_per_pass()))
     dist.barrier()
@@ -97,7 +100,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,replicate_below", [(2, 0), (3, 0), (2, 2)])
+@pytest.mark.parametrize("world,replicate_below", [(2, 0), (3, 0), (2, 2), (1, 0)])  # world 1: the forced single-rank form
 def test_sharded_runner_matches_single_process(world, replicate_below):
     ck, orc, arrays, wires, index, bits = _setup()
     single = wires.copy()

@@ -201,3 +201,45 @@ def test_random_levelised_dags_property():
             assert np.array_equal(_plain_run(*packed[:6], vals), want), (trial, quantum)
             # no more launches than levels plus one per quantum of work plus the drain
             assert len(packed[5]) - 1 <= len(off) - 1 + int(per_launch.sum()) // max(1, quantum) + 2
+
+
+def test_cost_aware_packing_takes_the_engines_best_width():
+    """helm_host_pack_levels_costed (round 4): with the engine's cost per launch width (at most 1/4, 2/4, 3/4, 4/4 of a
+    round: 0.43 / 0.66 / 0.90 / 1, helm_hip_launch_costs) a launch narrower than a round takes the width with the best
+    bootstraps-per-cost and leaves the rest to the next launch - what keeps a rank's chunk of a sharded launch (quantum =
+    world x round) on the widths the engine runs well.  Same permutation, same dependency order, same values on every wire;
+    at the drain everything goes."""
+    blocks, quantum = 4, 2048  # levels of 4 AES blocks are ~630 bootstraps wide: always narrower than this quantum
+    cost = [0.43, 0.66, 0.90, 1.0]
+    ops, i0, i1, i2, out, off, index, nw = _tiled_aes(blocks)
+    plain = pack_levels(ops, i0, i1, i2, out, off, quantum)
+    costed = pack_levels(ops, i0, i1, i2, out, off, quantum, quarter_cost=cost)
+    per_plain = _check_schedule((ops, i0, i1, i2, out, off), plain, quantum)
+    per_costed = _check_schedule((ops, i0, i1, i2, out, off), costed, quantum)
+    q = quantum // 4
+
+    def modelled(per_launch):  # cost of a schedule under the table: whole rounds + the width class of the remainder
+        total = 0.0
+        for w in per_launch:
+            full, rem = divmod(int(w), quantum)
+            total += full + (cost[min(3, (rem - 1) // q)] if rem else 0.0)
+        return total
+    # launches sit on the quarter steps far more often, and the schedule is cheaper under the engine's own table
+    on_step = lambda per: sum(1 for w in per if w and w % q == 0)
+    assert on_step(per_costed) > 2 * on_step(per_plain) and on_step(per_costed) > len(per_costed) // 3
+    assert modelled(per_costed) < 0.95 * modelled(per_plain)
+    assert len(per_costed) < 1.3 * len(per_plain)
+    # nothing is ever left behind for good, and the values agree with the level schedule on every wire
+    rng = np.random.default_rng(5)
+    vals = np.zeros(nw * blocks, dtype=np.uint8)
+    n_in = 256
+    for b in range(blocks):
+        vals[b * nw:b * nw + n_in] = rng.integers(0, 2, n_in)
+    want = _plain_run(ops, i0, i1, i2, out, off, vals)
+    assert np.array_equal(_plain_run(*costed[:6], vals), want)
+    # uniform costs change nothing; non-positive costs are refused
+    same = pack_levels(ops, i0, i1, i2, out, off, quantum, quarter_cost=[1.0, 1.0, 1.0, 1.0])
+    assert np.array_equal(same[5], plain[5])
+    from helm_amd._host import Panic
+    with pytest.raises(Panic, match="positive"):
+        pack_levels(ops, i0, i1, i2, out, off, quantum, quarter_cost=[0.0, 0.5, 0.9, 1.0])
