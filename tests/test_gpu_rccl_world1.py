@@ -142,6 +142,11 @@ def _worker(_rank, port, result_path):
     res["si_torch_same"] = bool(np.array_equal(sw3.download(), swant))
     res["si_torch_stats"] = list(ssk.exchange_stats())
     ssk.set_exchange(dist, 0, 1)
+    # the way bench.py creates the communicator: rank 0 draws the id, torch.distributed carries it to the other ranks
+    c2 = hc.Comm.from_torch_dist(dist, 0)
+    res["comm_from_dist"] = c2.info()
+    res["comm_from_dist_max"] = c2.all_reduce(7.0, "max")
+    c2.destroy()
     dist.destroy_process_group()
     c.destroy()
     ssk.close()
@@ -194,3 +199,4 @@ def test_torch_nccl_backend_world_size_one(world1):
         assert r[name + "_sharded_levels"] == r["levels_with_bootstraps"]
     assert r["si_torch_same"]
     assert r["si_torch_stats"][0] == 3
+    assert r["comm_from_dist"]["world_size"] == 1 and r["comm_from_dist_max"] == 7.0
