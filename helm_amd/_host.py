@@ -47,6 +47,7 @@ HOST_API = {
     "helm_host_gate_circuit_log": (vp, [vp]),
     "helm_host_gate_circuit_pbs_per_cycle": (C.c_int64, [vp]),
     "helm_host_gate_circuit_memo_hits": (C.c_int64, [vp]),
+    "helm_host_gate_circuit_shard_over": (C.c_int, [vp, vp, C.c_int64]),
     "helm_host_si_circuit_new": (C.c_int, [C.c_int, vp, vp, vp, C.POINTER(vp)]),
     "helm_host_si_circuit_free": (None, [vp]),
     "helm_host_si_circuit_encrypt_inputs": (C.c_int, [vp, cp, cp, C.POINTER(vp)]),

@@ -304,6 +304,10 @@ int helm_host_gate_circuit_decrypt_outputs(helm_gate_circuit *gc, const helm_enc
 }
 char *helm_host_gate_circuit_log(helm_gate_circuit *gc) { return dup(gc->gc->log()); }
 int64_t helm_host_gate_circuit_pbs_per_cycle(const helm_gate_circuit *gc) { return gc->gc->pbs_per_cycle(); }
+int helm_host_gate_circuit_shard_over(helm_gate_circuit *gc, helm_comm *comm, int64_t replicate_below)
+{
+    return guard([&] { gc->gc->shard_over(comm, replicate_below); });
+}
 int64_t helm_host_gate_circuit_memo_hits(const helm_gate_circuit *gc) { return gc->gc->memo_hits(); }
 
 void helm_host_enc_map_free(helm_enc_map *m) { delete m; }

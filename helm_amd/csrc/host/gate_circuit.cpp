@@ -147,6 +147,21 @@ GateCircuit::~GateCircuit()
     if (prog_) helm_hip_program_destroy(server_key_, prog_);
 }
 
+void GateCircuit::shard_over(helm_comm *comm, int64_t replicate_below)
+{
+    int world = 1;
+    if (comm) hip_ok(helm_comm_info(comm, nullptr, &world, nullptr, nullptr), "comm_info");
+    if (replicate_below < 0) throw Panic("shard_over: replicate_below must not be negative");
+    if (comm != comm_ || world != comm_world_) { // the launches are packed for the world size: plan the program again
+        if (prog_) helm_hip_program_destroy(server_key_, prog_);
+        prog_ = nullptr;
+    }
+    comm_ = comm;
+    comm_world_ = world;
+    replicate_below_ = replicate_below;
+    memo_.valid = false;
+}
+
 // reference src/circuit.rs:450-480
 std::unique_ptr<EncWireMap> GateCircuit::encrypt_inputs(const std::set<std::string> &wire_set,
                                                         const std::map<std::string, PtxtType> &input_wire_map)
@@ -330,7 +345,7 @@ std::unique_ptr<EncWireMap> GateCircuit::evaluate_encrypted(const EncWireMap &en
         // launch packing (level_pack.cpp): wide levels are re-timed into whole lockstep rounds; a netlist
         // whose levels are narrower than one round keeps its level schedule unchanged
         {
-            const int64_t quantum = helm_hip_launch_quantum(server_key_);
+            const int64_t quantum = helm_hip_launch_quantum(server_key_) * comm_world_; // a round per rank
             double quarter_cost[4]; // the engine's cost per launch width: launches narrower than a round take its best width
             const bool costed = helm_hip_launch_costs(server_key_, quarter_cost) == 0;
             std::vector<int64_t> order, poff;
@@ -365,7 +380,12 @@ std::unique_ptr<EncWireMap> GateCircuit::evaluate_encrypted(const EncWireMap &en
     if (n_scratch_ > 0) eval_values->scratch(n_scratch_); // the copies of rows a level both reads and rewrites
     const int64_t total_levels = (int64_t)circuit_.level_map().size();
     std::ostringstream os;
-    if (!packed_) {
+    if (comm_) {
+        // every launch of more than replicate_below_ bootstraps split over the ranks, outputs all-gathered inside the engine
+        hip_ok(helm_hip_program_run_sharded_comm(server_key_, prog_, eval_values->table(), comm_, replicate_below_), "program_run_sharded_comm");
+        os << "  Evaluated gates of " << total_levels << " levels in " << prog_launches_ << " launches sharded over " << comm_world_
+           << " rank(s)\n";
+    } else if (!packed_) {
         int64_t l = 0;
         size_t li = 0;
         for (auto &kv : circuit_.level_map()) {

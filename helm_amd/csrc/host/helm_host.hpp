@@ -26,6 +26,7 @@
 #include "../../../include/helm_client.h"
 #include "../../../include/helm_wopbs.h"
 #include "../../../include/helm_hip.h"
+#include "../../../include/helm_comm.h"
 #include "../../../include/helm_shortint.h"
 #include "../../../include/helm_wopbs.h"
 
@@ -247,6 +248,12 @@ class GateCircuit : public EvalCircuit<EncWireMap> {
     const Circuit &circuit() const { return circuit_; }
     int64_t pbs_per_cycle() const { return pbs_count_; }
     std::string log() { std::string s; s.swap(log_); return s; } // progress lines (circuit.rs:542)
+    // Multi-GPU (one process per GPU; keys, circuit and input ciphertexts the same on every rank): from the next
+    // evaluate_encrypted on, the launches are packed for the communicator's world size and every launch of more than
+    // `replicate_below` bootstraps is split over its ranks, the output ciphertexts all-gathered with ncclAllGather inside
+    // the engine (helm_hip_program_run_sharded_comm, include/helm_comm.h) - the level of circuit.rs:531 is the sharded
+    // unit.  Every rank ends with the wire map of a one-GPU evaluation.  comm = nullptr: back to one GPU.
+    void shard_over(helm_comm *comm, int64_t replicate_below);
 
   private:
     helm_client_key *client_key_;
@@ -261,6 +268,9 @@ class GateCircuit : public EvalCircuit<EncWireMap> {
     int64_t prog_launches_ = 0;
     std::vector<int64_t> level_end_; // program level at which each circuit level ends (unpacked schedule)
     int64_t n_scratch_ = 0;          // scratch rows the program uses behind the named rows (copies for flip-flop chains)
+    helm_comm *comm_ = nullptr;      // shard_over(): the engine's RCCL communicator, or null
+    int comm_world_ = 1;
+    int64_t replicate_below_ = 256;
     bool packed_ = false; // the program's launches are packed rounds, not the circuit's levels
     std::string log_;
     // Same cycle AND the very input map (unmodified): the cached wire map is returned without a launch.  The

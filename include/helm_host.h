@@ -114,6 +114,14 @@ int64_t helm_host_gate_circuit_pbs_per_cycle(const helm_gate_circuit *gc);
  * counts those calls.  (The reference's boolean cache probe is commented out, gates.rs:247-252, so the memo is only
  * allowed where it cannot be observed: identical inputs.) */
 int64_t helm_host_gate_circuit_memo_hits(const helm_gate_circuit *gc);
+/* Multi-GPU, one process per GPU: from the next evaluate_encrypted on the launches are packed for the world size of
+ * `comm` (include/helm_comm.h: the engine's own RCCL communicator) and every launch of more than `replicate_below`
+ * bootstraps is split over its ranks - the level of reference src/circuit.rs:531 is the sharded unit - the output
+ * ciphertexts all-gathered with ncclAllGather inside the engine (helm_hip_program_run_sharded_comm).  Keys, circuit and
+ * input ciphertexts must be the same on every rank; every rank gets the wire map of a one-GPU evaluation.
+ * comm = NULL: back to one GPU. */
+struct helm_comm;
+int helm_host_gate_circuit_shard_over(helm_gate_circuit *gc, struct helm_comm *comm, int64_t replicate_below);
 
 /* ---- LUT mode / arithmetic mode (include/helm_shortint.h) ------------------------------
  * LutCircuit (circuit.rs:969-1120) and ArithCircuit (circuit.rs:1112-1500); `mode` 0 = LUT,

@@ -98,6 +98,26 @@ def _worker(_rank, port, result_path):
     res["comm_allreduce_sum"] = c.all_reduce(2.25, "sum")
     c.barrier()
 
+    # ---- (1b) the evaluator API: GateCircuit.shard_over (helm_host_gate_circuit_shard_over) ---------------------------
+    from helm_amd import Circuit, GateCircuit, PtxtType, verilog_parser
+    here = os.path.dirname(os.path.abspath(__file__))
+    gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_file(os.path.join(here, "netlists", "alu-c880-class.v"), False)
+    circ = Circuit(gates, inputs, outputs, dffs)
+    circ.sort_circuit()
+    circ.compute_levels()
+    gc = GateCircuit(ck, sk, circ)
+    vals = {w: PtxtType.Bool(bool(v)) for w, v in zip(inputs, np.random.default_rng(8).integers(0, 2, len(inputs)))}
+    enc_in = gc.encrypt_inputs(wire_set, vals)
+    one_gpu = gc.evaluate_encrypted(enc_in, 1, "bool")
+    gc.shard_over(c, 0)
+    before = c.stats()["collectives"]
+    sharded = gc.evaluate_encrypted(enc_in, 2, "bool")
+    res["gc_collectives"] = c.stats()["collectives"] - before
+    res["gc_same"] = all(np.array_equal(one_gpu[w], sharded[w]) for w in one_gpu.keys())
+    res["gc_log"] = gc.log()
+    gc.shard_over(None)
+    res["gc_back"] = all(np.array_equal(one_gpu[w], gc.evaluate_encrypted(enc_in, 3, "bool")[w]) for w in list(one_gpu.keys())[:8])
+
     # ---- (2) the 64-bit-torus engine through the same communicator: helm_si_set_exchange_comm ---------------------
     sck = helm_amd.SiClientKey.generate("si_toy_1024", seed=1)
     ssk = helm_amd.SiServerKey(sck, device=0)
@@ -177,9 +197,12 @@ def test_in_library_communicator_carries_every_launch(world1):
     assert r["comm_sharded_levels"] == r["levels_with_bootstraps"] > 0
     assert r["comm_exchange_count"] == 2 * r["comm_sharded_levels"]
     assert r["comm_exchange_bytes"] == 2 * r["comm_bytes_per_pass"] > 0
-    assert r["comm_stats"]["collectives"] == r["comm_exchange_count"]
+    assert r["comm_stats"]["collectives"] == r["comm_exchange_count"]  # (read before the evaluator test below issues more)
     assert r["comm_exchange_ms"] > 0.0
     assert r["comm_allreduce_max"] == 41.5 and r["comm_allreduce_sum"] == 2.25
+    # the evaluator API on top of it: GateCircuit.shard_over
+    assert r["gc_same"] and r["gc_back"] and r["gc_collectives"] > 0
+    assert "sharded over 1 rank(s)" in r["gc_log"]
 
 
 def test_shortint_engine_through_the_library_communicator(world1):
