@@ -1085,6 +1085,251 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
     }
 }
 
+// ------------------------------------------------------------------------------------
+// k_pbs_sym: two bootstraps per workgroup like k_pbs_duo, but every wave does THE SAME work: 2 (k+1) waves per bootstrap =
+// (polynomial r, transform half h).  A 512-point negacyclic transform splits after its first stage into two independent
+// 256-point transforms on the index halves (ntt_fp64.h: half transforms, four values per lane); wave (r, h)
+//   - rotates / subtracts / decomposes polynomial r (all of it: both waves of a polynomial do, 165 integer instructions),
+//     does the first stage for its half and the L half transforms of the digit polynomials together,
+//   - multiplies them with its half of the key words of row r (the key's layout is the full transform's: spectrum position
+//     (h << 8) | p), sums over the levels in registers, keeps column r and hands the k other column sums over through LDS,
+//   - after barrier 1 adds the k sums it receives, runs the inverse half transform of column r, publishes it, and after
+//     barrier 2 does its half of the joining stage (h = 0: z0 + z1 -> coefficients j; h = 1: (z0 - z1) psi^-(N/2) ->
+//     coefficients j + N/2), lifts and updates its half of the accumulator copy both waves read after barrier 3.
+// Twelve identical waves, three per SIMD: no SIMD waits for another inside an interval, and no wave waits while others
+// invert.  Measured (profiles/r04/duo_experiments.txt (7)): 1.3 % faster than k_pbs_duo on the same box - 78 % of the issue
+// slots instead of 72 %, but 1,150 vector instructions per wave-step instead of 1,059 (both waves of a polynomial run its
+// whole decomposition and the first stage's products; three transposes per half transform, three barriers per step).
+// Opt-in (HELM_HIP_DUO=3, HELM_HIP_PBS_VARIANT=8): k_pbs_duo stays the size dispatch's choice.
+// Same exact integers as every other build: identical ciphertexts.  N = 512 only.
+// ------------------------------------------------------------------------------------
+template <typename F_, int K_, int L_>
+struct SymCfg {
+    using F = F_;
+    static constexpr int LOGN = 9, K = K_, L = L_, K1 = K_ + 1, NB = 2, NWB = 2 * (K_ + 1), NW = 4 * (K_ + 1);
+    using G = Geo<9>;
+    using HG = HalfGeo9;
+    static constexpr int MAX_SMALL_N = 1024;
+    static constexpr int ACC3 = (3 * G::N - 64 + 1) / 2 * 2; // u32 entries per polynomial (see PbsCfg)
+    // per wave: forward scratch L x XPAD doubles (the inverse uses the first XPAD); the K hand-over slots of 256 doubles
+    // start behind the inverse's scratch (they are read while their owner already inverts); the published half inverse
+    // (256 doubles) behind them
+    static constexpr int HO_OFF = HG::XPAD, ZX_OFF = HG::XPAD + K * 256;
+    static constexpr int WAVE_DOUBLES = (L * HG::XPAD > ZX_OFF + 256 ? L * HG::XPAD : ZX_OFF + 256);
+    static constexpr size_t X_OFF = 0;                                                 // double [NWB][WAVE_DOUBLES]
+    static constexpr size_t ACC_OFF = X_OFF + sizeof(double) * NWB * WAVE_DOUBLES;     // u32 [K1][ACC3]
+    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint32_t) * K1 * ACC3;           // u16 [n+1]
+    static constexpr size_t BOOT_BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
+    static constexpr size_t BYTES = BOOT_BYTES * NB;
+};
+
+template <typename C>
+__global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_sym(const PbsJob *__restrict__ jobs, const uint32_t *__restrict__ wires,
+                                                           const uint32_t *__restrict__ raw_in, const uint32_t *__restrict__ tvs,
+                                                           const double *__restrict__ bsk, const double *__restrict__ tw_fwd,
+                                                           const double *__restrict__ tw_inv, uint32_t *__restrict__ out_big, int n,
+                                                           int logB, int flags, int count)
+{
+    constexpr int K = C::K, L = C::L, K1 = C::K1, NB = C::NB, NWB = C::NWB;
+    using F = typename C::F;
+    using G = Geo<9>;
+    constexpr int N = G::N, E = G::E;
+    extern __shared__ __align__(16) unsigned char smem_wg[];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = w / NWB, wb = w - b * NWB; // bootstrap of the workgroup, wave of the bootstrap
+    const int r = wb >> 1, h = wb & 1;       // polynomial, transform half
+    const int jix = (int)blockIdx.x * NB + b;
+    if (jix >= count) return; // the hardware barrier counts the surviving waves only
+    unsigned char *smem = smem_wg + (size_t)b * C::BOOT_BYTES;
+    double *X = reinterpret_cast<double *>(smem + C::X_OFF);
+    uint32_t *ACC = reinterpret_cast<uint32_t *>(smem + C::ACC_OFF);
+    uint16_t *MS = reinterpret_cast<uint16_t *>(smem + C::MS_OFF);
+    const int tid = wb * 64 + lane;
+    const PbsJob job = jobs[jix];
+    const size_t row = (size_t)n + 1;
+    {
+        const uint32_t *a0 = nullptr, *a1 = nullptr, *a2 = nullptr;
+        if (job.op < 0) a0 = raw_in + row * (size_t)job.in0;
+        else {
+            if (job.in0 >= 0) a0 = wires + row * (size_t)job.in0;
+            if (job.in1 >= 0) a1 = wires + row * (size_t)job.in1;
+            if (job.in2 >= 0) a2 = wires + row * (size_t)job.in2;
+        }
+        for (int i = tid; i <= n; i += 64 * NWB) {
+            uint32_t v;
+            if (job.op < 0) v = a0[i];
+            else v = gate_lincomb(job.op, job.which, a0 ? a0[i] : 0u, a1 ? a1[i] : 0u, a2 ? a2[i] : 0u, i == n);
+            MS[i] = (uint16_t)modswitch(v, 10);
+        }
+    }
+    HalfTw twf, twi;
+    twf.fill(tw_fwd, h, lane);
+    twi.fill(tw_inv, h, lane);
+    const double w8 = tw_fwd[1], w8i = tw_inv[1]; // the joining stage (stride bit 8): psi^(N/2) and its inverse
+    __syncthreads();
+
+    // accumulator (0, ..., 0, X^{-b~} tv): wave (r, h) owns the coefficients j0(lane, e) + 256 h = jA(lane, e + 4 h) of
+    // polynomial r and publishes them in the negacyclically unrolled u32 copy both waves of the polynomial read
+    uint32_t *acc_r = ACC + (size_t)r * C::ACC3;
+    uint32_t accr[4];
+    auto acc_store = [&]() {
+        uint32_t *aw = acc_r + lane + 256 * h;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            aw[64 * e] = accr[e];
+            aw[64 * e + N] = 0u - accr[e];
+            if (4 * h + e < E - 1) aw[64 * e + 2 * N] = accr[e];
+        }
+    };
+    {
+        const int bt = (int)MS[n];
+        const uint32_t *tv = tvs + (size_t)job.tv * N;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            uint32_t v = 0;
+            if (r == K) {
+                const int idx = (G::jA(lane, e + 4 * h) + bt) & (2 * N - 1);
+                v = tv[idx & (N - 1)];
+                if (idx >= N) v = 0u - v;
+            }
+            accr[e] = v;
+        }
+        acc_store();
+    }
+    __syncthreads();
+
+    double *xb = X + (size_t)wb * C::WAVE_DOUBLES;
+    const unsigned poly_bytes = (unsigned)(N / 2) * 16u;
+    const unsigned step_bytes = (unsigned)(K1 * K1 * L) * poly_bytes;
+    const unsigned row_off = (unsigned)(r * K1 * L) * poly_bytes; // + (c * L + lev) * poly_bytes
+    KeyBuf kb;
+    kb.init(bsk, (size_t)n * step_bytes, lane);
+    // this wave's four spectrum positions (h << 8) | (lane << 2 | e) sit in the full-transform layout [e_f / 2][lane_f][2]
+    // at lane_f = h * 32 + (lane >> 1), e_f = (lane & 1) * 4 + e: double2 number (lane & 1) * 2 + e / 2 of that lane
+    kb.lane16 = (lane & 1) * 2048 + (h * 32 + (lane >> 1)) * 16;
+    const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+    const int neg_B = -(1 << logB);
+    const int rep = logB * L;
+    const bool prio = (flags & 1) != 0;
+
+    double2 kw[2][K1][2]; // the key words of two levels: one in use, one on its way
+    auto load_keys = [&](int buf, int ii, int lev) {
+        const unsigned so = (unsigned)ii * step_bytes + row_off + (unsigned)lev * poly_bytes;
+#pragma unroll
+        for (int c = 0; c < K1; c++)
+#pragma unroll
+            for (int e2 = 0; e2 < 2; e2++) kw[buf][c][e2] = kb.load(so + (unsigned)(c * L) * poly_bytes, e2 * 1024);
+    };
+    load_keys(0, 0, 0);
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    STAMP_DECL
+    for (int i = 0; i < n; i++) {
+        STAMP_BEGIN
+        // a zero rotation is not skipped: the bootstraps of a workgroup meet at the same barriers (its product is exactly zero)
+        const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
+        // ---- rotation, digits, the first transform stage for this half ---------------------------------------------
+        double x[L][4];
+        {
+            uint32_t st[E];
+            const uint32_t *ar = acc_r + ((lane - a) & (2 * N - 1));
+            const uint32_t *ac = acc_r + lane;
+#pragma unroll
+            for (int e = 0; e < E; e++) st[e] = ((ar[64 * e] - ac[64 * e]) + (1u << (31 - rep))) >> (32 - rep);
+#pragma unroll
+            for (int lev = L - 1; lev >= 0; lev--) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const double U = (double)decompose_step(st[e], logB, half_m1, neg_B);
+                    const double V = mulmod<F>((double)decompose_step(st[e + 4], logB, half_m1, neg_B), w8);
+                    x[lev][e] = h ? U - V : U + V;
+                }
+            }
+        }
+        ntt_half_forward<F, L>(x, xb, twf, lane);
+        if (prio) __builtin_amdgcn_s_setprio(2);
+        // ---- products with this half of row r, summed over the levels; level lev's words were fetched during level lev - 1
+        double part[K1][4];
+#pragma unroll
+        for (int lev = 0; lev < L; lev++) {
+            if (lev + 1 < L) load_keys((lev + 1) & 1, i, lev + 1);
+#pragma unroll
+            for (int c = 0; c < K1; c++)
+#pragma unroll
+                for (int e2 = 0; e2 < 2; e2++) {
+                    const double2 q = kw[lev & 1][c][e2];
+                    const double t0 = reduce_unless_lazy<F>(mulmod<F>(x[lev][2 * e2], q.x));
+                    const double t1 = reduce_unless_lazy<F>(mulmod<F>(x[lev][2 * e2 + 1], q.y));
+                    part[c][2 * e2] = lev ? part[c][2 * e2] + t0 : t0;
+                    part[c][2 * e2 + 1] = lev ? part[c][2 * e2 + 1] + t1 : t1;
+                }
+        }
+        // hand-over: the sum for column c != r goes to wave (c, h), which reads slot (r < c ? r : r - 1) of this wave
+#pragma unroll
+        for (int c = 0; c < K1; c++) {
+            if (c == r) continue;
+            double *dst = xb + C::HO_OFF + (c < r ? c : c - 1) * 256 + lane;
+#pragma unroll
+            for (int e = 0; e < 4; e++) dst[64 * e] = part[c][e];
+        }
+        if (i + 1 < n) load_keys(0, i + 1, 0); // in flight during the inverse side of the step
+        STAMP(0) // rotation, digits, forward half transforms, products
+        lds_block_sync();
+        STAMP(1) // barrier 1
+        if (prio) __builtin_amdgcn_s_setprio(3);
+        double mine[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) mine[e] = part[r][e];
+#pragma unroll
+        for (int q = 0; q < K1; q++) {
+            if (q == r) continue;
+            const double *src = X + (size_t)(2 * q + h) * C::WAVE_DOUBLES + C::HO_OFF + (r < q ? r : r - 1) * 256 + lane;
+#pragma unroll
+            for (int e = 0; e < 4; e++) mine[e] += src[64 * e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) mine[e] = reduce<F>(mine[e]);
+        ntt_half_inverse<F>(mine, xb, twi, lane);
+        {
+            double *zx = xb + C::ZX_OFF + lane;
+#pragma unroll
+            for (int e = 0; e < 4; e++) zx[64 * e] = mine[e];
+        }
+        STAMP(2) // hand-over summed, inverse half transform, published
+        lds_block_sync();
+        STAMP(3) // barrier 2
+        {
+            const double *zp = X + (size_t)(2 * r + (1 - h)) * C::WAVE_DOUBLES + C::ZX_OFF + lane;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const double o = zp[64 * e];
+                // h = 0: z0 + z1 -> coefficient j;  h = 1: (z0 - z1) psi^-(N/2) -> coefficient j + N / 2 (own = z1, other = z0)
+                const double v = h ? mulmod<F>(o - mine[e], w8i) : mine[e] + o;
+                accr[e] += to_torus32(reduce<F>(v));
+            }
+        }
+        acc_store();
+        STAMP(4) // joining stage, lift, accumulator update
+        lds_block_sync();
+        STAMP(5) // barrier 3
+    }
+    STAMP_END(w)
+
+    // ---- sample extract (coefficient 0): every wave writes its half of its polynomial -------------------------------
+    uint32_t *ob = out_big + (size_t)jix * ((size_t)K * N + 1);
+    if (r < K) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int j = G::jA(lane, e + 4 * h);
+            if (j == 0) ob[r * N] = accr[e];
+            else ob[r * N + (N - j)] = 0u - accr[e];
+        }
+    } else if (h == 0 && lane == 0) {
+        ob[K * N] = accr[0];
+    }
+}
+
 #if HELM_HIP_TU == 0 // the keyswitch, linear and table kernels: main translation unit only (see launch_pbs_wide)
 // ------------------------------------------------------------------------------------
 // k_keyswitch: grid (ceil(jobs / 4), column chunks); 256 threads; one output column per
@@ -1503,8 +1748,8 @@ struct helm_hip_ctx {
     int narrow_variant = 4;  // build for launches of at most one workgroup per CU: 4 wide, 1 latency (HELM_HIP_NARROW)
     int clock_probe = 0;     // HELM_HIP_CLOCK_PROBE: print the in-kernel clock of every k_pbs launch
     int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput, 4 wide, 5 lockstep, 6 duo (the two
-                             // bootstraps of a workgroup in step), 7 duo staggered (HELM_HIP_PBS_VARIANT)
-    int duo_build = 1;       // the k_pbs_duo form the size dispatch uses: 1 in step, 2 staggered, 0 none (HELM_HIP_DUO)
+                             // bootstraps of a workgroup in step), 7 duo staggered, 8 sym (HELM_HIP_PBS_VARIANT)
+    int duo_build = 1;       // the two-per-CU build the size dispatch uses: 1 k_pbs_duo in step, 2 staggered, 3 k_pbs_sym, 0 none (HELM_HIP_DUO)
     int duo_flags = 1;       // bit 0: issue-priority staging inside k_pbs_duo (HELM_HIP_DUO_FLAGS)
     // per-call scratch
     DevBuf<PbsJob> d_pbs;
@@ -1758,11 +2003,37 @@ static hipError_t launch_pbs_duo(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t 
     return hipGetLastError();
 }
 
+template <typename C>
+static hipError_t launch_pbs_sym(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
+                                 const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
+{
+    static bool attr_done[64] = {false};
+    auto kern = k_pbs_sym<C>;
+    if (!attr_done[ctx->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
+        if (e != hipSuccess) return e;
+        attr_done[ctx->device & 63] = true;
+        if (getenv("HELM_HIP_VERBOSE")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 64 * C::NW, C::BYTES);
+            hipFuncAttributes fa{};
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
+            fprintf(stderr, "[helm_hip] k_pbs_sym: %d waves, LDS %zu B, regs %d, scratch %zu B, max %d workgroups/CU\n", C::NW,
+                    (size_t)C::BYTES, fa.numRegs, (size_t)fa.localSizeBytes, nb);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((count + C::NB - 1) / C::NB)), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, wires,
+                       raw, tvs, ctx->bsk, ctx->tw_fwd, ctx->tw_inv, out_big, ctx->P.n, ctx->P.pbs_logB, ctx->duo_flags, (int)count);
+    print_stamps(ctx, C::NW, "sym: forward | bar1 | inverse | bar2 | join | bar3");
+    return hipGetLastError();
+}
+
 // Two translation units from this one source (Makefile): the whole file is compiled under the compiler's max-ILP scheduling
 // strategy (-mllvm -amdgpu-sched-strategy=max-ilp: +1.9 % on the lockstep k_pbs, same box, alternating, identical
 // ciphertexts), except k_pbs_wide, which that strategy slows down by 0.9 % and which is therefore compiled a second time
 // with -DHELM_HIP_TU=1 under the default strategy - that unit holds this launcher and nothing else of the host side.
-// build: 0 = k_pbs_wide, 1 = k_pbs_duo with the two bootstraps of a workgroup in step, 2 = k_pbs_duo staggered
+// build: 0 = k_pbs_wide, 1 = k_pbs_duo with the two bootstraps of a workgroup in step, 2 = k_pbs_duo staggered, 3 = k_pbs_sym
 __attribute__((visibility("hidden"))) hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int logn, int k,
                                                                         int l, const PbsJob *jobs, int64_t count,
                                                                         const uint32_t *wires, const uint32_t *raw,
@@ -1775,6 +2046,7 @@ hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int
     if (field == FB && logn == LN && k == KK && l == LL) {                                                               \
         if (build == 1) return launch_pbs_duo<DuoCfg<Fp<FB>, LN, KK, LL, false>>(ctx, jobs, count, wires, raw, tvs, out_big); \
         if (build == 2) return launch_pbs_duo<DuoCfg<Fp<FB>, LN, KK, LL, true>>(ctx, jobs, count, wires, raw, tvs, out_big); \
+        if (build == 3) return launch_pbs_sym<SymCfg<Fp<FB>, KK, LL>>(ctx, jobs, count, wires, raw, tvs, out_big);            \
         return launch_pbs_wide<WideCfg<Fp<FB>, LN, KK, LL>>(ctx, jobs, count, wires, raw, tvs, out_big);                  \
     }
     WIDE_CASE(49, 9, 2, 3) WIDE_CASE(49, 9, 1, 3) WIDE_CASE(49, 9, 1, 2)
@@ -1800,6 +2072,7 @@ static hipError_t wide_launch(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t cou
     if constexpr (LOGN == 9) {
         if (build == 1) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, false>>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (build == 2) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, true>>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if (build == 3) return launch_pbs_sym<SymCfg<F, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
     }
     if (build) return hipErrorInvalidValue;
     return launch_pbs_wide<WideCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
@@ -1850,7 +2123,7 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
             v = count <= ctx->n_cus ? ctx->narrow_variant : ctx->duo_build ? 5 + ctx->duo_build : 3;
         }
         if (v == 4) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
-        if (v == 6 || v == 7) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big, v - 5);
+        if (v == 6 || v == 7 || v == 8) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big, v - 5);
         if (v == 1) return launch_pbs_v<Lat>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (v == 2) return launch_pbs_v<Bal>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (v == 5) return launch_pbs_v<Lock>(ctx, jobs, count, wires, raw, tvs, out_big);
@@ -2057,7 +2330,7 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         ctx->n_cus = prop.multiProcessorCount;
         if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) ctx->pbs_variant = atoi(v);
         if (const char *v = getenv("HELM_HIP_NARROW")) ctx->narrow_variant = atoi(v) == 4 ? 4 : 1;
-        if (const char *v = getenv("HELM_HIP_DUO")) ctx->duo_build = atoi(v) == 2 ? 2 : atoi(v) == 0 ? 0 : 1;
+        if (const char *v = getenv("HELM_HIP_DUO")) ctx->duo_build = atoi(v) >= 0 && atoi(v) <= 3 ? atoi(v) : 1;
         if (const char *v = getenv("HELM_HIP_DUO_FLAGS")) ctx->duo_flags = atoi(v);
         if (const char *v = getenv("HELM_HIP_CLOCK_PROBE")) ctx->clock_probe = atoi(v);
         if (const char *v = getenv("HELM_HIP_KS_MFMA")) ctx->ks_mfma = atoi(v);

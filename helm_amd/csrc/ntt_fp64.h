@@ -655,4 +655,165 @@ __device__ __forceinline__ void ntt_inverse_sw10(double (&x)[16], double *xbuf, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Half transforms (N = 512).  After its first stage (stride bit 8: pairs j, j + 256, twiddle table[1]) a negacyclic
+// 512-point transform is two independent 256-point transforms on the index halves h = 0, 1 whose butterflies and twiddles
+// are exactly the full transform's stages 7 .. 0 restricted to indices with top bit h:
+//   twiddle of the butterfly on stride bit sb for half index j:  table[(512 >> (sb + 1)) + (((h << 8) | j) >> (sb + 1))]
+// so a half's values are the full transform's values at spectrum positions (h << 8) | p, p = 0 .. 255 - the bootstrapping
+// key needs no second layout.  One wave holds a half as FOUR values per lane; the eight stages run as four blocks of two
+// stages in four register layouts with three wave-private LDS transposes:
+//   L0: j = e << 6 | lane             (slot bits = index bits 7, 6)     stages 7, 6   (twiddles uniform over the wave)
+//   L1: j = (lane >> 4) << 6 | e << 4 | (lane & 15)        (5, 4)       stages 5, 4
+//   L2: j = (lane >> 2) << 4 | e << 2 | (lane & 3)         (3, 2)       stages 3, 2
+//   L3: j = lane << 2 | e                                  (1, 0)       stages 1, 0
+// LDS address of index j: j + (j >> 2) (320 doubles per polynomial), which is (per-lane base) + (constant) * e in every
+// layout and keeps the 32 lanes of a half-wave on all sixteen 8-byte bank pairs (L2, L3) or on thirteen of them (L0, L1).
+// The inverse runs the blocks backwards (Gentleman-Sande, inverse table, same indices).  Used by k_pbs_sym.
+// ---------------------------------------------------------------------------------------------------------------------
+struct HalfGeo9 {
+    static constexpr int N = 512, H = 256, E = 4, XPAD = 320;
+    __device__ static __forceinline__ int j0(int lane, int e) { return (e << 6) | lane; }
+    __device__ static __forceinline__ int j1(int lane, int e) { return ((lane >> 4) << 6) | (e << 4) | (lane & 15); }
+    __device__ static __forceinline__ int j2(int lane, int e) { return ((lane >> 2) << 4) | (e << 2) | (lane & 3); }
+    __device__ static __forceinline__ int j3(int lane, int e) { return (lane << 2) | e; }
+    // padded address = base(lane) + STEP * e
+    __device__ static __forceinline__ int base0(int lane) { return lane + (lane >> 2); }
+    __device__ static __forceinline__ int base1(int lane) { return 80 * (lane >> 4) + (lane & 15) + ((lane & 15) >> 2); }
+    __device__ static __forceinline__ int base2(int lane) { return 20 * (lane >> 2) + (lane & 3); }
+    __device__ static __forceinline__ int base3(int lane) { return 5 * lane; }
+    static constexpr int STEP0 = 80, STEP1 = 20, STEP2 = 5, STEP3 = 1;
+};
+
+// the twiddles one lane needs for the half transforms of half h, one direction: per block the twiddle of its first stage
+// (one per lane) and the two of its second stage (by the upper slot bit)
+struct HalfTw {
+    double hi[4], lo[4][2];
+    // table: tw_fwd (forward) or tw_inv (inverse), both indexed as above
+    __device__ __forceinline__ void fill(const double *__restrict__ table, int h, int lane)
+    {
+        const int jb[4] = {HalfGeo9::j0(lane, 0), HalfGeo9::j1(lane, 0), HalfGeo9::j2(lane, 0), HalfGeo9::j3(lane, 0)};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int sbhi = 7 - 2 * k, sblo = 6 - 2 * k;
+            const int jp = (h << 8) | jb[k];
+            hi[k] = table[(512 >> (sbhi + 1)) + (jp >> (sbhi + 1))];
+#pragma unroll
+            for (int t = 0; t < 2; t++) lo[k][t] = table[(512 >> (sblo + 1)) + ((jp | (t << sbhi)) >> (sblo + 1))];
+        }
+    }
+};
+
+// two Cooley-Tukey stages of block k on M half polynomials (slot bit 1 = the block's upper index bit)
+template <typename F, int M>
+__device__ __forceinline__ void half_fwd_block(double (&x)[M][4], const HalfTw &tw, int k)
+{
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const double U = x[m][e], V = mulmod<F>(x[m][e + 2], tw.hi[k]);
+            x[m][e] = U + V;
+            x[m][e + 2] = U - V;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const double U = x[m][2 * t], V = mulmod<F>(x[m][2 * t + 1], tw.lo[k][t]);
+            x[m][2 * t] = U + V;
+            x[m][2 * t + 1] = U - V;
+        }
+    }
+}
+template <typename F>
+__device__ __forceinline__ void half_inv_block(double (&x)[4], const HalfTw &tw, int k)
+{
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const double U = x[2 * t], V = x[2 * t + 1];
+        x[2 * t] = U + V;
+        x[2 * t + 1] = mulmod<F>(U - V, tw.lo[k][t]);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const double U = x[e], V = x[e + 2];
+        x[e] = U + V;
+        x[e + 2] = mulmod<F>(U - V, tw.hi[k]);
+    }
+}
+
+// Forward half transforms of M polynomials.  in: x[m][e] = value at half index j0(lane, e) (after the stride-8 stage);
+// out: x[m][e] = spectrum position (h << 8) | j3(lane, e).  xbuf: wave-private, M * XPAD doubles.
+template <typename F, int M>
+__device__ __forceinline__ void ntt_half_forward(double (&x)[M][4], double *xbuf, const HalfTw &tw, int lane)
+{
+    using G = HalfGeo9;
+    double *p0 = xbuf + G::base0(lane), *p1 = xbuf + G::base1(lane), *p2 = xbuf + G::base2(lane), *p3 = xbuf + G::base3(lane);
+    half_fwd_block<F, M>(x, tw, 0);
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) p0[m * G::XPAD + G::STEP0 * e] = reduce_unless_lazy<F>(x[m][e]);
+    lds_wave_sync();
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) x[m][e] = p1[m * G::XPAD + G::STEP1 * e];
+    lds_wave_sync();
+    half_fwd_block<F, M>(x, tw, 1);
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) p1[m * G::XPAD + G::STEP1 * e] = reduce_unless_lazy<F>(x[m][e]);
+    lds_wave_sync();
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) x[m][e] = p2[m * G::XPAD + G::STEP2 * e];
+    lds_wave_sync();
+    half_fwd_block<F, M>(x, tw, 2);
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) p2[m * G::XPAD + G::STEP2 * e] = reduce_unless_lazy<F>(x[m][e]);
+    lds_wave_sync();
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) x[m][e] = p3[m * G::XPAD + G::STEP3 * e];
+    lds_wave_sync();
+    half_fwd_block<F, M>(x, tw, 3);
+}
+
+// Inverse half transform (stages 0 .. 7; the joining stage on stride bit 8 and the 1/N factor are the caller's).
+// in: x[e] = spectrum position j3(lane, e), |x| <= 0.5 p; out: x[e] = half index j0(lane, e), not recentred
+// (|x| <= 4 * 0.5 p after the last two-stage block).
+template <typename F>
+__device__ __forceinline__ void ntt_half_inverse(double (&x)[4], double *xbuf, const HalfTw &tw, int lane)
+{
+    using G = HalfGeo9;
+    double *p0 = xbuf + G::base0(lane), *p1 = xbuf + G::base1(lane), *p2 = xbuf + G::base2(lane), *p3 = xbuf + G::base3(lane);
+    half_inv_block<F>(x, tw, 3);
+#pragma unroll
+    for (int e = 0; e < 4; e++) p3[G::STEP3 * e] = reduce<F>(x[e]);
+    lds_wave_sync();
+#pragma unroll
+    for (int e = 0; e < 4; e++) x[e] = p2[G::STEP2 * e];
+    lds_wave_sync();
+    half_inv_block<F>(x, tw, 2);
+#pragma unroll
+    for (int e = 0; e < 4; e++) p2[G::STEP2 * e] = reduce<F>(x[e]);
+    lds_wave_sync();
+#pragma unroll
+    for (int e = 0; e < 4; e++) x[e] = p1[G::STEP1 * e];
+    lds_wave_sync();
+    half_inv_block<F>(x, tw, 1);
+#pragma unroll
+    for (int e = 0; e < 4; e++) p1[G::STEP1 * e] = reduce<F>(x[e]);
+    lds_wave_sync();
+#pragma unroll
+    for (int e = 0; e < 4; e++) x[e] = p0[G::STEP0 * e];
+    lds_wave_sync();
+    half_inv_block<F>(x, tw, 0);
+}
+
 } // namespace helm

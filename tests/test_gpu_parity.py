@@ -199,9 +199,9 @@ def test_upload_rejects_duplicate_rows():
 
 
 @pytest.mark.parametrize("variant,name", [(1, "toy_k2"), (2, "toy_k2"), (3, "toy_k2"), (4, "toy_k2"), (5, "toy_k2"),
-                                          (6, "toy_k2"), (7, "toy_k2"),                    # duo: two / one bootstrap per workgroup
+                                          (6, "toy_k2"), (7, "toy_k2"), (8, "toy_k2"),     # duo in step / staggered, sym (transform halves)
                                           (1, "toy"), (3, "toy"), (4, "toy"), (5, "toy"),  # k = 2, l = 3 and k = 1, l = 2
-                                          (6, "toy"), (7, "toy"),
+                                          (6, "toy"), (7, "toy"), (8, "toy"),
                                           (1, "toy_1024"), (4, "toy_1024"), (5, "toy_1024")])  # N = 1024: two-wave, wide, lockstep
 def test_every_build_of_k_pbs_bit_exact(variant, name, monkeypatch):
     """HELM_HIP_PBS_VARIANT forces one build of the blind-rotate kernel for a whole launch (latency,
