@@ -832,8 +832,11 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
 //                 per-phase stamps (profiles/r04) show 11.4 k cycles of forward interval and 5.5 k of inverse interval in
 //                 which nine of twelve waves wait.
 //   STAG = true   bootstrap 1 runs ONE INTERVAL BEHIND bootstrap 0 and the two share all four SIMDs: while one bootstrap's
-//                 three inverse waves walk their latency chain (at high issue priority), the other's six waves fill the issue
-//                 slots with its forward interval.  Same barriers per step, same arithmetic: identical ciphertexts.
+//                 three inverse waves walk their latency chain, the other's six waves fill the issue slots with its forward
+//                 interval.  The priorities decide it: with the inverse waves ABOVE the forward waves the forward interval
+//                 stretches from 5.7 k to 9 k cycles (5 % slower than in step); BELOW them (they only have to be done by the
+//                 end of the interval) and the forward waves at one flat priority: 4 % FASTER than in step - the default.
+//                 Same barriers per step, same arithmetic: identical ciphertexts.
 // ------------------------------------------------------------------------------------
 template <typename F_, int LOGN_, int K_, int L_, bool STAG_>
 struct DuoCfg {
@@ -969,6 +972,7 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
     const int neg_B = -(1 << logB);
     const int rep = logB * L;
     const bool prio = (flags & 1) != 0;
+    const bool flat = (flags & 4) != 0; // forward waves keep one priority (2) instead of stepping 3 -> 2 -> 1
 
     // key words of one level of this wave's row: k+1 polynomials
     double2 kw[K1][E / 2];
@@ -994,7 +998,10 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
         const int i = tt >> 1;
         if (tt >= 0 && tt < 2 * n && !(tt & 1)) {
             // ---- forward interval of step i --------------------------------------------------------------------------
-            if (prio) __builtin_amdgcn_s_setprio(3);
+            if (prio) {
+                if (flat) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
+            }
             const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
             uint32_t st[E];
             {
@@ -1008,7 +1015,7 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
 #pragma unroll
                 for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(st[e], logB, half_m1, neg_B);
                 ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
-                if (prio) __builtin_amdgcn_s_setprio(1);
+                if (prio && !flat) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int c = 0; c < K1; c++) {
                     double *col = COL + (size_t)c * N + lane;
@@ -1030,7 +1037,7 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
                     for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(st[e], logB, half_m1, neg_B);
                     if (lev != L - 2) load_keys(i, lev); // (the first level's words came an interval ahead)
                     ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
-                    if (prio) { // a wave steps its priority down as it advances: whoever is behind goes first (see k_pbs)
+                    if (prio && !flat) { // a wave steps its priority down as it advances: whoever is behind goes first (see k_pbs)
                         if (lev) __builtin_amdgcn_s_setprio(2);
                         else __builtin_amdgcn_s_setprio(1);
                     }
@@ -1048,7 +1055,12 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
             STAMP(0) // rotation, digits, forward transforms, products
         } else if (tt >= 0 && tt < 2 * n) {
             // ---- inverse interval of step i: every product of the step is in its column ------------------------------
-            if (prio) __builtin_amdgcn_s_setprio(3); // (staggered: the latency chain goes first, the other bootstrap's forward waves fill in)
+            // in step: everybody waits for the inverse waves, they go first.  Staggered: flag 2 puts the inverse chain BELOW the
+            // other bootstrap's forward waves instead (it only has to be done by the end of their interval)
+            if (prio) {
+                if (C::STAG && (flags & 2)) __builtin_amdgcn_s_setprio(0);
+                else __builtin_amdgcn_s_setprio(3);
+            }
             if (g == 1) {
                 double mine[E];
                 double *col = COL + (size_t)r * N + lane;
@@ -1749,8 +1761,9 @@ struct helm_hip_ctx {
     int clock_probe = 0;     // HELM_HIP_CLOCK_PROBE: print the in-kernel clock of every k_pbs launch
     int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput, 4 wide, 5 lockstep, 6 duo (the two
                              // bootstraps of a workgroup in step), 7 duo staggered, 8 sym (HELM_HIP_PBS_VARIANT)
-    int duo_build = 1;       // the two-per-CU build the size dispatch uses: 1 k_pbs_duo in step, 2 staggered, 3 k_pbs_sym, 0 none (HELM_HIP_DUO)
-    int duo_flags = 1;       // bit 0: issue-priority staging inside k_pbs_duo (HELM_HIP_DUO_FLAGS)
+    int duo_build = 2;       // the two-per-CU build the size dispatch uses: 1 k_pbs_duo in step, 2 staggered, 3 k_pbs_sym, 0 none (HELM_HIP_DUO)
+    int duo_flags = 7;       // k_pbs_duo's issue priorities (HELM_HIP_DUO_FLAGS): bit 0 on at all; bit 1 staggered build: the inverse
+                             // waves BELOW the other bootstrap's forward waves; bit 2 forward waves at one priority instead of stepping down
     // per-call scratch
     DevBuf<PbsJob> d_pbs;
     DevBuf<KsJob> d_ks;
@@ -2330,7 +2343,7 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         ctx->n_cus = prop.multiProcessorCount;
         if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) ctx->pbs_variant = atoi(v);
         if (const char *v = getenv("HELM_HIP_NARROW")) ctx->narrow_variant = atoi(v) == 4 ? 4 : 1;
-        if (const char *v = getenv("HELM_HIP_DUO")) ctx->duo_build = atoi(v) >= 0 && atoi(v) <= 3 ? atoi(v) : 1;
+        if (const char *v = getenv("HELM_HIP_DUO")) ctx->duo_build = atoi(v) >= 0 && atoi(v) <= 3 ? atoi(v) : 2;
         if (const char *v = getenv("HELM_HIP_DUO_FLAGS")) ctx->duo_flags = atoi(v);
         if (const char *v = getenv("HELM_HIP_CLOCK_PROBE")) ctx->clock_probe = atoi(v);
         if (const char *v = getenv("HELM_HIP_KS_MFMA")) ctx->ks_mfma = atoi(v);
