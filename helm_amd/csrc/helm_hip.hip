@@ -2471,12 +2471,12 @@ int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4])
 {
     if (!ctx || !cost) return fail(HELM_ERR_INVALID, "null argument");
     // launch_pbs_f's dispatch, measured (profiles/r04/microbench.jsonl and the other boxes of the round; boolean_default:
-    // 3.5 / 5.3 - 5.6 / 7.5 / 8.2 - 8.5 ms for <= 256 / 512 / 768 / 1,024 bootstraps - wide, duo, partial and full lockstep
+    // 3.5 / 5.1 - 5.6 / 7.5 / 8.2 - 8.7 ms for <= 256 / 512 / 768 / 1,024 bootstraps - wide, duo, partial and full lockstep
     // round; without k_pbs_duo the throughput build takes 6.7 ms for <= 512)
     if (ctx->P.N == 512) {
-        cost[0] = ctx->narrow_variant == 4 ? 0.43 : 0.50;
-        cost[1] = ctx->duo_build ? 0.66 : 0.80;
-        cost[2] = 0.90;
+        cost[0] = ctx->narrow_variant == 4 ? 0.42 : 0.50;
+        cost[1] = ctx->duo_build ? 0.64 : 0.80;
+        cost[2] = 0.89;
     } else { // N = 1024 (helm_cuda: 3.9 / 6.2 / 8.5 / 8.7 ms - wide, two all-levels workgroups per CU, lockstep rounds)
         cost[0] = ctx->narrow_variant == 4 ? 0.45 : 0.64;
         cost[1] = 0.71;

@@ -205,12 +205,12 @@ def test_random_levelised_dags_property():
 
 def test_cost_aware_packing_takes_the_engines_best_width():
     """helm_host_pack_levels_costed (round 4): with the engine's cost per launch width (at most 1/4, 2/4, 3/4, 4/4 of a
-    round: 0.43 / 0.66 / 0.90 / 1, helm_hip_launch_costs) a launch narrower than a round takes the width with the best
+    round: 0.42 / 0.64 / 0.89 / 1, helm_hip_launch_costs) a launch narrower than a round takes the width with the best
     bootstraps-per-cost and leaves the rest to the next launch - what keeps a rank's chunk of a sharded launch (quantum =
     world x round) on the widths the engine runs well.  Same permutation, same dependency order, same values on every wire;
     at the drain everything goes."""
     blocks, quantum = 4, 2048  # levels of 4 AES blocks are ~630 bootstraps wide: always narrower than this quantum
-    cost = [0.43, 0.66, 0.90, 1.0]
+    cost = [0.42, 0.64, 0.89, 1.0]
     ops, i0, i1, i2, out, off, index, nw = _tiled_aes(blocks)
     plain = pack_levels(ops, i0, i1, i2, out, off, quantum)
     costed = pack_levels(ops, i0, i1, i2, out, off, quantum, quarter_cost=cost)

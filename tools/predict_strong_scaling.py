@@ -3,9 +3,9 @@
 launch lists alone.  The job's level schedule is launch-packed for N ranks (quantum = N x 4 x CUs; with `--costed` the
 packer also knows what a launch of 1/4, 2/4, 3/4 of a round costs and picks the best width, helm_host_pack_levels_costed),
 every launch cut into N contiguous chunks; a rank's chunk of c bootstraps is priced with the kernel table measured on one
-MI355X (`--table r03|r04`; r04: profiles/r04/microbench.jsonl: whole lockstep rounds of 1,024 at 8.5 ms, a remainder of
-<= 256 on the wide build 3.55 ms, <= 512 on k_pbs_duo 5.3 ms (r03: throughput build 7.4 ms), <= 768 in a partial lockstep
-round 7.5 ms (r03: 8.5)); launches of <= 256 bootstraps are computed on every rank.  The exchange is priced at bytes /
+MI355X (`--table r03|r04`; r04: profiles/r04/microbench.jsonl: whole lockstep rounds of 1,024 at 8.67 ms, a remainder of
+<= 256 on the wide build 3.55 ms, <= 512 on k_pbs_duo 5.50 ms (r03: throughput build 7.4 ms), <= 768 in a partial lockstep
+round 7.50 ms (r03: 8.5)); launches of <= 256 bootstraps are computed on every rank.  The exchange is priced at bytes /
 50 GB/s + 40 us per all-gather.  Runs on the CPU (host library only).
 usage: predict_strong_scaling.py [--blocks 32] [--table r04] [--costed] [--json]"""
 import argparse
@@ -22,7 +22,7 @@ from helm_amd.netlists import aes128  # noqa: E402
 
 TABLES = {  # ms for <= 1/4, 2/4, 3/4, 4/4 of a round of 4 x CUs bootstraps
     "r03": (3.6, 7.4, 8.5, 8.5),
-    "r04": (3.55, 5.3, 7.5, 8.5),
+    "r04": (3.55, 5.50, 7.50, 8.67),  # profiles/r04/microbench.jsonl (one box: 256 / 512 / 768 / 1,024)
 }
 
 
