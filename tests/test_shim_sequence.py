@@ -55,3 +55,28 @@ def test_shortint_shim_sequence_on_the_gpu(tmp_path, params):
     exe = _build(tmp_path, "shim_sequence_si")
     r = subprocess.run([exe, params], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+
+
+def test_communicator_sequence_builds_and_refuses_to_run_without_a_gpu(tmp_path):
+    """tests/c/shim_sequence_comm.c = the calls of rust/helm-hip/src/multi_gpu.rs (HipComm, shard_over, the sharded
+    evaluate_encrypted) over include/helm_comm.h + include/helm_hip.h, in a process without Python or torch."""
+    from helm_amd import _native
+    exe = _build(tmp_path, "shim_sequence_comm")
+    if _native.hip.helm_hip_device_count() > 0:
+        pytest.skip("a GPU is present: the run is covered by the gpu test")
+    r = subprocess.run([exe, "toy"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "helm_hip_ctx_create failed" in r.stderr and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("params", ["boolean_default", "toy_k2"])
+def test_communicator_sequence_on_the_gpu(tmp_path, params):
+    """A process that holds only libhelm_hip.so and libhelm_host.so creates the library's RCCL communicator (RCCL comes
+    from the loader's search path / /opt/rocm: nothing has loaded one before), packs the 2-bit adder for the world size
+    and sends every launch through ncclAllGather inside the library: same wire table as helm_hip_program_run, the
+    reference's known answer (tests/circuit_test.rs:17-45) decrypts."""
+    exe = _build(tmp_path, "shim_sequence_comm")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([exe, params], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "ok:" in r.stdout, r.stdout + r.stderr
