@@ -181,7 +181,8 @@ static __device__ unsigned long long g_wide_stamps[2 * 16 * 6];
 //              three waves on every SIMD doing the same work at the same time.  The full rounds
 //              of every wide launch: the dominant kernel of the benchmark.
 // ------------------------------------------------------------------------------------
-enum { TW_REG = 0, TW_LANE = 1 /* lane-major LDS table of forward twiddles, inverse reads it mirrored */ };
+enum { TW_REG = 0, TW_LANE = 1 /* lane-major LDS table of forward twiddles, inverse reads it mirrored */,
+       TW_LANE_FREG = 2 /* the same, the forward direction's per-lane twiddles copied into registers once */ };
 
 template <typename F_, int LOGN_, int K_, int L_, int M_, int TW_, bool PREFETCH_, int MINW_, int NB_ = 1>
 struct PbsCfg {
@@ -215,7 +216,7 @@ struct PbsCfg {
     static constexpr int WAVE_STRIDE_X = G::XPAD + (SLOTS - 1) * SLOT_STRIDE;
     static constexpr int WAVE_STRIDE = WAVE_STRIDE_X > (ACC3 + 1) / 2 ? WAVE_STRIDE_X : (ACC3 + 1) / 2;
     static constexpr int slot_off(int s) { return s == 0 ? 0 : G::XPAD + (s - 1) * SLOT_STRIDE; }
-    static constexpr int TW_ROWS = TW == TW_LANE ? G::TWB + G::TWC : 0;
+    static constexpr int TW_ROWS = TW != TW_REG ? G::TWB + G::TWC : 0;
     static constexpr size_t X_OFF = 0;                                                // double [K1][WAVE_STRIDE]
     static constexpr size_t TW_OFF = X_OFF + sizeof(double) * K1 * WAVE_STRIDE;       // double [TW_ROWS][64]
     static constexpr size_t MS_OFF = TW_OFF + sizeof(double) * TW_ROWS * 64;          // u16 [n+1]
@@ -270,8 +271,10 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
         }
     }
     // ---- twiddles: registers, or the lane-major LDS table -----------------------------
-    using TwF = typename std::conditional<C::TW == TW_REG, TwReg<G::NTW>, TwLane<LOGN, false>>::type;
+    using TwF0 = typename std::conditional<C::TW == TW_REG, TwReg<G::NTW>, TwLane<LOGN, false>>::type;
+    using TwF = typename std::conditional<C::TW == TW_LANE_FREG, TwLaneFwdReg<LOGN>, TwF0>::type;
     using TwI = typename std::conditional<C::TW == TW_REG, TwReg<G::NTW>, TwLane<LOGN, true>>::type;
+    TwF0 twf0;
     TwF twf;
     TwI twi;
     if constexpr (C::TW == TW_REG) {
@@ -280,12 +283,14 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
     } else {
         double *TW = reinterpret_cast<double *>(smem + C::TW_OFF);
         for (int r = p; r < C::TW_ROWS; r += K1) TW[r * 64 + lane] = tw_fwd[tw_lane_index<LOGN>(r, lane)];
-        twf.base = TW + lane;
+        twf0.base = TW + lane;
         twi.base = TW + (63 - lane);
-        twf.fill_uniform(tw_fwd);
+        twf0.fill_uniform(tw_fwd);
         twi.fill_uniform(tw_fwd);
+        if constexpr (C::TW == TW_LANE) twf = twf0;
     }
     __syncthreads();
+    if constexpr (C::TW == TW_LANE_FREG) twf.load(twf0); // the table is complete: this lane's forward twiddles into registers
 
     // ---- accumulator init: (0,...,0, X^{-b~} * tv) ------------------------------------
     double *xb = X + (size_t)p * C::WAVE_STRIDE; // this wave's exchange slots
@@ -2112,7 +2117,15 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
         using Lat = PbsCfg<F, LOGN, K, L, L, TW_REG, true, 1>;
         using Bal = PbsCfg<F, LOGN, K, L, L, TW_LANE, true, 2>;
         using Thr = PbsCfg<F, LOGN, K, L, 1, TW_LANE, false, 3>;
-        using Lock = PbsCfg<F, LOGN, K, L, 1, TW_LANE, false, 1, 4>;
+        // Round 4: the lane's block-B / block-C twiddles of the FORWARD direction sit in registers (TW_LANE_FREG: 28 of them,
+        // 140 -> 162 registers, still three waves per SIMD) instead of being read from the LDS lane table in every one of the
+        // three forward transforms of a step: 42 LDS reads fewer per wave-step (of 145 LDS instructions), **+1.9 %** on the
+        // headline kernel (4,096 bootstraps: 33.49 -> 32.84 ms, same box, alternating, identical ciphertexts;
+        // profiles/r04/lockstep_twiddle_registers.txt).  -DHELM_LOCK_TW=TW_LANE is round 3's form.
+#ifndef HELM_LOCK_TW
+#define HELM_LOCK_TW TW_LANE_FREG
+#endif
+        using Lock = PbsCfg<F, LOGN, K, L, 1, HELM_LOCK_TW, false, 1, 4>;
         int v = ctx->pbs_variant;
         if (v == 0) {
             const int64_t round = 4 * (int64_t)ctx->n_cus;

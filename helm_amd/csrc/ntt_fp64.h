@@ -306,6 +306,30 @@ struct TwLane {
     }
 };
 
+// TwLane with the lane's block-B and block-C twiddles of the FORWARD direction copied into registers once per kernel
+// (they do not change from step to step): TWB + TWC fewer LDS reads per forward transform, for kernels that have the
+// registers.  (The inverse direction keeps reading the table mirrored.)
+template <int LOGN>
+struct TwLaneFwdReg {
+    static constexpr bool MIRROR = false;
+    using G = Geo<LOGN>;
+    double ua[G::TWA];          // block A: lane-uniform
+    double c[G::TWB + G::TWC];  // blocks B and C: this lane's
+    __device__ __forceinline__ void load(const TwLane<LOGN, false> &t)
+    {
+#pragma unroll
+        for (int r = 0; r < G::TWA; r++) ua[r] = t.ua[r];
+#pragma unroll
+        for (int r = 0; r < G::TWB + G::TWC; r++) c[r] = t.base[r * 64];
+    }
+    __device__ __forceinline__ double get(int sb, int hi, int, int, int) const
+    {
+        const int fs = tw_fwd_slot<LOGN>(sb, hi);
+        if (fs < G::TWA) return ua[fs];
+        return c[fs - G::TWA];
+    }
+};
+
 // Index table for blocks A and B (entries below N >> BC: few, read with few distinct
 // addresses per instruction) + lane-major table for block C, whose per-lane indices stride
 // by E through an index table (E-way bank conflicts for E = 16, 32).
