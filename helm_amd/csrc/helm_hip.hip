@@ -666,13 +666,28 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
     }
     for (int q = w; q < C::TW_ROWS; q += NW) TW[q * 64 + lane] = tw_fwd[tw_lane_index<LOGN>(q, lane)];
     for (int j = tid; j < K1 * N; j += 64 * NW) COL[j] = 0.0;
-    TwLane<LOGN, false> twf;
-    TwLane<LOGN, true> twi;
-    twf.base = TW + lane;
-    twi.base = TW + (63 - lane);
-    twf.fill_uniform(tw_fwd);
-    twi.fill_uniform(tw_fwd);
+    // Round 4: at N = 512 the lane's block-B / block-C twiddles of BOTH directions are copied into registers once per
+    // kernel (2 x 14 doubles: 110 -> 166 registers, the limit for the three waves of SIMD 0 is 168) instead of read from the
+    // LDS lane table in every transform - the reads sat on the latency chain of a step: 3.5 % faster (64 bootstraps: 3.136
+    // -> 3.024 ms, 256: 3.444 -> 3.324 ms, same box, alternating, identical ciphertexts; forward direction alone: 1.4 %).
+    // N = 1024 keeps the table (2 x 28 doubles spill).  -DHELM_WIDE_TW_REG=0 is round 3's form.
+#ifndef HELM_WIDE_TW_REG
+#define HELM_WIDE_TW_REG 3 /* bit 0: forward twiddles in registers, bit 1: inverse */
+#endif
+    constexpr int TWR = LOGN == 9 ? HELM_WIDE_TW_REG : 0;
+    TwLane<LOGN, false> twf0;
+    TwLane<LOGN, true> twi0;
+    twf0.base = TW + lane;
+    twi0.base = TW + (63 - lane);
+    twf0.fill_uniform(tw_fwd);
+    twi0.fill_uniform(tw_fwd);
     __syncthreads();
+    typename std::conditional<(TWR & 1) != 0, TwLaneReg<LOGN, false>, TwLane<LOGN, false>>::type twf;
+    typename std::conditional<(TWR & 2) != 0, TwLaneReg<LOGN, true>, TwLane<LOGN, true>>::type twi;
+    if constexpr ((TWR & 1) != 0) twf.load(twf0);
+    else twf = twf0;
+    if constexpr ((TWR & 2) != 0) twi.load(twi0);
+    else twi = twi0;
 
     // accumulator (0, ..., 0, X^{-b~} tv): the lev = 0 wave of polynomial r owns it (registers)
     // and publishes the negacyclically unrolled u32 copy every wave of the polynomial reads
@@ -930,13 +945,20 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
     }
     for (int q = wb; q < C::TW_ROWS; q += NWB) TW[q * 64 + lane] = tw_fwd[tw_lane_index<LOGN>(q, lane)];
     for (int j = tid; j < K1 * N; j += 64 * NWB) COL[j] = 0.0;
-    TwLane<LOGN, false> twf;
+    // the forward direction's per-lane twiddles in registers (123 -> 151): 1.5 % (same-box A/B with the wide kernel's)
+#ifndef HELM_DUO_TW_REG
+#define HELM_DUO_TW_REG 1
+#endif
+    TwLane<LOGN, false> twf0;
     TwLane<LOGN, true> twi;
-    twf.base = TW + lane;
+    twf0.base = TW + lane;
     twi.base = TW + (63 - lane);
-    twf.fill_uniform(tw_fwd);
+    twf0.fill_uniform(tw_fwd);
     twi.fill_uniform(tw_fwd);
     __syncthreads();
+    typename std::conditional<(HELM_DUO_TW_REG & 1) != 0, TwLaneReg<LOGN, false>, TwLane<LOGN, false>>::type twf;
+    if constexpr ((HELM_DUO_TW_REG & 1) != 0) twf.load(twf0);
+    else twf = twf0;
 
     // accumulator (0, ..., 0, X^{-b~} tv): part B of polynomial r owns it (registers) and publishes the unrolled u32 copy
     uint32_t *acc_r = ACC + (size_t)r * C::ACC3;

@@ -309,26 +309,27 @@ struct TwLane {
 // TwLane with the lane's block-B and block-C twiddles of the FORWARD direction copied into registers once per kernel
 // (they do not change from step to step): TWB + TWC fewer LDS reads per forward transform, for kernels that have the
 // registers.  (The inverse direction keeps reading the table mirrored.)
-template <int LOGN>
-struct TwLaneFwdReg {
-    static constexpr bool MIRROR = false;
+template <int LOGN, bool MIRROR_ = false>
+struct TwLaneReg {
+    static constexpr bool MIRROR = MIRROR_;
     using G = Geo<LOGN>;
     double ua[G::TWA];          // block A: lane-uniform
-    double c[G::TWB + G::TWC];  // blocks B and C: this lane's
-    __device__ __forceinline__ void load(const TwLane<LOGN, false> &t)
+    double c[G::TWB + G::TWC];  // blocks B and C: this lane's (MIRROR: lane 63 - lane's, read in mirrored slot order)
+    __device__ __forceinline__ void load(const TwLane<LOGN, MIRROR_> &t)
     {
 #pragma unroll
         for (int r = 0; r < G::TWA; r++) ua[r] = t.ua[r];
 #pragma unroll
         for (int r = 0; r < G::TWB + G::TWC; r++) c[r] = t.base[r * 64];
     }
-    __device__ __forceinline__ double get(int sb, int hi, int, int, int) const
+    __device__ __forceinline__ double get(int sb, int hi, int cnt, int, int) const
     {
-        const int fs = tw_fwd_slot<LOGN>(sb, hi);
+        const int fs = tw_fwd_slot<LOGN>(sb, MIRROR ? cnt - 1 - hi : hi);
         if (fs < G::TWA) return ua[fs];
         return c[fs - G::TWA];
     }
 };
+template <int LOGN> using TwLaneFwdReg = TwLaneReg<LOGN, false>;
 
 // Index table for blocks A and B (entries below N >> BC: few, read with few distinct
 // addresses per instruction) + lane-major table for block C, whose per-lane indices stride
