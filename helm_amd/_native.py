@@ -170,10 +170,12 @@ SI_API = {
 }
 
 # every symbol include/helm_comm.h declares (the library's own RCCL communicator)
+COMM_ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp, C.c_size_t, vp)  # helm_comm_all_gather_fn
 COMM_API = {
     "helm_comm_available": (C.c_int, []),
     "helm_comm_get_unique_id": (C.c_int, [u8p]),
     "helm_comm_create": (C.c_int, [C.c_int, u8p, C.c_int, C.c_int, C.POINTER(vp)]),
+    "helm_comm_create_with_transport": (C.c_int, [C.c_int, C.c_int, C.c_int, COMM_ALL_GATHER_FN, vp, C.POINTER(vp)]),
     "helm_comm_destroy": (C.c_int, [vp]),
     "helm_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "helm_comm_stats": (C.c_int, [vp, i64p, i64p]),

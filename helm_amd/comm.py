@@ -50,6 +50,53 @@ class Comm:
         dist.broadcast_object_list(box, src=0)
         return cls(device, np.frombuffer(box[0], dtype=np.uint8).copy(), rank, world)
 
+    @classmethod
+    def with_transport(cls, device, rank, world, all_gather):
+        """A communicator over a transport the host brings (helm_comm_create_with_transport):
+        `all_gather(send_ptr, recv_ptr, bytes_per_rank, stream_ptr)` gathers every rank's bytes into recv_ptr in rank
+        order, ordered behind / ahead of the work on the HIP stream `stream_ptr`; an exception fails the collective."""
+        self = cls.__new__(cls)
+
+        def trampoline(_user, send, recv, nbytes, stream):
+            try:
+                all_gather(int(send or 0), int(recv or 0), int(nbytes), int(stream or 0))
+                return 0
+            except Exception:  # noqa: BLE001 - reported through the status code
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = nv.COMM_ALL_GATHER_FN(trampoline)  # kept alive as long as the communicator
+        h = nv.vp()
+        hip_check(hip.helm_comm_create_with_transport(int(device), int(rank), int(world), self._cb, None, C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        return self
+
+    @classmethod
+    def over_torch_dist(cls, dist, device):
+        """The transport form over ANY torch.distributed backend, staged through host memory (gloo is enough): for
+        hosts without RCCL and for rehearsing the rank > 0 paths with several ranks on one GPU.  Slow by construction
+        (device -> host -> peers -> device per collective); `from_torch_dist` is the RCCL communicator."""
+        import torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+
+        class _Raw:  # a device range as something torch.as_tensor understands
+            def __init__(self, ptr, nbytes):
+                self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+        def all_gather(send, recv, nbytes, stream):
+            dev = torch.device("cuda", int(device))
+            s = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
+            with torch.cuda.stream(s):
+                mine = torch.as_tensor(_Raw(send, nbytes), device=dev).cpu()  # waits for the stream's earlier work
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                torch.as_tensor(_Raw(recv, nbytes * world), device=dev).copy_(torch.cat(parts))
+                s.synchronize()
+
+        return cls.with_transport(device, rank, world, all_gather)
+
     def info(self):
         """What RCCL reports: rank, world size, device, library version."""
         r, w, d, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()

@@ -19,6 +19,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
+#include <algorithm>
 
 int helm_hip_fail_(int code, const std::string &msg); // helm_hip.hip: sets helm_hip_last_error()
 
@@ -113,6 +115,8 @@ struct helm_comm {
     hipStream_t side = nullptr; // the host-side helpers' own stream
     double *scratch = nullptr;  // one double on the device for them
     int64_t collectives = 0, bytes_sent = 0;
+    helm_comm_all_gather_fn transport = nullptr; // helm_comm_create_with_transport: the host's all-gather instead of RCCL
+    void *transport_user = nullptr;
 };
 
 extern "C" {
@@ -164,6 +168,34 @@ int helm_comm_create(int device_id, const uint8_t id[HELM_COMM_ID_BYTES], int ra
     return 0;
 }
 
+int helm_comm_create_with_transport(int device_id, int rank, int world, helm_comm_all_gather_fn all_gather, void *user,
+                                    helm_comm **out)
+{
+    if (!all_gather || !out) return helm_hip_fail_(HELM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world)
+        return helm_hip_fail_(HELM_ERR_INVALID, "helm_comm_create_with_transport: bad rank / world");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device_id < 0 || device_id >= n_dev)
+        return helm_hip_fail_(HELM_ERR_NO_DEVICE, "helm_comm_create_with_transport: no such device");
+    HIPC_TRY(hipSetDevice(device_id));
+    helm_comm *c = new (std::nothrow) helm_comm();
+    if (!c) return helm_hip_fail_(HELM_ERR_OOM, "communicator");
+    c->device = device_id;
+    c->rank = rank;
+    c->world = world;
+    c->transport = all_gather;
+    c->transport_user = user;
+    // the host-side helpers gather one double per rank
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&c->scratch, sizeof(double) * (size_t)world) != hipSuccess) {
+        helm_comm_destroy(c);
+        return helm_hip_fail_(HELM_ERR_HIP, "helm_comm_create_with_transport: side stream / scratch");
+    }
+    *out = c;
+    return 0;
+}
+
 int helm_comm_destroy(helm_comm *c)
 {
     if (!c) return 0;
@@ -184,6 +216,13 @@ int helm_comm_info(const helm_comm *c, int *rank, int *world, int *device, int *
 {
     if (!c) return helm_hip_fail_(HELM_ERR_INVALID, "null communicator");
     int v = 0;
+    if (c->transport) {
+        if (rank) *rank = c->rank;
+        if (world) *world = c->world;
+        if (device) *device = c->device;
+        if (rccl_version) *rccl_version = 0;
+        return 0;
+    }
     if (rank) NCCL_TRY(g_rccl.CommUserRank(c->comm, rank));
     if (world) NCCL_TRY(g_rccl.CommCount(c->comm, world));
     if (device) NCCL_TRY(g_rccl.CommCuDevice(c->comm, device));
@@ -206,6 +245,13 @@ int helm_comm_all_gather(helm_comm *c, const void *send_dev, void *recv_dev, siz
 {
     if (!c || !send_dev || !recv_dev) return helm_hip_fail_(HELM_ERR_INVALID, "helm_comm_all_gather: null argument");
     if (bytes_per_rank == 0) return 0;
+    if (c->transport) {
+        if (int rc = c->transport(c->transport_user, send_dev, recv_dev, bytes_per_rank, hip_stream))
+            return helm_hip_fail_(HELM_ERR_STATE, "helm_comm_all_gather: the host's transport failed (" + std::to_string(rc) + ")");
+        c->collectives++;
+        c->bytes_sent += (int64_t)bytes_per_rank;
+        return 0;
+    }
     // words where the size allows it (rows of u32 / u64 always do), bytes otherwise
     if (bytes_per_rank % 4 == 0)
         NCCL_TRY(g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank / 4, ncclUint32, c->comm, static_cast<hipStream_t>(hip_stream)));
@@ -220,6 +266,20 @@ int helm_comm_all_reduce_f64(helm_comm *c, double *value, int op)
 {
     if (!c || !value || (op != 0 && op != 1)) return helm_hip_fail_(HELM_ERR_INVALID, "helm_comm_all_reduce_f64: bad argument");
     HIPC_TRY(hipSetDevice(c->device));
+    if (c->transport) { // one double per rank through the host's all-gather, reduced here
+        HIPC_TRY(hipMemcpyAsync(c->scratch + c->rank, value, sizeof(double), hipMemcpyHostToDevice, c->side));
+        if (int rc = c->transport(c->transport_user, c->scratch + c->rank, c->scratch, sizeof(double), c->side))
+            return helm_hip_fail_(HELM_ERR_STATE, "helm_comm_all_reduce_f64: the host's transport failed (" + std::to_string(rc) + ")");
+        std::vector<double> all((size_t)c->world);
+        HIPC_TRY(hipMemcpyAsync(all.data(), c->scratch, sizeof(double) * all.size(), hipMemcpyDeviceToHost, c->side));
+        HIPC_TRY(hipStreamSynchronize(c->side));
+        double r = all[0];
+        for (size_t i = 1; i < all.size(); i++) r = op == 0 ? r + all[i] : std::max(r, all[i]);
+        *value = r;
+        c->collectives++;
+        c->bytes_sent += (int64_t)sizeof(double);
+        return 0;
+    }
     HIPC_TRY(hipMemcpyAsync(c->scratch, value, sizeof(double), hipMemcpyHostToDevice, c->side));
     NCCL_TRY(g_rccl.AllReduce(c->scratch, c->scratch, 1, ncclFloat64, op == 0 ? ncclSum : ncclMax, c->comm, c->side));
     HIPC_TRY(hipMemcpyAsync(value, c->scratch, sizeof(double), hipMemcpyDeviceToHost, c->side));

@@ -1,5 +1,6 @@
 /*
- * helm_comm.h — C ABI of the multi-GPU exchange: an RCCL communicator owned by the library.
+ * helm_comm.h — C ABI of the multi-GPU exchange: an RCCL communicator owned by the library
+ * (or, helm_comm_create_with_transport, one over a transport the host brings).
  *
  * The reference has no multi-GPU code; its unit of parallelism is the level
  * (reference src/circuit.rs:531 `gates.par_iter_mut()` for gates mode, :1057 for LUT mode,
@@ -43,6 +44,16 @@ int helm_comm_get_unique_id(uint8_t id[HELM_COMM_ID_BYTES]);
 /* ncclCommInitRank on `device_id`: collective over the `world` processes that share `id`
  * (world = 1 is a valid communicator: every collective still goes through RCCL). */
 int helm_comm_create(int device_id, const uint8_t id[HELM_COMM_ID_BYTES], int rank, int world, helm_comm **out);
+/* A communicator over a transport the HOST brings (MPI, a socket ring, a host framework's process group) instead of
+ * RCCL: every collective of this header - and with it helm_hip_program_run_sharded_comm() and
+ * helm_si_set_exchange_comm() - then calls `all_gather(user, send_dev, recv_dev, bytes_per_rank, hip_stream)`, which
+ * must gather bytes_per_rank bytes of every rank into recv_dev in rank order (send_dev may be recv_dev + rank *
+ * bytes_per_rank), ordered behind the work already queued on hip_stream, and return 0; the result must be in place for
+ * work queued on hip_stream afterwards.  No RCCL is needed or touched (helm_comm_info reports rccl_version 0).  Also
+ * how the rank > 0 offsets of the sharded paths are tested where every rank shares one GPU (tests/test_gpu_two_ranks*.py). */
+typedef int (*helm_comm_all_gather_fn)(void *user, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *hip_stream);
+int helm_comm_create_with_transport(int device_id, int rank, int world, helm_comm_all_gather_fn all_gather, void *user,
+                                    helm_comm **out);
 /* ncclCommDestroy.  NULL is accepted. */
 int helm_comm_destroy(helm_comm *comm);
 /* What RCCL itself reports for the communicator (ncclCommUserRank / ncclCommCount / ncclCommCuDevice /

@@ -131,6 +131,10 @@ extern "C" {
     pub fn helm_comm_available() -> c_int;
     pub fn helm_comm_get_unique_id(id: *mut u8) -> c_int;
     pub fn helm_comm_create(device_id: c_int, id: *const u8, rank: c_int, world: c_int, out: *mut *mut helm_comm) -> c_int;
+    // a communicator over a transport the host brings (MPI, ...) instead of RCCL
+    pub fn helm_comm_create_with_transport(device_id: c_int, rank: c_int, world: c_int,
+                                           all_gather: extern "C" fn(*mut c_void, *const c_void, *mut c_void, usize, *mut c_void) -> c_int,
+                                           user: *mut c_void, out: *mut *mut helm_comm) -> c_int;
     pub fn helm_comm_destroy(comm: *mut helm_comm) -> c_int;
     pub fn helm_comm_info(comm: *const helm_comm, rank: *mut c_int, world: *mut c_int, device: *mut c_int,
                           rccl_version: *mut c_int) -> c_int;

@@ -51,6 +51,14 @@ def _worker(rank, world, port, blocks, result_dir, backend="gloo", overlap=False
     deps = None
     t0, t1, t2, tout = tile(i0), tile(i1), tile(i2), tile(out)
     in_library = overlap == "library"
+    comm = None
+    if overlap == "comm":
+        # the library's communicator over a host transport (helm_comm_create_with_transport): launch loop, in-place slot
+        # of rank 1, gather and scatter all inside libhelm_hip.so, exactly the path bench.py takes over RCCL
+        from helm_amd.comm import Comm
+        comm = Comm.over_torch_dist(dist, dev)
+        assert comm.info() == {"rank": rank, "world_size": world, "device": dev, "rccl_version": 0}
+        assert comm.all_reduce(float(rank + 1), "sum") == world * (world + 1) / 2 and comm.all_reduce(float(rank), "max") == world - 1
     overlap = overlap is True
     if overlap:
         # the overlapped schedule: levels cut into sub-launches of <= 300 bootstraps, each launch's all-gather and scatter
@@ -65,9 +73,11 @@ def _worker(rank, world, port, blocks, result_dir, backend="gloo", overlap=False
     rows = np.concatenate([b * nw + np.arange(len(inputs)) for b in range(blocks)]).astype(np.int32)
     wires.upload(rows, ck.encrypt(bits.reshape(-1)))
     runner = ShardedRunner(GpuLevelExecutor(prog, wires), rank, world, dist, depends_on=deps,
-                           replicate_below=64 if overlap else 256, in_library=in_library)
+                           replicate_below=64 if overlap else 256, in_library=in_library, comm=comm)
     assert runner.in_library == in_library
     runner.run()
+    if comm is not None:
+        assert comm.stats()["collectives"] == len(runner.sharded_levels) + 2  # (+ the two all-reduces above)
     if overlap:
         runner.run()  # a second pass right behind the first: the ring of staging pairs and the events are reused
     torch.cuda.synchronize()
@@ -121,6 +131,21 @@ def test_two_ranks_through_the_c_abi_pass(tmp_path):
     for r in range(2):
         same, sharded, nl = np.load(tmp_path / f"rank{r}.npy")
         assert same == 1, f"rank {r}: the in-library sharded pass differs from the single-process one"
+        assert 0 < sharded <= nl
+
+
+def test_two_ranks_through_the_library_communicator(tmp_path):
+    """helm_hip_program_run_sharded_comm at world size 2: the communicator is the library's (include/helm_comm.h), its
+    all-gather carried by a host transport because both ranks share one GPU (RCCL wants one per rank).  Everything
+    bench.py's N > 1 run does except RCCL itself - rank 1's slot offset, padded chunks, scatter - against one process."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, 4, str(tmp_path), "gloo", "comm"), nprocs=2, join=True)
+    for r in range(2):
+        same, sharded, nl = np.load(tmp_path / f"rank{r}.npy")
+        assert same == 1, f"rank {r}: the pass through the library's communicator differs from the single-process one"
         assert 0 < sharded <= nl
 
 

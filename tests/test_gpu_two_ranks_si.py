@@ -27,10 +27,13 @@ def _circuit(path, is_arith):
     return c, wire_set
 
 
-def _both_ways(circ, sk, wire_set, inputs, ptxt_type, blocks, rank, world):
+def _both_ways(circ, sk, wire_set, inputs, ptxt_type, blocks, rank, world, comm=None):
     """(wires of the sharded run, wires of the single-GPU run on the same inputs, sharded batches)"""
     from helm_amd import SiEncWireMap
-    sk.set_exchange(dist, rank, world, min_batch=2, capacity_rows=24)
+    if comm is not None:
+        sk.set_exchange_comm(comm, min_batch=2, capacity_rows=24)
+    else:
+        sk.set_exchange(dist, rank, world, min_batch=2, capacity_rows=24)
     enc_in = circ.encrypt_inputs(wire_set, inputs)
     saved = {w: np.array(enc_in[w], copy=True) for w in enc_in.keys()}
     out = circ.evaluate_encrypted(enc_in, 1, ptxt_type)
@@ -38,7 +41,10 @@ def _both_ways(circ, sk, wire_set, inputs, ptxt_type, blocks, rank, world):
     sharded = {w: np.array(out[w], copy=True) for w in out.keys()}
     batches, rows = sk.exchange_stats()
     dist.barrier()
-    sk.set_exchange(dist, rank, 1)
+    if comm is not None:
+        sk.set_exchange_comm(None)
+    else:
+        sk.set_exchange(dist, rank, 1)
     again = SiEncWireMap(sk, blocks=blocks)
     for w, ct in saved.items():
         again[w] = ct
@@ -47,7 +53,7 @@ def _both_ways(circ, sk, wire_set, inputs, ptxt_type, blocks, rank, world):
     return sharded, single, batches, out
 
 
-def _worker(rank, world, port, result_dir, set_name):
+def _worker(rank, world, port, result_dir, set_name, through_comm=False):
     import helm_amd
     from helm_amd import ArithCircuit, LutCircuit, PtxtType, verilog_parser
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -55,6 +61,12 @@ def _worker(rank, world, port, result_dir, set_name):
     torch.cuda.set_device(0)
     ck, sk = helm_amd.gen_keys_shortint(set_name, seed=1)  # same seed: same keys and encryptions on every rank
     res = []
+    comm = None
+    if through_comm:
+        # helm_si_set_exchange_comm at world size 2: the library's communicator over a host transport (both ranks share the
+        # GPU, RCCL wants one each) - rank 1's slot in the engine-owned gather buffer, several exchange rounds per batch
+        from helm_amd.comm import Comm
+        comm = Comm.over_torch_dist(dist, 0)
 
     # LUT mode: the 8-bit adder of 3-input LUTs (BASELINE config 3)
     circuit, wire_set = _circuit(f"{NET}/8-bit-adder-lut-3-1.v", False)
@@ -63,7 +75,7 @@ def _worker(rank, world, port, result_dir, set_name):
     inputs.update({f"b[{i}]": PtxtType.Bool((b >> i) & 1) for i in range(8)})
     inputs["cin"] = PtxtType.Bool(cin)
     lc = LutCircuit(ck, sk, circuit)
-    sharded, single, batches, out = _both_ways(lc, sk, wire_set, inputs, "bool", 1, rank, world)
+    sharded, single, batches, out = _both_ways(lc, sk, wire_set, inputs, "bool", 1, rank, world, comm)
     same = set(sharded) == set(single) and all(np.array_equal(sharded[w], single[w]) for w in single)
     dec = lc.decrypt_outputs(out, True)
     total = sum(dec[f"sum[{i}]"].value << i for i in range(8)) + (dec["cout"].value << 8)
@@ -73,7 +85,7 @@ def _worker(rank, world, port, result_dir, set_name):
     circuit, wire_set = _circuit(f"{NET}/chi_squared_arith.v", True)
     inputs = verilog_parser.read_input_wires(os.path.join(HERE, "golden", "chi_squared_arith_1.inputs.csv"), "u32")
     ac = ArithCircuit(ck, sk, circuit)
-    sharded, single, batches, out = _both_ways(ac, sk, wire_set, inputs, "u32", 16, rank, world)
+    sharded, single, batches, out = _both_ways(ac, sk, wire_set, inputs, "u32", 16, rank, world, comm)
     same = set(sharded) == set(single) and all(np.array_equal(sharded[w], single[w]) for w in single)
     dec = {k: v.value for k, v in ac.decrypt_outputs(out, True).items()}
     res += [int(same), batches, int(dec == {"alpha": 529, "beta1": 242, "beta2": 275, "beta3": 1250})]
@@ -96,4 +108,18 @@ def test_lut_and_arith_modes_two_ranks_on_one_gpu(tmp_path, set_name):
         assert ar_same == 1, f"rank {r}: sharded arithmetic evaluation differs from the single-GPU one"
         assert lut_ok == 1 and ar_ok == 1
         # the adder: 2 look-ups per level; chi-squared: 39 rounds, the wide ones in several exchanges of 48 rows
+        assert lut_batches >= 4 and ar_batches > 39, (lut_batches, ar_batches)
+
+
+def test_lut_and_arith_modes_two_ranks_through_the_library_communicator(tmp_path):
+    """The same through helm_si_set_exchange_comm (what bench.py's other_modes and a Rust host use over RCCL)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), "shortint_m2c2", True), nprocs=2, join=True)
+    for r in range(2):
+        lut_same, lut_batches, lut_ok, ar_same, ar_batches, ar_ok = np.load(tmp_path / f"rank{r}.npy")
+        assert lut_same == 1 and ar_same == 1, f"rank {r}: sharded evaluation differs from the single-GPU one"
+        assert lut_ok == 1 and ar_ok == 1
         assert lut_batches >= 4 and ar_batches > 39, (lut_batches, ar_batches)
