@@ -277,6 +277,11 @@ class Bench:
                     self.comm.destroy()
                     self.comm = None
                     self.comm_error = self.comm_error or "another rank could not create its communicator"
+            if self.rehearse and not args.overlap:
+                # the same code path as the real run (helm_hip_program_run_sharded_comm, helm_si_set_exchange_comm), the
+                # library's communicator carried by a host transport because the ranks share the GPU
+                from helm_amd import comm as hc
+                self.comm = hc.Comm.over_torch_dist(dist, local_rank)
         elif args.force_comm:
             from helm_amd import comm as hc
             with _StdoutToStderr():
@@ -529,7 +534,10 @@ def fill_result(bench, result):
             "value_is": f"a batch of {head['blocks_total']} independent AES-128 evaluations run together (the blocks share no wires, so launches "
                         "hold whole lockstep rounds); ONE evaluation, what helm.rs:256-262 runs, is `single_block` with its own roofline",
             "parallelism": ("single GPU" if world == 1 else
-                            f"launch-shard x{world} + ncclAllGather of launch outputs inside the library (RCCL), keys and wire table replicated" if sharded else
+                            f"launch-shard x{world} + all-gather of launch outputs " +
+                            ("inside the library (ncclAllGather, RCCL)" if bench.comm is not None and bench.comm.info()["rccl_version"] else
+                             "through the library's communicator over a host transport (REHEARSAL on one GPU)" if bench.comm is not None else
+                             "through torch.distributed") + ", keys and wire table replicated" if sharded else
                             f"block-parallel x{world}: independent blocks per GPU, keys replicated, no data-path collective"),
             "sharded_launches": head["sharded_launches"],
             "exchanged_MB_per_step": round(head["exchanged_MB_per_step"], 2),
@@ -567,11 +575,13 @@ def fill_result(bench, result):
         if bench.comm is not None:
             info = bench.comm.info()   # what RCCL itself reports for the library's communicator
             result["rccl_ranks"] = {"world_size": info["world_size"], "rank_of_this_line": info["rank"], "rccl_version": info["rccl_version"],
-                                    "communicator": "helm_comm: ncclCommInitRank / ncclAllGather inside libhelm_hip.so (include/helm_comm.h)",
+                                    "communicator": ("helm_comm: ncclCommInitRank / ncclAllGather inside libhelm_hip.so (include/helm_comm.h)"
+                                                     if info["rccl_version"] else
+                                                     "helm_comm over a HOST TRANSPORT (gloo through host memory): rehearsal on one GPU, RCCL NOT used"),
                                     "collectives_issued_by_rank_0": bench.comm.stats()["collectives"],
                                     "control_plane": (f"torch.distributed {bench.dist.get_backend()} (barrier, max over ranks, unique id)"
                                                       if world > 1 else "none (one process)"),
-                                    "one_process_per_gpu": True}
+                                    "one_process_per_gpu": not bench.rehearse}
         else:
             result["rccl_ranks"] = {"world_size": bench.dist.get_world_size(), "backend": bench.dist.get_backend(),
                                     "communicator": "torch.distributed (" + ("rehearsal on one GPU" if bench.rehearse else

@@ -64,7 +64,7 @@ def test_hung_worker_group_is_stopped_and_reported():
 
 @pytest.mark.gpu
 def test_rehearsal_two_ranks_on_one_gpu_reports_every_named_result():
-    """HELM_BENCH_REHEARSE=1: both ranks on cuda:0, collectives over gloo - the whole N > 1 path of bench.py, launcher
+    """HELM_BENCH_REHEARSE=1: both ranks on cuda:0, the library's communicator over a host transport - the whole N > 1 path of bench.py, launcher
     included: strong (headline), weak and sharded_weak each under its own name, rc 0."""
     rc, lines, err = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "4", "--side-steps", "1"],
                                {"HELM_BENCH_REHEARSE": "1"}, timeout=1100)
@@ -73,7 +73,11 @@ def test_rehearsal_two_ranks_on_one_gpu_reports_every_named_result():
     line = json.loads(lines[0])
     assert "error" not in line, line.get("error")
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2
-    assert line["rccl_ranks"]["world_size"] == 2 and line["rccl_ranks"]["backend"] == "gloo"
+    # the data path is the real run's (the library's communicator: helm_hip_program_run_sharded_comm), carried by a host
+    # transport in the rehearsal and labelled as such
+    rr = line["rccl_ranks"]
+    assert rr["world_size"] == 2 and rr["rccl_version"] == 0 and "HOST TRANSPORT" in rr["communicator"]
+    assert rr["one_process_per_gpu"] is False and rr["collectives_issued_by_rank_0"] > 0
     assert line["config"]["sharded_launches"] > 0 and line["config"]["exchanged_MB_per_step"] > 0
     for kind in ("strong", "weak", "sharded_weak"):
         assert line[kind]["value"] > 0, kind
