@@ -1369,6 +1369,336 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_sym(const PbsJob *__restr
     }
 }
 
+// ------------------------------------------------------------------------------------
+// k_pbs_trio: THREE bootstraps per workgroup of 12 waves, four waves per bootstrap - for the remainders of a launch that
+// hold between two and three bootstraps per CU (round 4: a lockstep round with one SIMD empty costs as much as a full one).
+// The (k+1) L = 9 forward transforms, 27 products and k+1 = 3 inverse transforms of a step are cut into four wave-roles of
+// three transforms each:
+//   polynomial wave p (k+1 of them)  rotates / subtracts polynomial p, produces the first digit of the signed decomposition
+//                                    (level L-1) and hands it to the helper, transforms levels L-2 .. 0 itself (level at a
+//                                    time, as the lockstep build), multiplies with their key rows, and after the hand-over of
+//                                    the column sums inverse-transforms column p and updates the accumulator;
+//   helper wave                      transforms the level-(L-1) digits of ALL k+1 polynomials and multiplies them with their
+//                                    key rows (k+1 transforms, (k+1)^2 products); idle during the inverse transforms.
+// Wave w serves bootstrap w % 3 in role w / 3: every SIMD carries three waves of about the same instruction count.  Three
+// workgroup barriers per step (digits published | column sums published | column sums consumed).  Ciphertexts identical
+// to every other build (exact integer sums in any order).
+// ------------------------------------------------------------------------------------
+template <typename F_, int LOGN_, int K_, int L_>
+struct TrioCfg {
+    using F = F_;
+    static constexpr int LOGN = LOGN_, K = K_, L = L_, K1 = K_ + 1, NB = 3, NWB = K_ + 2, NW = NWB * NB;
+    using G = Geo<LOGN>;
+    static_assert(K == 2 && L >= 2, "three column distances; the polynomial waves keep L - 1 levels");
+    static constexpr int HL = L - 1;                       // the helper's level: the first digit produced
+    static constexpr int ACC3 = 3 * G::N - 64;             // accumulator copy, unrolled negacyclically (see PbsCfg)
+    static constexpr int PW = G::XPAD + G::N;              // polynomial wave: transform scratch (= slot 0) + slot 1, doubles
+    static_assert(PW >= (ACC3 + 1) / 2, "the accumulator copy lives in the wave's slots between steps");
+    static constexpr int HW = G::XPAD + K * G::N + K1 * G::N / 2; // helper: scratch (= slot 0) + slots 1..K + the int32 digits
+    static constexpr int slot_off(int s) { return s == 0 ? 0 : G::XPAD + (s - 1) * G::N; }
+    static constexpr int DIG_OFF = G::XPAD + K * G::N;     // (doubles) int32 digits [K1][N] behind the helper's slots
+    static constexpr int TW_ROWS = G::TWB + G::TWC;
+    static constexpr int MAX_SMALL_N = 1024;
+    static constexpr size_t TW_BYTES = sizeof(double) * TW_ROWS * 64; // one lane table for the workgroup
+    static constexpr size_t MS_OFF = sizeof(double) * (K1 * PW + HW);
+    static constexpr size_t BOOT_BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
+    static constexpr size_t BYTES = TW_BYTES + BOOT_BYTES * NB;
+};
+
+template <typename C, bool PRIO>
+__global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_trio(const PbsJob *__restrict__ jobs, const uint32_t *__restrict__ wires,
+                                                            const uint32_t *__restrict__ raw_in, const uint32_t *__restrict__ tvs,
+                                                            const double *__restrict__ bsk, const double *__restrict__ tw_fwd,
+                                                            uint32_t *__restrict__ out_big, int n, int logB, int count)
+{
+    constexpr int LOGN = C::LOGN, K = C::K, L = C::L, NB = C::NB, K1 = C::K1, HL = C::HL;
+    constexpr bool prio = PRIO; // compile-time: as a run-time flag the branches cost the helper role 98 spilled registers
+    using F = typename C::F;
+    using G = Geo<LOGN>;
+    constexpr int N = G::N, E = G::E;
+    extern __shared__ __align__(16) unsigned char smem_wg[];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int role = wv / NB;                          // 0..K: polynomial, K1: helper
+    const int jix = (int)blockIdx.x * NB + wv % NB;    // this wave's bootstrap
+    const bool helper = role == K1;
+    const int p = role;
+    double *TW = reinterpret_cast<double *>(smem_wg);
+    // the lane table of the forward twiddles, one for the workgroup: filled by every wave BEFORE the waves without a
+    // bootstrap leave (the hardware barrier counts the surviving waves only)
+    for (int r = wv; r < C::TW_ROWS; r += C::NW) TW[r * 64 + lane] = tw_fwd[tw_lane_index<LOGN>(r, lane)];
+    __syncthreads();
+    if (jix >= count) return;
+    unsigned char *smem = smem_wg + C::TW_BYTES + (size_t)(wv % NB) * C::BOOT_BYTES;
+    double *X = reinterpret_cast<double *>(smem);
+    double *HX = X + (size_t)K1 * C::PW;               // the helper's slots
+    int *DIG = reinterpret_cast<int *>(HX + C::DIG_OFF);
+    uint16_t *MS = reinterpret_cast<uint16_t *>(smem + C::MS_OFF);
+    const PbsJob job = jobs[jix];
+    const size_t row = (size_t)n + 1;
+    const int tid = role * 64 + lane;
+
+    // ---- gate linear step + modulus switch (the bootstrap's four waves) ----------------
+    {
+        const uint32_t *a0 = nullptr, *a1 = nullptr, *a2 = nullptr;
+        if (job.op < 0) a0 = raw_in + row * (size_t)job.in0;
+        else {
+            if (job.in0 >= 0) a0 = wires + row * (size_t)job.in0;
+            if (job.in1 >= 0) a1 = wires + row * (size_t)job.in1;
+            if (job.in2 >= 0) a2 = wires + row * (size_t)job.in2;
+        }
+        for (int i = tid; i <= n; i += 64 * C::NWB) {
+            uint32_t v;
+            if (job.op < 0) v = a0[i];
+            else v = gate_lincomb(job.op, job.which, a0 ? a0[i] : 0u, a1 ? a1[i] : 0u, a2 ? a2[i] : 0u, i == n);
+            MS[i] = (uint16_t)modswitch(v, LOGN + 1);
+        }
+    }
+    TwLane<LOGN, false> twf0;
+    TwLane<LOGN, true> twi;
+    TwLaneFwdReg<LOGN> twf;
+    twf0.base = TW + lane;
+    twi.base = TW + (63 - lane);
+    twf0.fill_uniform(tw_fwd);
+    twi.fill_uniform(tw_fwd);
+    twf.load(twf0); // this lane's forward twiddles of blocks B and C in registers (as the lockstep build)
+    __syncthreads(); // MS complete
+
+    const unsigned poly_bytes = (unsigned)(N / 2) * 16u;
+    const unsigned step_bytes = (unsigned)(K1 * K1 * L) * poly_bytes;
+    KeyBuf kb;
+    kb.init(bsk, (size_t)n * step_bytes, lane);
+    const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+    const int neg_B = -(1 << logB);
+    STAMP_DECL
+
+    if (helper) {
+        // ================= helper wave: level HL of every polynomial ======================================
+        for (int i = 0; i < n; i++) {
+            STAMP_BEGIN
+            lds_block_sync(); // A: the digits of this step are published
+            STAMP(1)
+            if (prio) __builtin_amdgcn_s_setprio(2);
+            double s0[E], s1[E];
+#pragma unroll
+            for (int q = 0; q < K1; q++) {
+                const unsigned so = (unsigned)i * step_bytes + (unsigned)(q * K1 * L + HL) * poly_bytes;
+                double x[1][E];
+                {
+                    const int *dq = DIG + q * N + lane;
+#pragma unroll
+                    for (int e = 0; e < E; e++) x[0][e] = (double)dq[64 * e];
+                }
+                double2 bwl[K1][E / 2];
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int e2 = 0; e2 < E / 2; e2++) bwl[c][e2] = kb.load(so + (unsigned)(c * L) * poly_bytes, e2 * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+                ntt_forward<F, LOGN, 1>(x, HX, twf, lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 2; c < K1; c++)
+#pragma unroll
+                    for (int e2 = 0; e2 < E / 2; e2++) bwl[c][e2] = kb.load(so + (unsigned)(c * L) * poly_bytes, e2 * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+                if (prio && q == K1 - 1) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                for (int c = 0; c < K1; c++)
+#pragma unroll
+                    for (int e2 = 0; e2 < E / 2; e2++) {
+                        const double2 w = bwl[c][e2];
+                        const double t0 = mulmod<F>(x[0][2 * e2], w.x), t1 = mulmod<F>(x[0][2 * e2 + 1], w.y);
+                        if (c == 0) {
+                            s0[2 * e2] = q == 0 ? t0 : s0[2 * e2] + t0;
+                            s0[2 * e2 + 1] = q == 0 ? t1 : s0[2 * e2 + 1] + t1;
+                        } else if (c == 1) {
+                            s1[2 * e2] = q == 0 ? t0 : s1[2 * e2] + t0;
+                            s1[2 * e2 + 1] = q == 0 ? t1 : s1[2 * e2 + 1] + t1;
+                        } else {
+                            double *dst = HX + C::slot_off(c) + lane;
+                            if (q == 0) {
+                                dst[(2 * e2) * 64] = t0;
+                                dst[(2 * e2 + 1) * 64] = t1;
+                            } else {
+                                lds_add(dst + (2 * e2) * 64, t0);
+                                lds_add(dst + (2 * e2 + 1) * 64, t1);
+                            }
+                        }
+                    }
+                if (prio && q == 0) __builtin_amdgcn_s_setprio(1);
+            }
+            lds_wave_sync(); // the last transform's reads of the scratch (= slot 0) are done
+            {
+                double *d0 = HX + C::slot_off(0) + lane, *d1 = HX + C::slot_off(1) + lane;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    d0[e * 64] = s0[e];
+                    d1[e * 64] = s1[e];
+                }
+            }
+            STAMP(2)
+            lds_block_sync(); // B: column sums published
+            lds_block_sync(); // C: column sums consumed
+            STAMP(3)
+        }
+        STAMP_END(wv)
+        return;
+    }
+
+    // ================= polynomial wave p ==================================================================
+    double *xb = X + (size_t)p * C::PW;
+    uint32_t *acc_p = reinterpret_cast<uint32_t *>(xb);
+    uint32_t accr[E];
+    {
+        const int bt = (int)MS[n];
+        const uint32_t *tv = tvs + (size_t)job.tv * N;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int j = G::jA(lane, e);
+            uint32_t v = 0;
+            if (p == K) {
+                const int idx = (j + bt) & (2 * N - 1);
+                v = tv[idx & (N - 1)];
+                if (idx >= N) v = 0u - v;
+            }
+            accr[e] = v;
+        }
+    }
+    auto acc_store = [&]() {
+        uint32_t *aw = acc_p + lane;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            aw[64 * e] = accr[e];
+            aw[64 * e + N] = 0u - accr[e];
+            if (e < E - 1) aw[64 * e + 2 * N] = accr[e];
+        }
+    };
+    acc_store();
+    lds_wave_sync();
+    const unsigned row_off = (unsigned)(p * K1 * L) * poly_bytes;
+    int cd[K1]; // wave-uniform column of each distance
+#pragma unroll
+    for (int d = 0; d < K1; d++) cd[d] = p + d >= K1 ? p + d - K1 : p + d;
+    if (prio) __builtin_amdgcn_s_setprio(3);
+
+    for (int i = 0; i < n; i++) {
+        STAMP_BEGIN
+        const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
+        const unsigned so_i = (unsigned)i * step_bytes + row_off;
+        uint32_t state[E];
+        {
+            const int rep = logB * L;
+            const uint32_t *ar = acc_p + ((lane - a) & (2 * N - 1)); // (X^a acc)[jA(lane, e)] = ar[64 e]
+#pragma unroll
+            for (int e = 0; e < E; e++) state[e] = ((ar[64 * e] - accr[e]) + (1u << (31 - rep))) >> (32 - rep);
+            int *dq = DIG + p * N + lane;
+#pragma unroll
+            for (int e = 0; e < E; e++) dq[64 * e] = decompose_step(state[e], logB, half_m1, neg_B); // level L-1: the helper's
+        }
+        STAMP(0)
+        lds_block_sync(); // A: digits published (the accumulator copy in this wave's slots has been read)
+        STAMP(1)
+        if (prio) __builtin_amdgcn_s_setprio(2);
+        double mine[E], keep[E];
+#pragma unroll
+        for (int lev = L - 2; lev >= 0; lev--) {
+            double x[1][E];
+#pragma unroll
+            for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(state[e], logB, half_m1, neg_B);
+            double2 bwl[K1][E / 2];
+#pragma unroll
+            for (int d = 0; d < 2; d++)
+#pragma unroll
+                for (int e2 = 0; e2 < E / 2; e2++) bwl[d][e2] = kb.load(so_i + (unsigned)(cd[d] * L + lev) * poly_bytes, e2 * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 2; d < K1; d++)
+#pragma unroll
+                for (int e2 = 0; e2 < E / 2; e2++) bwl[d][e2] = kb.load(so_i + (unsigned)(cd[d] * L + lev) * poly_bytes, e2 * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            if (prio && lev == 0) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int d = 0; d < K1; d++)
+#pragma unroll
+                for (int e2 = 0; e2 < E / 2; e2++) {
+                    const double2 w = bwl[d][e2];
+                    const double t0 = mulmod<F>(x[0][2 * e2], w.x), t1 = mulmod<F>(x[0][2 * e2 + 1], w.y);
+                    if (d == 0) {
+                        mine[2 * e2] = lev == L - 2 ? t0 : mine[2 * e2] + t0;
+                        mine[2 * e2 + 1] = lev == L - 2 ? t1 : mine[2 * e2 + 1] + t1;
+                    } else if (d == 1) {
+                        keep[2 * e2] = lev == L - 2 ? t0 : keep[2 * e2] + t0;
+                        keep[2 * e2 + 1] = lev == L - 2 ? t1 : keep[2 * e2 + 1] + t1;
+                    } else {
+                        double *dst = xb + C::slot_off(d - 1) + lane;
+                        if (lev == L - 2) {
+                            dst[(2 * e2) * 64] = t0;
+                            dst[(2 * e2 + 1) * 64] = t1;
+                        } else {
+                            lds_add(dst + (2 * e2) * 64, t0);
+                            lds_add(dst + (2 * e2 + 1) * 64, t1);
+                        }
+                    }
+                }
+            if (prio && lev == L - 2 && lev != 0) __builtin_amdgcn_s_setprio(1);
+        }
+        {
+            double *dst = xb + C::slot_off(0) + lane;
+#pragma unroll
+            for (int e = 0; e < E; e++) dst[e * 64] = keep[e];
+        }
+        STAMP(2)
+        lds_block_sync(); // B
+        STAMP(3)
+        if constexpr (!F::LAZY) {
+#pragma unroll
+            for (int e = 0; e < E; e++) mine[e] = reduce<F>(mine[e]);
+        }
+        // the sum for column p computed at distance d sits in wave (p - d) mod K1, slot d - 1; the helper's in its slot p
+#pragma unroll
+        for (int d = 1; d < K1; d++) {
+            const int q = p - d < 0 ? p - d + K1 : p - d;
+            const double *src = X + (size_t)q * C::PW + C::slot_off(d - 1);
+#pragma unroll
+            for (int e = 0; e < E; e++) mine[e] += reduce_unless_lazy<F>(src[e * 64 + lane]);
+        }
+        {
+            const double *src = HX + C::slot_off(p);
+#pragma unroll
+            for (int e = 0; e < E; e++) mine[e] += reduce_unless_lazy<F>(src[e * 64 + lane]);
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) mine[e] = reduce<F>(mine[e]);
+        lds_block_sync(); // C: every hand-over slot has been read
+        STAMP(4)
+        if (prio) __builtin_amdgcn_s_setprio(3);
+        ntt_inverse<F, LOGN>(mine, xb, twi, lane);
+#pragma unroll
+        for (int e = 0; e < E; e++) accr[e] += to_torus32(mine[e]);
+        acc_store();
+        lds_wave_sync();
+        STAMP(5)
+    }
+    STAMP_END(wv)
+
+    // ---- sample extract (coefficient 0): wave p writes its own polynomial -------------
+    uint32_t *ob = out_big + (size_t)jix * ((size_t)K * N + 1);
+    if (p < K) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int j = G::jA(lane, e);
+            if (j == 0) ob[p * N] = accr[e];
+            else ob[p * N + (N - j)] = 0u - accr[e];
+        }
+    } else if (lane == 0) {
+        ob[K * N] = accr[0];
+    }
+}
+
 #if HELM_HIP_TU == 0 // the keyswitch, linear and table kernels: main translation unit only (see launch_pbs_wide)
 // ------------------------------------------------------------------------------------
 // k_keyswitch: grid (ceil(jobs / 4), column chunks); 256 threads; one output column per
@@ -1787,8 +2117,10 @@ struct helm_hip_ctx {
     int narrow_variant = 4;  // build for launches of at most one workgroup per CU: 4 wide, 1 latency (HELM_HIP_NARROW)
     int clock_probe = 0;     // HELM_HIP_CLOCK_PROBE: print the in-kernel clock of every k_pbs launch
     int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput, 4 wide, 5 lockstep, 6 duo (the two
-                             // bootstraps of a workgroup in step), 7 duo staggered, 8 sym (HELM_HIP_PBS_VARIANT)
+                             // bootstraps of a workgroup in step), 7 duo staggered, 8 sym, 9 trio (HELM_HIP_PBS_VARIANT)
     int duo_build = 2;       // the two-per-CU build the size dispatch uses: 1 k_pbs_duo in step, 2 staggered, 3 k_pbs_sym, 0 none (HELM_HIP_DUO)
+    int trio = 1;            // remainders of two to three bootstraps per CU on k_pbs_trio (HELM_HIP_TRIO=0: a partial lockstep round, round 3's choice)
+    int trio_flags = 1;      // bit 0: issue-priority staging (HELM_HIP_TRIO_FLAGS)
     int duo_flags = 7;       // k_pbs_duo's issue priorities (HELM_HIP_DUO_FLAGS): bit 0 on at all; bit 1 staggered build: the inverse
                              // waves BELOW the other bootstrap's forward waves; bit 2 forward waves at one priority instead of stepping down
     // per-call scratch
@@ -2044,6 +2376,36 @@ static hipError_t launch_pbs_duo(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t 
 }
 
 template <typename C>
+static hipError_t launch_pbs_trio(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
+                                  const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
+{
+    static bool attr_done[64] = {false};
+    auto kern = (ctx->trio_flags & 1) ? k_pbs_trio<C, true> : k_pbs_trio<C, false>;
+    for (auto kk : {k_pbs_trio<C, true>, k_pbs_trio<C, false>})
+        if (!attr_done[ctx->device & 63]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)C::BYTES);
+            if (e != hipSuccess) return e;
+        }
+    if (!attr_done[ctx->device & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
+        if (e != hipSuccess) return e;
+        attr_done[ctx->device & 63] = true;
+        if (getenv("HELM_HIP_VERBOSE")) {
+            hipFuncAttributes fa{};
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
+            fprintf(stderr, "[helm_hip] k_pbs_trio: %d waves, LDS %zu B, regs %d, scratch %zu B\n", C::NW, (size_t)C::BYTES,
+                    fa.numRegs, (size_t)fa.localSizeBytes);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((count + C::NB - 1) / C::NB)), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, wires,
+                       raw, tvs, ctx->bsk, ctx->tw_fwd, out_big, ctx->P.n, ctx->P.pbs_logB, (int)count);
+    print_stamps(ctx, C::NW, "trio: rotate+publish | bar A | forward work | bar B (helper: B+C) | sums + bar C | inverse + lift");
+    return hipGetLastError();
+}
+
+template <typename C>
 static hipError_t launch_pbs_sym(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
                                  const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
 {
@@ -2127,10 +2489,12 @@ static hipError_t wide_launch(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t cou
 //   throughput 4.9, 7.4, 9.9, 12.4 ms for up to 1..4 workgroups per CU (12 waves per CU, three per
 //              SIMD), 10.6 ms per 1,024 in longer launches
 //   lockstep   9.0 - 9.2 ms per round of <= 1,024 (four bootstraps per workgroup, one per SIMD)
+// (round 1; round 4, profiles/r04: wide 3.0 - 3.5, duo 5.1 - 5.6 per <= 512, trio 7.0 - 7.15 per <= 768, lockstep 8.2 - 8.7)
 // so a launch runs its full rounds of 4 bootstraps per CU in lockstep and the remainder by size:
-// up to one per CU wide (HELM_HIP_NARROW=1: latency), up to two per CU throughput, more another
-// lockstep round.  HELM_HIP_PBS_VARIANT=1|2|3|4|5 forces latency | balanced | throughput | wide |
-// lockstep for the whole launch.
+// up to one per CU wide (HELM_HIP_NARROW=1: latency), up to two per CU duo (round 3: throughput), up to three per CU
+// trio (k = 2; round 3: a partial lockstep round), more another lockstep round.
+// HELM_HIP_PBS_VARIANT=1|2|3|4|5|6|7|8|9 forces latency | balanced | throughput | wide | lockstep | duo in step | duo
+// staggered | sym | trio for the whole launch.
 template <typename F, int LOGN, int K, int L>
 static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
                                const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
@@ -2152,7 +2516,9 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
         if (v == 0) {
             const int64_t round = 4 * (int64_t)ctx->n_cus;
             int64_t full = count / round * round;
-            if (count - full > 2 * (int64_t)ctx->n_cus) full = count;
+            // a remainder of more than three per CU (two without k_pbs_trio) is another lockstep round
+            const bool trio = K == 2 && ctx->trio;
+            if (count - full > (trio ? 3 : 2) * (int64_t)ctx->n_cus) full = count;
             if (full) {
                 hipError_t e;
                 {
@@ -2167,8 +2533,12 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
                 count -= full;
             }
             // the remainder: up to one per CU wide, up to two per CU duo (each bootstrap on two SIMDs; HELM_HIP_DUO=0: the
-            // throughput build as in round 3)
-            v = count <= ctx->n_cus ? ctx->narrow_variant : ctx->duo_build ? 5 + ctx->duo_build : 3;
+            // throughput build as in round 3), up to three per CU trio (four waves per bootstrap)
+            v = count <= ctx->n_cus ? ctx->narrow_variant : count > 2 * (int64_t)ctx->n_cus ? 9 : ctx->duo_build ? 5 + ctx->duo_build : 3;
+        }
+        if (v == 9) {
+            if constexpr (K == 2) return launch_pbs_trio<TrioCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
+            else return launch_pbs_v<Lock>(ctx, jobs, count, wires, raw, tvs, out_big);
         }
         if (v == 4) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (v == 6 || v == 7 || v == 8) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big, v - 5);
@@ -2380,6 +2750,8 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         if (const char *v = getenv("HELM_HIP_NARROW")) ctx->narrow_variant = atoi(v) == 4 ? 4 : 1;
         if (const char *v = getenv("HELM_HIP_DUO")) ctx->duo_build = atoi(v) >= 0 && atoi(v) <= 3 ? atoi(v) : 2;
         if (const char *v = getenv("HELM_HIP_DUO_FLAGS")) ctx->duo_flags = atoi(v);
+        if (const char *v = getenv("HELM_HIP_TRIO")) ctx->trio = atoi(v) != 0;
+        if (const char *v = getenv("HELM_HIP_TRIO_FLAGS")) ctx->trio_flags = atoi(v);
         if (const char *v = getenv("HELM_HIP_CLOCK_PROBE")) ctx->clock_probe = atoi(v);
         if (const char *v = getenv("HELM_HIP_KS_MFMA")) ctx->ks_mfma = atoi(v);
         if (const char *v = getenv("HELM_HIP_WIDE_MAP")) ctx->wide_map = atoi(v);
@@ -2506,12 +2878,13 @@ int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4])
 {
     if (!ctx || !cost) return fail(HELM_ERR_INVALID, "null argument");
     // launch_pbs_f's dispatch, measured (profiles/r04/microbench.jsonl and the other boxes of the round; boolean_default:
-    // 3.5 / 5.1 - 5.6 / 7.5 / 8.2 - 8.7 ms for <= 256 / 512 / 768 / 1,024 bootstraps - wide, duo, partial and full lockstep
-    // round; without k_pbs_duo the throughput build takes 6.7 ms for <= 512)
+    // 3.3 - 3.5 / 5.1 - 5.6 / 7.0 - 7.15 / 8.2 - 8.7 ms for <= 256 / 512 / 768 / 1,024 bootstraps - wide, duo, trio and a full
+    // lockstep round; without k_pbs_duo the throughput build takes 6.7 ms for <= 512, without k_pbs_trio a lockstep round of
+    // three per CU 7.4 - 7.5 ms for <= 768)
     if (ctx->P.N == 512) {
         cost[0] = ctx->narrow_variant == 4 ? 0.42 : 0.50;
         cost[1] = ctx->duo_build ? 0.64 : 0.80;
-        cost[2] = 0.89;
+        cost[2] = ctx->P.k == 2 && ctx->trio ? 0.86 : 0.89;
     } else { // N = 1024 (helm_cuda: 3.9 / 6.2 / 8.5 / 8.7 ms - wide, two all-levels workgroups per CU, lockstep rounds)
         cost[0] = ctx->narrow_variant == 4 ? 0.45 : 0.64;
         cost[1] = 0.71;

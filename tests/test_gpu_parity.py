@@ -200,6 +200,7 @@ def test_upload_rejects_duplicate_rows():
 
 @pytest.mark.parametrize("variant,name", [(1, "toy_k2"), (2, "toy_k2"), (3, "toy_k2"), (4, "toy_k2"), (5, "toy_k2"),
                                           (6, "toy_k2"), (7, "toy_k2"), (8, "toy_k2"),     # duo in step / staggered, sym (transform halves)
+                                          (9, "toy_k2"),                                   # trio: three per workgroup, four waves each
                                           (1, "toy"), (3, "toy"), (4, "toy"), (5, "toy"),  # k = 2, l = 3 and k = 1, l = 2
                                           (6, "toy"), (7, "toy"), (8, "toy"),
                                           (1, "toy_1024"), (4, "toy_1024"), (5, "toy_1024")])  # N = 1024: two-wave, wide, lockstep
@@ -215,11 +216,12 @@ def test_every_build_of_k_pbs_bit_exact(variant, name, monkeypatch):
     orc = oracle.Oracle(ck.params.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True)
     p = ck.params
     rng = np.random.default_rng(20 + variant)
-    lwe = rng.integers(0, 2**32, size=(9, p.n + 1), dtype=np.uint32)
+    cts = 11 if variant == 9 else 9  # trio: three full workgroups and one with two of its three bootstraps
+    lwe = rng.integers(0, 2**32, size=(cts, p.n + 1), dtype=np.uint32)
     lwe[0] = ck.encrypt(True)
     lwe[3, :] = 0
     tvs = rng.integers(0, 2**32, size=(2, p.N), dtype=np.uint32)
-    idx = rng.integers(0, 2, size=9).astype(np.int32)
+    idx = rng.integers(0, 2, size=cts).astype(np.int32)
     got = sk.pbs_batch(lwe, tvs, idx)
     for g in range(len(lwe)):
         assert np.array_equal(got[g], orc.bootstrap_noks(lwe[g], tvs[idx[g]])), f"variant {variant}, ciphertext {g}"
@@ -279,7 +281,9 @@ def test_full_size_lockstep_rounds_bit_exact(name):
       4 CU + 7        one full lockstep round + a remainder that goes to the wide (N = 512) / all-levels
                       (N = 1024) build
       5 CU + 5        lockstep round + a remainder of more than one bootstrap per CU (throughput build)
-      6 CU + CU/2 + 2 more than two per CU left over: the whole launch in lockstep, last workgroup partial
+      6 CU + CU/2 + 2 between two and three per CU left over: k_pbs_trio (three bootstraps per workgroup, four waves each;
+                      k = 2 only - at N = 1024 the whole launch runs in lockstep, last workgroup partial)
+      7 CU + CU/2 + 2 more than three per CU left over: the whole launch in lockstep, last workgroup partial
     Rows of the first and last lockstep workgroup, of the partial workgroup and of the remainder build are
     compared bit for bit with the oracle (same gate formulas as tests/gates_test.rs:82-107 decrypts); every
     output is checked after decryption."""
@@ -294,7 +298,7 @@ def test_full_size_lockstep_rounds_bit_exact(name):
     bits = rng.integers(0, 2, n_in)
     ct = ck.encrypt(bits.astype(bool))
     two_in = [oracle.AND, oracle.OR, oracle.NAND, oracle.NOR, oracle.XOR, oracle.XNOR]
-    for count in (4 * cu + 7, 5 * cu + 5, 6 * cu + cu // 2 + 2):
+    for count in (4 * cu + 7, 5 * cu + 5, 6 * cu + cu // 2 + 2, 7 * cu + cu // 2 + 2):
         ops = rng.choice(two_in, size=count).astype(np.int32)
         i0 = rng.integers(0, n_in, count).astype(np.int32)
         i1 = rng.integers(0, n_in, count).astype(np.int32)
@@ -308,11 +312,13 @@ def test_full_size_lockstep_rounds_bit_exact(name):
         want_bits = [GATES2[int(o)](int(bits[a]), int(bits[b])) for o, a, b in zip(ops, i0, i1)]
         assert list(ck.decrypt(got[n_in:]).astype(int)) == want_bits, f"{name}: launch of {count} decrypts wrong"
         full = count // (4 * cu) * (4 * cu)
-        if count - full > 2 * cu:
+        if count - full > (3 if p.k == 2 else 2) * cu:
             full = count
         sample = sorted({0, 1, 2, 3, 5, 4 * cu // 2 + 1, full - 4, full - 3, full - 2, full - 1,  # lockstep part
                          min(full, count - 1), count - 3, count - 2, count - 1,                    # remainder build
-                         (count - 1) // 4 * 4, count // 2})                                        # last (partial) workgroup
+                         (count - 1) // 4 * 4, count // 2,                                         # last (partial) workgroup
+                         min(count - 1, full + (count - full) // 2),                               # (of the remainder build)
+                         min(count - 1, full + max(0, count - full - 1) // 3 * 3)})
         ref = np.zeros_like(got)
         ref[:n_in] = ct
         orc.eval_level(ref, ops[sample], i0[sample], i1[sample], i2[sample], outs[sample])

@@ -23,6 +23,7 @@ from helm_amd.netlists import aes128  # noqa: E402
 TABLES = {  # ms for <= 1/4, 2/4, 3/4, 4/4 of a round of 4 x CUs bootstraps
     "r03": (3.6, 7.4, 8.5, 8.5),
     "r04": (3.55, 5.50, 7.50, 8.67),  # profiles/r04/microbench.jsonl (one box: 256 / 512 / 768 / 1,024)
+    "r04b": (3.26, 5.40, 7.13, 8.25),  # with k_pbs_trio and the twiddle registers (profiles/r04/trio_experiments.txt, one box)
 }
 
 
