@@ -128,6 +128,12 @@ def test_communicator_binds_rccl_lazily_and_validates_without_a_device(have_gpu)
     assert nv.hip.helm_comm_available() in (0, 1)
     if not have_gpu and nv.hip.helm_comm_available():
         assert nv.hip.helm_comm_create(0, nv.as_u8p(ident), 0, 1, C.byref(h)) == -2   # HELM_ERR_NO_DEVICE: no fallback
+    # the transport form (a host-supplied all-gather instead of RCCL) validates the same way and needs no RCCL at all
+    cb = nv.COMM_ALL_GATHER_FN(lambda *_: 0)
+    assert nv.hip.helm_comm_create_with_transport(0, 0, 1, nv.COMM_ALL_GATHER_FN(0), None, C.byref(h)) == -1   # no callback
+    assert nv.hip.helm_comm_create_with_transport(0, 3, 2, cb, None, C.byref(h)) == -1                       # rank outside the world
+    if not have_gpu:
+        assert nv.hip.helm_comm_create_with_transport(0, 0, 1, cb, None, C.byref(h)) == -2
 
 
 def test_no_cpu_fallback(have_gpu):
