@@ -106,6 +106,7 @@ HIP_API = {
     "helm_hip_sync": (C.c_int, [vp]),
     "helm_hip_launch_quantum": (C.c_int64, [vp]),
     "helm_hip_launch_costs": (C.c_int, [vp, C.POINTER(C.c_double)]),
+    "helm_hip_field_bits": (C.c_int, [vp]),
     "helm_hip_load_bootstrap_key": (C.c_int, [vp, u32p, C.c_size_t]),
     "helm_hip_load_keyswitch_key": (C.c_int, [vp, u32p, C.c_size_t]),
     "helm_hip_wires_alloc": (C.c_int, [vp, C.c_int64, C.POINTER(vp)]),

@@ -17,6 +17,7 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
                     for (int lev = 0; lev < L; lev++) x[lev][e] = (double)dig[lev];
                 }
             }
-            ntt_forward<F, LOGN, L>(x, xb, twf, lane);
+            ntt_forward_digits<F, LOGN, L>(x, xb, twf, lane);
             // part[c] = sum_lev x[lev] * BSK_i[p][c][lev]; the partial sums of the other
             // polynomials are handed over through this wave's exchange slots 0..K-1 (idle
             // until the inverse transform, which starts after the second barrier)
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
 #pragma unroll
                     for (int e2 = 0; e2 < E / 2; e2++) bwl[d][e2] = kb.load(so_i + (unsigned)(cd[d] * L + lev) * poly_bytes, e2 * 1024);
                 __builtin_amdgcn_sched_barrier(0);
-                ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+                ntt_forward_digits<F, LOGN, 1>(x, xb, twf, lane);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int d = EARLY; d < K1; d++)
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
         STAMP(0) // loads issued, rotation, decomposition
         // the SIMD that hosts three of the nine waves bounds this phase: stepping the issue priority down
         // block by block keeps its waves abreast instead of letting the youngest finish alone
-        ntt_forward<F, LOGN, 1, decltype(twf), C::PRIO ? 3 : 0>(x, xb, twf, lane);
+        ntt_forward_digits<F, LOGN, 1, C::PRIO ? 3 : 0>(x, xb, twf, lane);
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
         STAMP(1) // forward transform
 #pragma unroll
@@ -1041,7 +1042,7 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
             if (g == 1) {
 #pragma unroll
                 for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(st[e], logB, half_m1, neg_B);
-                ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+                ntt_forward_digits<F, LOGN, 1>(x, xb, twf, lane);
                 if (prio && !flat) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int c = 0; c < K1; c++) {
@@ -1063,7 +1064,7 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
 #pragma unroll
                     for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(st[e], logB, half_m1, neg_B);
                     if (lev != L - 2) load_keys(i, lev); // (the first level's words came an interval ahead)
-                    ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+                    ntt_forward_digits<F, LOGN, 1>(x, xb, twf, lane);
                     if (prio && !flat) { // a wave steps its priority down as it advances: whoever is behind goes first (see k_pbs)
                         if (lev) __builtin_amdgcn_s_setprio(2);
                         else __builtin_amdgcn_s_setprio(1);
@@ -1496,7 +1497,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_trio(const PbsJob *__rest
 #pragma unroll
                     for (int e2 = 0; e2 < E / 2; e2++) bwl[c][e2] = kb.load(so + (unsigned)(c * L) * poly_bytes, e2 * 1024);
                 __builtin_amdgcn_sched_barrier(0);
-                ntt_forward<F, LOGN, 1>(x, HX, twf, lane);
+                ntt_forward_digits<F, LOGN, 1>(x, HX, twf, lane);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c = 2; c < K1; c++)
@@ -1613,7 +1614,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_trio(const PbsJob *__rest
 #pragma unroll
                 for (int e2 = 0; e2 < E / 2; e2++) bwl[d][e2] = kb.load(so_i + (unsigned)(cd[d] * L + lev) * poly_bytes, e2 * 1024);
             __builtin_amdgcn_sched_barrier(0);
-            ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+            ntt_forward_digits<F, LOGN, 1>(x, xb, twf, lane);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int d = 2; d < K1; d++)
@@ -2112,7 +2113,7 @@ struct helm_hip_ctx {
     DevBuf<uint32_t> d_body;
     uint32_t *tv_bool = nullptr; // one row: all +1/8
     bool have_bsk = false, have_ksk = false;
-    int field = 51; // Fp<51> or Fp<49> (lazy), chosen from the parameter set
+    int field = 51; // 51: Fp<51>, 49: FpG (lazy, short eighth roots of unity), chosen from the parameter set
     int n_cus = 256;
     int narrow_variant = 4;  // build for launches of at most one workgroup per CU: 4 wide, 1 latency (HELM_HIP_NARROW)
     int clock_probe = 0;     // HELM_HIP_CLOCK_PROBE: print the in-kernel clock of every k_pbs launch
@@ -2440,16 +2441,19 @@ __attribute__((visibility("hidden"))) hipError_t helm_hip_tu1_launch_wide(helm_h
                                                                         int l, const PbsJob *jobs, int64_t count,
                                                                         const uint32_t *wires, const uint32_t *raw,
                                                                         const uint32_t *tvs, uint32_t *out_big);
+// field id of the engine context -> field type of the boolean kernels (49: the lazy FpG)
+template <int ID> struct BoolField { using type = Fp<ID>; };
+template <> struct BoolField<49> { using type = FpG; };
 #if HELM_HIP_TU == 1
 hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int logn, int k, int l, const PbsJob *jobs, int64_t count,
                                     const uint32_t *wires, const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
 {
 #define WIDE_CASE(FB, LN, KK, LL)                                                                                        \
     if (field == FB && logn == LN && k == KK && l == LL) {                                                               \
-        if (build == 1) return launch_pbs_duo<DuoCfg<Fp<FB>, LN, KK, LL, false>>(ctx, jobs, count, wires, raw, tvs, out_big); \
-        if (build == 2) return launch_pbs_duo<DuoCfg<Fp<FB>, LN, KK, LL, true>>(ctx, jobs, count, wires, raw, tvs, out_big); \
-        if (build == 3) return launch_pbs_sym<SymCfg<Fp<FB>, KK, LL>>(ctx, jobs, count, wires, raw, tvs, out_big);            \
-        return launch_pbs_wide<WideCfg<Fp<FB>, LN, KK, LL>>(ctx, jobs, count, wires, raw, tvs, out_big);                  \
+        if (build == 1) return launch_pbs_duo<DuoCfg<BoolField<FB>::type, LN, KK, LL, false>>(ctx, jobs, count, wires, raw, tvs, out_big); \
+        if (build == 2) return launch_pbs_duo<DuoCfg<BoolField<FB>::type, LN, KK, LL, true>>(ctx, jobs, count, wires, raw, tvs, out_big); \
+        if (build == 3) return launch_pbs_sym<SymCfg<BoolField<FB>::type, KK, LL>>(ctx, jobs, count, wires, raw, tvs, out_big);            \
+        return launch_pbs_wide<WideCfg<BoolField<FB>::type, LN, KK, LL>>(ctx, jobs, count, wires, raw, tvs, out_big);                  \
     }
     WIDE_CASE(49, 9, 2, 3) WIDE_CASE(49, 9, 1, 3) WIDE_CASE(49, 9, 1, 2)
     WIDE_CASE(51, 9, 2, 3) WIDE_CASE(51, 9, 1, 3) WIDE_CASE(51, 9, 1, 2)
@@ -2468,7 +2472,7 @@ static hipError_t wide_launch(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t cou
                               const uint32_t *tvs, uint32_t *out_big, int build = 0)
 {
 #if HELM_HIP_SPLIT_TU
-    return helm_hip_tu1_launch_wide(ctx, build, std::is_same<F, Fp<49>>::value ? 49 : 51, LOGN, K, L, jobs, count, wires, raw, tvs,
+    return helm_hip_tu1_launch_wide(ctx, build, std::is_same<F, FpG>::value ? 49 : 51, LOGN, K, L, jobs, count, wires, raw, tvs,
                                     out_big);
 #else
     if constexpr (LOGN == 9) {
@@ -2588,7 +2592,7 @@ static hipError_t launch_pbs_t(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
                                const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
 {
     if constexpr (LOGN == 9) {
-        if (ctx->field == 49) return launch_pbs_f<Fp<49>, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if (ctx->field == 49) return launch_pbs_f<FpG, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
     }
     return launch_pbs_f<Fp<51>, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
 }
@@ -2763,11 +2767,22 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         const int N = P.N, logN = ctx->logN;
         // the 49-bit prime (no recentring inside transforms) when the set's exact products fit
         // below its half and a lazy build exists (N = 512); HELM_HIP_FIELD=51 forces the other
-        ctx->field = (N == 512 && bound * 1.002 < Fp<49>::P / 2) ? 49 : 51;
+        // ("49": the lazy field of the boolean kernels is FpG, p = 5072^4 + 1 = 2^49.23, ntt_fp64.h; its first two forward stages
+        // on digits need 2^(logB-1) b^3 far below p/2: any logB <= 12)
+        ctx->field = (N == 512 && bound * 1.002 < FpG::P / 2 && P.pbs_logB <= 12) ? 49 : 51;
         if (const char *v = getenv("HELM_HIP_FIELD")) if (atoi(v) == 51) ctx->field = 51;
-        const uint64_t pm = ctx->field == 49 ? Fp<49>::P_U64 : Fp<51>::P_U64;
-        const uint64_t gen = ctx->field == 49 ? Fp<49>::GEN : Fp<51>::GEN;
-        const uint64_t psi = powmod_u64(gen, (pm - 1) / (2 * (uint64_t)N), pm);
+        const uint64_t pm = ctx->field == 49 ? FpG::P_U64 : Fp<51>::P_U64;
+        const uint64_t gen = ctx->field == 49 ? FpG::GEN : Fp<51>::GEN;
+        uint64_t psi = powmod_u64(gen, (pm - 1) / (2 * (uint64_t)N), pm);
+        if (ctx->field == 49) {
+            // the kernels' first two forward stages assume psi^(N/4) = b (then psi^(N/2) = b^2, psi^(3N/4) = b^3): psi^(N/4) is
+            // one of the four primitive eighth roots b, b^3, -b, -b^3 - an odd power of psi puts it on b
+            uint64_t pick = 0;
+            for (uint64_t t = 1; t < 8 && !pick; t += 2)
+                if (powmod_u64(powmod_u64(psi, t, pm), (uint64_t)N / 4, pm) == (uint64_t)FpG::B1) pick = t;
+            if (!pick) return fail(HELM_ERR_STATE, "internal: no 2N-th root of unity with psi^(N/4) = b");
+            psi = powmod_u64(psi, pick, pm);
+        }
         const uint64_t psi_inv = powmod_u64(psi, pm - 2, pm);
         std::vector<double> tf(N), ti(N);
         uint64_t a = 1, b = 1;
@@ -2777,6 +2792,8 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
             a = mulmod_u64(a, psi, pm);
             b = mulmod_u64(b, psi_inv, pm);
         }
+        if (ctx->field == 49 && (tf[1] != FpG::B2 || tf[2] != FpG::B1 || tf[3] != FpG::B3))
+            return fail(HELM_ERR_STATE, "internal: the first twiddles are not the constants the kernels assume");
         ctx->n_inv = centred(powmod_u64((uint64_t)N, pm - 2, pm), pm);
         HIP_TRY(hipMalloc(&ctx->tw_fwd, sizeof(double) * N));
         HIP_TRY(hipMalloc(&ctx->tw_inv, sizeof(double) * N));
@@ -2874,6 +2891,12 @@ int64_t helm_hip_launch_quantum(const helm_hip_ctx *ctx)
     return 4 * (int64_t)ctx->n_cus; // PbsCfg::NB bootstraps per workgroup, one workgroup per CU
 }
 
+int helm_hip_field_bits(const helm_hip_ctx *ctx)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null argument");
+    return ctx->field;
+}
+
 int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4])
 {
     if (!ctx || !cost) return fail(HELM_ERR_INVALID, "null argument");
@@ -2909,7 +2932,7 @@ int helm_hip_load_bootstrap_key(helm_hip_ctx *ctx, const uint32_t *bsk_std, size
     if (!ctx->bsk) HIP_TRY(hipMalloc(&ctx->bsk, n_words * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(d_std.p, bsk_std, n_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     if (P.N == 512 && ctx->field == 49)
-        hipLaunchKernelGGL((k_bsk_convert<Fp<49>, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
+        hipLaunchKernelGGL((k_bsk_convert<FpG, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
                            ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
     else if (P.N == 512)
         hipLaunchKernelGGL((k_bsk_convert<Fp<51>, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
@@ -3560,7 +3583,7 @@ int helm_hip_ntt_roundtrip(helm_hip_ctx *ctx, const uint32_t *poly_in, uint32_t 
     HIP_TRY(d_out.alloc((size_t)count * N));
     HIP_TRY(hipMemcpyAsync(d_in.p, poly_in, (size_t)count * N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     if (N == 512 && ctx->field == 49)
-        hipLaunchKernelGGL((k_ntt_roundtrip<Fp<49>, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,
+        hipLaunchKernelGGL((k_ntt_roundtrip<FpG, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,
                            ctx->tw_fwd, ctx->tw_inv, ctx->n_inv);
     else if (N == 512)
         hipLaunchKernelGGL((k_ntt_roundtrip<Fp<51>, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,

@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace helm {
 
@@ -46,6 +47,24 @@ template <> struct Fp<49> {
     static constexpr uint64_t GEN = 5;
     static constexpr bool LAZY = true;
 };
+
+// The lazy field of the BOOLEAN kernels (round 4): p = b^4 + 1 with b = 5072 = 2^12.3 (generator 3; 2^11 | p - 1).
+// b is a primitive EIGHTH root of unity, so the twiddles of a transform's first two stages - psi^(N/2) and psi^(N/4),
+// psi^(3N/4), with psi chosen such that psi^(N/4) = b (helm_hip_ctx_create) - are b^2, b, b^3: 25, 12 and 37 bits.
+// On decomposition digits (|d| <= 2^(logB-1)) every product of those two stages is an exact double far inside (-p/2, p/2):
+// the radix-4 butterfly on four digits is 10 plain operations instead of 6 modular multiplications and 8 additions
+// (fwd_top2_digits: 20 instead of 56 per transform and polynomial at N = 512).  p / 2 = 2^48.23 still covers tfhe boolean
+// DEFAULT's exact products (2^48.17); 2^53 / p = 13.6: the lazy bounds of Fp<49> (hand-over sums <= 11.4 p, inverse
+// sums <= 8 p) hold with room, the forward outputs being smaller than there (two stages add nothing to them).
+struct FpG {
+    static constexpr double P = 661785091833857.0;
+    static constexpr uint64_t P_U64 = 661785091833857ull;
+    static constexpr uint64_t GEN = 3;
+    static constexpr bool LAZY = true;
+    static constexpr double B1 = 5072.0, B2 = 25725184.0, B3 = 130478133248.0; // b, b^2, b^3 (b^4 = -1)
+};
+template <typename F> struct has_short_roots : std::false_type {};
+template <> struct has_short_roots<FpG> : std::true_type {};
 
 // A second lazy 49-bit prime (0x24007A8500001, generator 5): with Fp<49> it forms the CRT pair
 // of the 64-bit-torus kernels (p * q / 2 = 2^97.35 covers their exact products); an 11-stage
@@ -475,12 +494,42 @@ struct NoHook {
 };
 // before_last: called between the second transpose and the last block (both LDS round trips behind, a block of pure
 // arithmetic ahead): the place to issue global loads whose latency the block then covers.
-template <typename F, int LOGN, int M, typename TW, int PRIO = 0, typename HOOK = NoHook>
+// The first TWO stages of a 512-point forward transform on decomposition digits in a field whose eighth roots of unity
+// are short (FpG): slots (e, e + 2, e + 4, e + 6) form a radix-4 group,
+//   stage 1  a0 = d0 + b^2 d4, a4 = d0 - b^2 d4, (a2, a6 likewise from d2, d6)
+//   stage 2  x0, x2 = a0 +- b a2;  x4, x6 = a4 +- b^3 a6
+// and with b a2 = b d2 + b^3 d6, b^3 a6 = b^3 d2 - b^5 d6 = b^3 d2 + b d6 every term is digit x (at most 37 bits): exact,
+// |x| <= 2^(logB + 37), no reduction.  Same residues as the general stages, much smaller representatives.
+template <typename F, int M>
+__device__ __forceinline__ void fwd_top2_digits(double (&x)[M][8])
+{
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const double d0 = x[m][e], d2 = x[m][e + 2], d4 = x[m][e + 4], d6 = x[m][e + 6];
+            const double a0 = __builtin_fma(d4, F::B2, d0), a4 = __builtin_fma(d4, -F::B2, d0);
+            const double u = __builtin_fma(d6, F::B3, d2 * F::B1), v = __builtin_fma(d6, F::B1, d2 * F::B3);
+            x[m][e] = a0 + u;
+            x[m][e + 2] = a0 - u;
+            x[m][e + 4] = a4 + v;
+            x[m][e + 6] = a4 - v;
+        }
+}
+
+// DIGITS: the inputs are decomposition digits (|x| <= 2^(logB-1)): fields with short eighth roots of unity (FpG) run the
+// first two stages as fwd_top2_digits.
+template <typename F, int LOGN, int M, typename TW, int PRIO = 0, typename HOOK = NoHook, bool DIGITS = false>
 __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double *xbuf, const TW &tw, int lane,
                                             const HOOK &before_last = HOOK())
 {
     using G = Geo<LOGN>;
-    fwd_block<F, LOGN, M, 6, LOGN - 1, LOGN - G::BA, 0>(x, tw, G::jA(lane, 0));
+    if constexpr (DIGITS && has_short_roots<F>::value) {
+        static_assert(LOGN == 9 && G::BA == 3, "eight values per lane: stages 1 and 2 pair slots e, e + 4 and e, e + 2");
+        fwd_top2_digits<F, M>(x);
+        fwd_block<F, LOGN, M, 6, LOGN - 3, LOGN - G::BA, 3>(x, tw, G::jA(lane, 0)); // block A's third stage
+    } else
+        fwd_block<F, LOGN, M, 6, LOGN - 1, LOGN - G::BA, 0>(x, tw, G::jA(lane, 0));
     if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);
     double *pA = xbuf + G::baseA(lane), *pB = xbuf + G::baseB(lane), *pC = xbuf + G::baseC(lane);
 #pragma unroll
@@ -507,6 +556,16 @@ __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double
     lds_wave_sync();
     before_last();
     fwd_block<F, LOGN, M, 0, G::BC - 1, 0, G::TWA + G::TWB>(x, tw, G::jC(lane, 0));
+}
+
+// ntt_forward on decomposition digits (see DIGITS above).  -DHELM_SHORT_ROOT_STAGES=0 keeps the general stages (A/B).
+#ifndef HELM_SHORT_ROOT_STAGES
+#define HELM_SHORT_ROOT_STAGES 1
+#endif
+template <typename F, int LOGN, int M, int PRIO = 0, typename TW>
+__device__ __forceinline__ void ntt_forward_digits(double (&x)[M][Geo<LOGN>::E], double *xbuf, const TW &tw, int lane)
+{
+    ntt_forward<F, LOGN, M, TW, PRIO, NoHook, HELM_SHORT_ROOT_STAGES != 0>(x, xbuf, tw, lane);
 }
 
 // Inverse (without the 1/N factor, which is folded into the bootstrapping key).

@@ -172,6 +172,14 @@ class ServerKey:
         hip_check(hip.helm_hip_launch_costs(self._h, c))
         return [float(x) for x in c]
 
+    def field_bits(self):
+        """49: the blind-rotate kernels compute in the lazy field p = 5072^4 + 1 (short eighth roots of unity: two forward
+        stages on digits without modular reductions), 51: in the 51-bit field (helm_hip_field_bits)."""
+        v = int(hip.helm_hip_field_bits(self._h))
+        if v < 0:
+            hip_check(v)
+        return v
+
     def kernel_clock_ghz(self):
         """Shader clock held during the most recent k_pbs launch (None before the first one)."""
         g, ms = C.c_double(), C.c_double()

@@ -115,10 +115,18 @@ int64_t helm_hip_launch_quantum(const helm_hip_ctx *ctx);
 
 /* What a launch of at most 1/4, 2/4, 3/4 and 4/4 of helm_hip_launch_quantum() bootstraps costs on this context, relative to
  * a full round (cost[3] = 1): the engine runs a different build of the blind-rotate kernel per width (k_pbs_wide: one
- * bootstrap per CU on four SIMDs, k_pbs_duo: two per CU on two SIMDs each, partial and full lockstep rounds).  Measured on
+ * bootstrap per CU on four SIMDs, k_pbs_duo: two per CU on two SIMDs each, k_pbs_trio: three per CU on four waves each, full
+ * lockstep rounds).  Measured on
  * MI355X (profiles/r04/microbench.jsonl); the host's launch packing (helm_host_pack_levels_costed) sizes launches that are
  * narrower than a round with it. */
 int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4]);
+
+/* The prime field the blind-rotate kernels of this context compute in, as its size class: 49 = the lazy field p = 5072^4 + 1
+ * (2^49.2; N = 512 sets whose exact products fit below p/2: no recentring inside transforms, and the first two stages of
+ * every forward transform on decomposition digits as plain multiplications by the short eighth roots of unity 5072^k), 51 =
+ * the 51-bit field.  Results do not depend on it (exact integer arithmetic either way); reported by benchmarks because the
+ * operation count of the kernels does.  Negative on error. */
+int helm_hip_field_bits(const helm_hip_ctx *ctx);
 
 /* -- keys ------------------------------------------------------------------ */
 /* Replaces convert_lwe_bootstrap_key / convert_lwe_keyswitch_key (reference

@@ -101,6 +101,7 @@ extern "C" {
     pub fn helm_hip_sync(ctx: *mut helm_hip_ctx) -> c_int;
     pub fn helm_hip_launch_quantum(ctx: *const helm_hip_ctx) -> i64;
     pub fn helm_hip_launch_costs(ctx: *const helm_hip_ctx, cost: *mut f64) -> c_int;
+    pub fn helm_hip_field_bits(ctx: *const helm_hip_ctx) -> c_int;
     pub fn helm_hip_load_bootstrap_key(ctx: *mut helm_hip_ctx, bsk_std: *const u32, n_words: usize) -> c_int;
     pub fn helm_hip_load_keyswitch_key(ctx: *mut helm_hip_ctx, ksk: *const u32, n_words: usize) -> c_int;
     pub fn helm_hip_wires_alloc(ctx: *mut helm_hip_ctx, n_wires: i64, out: *mut *mut helm_hip_wires) -> c_int;

@@ -10,14 +10,14 @@ echo "== 0 the bench line itself, default arguments (same box as everything belo
 timeout -k 10 600 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err || { tail -5 $O/bench_n1.err; exit 1; }
 echo "== 1 kernel-trace stats, gates mode (bench.py $BENCH)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 bench.py $BENCH > $O/bench.log 2>&1 || { tail -5 $O/bench.log; exit 1; }
-echo "== 2 kernel-trace stats of one launch per width: 256 (wide), 512 (duo), 768 and 1,024 (lockstep), 5 launches each"
+echo "== 2 kernel-trace stats of one launch per width: 256 (wide), 512 (duo), 768 (trio), 1,024 (lockstep), 5 launches each"
 for B in 256 512 768 1024; do
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/w$B -o w$B -- python3 tools/prof_pbs.py boolean_default $B 5 > $O/w$B.log 2>&1 || { tail -5 $O/w$B.log; exit 1; }
 done
-echo "== 3 issue-slot and LDS counters of k_pbs_duo (512), the lockstep k_pbs (1,024) and k_pbs_wide (256)"
+echo "== 3 issue-slot and LDS counters of k_pbs_duo (512), k_pbs_trio (768), the lockstep k_pbs (1,024) and k_pbs_wide (256)"
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_LDS"
 SQ2="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE"
-for B in 256 512 1024; do
+for B in 256 512 768 1024; do
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv --pmc $SQ1 -d $O/sq1_w$B -o a -- python3 tools/prof_pbs.py boolean_default $B 3 > $O/sq1_w$B.log 2>&1 || tail -5 $O/sq1_w$B.log
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv --pmc $SQ2 -d $O/sq2_w$B -o b -- python3 tools/prof_pbs.py boolean_default $B 3 > $O/sq2_w$B.log 2>&1 || tail -5 $O/sq2_w$B.log
 done
