@@ -647,11 +647,11 @@ def fill_result(bench, result):
                 "occupancy": round(occ, 3),
                 "frac_of_the_busy_cus": round(ach1 / (peak_tops * max(occ, 1e-9)), 4),
                 "avg_launch_ms": round(avg_ms, 4), "avg_bootstraps_per_launch": round(avg_w, 1), "launches_timed": int(n_l),
-                "cycles_per_step": round(cyc), "cycles_per_step_if_the_four_simds_were_perfectly_packed": 8400,
+                "cycles_per_step": round(cyc), "cycles_per_step_if_the_four_simds_were_perfectly_packed": 5800,
+                "packed_bound_is": "5,778 vector instructions per bootstrap-step (9 waves x 642: profiles/r04/pmc_and_stats_summary.txt) x 4 cycles / 4 SIMDs",
                 "cycles_per_step_clock": "the clock k_pbs held in the timed region (k_pbs_wide has no probe of its own)" if clock_ghz else "nominal",
                 "algorithmic_lane_ops_per_bootstrap": int(algo_ops),
-                "issue_slot_fraction": "0.60 (VALU active 0.266 per wave x 2.25 waves per SIMD: profiles/r03/pmc_and_stats_summary.txt; "
-                                       "the kernel is unchanged since)",
+                "issue_slot_fraction": "0.61 (VALU active 0.272 per wave x 2.25 waves per SIMD: profiles/r04/pmc_and_stats_summary.txt)",
                 "traffic": None,
             }}
         prog1.destroy()
