@@ -2113,7 +2113,7 @@ struct helm_hip_ctx {
     DevBuf<uint32_t> d_body;
     uint32_t *tv_bool = nullptr; // one row: all +1/8
     bool have_bsk = false, have_ksk = false;
-    int field = 51; // 51: Fp<51>, 49: FpG (lazy, short eighth roots of unity), chosen from the parameter set
+    int field = 51; // 51: FpH, 49: FpG (lazy) - both with short eighth roots of unity -, chosen from the parameter set
     int n_cus = 256;
     int narrow_variant = 4;  // build for launches of at most one workgroup per CU: 4 wide, 1 latency (HELM_HIP_NARROW)
     int clock_probe = 0;     // HELM_HIP_CLOCK_PROBE: print the in-kernel clock of every k_pbs launch
@@ -2442,8 +2442,9 @@ __attribute__((visibility("hidden"))) hipError_t helm_hip_tu1_launch_wide(helm_h
                                                                         const uint32_t *wires, const uint32_t *raw,
                                                                         const uint32_t *tvs, uint32_t *out_big);
 // field id of the engine context -> field type of the boolean kernels (49: the lazy FpG)
-template <int ID> struct BoolField { using type = Fp<ID>; };
+template <int ID> struct BoolField;
 template <> struct BoolField<49> { using type = FpG; };
+template <> struct BoolField<51> { using type = FpH; };
 #if HELM_HIP_TU == 1
 hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int logn, int k, int l, const PbsJob *jobs, int64_t count,
                                     const uint32_t *wires, const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
@@ -2460,9 +2461,9 @@ hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int
 #undef WIDE_CASE
     // N = 1024: two bootstraps of k_pbs_duo do not fit a CU's LDS (91 KB each): the wide build only
     if (build == 0 && field == 51 && logn == 10 && k == 1 && l == 3)
-        return launch_pbs_wide<WideCfg<Fp<51>, 10, 1, 3>>(ctx, jobs, count, wires, raw, tvs, out_big);
+        return launch_pbs_wide<WideCfg<FpH, 10, 1, 3>>(ctx, jobs, count, wires, raw, tvs, out_big);
     if (build == 0 && field == 51 && logn == 10 && k == 1 && l == 2)
-        return launch_pbs_wide<WideCfg<Fp<51>, 10, 1, 2>>(ctx, jobs, count, wires, raw, tvs, out_big);
+        return launch_pbs_wide<WideCfg<FpH, 10, 1, 2>>(ctx, jobs, count, wires, raw, tvs, out_big);
     return hipErrorInvalidValue;
 }
 #endif
@@ -2594,7 +2595,7 @@ static hipError_t launch_pbs_t(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
     if constexpr (LOGN == 9) {
         if (ctx->field == 49) return launch_pbs_f<FpG, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
     }
-    return launch_pbs_f<Fp<51>, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
+    return launch_pbs_f<FpH, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
 }
 
 static bool pbs_supported(const helm_hip_params &P)
@@ -2732,7 +2733,7 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         return fail(HELM_ERR_INVALID, "bad keyswitch decomposition (ks_logB <= 7, ks_l in {1..6,8})");
     // exactness: |sum| <= (k+1) * l * N * (B/2) * 2^31 must stay below p/2
     const double bound = (double)(P.k + 1) * P.pbs_l * P.N * (double)(1u << (P.pbs_logB - 1)) * 2147483648.0;
-    if (bound * 1.0001 >= Fp<51>::P / 2) return fail(HELM_ERR_INVALID, "parameter set exceeds the single-prime NTT capacity");
+    if (bound * 1.0001 >= FpH::P / 2) return fail(HELM_ERR_INVALID, "parameter set exceeds the single-prime NTT capacity");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(HELM_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
@@ -2771,15 +2772,17 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         // on digits need 2^(logB-1) b^3 far below p/2: any logB <= 12)
         ctx->field = (N == 512 && bound * 1.002 < FpG::P / 2 && P.pbs_logB <= 12) ? 49 : 51;
         if (const char *v = getenv("HELM_HIP_FIELD")) if (atoi(v) == 51) ctx->field = 51;
-        const uint64_t pm = ctx->field == 49 ? FpG::P_U64 : Fp<51>::P_U64;
-        const uint64_t gen = ctx->field == 49 ? FpG::GEN : Fp<51>::GEN;
+        const uint64_t pm = ctx->field == 49 ? FpG::P_U64 : FpH::P_U64;
+        const uint64_t gen = ctx->field == 49 ? FpG::GEN : FpH::GEN;
         uint64_t psi = powmod_u64(gen, (pm - 1) / (2 * (uint64_t)N), pm);
-        if (ctx->field == 49) {
+        const double b1 = ctx->field == 49 ? FpG::B1 : FpH::B1, b2 = ctx->field == 49 ? FpG::B2 : FpH::B2,
+                     b3 = ctx->field == 49 ? FpG::B3 : FpH::B3;
+        {
             // the kernels' first two forward stages assume psi^(N/4) = b (then psi^(N/2) = b^2, psi^(3N/4) = b^3): psi^(N/4) is
             // one of the four primitive eighth roots b, b^3, -b, -b^3 - an odd power of psi puts it on b
             uint64_t pick = 0;
             for (uint64_t t = 1; t < 8 && !pick; t += 2)
-                if (powmod_u64(powmod_u64(psi, t, pm), (uint64_t)N / 4, pm) == (uint64_t)FpG::B1) pick = t;
+                if (powmod_u64(powmod_u64(psi, t, pm), (uint64_t)N / 4, pm) == (uint64_t)b1) pick = t;
             if (!pick) return fail(HELM_ERR_STATE, "internal: no 2N-th root of unity with psi^(N/4) = b");
             psi = powmod_u64(psi, pick, pm);
         }
@@ -2792,7 +2795,7 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
             a = mulmod_u64(a, psi, pm);
             b = mulmod_u64(b, psi_inv, pm);
         }
-        if (ctx->field == 49 && (tf[1] != FpG::B2 || tf[2] != FpG::B1 || tf[3] != FpG::B3))
+        if (tf[1] != b2 || tf[2] != b1 || tf[3] != b3)
             return fail(HELM_ERR_STATE, "internal: the first twiddles are not the constants the kernels assume");
         ctx->n_inv = centred(powmod_u64((uint64_t)N, pm - 2, pm), pm);
         HIP_TRY(hipMalloc(&ctx->tw_fwd, sizeof(double) * N));
@@ -2935,10 +2938,10 @@ int helm_hip_load_bootstrap_key(helm_hip_ctx *ctx, const uint32_t *bsk_std, size
         hipLaunchKernelGGL((k_bsk_convert<FpG, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
                            ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
     else if (P.N == 512)
-        hipLaunchKernelGGL((k_bsk_convert<Fp<51>, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
+        hipLaunchKernelGGL((k_bsk_convert<FpH, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
                            ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
     else
-        hipLaunchKernelGGL((k_bsk_convert<Fp<51>, 10>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
+        hipLaunchKernelGGL((k_bsk_convert<FpH, 10>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
                            ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -3586,10 +3589,10 @@ int helm_hip_ntt_roundtrip(helm_hip_ctx *ctx, const uint32_t *poly_in, uint32_t 
         hipLaunchKernelGGL((k_ntt_roundtrip<FpG, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,
                            ctx->tw_fwd, ctx->tw_inv, ctx->n_inv);
     else if (N == 512)
-        hipLaunchKernelGGL((k_ntt_roundtrip<Fp<51>, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,
+        hipLaunchKernelGGL((k_ntt_roundtrip<FpH, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,
                            ctx->tw_fwd, ctx->tw_inv, ctx->n_inv);
     else
-        hipLaunchKernelGGL((k_ntt_roundtrip<Fp<51>, 10>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,
+        hipLaunchKernelGGL((k_ntt_roundtrip<FpH, 10>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,
                            ctx->tw_fwd, ctx->tw_inv, ctx->n_inv);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(poly_out, d_out.p, (size_t)count * N * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

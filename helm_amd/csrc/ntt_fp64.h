@@ -24,7 +24,9 @@
 
 namespace helm {
 
-// Two primes, chosen per context from the parameter set (helm_hip_ctx_create):
+// Fields.  The boolean kernels (helm_hip.hip) compute in FpG / FpH below - primes b^4 + 1 whose eighth roots of unity are
+// short - since round 4; Fp<51>, Fp<49> and Fp49b remain the fields of the 64-bit-torus kernels (helm_shortint.hip: Fp<49>
+// and Fp49b as a CRT pair) and document the bounds the b^4 + 1 primes inherit:
 //   Fp51: p = 0x6060002B00001 = 1695446975119361 (p-1 = 2^20 * 5 * 323380847, generator 3).
 //         p/2 = 0.7529 * 2^50 exceeds the largest exact coefficient of every supported set
 //         ((k+1) * l * N * B/2 * 2^31 <= 0.75 * 2^50); 2^53 / p = 5.3 of headroom for lazy
@@ -63,8 +65,19 @@ struct FpG {
     static constexpr bool LAZY = true;
     static constexpr double B1 = 5072.0, B2 = 25725184.0, B3 = 130478133248.0; // b, b^2, b^3 (b^4 = -1)
 };
+// The same for the 51-bit field of the boolean kernels (N = 1024 sets, and N = 512 sets too large for FpG):
+// p = 6432^4 + 1 = 2^50.6 (generator 5; 2^12 | p - 1), 1 % above Fp<51>'s prime: p/2 covers the same sets, 2^53 / p = 5.26
+// (Fp<51>: 5.32) with every bound of the recentring build at most 4.5 p.  b, b^2, b^3 = 13, 26, 38 bits.
+struct FpH {
+    static constexpr double P = 1711528530149377.0;
+    static constexpr uint64_t P_U64 = 1711528530149377ull;
+    static constexpr uint64_t GEN = 5;
+    static constexpr bool LAZY = false;
+    static constexpr double B1 = 6432.0, B2 = 41370624.0, B3 = 266095853568.0;
+};
 template <typename F> struct has_short_roots : std::false_type {};
 template <> struct has_short_roots<FpG> : std::true_type {};
+template <> struct has_short_roots<FpH> : std::true_type {};
 
 // A second lazy 49-bit prime (0x24007A8500001, generator 5): with Fp<49> it forms the CRT pair
 // of the 64-bit-torus kernels (p * q / 2 = 2^97.35 covers their exact products); an 11-stage
@@ -494,26 +507,28 @@ struct NoHook {
 };
 // before_last: called between the second transpose and the last block (both LDS round trips behind, a block of pure
 // arithmetic ahead): the place to issue global loads whose latency the block then covers.
-// The first TWO stages of a 512-point forward transform on decomposition digits in a field whose eighth roots of unity
-// are short (FpG): slots (e, e + 2, e + 4, e + 6) form a radix-4 group,
+// The first TWO stages of a forward transform on decomposition digits in a field whose eighth roots of unity are short
+// (FpG, FpH).  With E values per lane in layout A, slots (e, e + E/4, e + E/2, e + 3E/4) form a radix-4 group (d0, d2, d4,
+// d6 below are those four, named for E = 8):
 //   stage 1  a0 = d0 + b^2 d4, a4 = d0 - b^2 d4, (a2, a6 likewise from d2, d6)
 //   stage 2  x0, x2 = a0 +- b a2;  x4, x6 = a4 +- b^3 a6
-// and with b a2 = b d2 + b^3 d6, b^3 a6 = b^3 d2 - b^5 d6 = b^3 d2 + b d6 every term is digit x (at most 37 bits): exact,
-// |x| <= 2^(logB + 37), no reduction.  Same residues as the general stages, much smaller representatives.
-template <typename F, int M>
-__device__ __forceinline__ void fwd_top2_digits(double (&x)[M][8])
+// and with b a2 = b d2 + b^3 d6, b^3 a6 = b^3 d2 - b^5 d6 = b^3 d2 + b d6 every term is digit x (at most 38 bits): exact,
+// |x| <= 2^(logB + 38), no reduction.  Same residues as the general stages, much smaller representatives.
+template <typename F, int M, int E>
+__device__ __forceinline__ void fwd_top2_digits(double (&x)[M][E])
 {
+    constexpr int Q = E / 4;
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const double d0 = x[m][e], d2 = x[m][e + 2], d4 = x[m][e + 4], d6 = x[m][e + 6];
+        for (int e = 0; e < Q; e++) {
+            const double d0 = x[m][e], d2 = x[m][e + Q], d4 = x[m][e + 2 * Q], d6 = x[m][e + 3 * Q];
             const double a0 = __builtin_fma(d4, F::B2, d0), a4 = __builtin_fma(d4, -F::B2, d0);
             const double u = __builtin_fma(d6, F::B3, d2 * F::B1), v = __builtin_fma(d6, F::B1, d2 * F::B3);
             x[m][e] = a0 + u;
-            x[m][e + 2] = a0 - u;
-            x[m][e + 4] = a4 + v;
-            x[m][e + 6] = a4 - v;
+            x[m][e + Q] = a0 - u;
+            x[m][e + 2 * Q] = a4 + v;
+            x[m][e + 3 * Q] = a4 - v;
         }
 }
 
@@ -525,9 +540,9 @@ __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double
 {
     using G = Geo<LOGN>;
     if constexpr (DIGITS && has_short_roots<F>::value) {
-        static_assert(LOGN == 9 && G::BA == 3, "eight values per lane: stages 1 and 2 pair slots e, e + 4 and e, e + 2");
-        fwd_top2_digits<F, M>(x);
-        fwd_block<F, LOGN, M, 6, LOGN - 3, LOGN - G::BA, 3>(x, tw, G::jA(lane, 0)); // block A's third stage
+        static_assert(G::BA >= 3, "stages 1 and 2 pair slots e, e + E/2 and e, e + E/4 of block A");
+        fwd_top2_digits<F, M, G::E>(x);
+        fwd_block<F, LOGN, M, 6, LOGN - 3, LOGN - G::BA, 3>(x, tw, G::jA(lane, 0)); // the rest of block A
     } else
         fwd_block<F, LOGN, M, 6, LOGN - 1, LOGN - G::BA, 0>(x, tw, G::jA(lane, 0));
     if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);
