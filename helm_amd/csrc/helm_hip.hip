@@ -2381,17 +2381,13 @@ static hipError_t launch_pbs_trio(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t
                                   const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
 {
     static bool attr_done[64] = {false};
-    auto kern = (ctx->trio_flags & 1) ? k_pbs_trio<C, true> : k_pbs_trio<C, false>;
-    for (auto kk : {k_pbs_trio<C, true>, k_pbs_trio<C, false>})
-        if (!attr_done[ctx->device & 63]) {
+    auto kern = (ctx->trio_flags & 1) ? k_pbs_trio<C, true> : k_pbs_trio<C, false>; // priority staging on / off (A/B)
+    if (!attr_done[ctx->device & 63]) {
+        for (auto kk : {k_pbs_trio<C, true>, k_pbs_trio<C, false>}) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)C::BYTES);
             if (e != hipSuccess) return e;
         }
-    if (!attr_done[ctx->device & 63]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
-        if (e != hipSuccess) return e;
         attr_done[ctx->device & 63] = true;
         if (getenv("HELM_HIP_VERBOSE")) {
             hipFuncAttributes fa{};
@@ -2904,12 +2900,12 @@ int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4])
 {
     if (!ctx || !cost) return fail(HELM_ERR_INVALID, "null argument");
     // launch_pbs_f's dispatch, measured (profiles/r04/microbench.jsonl and the other boxes of the round; boolean_default:
-    // 3.3 - 3.5 / 5.1 - 5.6 / 7.0 - 7.15 / 8.2 - 8.7 ms for <= 256 / 512 / 768 / 1,024 bootstraps - wide, duo, trio and a full
-    // lockstep round; without k_pbs_duo the throughput build takes 6.7 ms for <= 512, without k_pbs_trio a lockstep round of
-    // three per CU 7.4 - 7.5 ms for <= 768)
+    // 3.2 - 3.3 / 5.0 - 5.3 / 6.6 - 6.7 / 7.6 - 8.0 ms for <= 256 / 512 / 768 / 1,024 bootstraps - wide, duo, trio and a full
+    // lockstep round, final build of round 4; without k_pbs_duo the throughput build is 0.80 of a round for <= 512, without
+    // k_pbs_trio a lockstep round of three per CU 0.89 - 0.90 for <= 768)
     if (ctx->P.N == 512) {
         cost[0] = ctx->narrow_variant == 4 ? 0.42 : 0.50;
-        cost[1] = ctx->duo_build ? 0.64 : 0.80;
+        cost[1] = ctx->duo_build ? 0.66 : 0.80;
         cost[2] = ctx->P.k == 2 && ctx->trio ? 0.86 : 0.89;
     } else { // N = 1024 (helm_cuda: 3.9 / 6.2 / 8.5 / 8.7 ms - wide, two all-levels workgroups per CU, lockstep rounds)
         cost[0] = ctx->narrow_variant == 4 ? 0.45 : 0.64;

@@ -24,13 +24,14 @@ TABLES = {  # ms for <= 1/4, 2/4, 3/4, 4/4 of a round of 4 x CUs bootstraps
     "r03": (3.6, 7.4, 8.5, 8.5),
     "r04": (3.55, 5.50, 7.50, 8.67),  # profiles/r04/microbench.jsonl (one box: 256 / 512 / 768 / 1,024)
     "r04b": (3.26, 5.40, 7.13, 8.25),  # with k_pbs_trio and the twiddle registers (profiles/r04/trio_experiments.txt, one box)
+    "r04c": (3.33, 5.20, 6.65, 7.74),  # final build of round 4: + the short-root field (profiles/r04/microbench.jsonl)
 }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--blocks", type=int, default=32)
-    ap.add_argument("--table", default="r04", choices=sorted(TABLES))
+    ap.add_argument("--table", default="r04c", choices=sorted(TABLES))
     ap.add_argument("--costed", action="store_true", help="cost-aware launch packing (helm_host_pack_levels_costed)")
     ap.add_argument("--json", action="store_true")
     a = ap.parse_args()
