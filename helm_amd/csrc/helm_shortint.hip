@@ -48,10 +48,23 @@ int helm_hip_fail_(int code, const std::string &msg); // helm_hip.hip: sets helm
 
 namespace {
 
-// CRT pair: two 49-bit primes whose 2^53 / p = 14.2 headroom lets a whole forward transform (up to
-// 11 stages, digits below 2^23), the pointwise products and their sums run without recentring
-using F0 = Fp<49>;
-using F1 = Fp49b;
+// CRT pair: two 49-bit primes whose 2^53 / p >= 13.3 headroom lets a whole forward transform (up to
+// 11 stages, digits below 2^23: <= 9.6 p), the pointwise products and their sums (<= 11.4 p, the largest bound in this
+// file) run without recentring.  Round 4: the pair is 5072^4 + 1 and 5096^4 + 1 (ntt_fp64.h FpG, FpG2; rounds 1-3:
+// Fp<49>, Fp49b with 2^53 / p = 14.2) - their fourth root of unity psi^(N/2) = +-b^2 is 25 bits long, so stage 1 of a
+// forward transform on digits (|d| <= 2^23: the split kernel is only chosen for pbs_logB <= 24) is ONE multiplication,
+// exact and inside (-p/2, p/2), instead of a modular one (HELM_SI_PLAIN_STAGE1; p0 p1 / 2 = 2^97.5 covers more than before).
+using F0 = FpG;
+using F1 = FpG2;
+#ifndef HELM_SI_PLAIN_STAGE1
+#define HELM_SI_PLAIN_STAGE1 1
+#endif
+template <typename F>
+__device__ __forceinline__ double stage1_digit_product(double digit, double w1)
+{
+    if constexpr (HELM_SI_PLAIN_STAGE1) return digit * w1; // |digit| <= 2^23, |w1| = b^2 < 2^24.7: exact, < p/2
+    else return mulmod<F>(digit, w1);
+}
 
 #ifdef HELM_WIDE_STAMPS
 __device__ unsigned long long g_stamps64[8 * 8];
@@ -219,7 +232,7 @@ __device__ __forceinline__ void pbs64_body(unsigned char *smem, const double *__
             fetch(0, ka);
             __builtin_amdgcn_sched_barrier(0);
             STAMP(0) // rotation, decomposition, first key chunk issued
-            ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+            ntt_forward<F, LOGN, 1, decltype(twf), 0, NoHook, HELM_SI_PLAIN_STAGE1>(x, xb, twf, lane); // (digits: stage 1 plain)
             STAMP(1) // forward transform
             __builtin_amdgcn_sched_barrier(0);
             fetch(1, kb2);
@@ -479,7 +492,7 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
 #pragma unroll
             for (int e = 0; e < E; e++) x[0][e] = digit(e);
 #endif
-            ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+            ntt_forward<F, LOGN, 1, decltype(twf), 0, NoHook, HELM_SI_PLAIN_STAGE1>(x, xb, twf, lane); // (digits: stage 1 plain)
 #pragma unroll
             for (int e = 0; e < E; e++) xb[e * 64 + lane] = x[0][e];
         }
@@ -534,7 +547,7 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
             const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
             x[0][e] = (double)((int)((st + half_m1) & bmask) - (int)half_m1); // st <= B/2 stays, above it st - B
         }
-        ntt_forward<F, LOGN, 1>(x, xb, twf, lane);
+        ntt_forward<F, LOGN, 1, decltype(twf), 0, NoHook, HELM_SI_PLAIN_STAGE1>(x, xb, twf, lane); // (digits: stage 1 plain)
         // the scratch becomes this wave's column sum: clear it, and wait until every wave is through its transform
 #pragma unroll
         for (int e = 0; e < E; e++) xb[e * 64 + lane] = 0.0;
@@ -895,7 +908,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
             for (int u = 0; u < Q / 2; u++) {
                 const int e = quarter * (Q / 2) + u;
                 const double U = digit(G::jA(lane, e)), D1 = digit(G::jA(lane, e + EH));
-                const double Vf = mulmod<F>(D1, w1), Vo = mulmod<FO>(D1, w1o);
+                const double Vf = stage1_digit_product<F>(D1, w1), Vo = stage1_digit_product<FO>(D1, w1o);
                 x_f0[e * 64] = U + Vf;
                 x_f1[e * 64] = U - Vf;
                 x_o0[e * 64] = U + Vo;
@@ -951,7 +964,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
                 const dig_t *dg = dig_p + lev * N + lane;
 #pragma unroll
                 for (int e = 0; e < EH; e++) {
-                    const double U = (double)dg[64 * e], V = mulmod<F>((double)dg[64 * (e + EH)], w1);
+                    const double U = (double)dg[64 * e], V = stage1_digit_product<F>((double)dg[64 * (e + EH)], w1);
                     x[0][e] = h ? U - V : U + V;
                 }
             }
@@ -1165,7 +1178,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
             for (int u = 0; u < Q / 2; u++) {
                 const int e = quarter * (Q / 2) + u;
                 const double U = digit(G::jA(lane, e)), D1 = digit(G::jA(lane, e + EH));
-                const double Vf = mulmod<F>(D1, w1), Vo = mulmod<FO>(D1, w1o);
+                const double Vf = stage1_digit_product<F>(D1, w1), Vo = stage1_digit_product<FO>(D1, w1o);
                 x_f0[e * 64] = U + Vf;
                 x_f1[e * 64] = U - Vf;
                 x_o0[e * 64] = U + Vo;
@@ -1194,7 +1207,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
             const dig_t *dg = dig_p + lane;
 #pragma unroll
             for (int e = 0; e < EH; e++) {
-                const double U = (double)dg[64 * e], V = mulmod<F>((double)dg[64 * (e + EH)], w1);
+                const double U = (double)dg[64 * e], V = stage1_digit_product<F>((double)dg[64 * (e + EH)], w1);
                 x[0][e] = h ? U - V : U + V;
             }
         }
@@ -2424,14 +2437,17 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
     if (!si_supported(P))
         return fail(HELM_ERR_INVALID, "unsupported (k,N,pbs_l): built variants are k = 1, N in {512,1024,2048}, pbs_l in {1,2}; k in {2,3}, N = 512, pbs_l = 1");
     if (P.n < 1 || P.n > 1024) return fail(HELM_ERR_INVALID, "n must be in [1,1024]");
-    if (P.pbs_logB < 2 || P.pbs_logB > 30 || P.pbs_logB * P.pbs_l > 31)
-        return fail(HELM_ERR_INVALID, "bad PBS decomposition (pbs_logB * pbs_l <= 31: every tfhe shortint set)");
+    // (pbs_logB <= 24: the kernels multiply digits by the field's fourth root of unity, 25 bits, without a reduction)
+    if (P.pbs_logB < 2 || P.pbs_logB > 24 || P.pbs_logB * P.pbs_l > 31)
+        return fail(HELM_ERR_INVALID, "bad PBS decomposition (pbs_logB <= 24 and pbs_logB * pbs_l <= 31: every tfhe shortint set)");
     if (P.ks_logB < 1 || P.ks_logB > 7 || P.ks_l < 1 || P.ks_l > 8 || P.ks_logB * P.ks_l > 63)
         return fail(HELM_ERR_INVALID, "bad keyswitch decomposition (ks_logB <= 7, ks_l <= 8)");
     const int t = P.message_modulus * P.carry_modulus;
     if (P.message_modulus < 2 || P.carry_modulus < 1 || (t & (t - 1)) || t > P.N / 2)
         return fail(HELM_ERR_INVALID, "message_modulus * carry_modulus must be a power of two <= N/2");
     const int group = P.grouping_factor > 1 ? P.grouping_factor : 1;
+    if (group > 1 && P.pbs_logB > 24) // (the multi-bit build only exists as the split kernel, whose stage 1 multiplies digits by b^2 plainly)
+        return fail(HELM_ERR_INVALID, "multi-bit sets need pbs_logB <= 24");
     if (P.grouping_factor < 0 || group > 3 || P.n % group)
         return fail(HELM_ERR_INVALID, "grouping_factor must be 0..3 and divide n");
     if (group > 1 && !(P.pbs_l == 1 && P.N >= 1024))
@@ -2495,7 +2511,7 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
     }
     // eight-wave kernel (split transforms) where it exists: N >= 1024, one or two levels (HELM_SI_SPLIT=0: off)
     static_assert(Pbs64sCfg<11, 2>::BYTES <= 160 * 1024, "k_pbs64s<11, 2> must fit the LDS of a CU");
-    ctx->use_split = (P.pbs_l == 1 || (P.pbs_l == 2 && P.pbs_logB <= 15)) && N >= 1024 && P.k == 1;
+    ctx->use_split = ((P.pbs_l == 1 && P.pbs_logB <= 24) || (P.pbs_l == 2 && P.pbs_logB <= 15)) && N >= 1024 && P.k == 1;
     if (const char *v = getenv("HELM_HIP_KS_MFMA")) ctx->ks_mfma = atoi(v);
     if (const char *v = getenv("HELM_SI_SPLIT")) ctx->use_split = (ctx->use_split && atoi(v) != 0) || group > 1;
     if (ctx->use_split) {

@@ -65,6 +65,16 @@ struct FpG {
     static constexpr bool LAZY = true;
     static constexpr double B1 = 5072.0, B2 = 25725184.0, B3 = 130478133248.0; // b, b^2, b^3 (b^4 = -1)
 };
+// FpG's partner in the CRT pair of the 64-bit-torus kernels (helm_shortint.hip): p = 5096^4 + 1 = 2^49.26 (generator 3,
+// 2^12 | p - 1: N <= 2048).  There the digits are up to 2^22, so only the FOURTH root b^2 (25 bits) is short enough:
+// digit x psi^(N/2) is an exact double inside (-p/2, p/2) - stage 1 of a forward transform as one multiplication.
+struct FpG2 {
+    static constexpr double P = 674400179654657.0;
+    static constexpr uint64_t P_U64 = 674400179654657ull;
+    static constexpr uint64_t GEN = 3;
+    static constexpr bool LAZY = true;
+    static constexpr double B1 = 5096.0, B2 = 25969216.0, B3 = 132339124736.0;
+};
 // The same for the 51-bit field of the boolean kernels (N = 1024 sets, and N = 512 sets too large for FpG):
 // p = 6432^4 + 1 = 2^50.6 (generator 5; 2^12 | p - 1), 1 % above Fp<51>'s prime: p/2 covers the same sets, 2^53 / p = 5.26
 // (Fp<51>: 5.32) with every bound of the recentring build at most 4.5 p.  b, b^2, b^3 = 13, 26, 38 bits.
@@ -77,6 +87,7 @@ struct FpH {
 };
 template <typename F> struct has_short_roots : std::false_type {};
 template <> struct has_short_roots<FpG> : std::true_type {};
+template <> struct has_short_roots<FpG2> : std::true_type {};
 template <> struct has_short_roots<FpH> : std::true_type {};
 
 // A second lazy 49-bit prime (0x24007A8500001, generator 5): with Fp<49> it forms the CRT pair
@@ -438,9 +449,12 @@ __device__ __forceinline__ void tw_fill_inverse(TwReg<Geo<LOGN>::NTW> &r, const 
 
 // Fused radix-2 Cooley-Tukey stages on stride bits SB_HI..SB_LO (descending), all of
 // which are register-slot bits (slot bit = stride bit - SHIFT), for M polynomials.
-template <typename F, int LOGN, int M, int SHIFT, int SB_HI, int SB_LO, int SLOT0, typename TW>
+// PLAIN_TOP: the block starts with the transform's FIRST stage (stride bit LOGN-1, the one twiddle psi^(N/2) = +-b^2 of a
+// b^4 + 1 field) on inputs short enough that the product is an exact double inside (-p/2, p/2): a plain multiplication.
+template <typename F, int LOGN, int M, int SHIFT, int SB_HI, int SB_LO, int SLOT0, typename TW, bool PLAIN_TOP = false>
 __device__ __forceinline__ void fwd_block(double (&x)[M][Geo<LOGN>::E], const TW &tw, int jbase)
 {
+    static_assert(!PLAIN_TOP || SB_HI == LOGN - 1, "the short twiddle is the first stage's");
     constexpr int E = Geo<LOGN>::E, N = Geo<LOGN>::N;
     int slot = SLOT0;
 #pragma unroll
@@ -455,7 +469,7 @@ __device__ __forceinline__ void fwd_block(double (&x)[M][Geo<LOGN>::E], const TW
                 const int e0 = (hi << (eb + 1)) | lo, e1 = e0 | (1 << eb);
 #pragma unroll
                 for (int m = 0; m < M; m++) {
-                    double U = x[m][e0], V = mulmod<F>(x[m][e1], w);
+                    double U = x[m][e0], V = (PLAIN_TOP && sb == SB_HI) ? x[m][e1] * w : mulmod<F>(x[m][e1], w);
                     x[m][e0] = U + V;
                     x[m][e1] = U - V;
                 }
@@ -532,14 +546,17 @@ __device__ __forceinline__ void fwd_top2_digits(double (&x)[M][E])
         }
 }
 
-// DIGITS: the inputs are decomposition digits (|x| <= 2^(logB-1)): fields with short eighth roots of unity (FpG) run the
-// first two stages as fwd_top2_digits.
-template <typename F, int LOGN, int M, typename TW, int PRIO = 0, typename HOOK = NoHook, bool DIGITS = false>
+// DIGITS (fields b^4 + 1 only): the inputs are decomposition digits -
+//   2  |x| <= 2^12 and the table normalised to psi^(N/4) = b (the boolean engine): the first two stages as fwd_top2_digits;
+//   1  |x| <= 2^23 (the 64-bit-torus engine): the first stage's products as plain multiplications by the table's psi^(N/2).
+template <typename F, int LOGN, int M, typename TW, int PRIO = 0, typename HOOK = NoHook, int DIGITS = 0>
 __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double *xbuf, const TW &tw, int lane,
                                             const HOOK &before_last = HOOK())
 {
     using G = Geo<LOGN>;
-    if constexpr (DIGITS && has_short_roots<F>::value) {
+    if constexpr (DIGITS == 1 && has_short_roots<F>::value)
+        fwd_block<F, LOGN, M, 6, LOGN - 1, LOGN - G::BA, 0, TW, true>(x, tw, G::jA(lane, 0));
+    else if constexpr (DIGITS == 2 && has_short_roots<F>::value) {
         static_assert(G::BA >= 3, "stages 1 and 2 pair slots e, e + E/2 and e, e + E/4 of block A");
         fwd_top2_digits<F, M, G::E>(x);
         fwd_block<F, LOGN, M, 6, LOGN - 3, LOGN - G::BA, 3>(x, tw, G::jA(lane, 0)); // the rest of block A
@@ -580,7 +597,7 @@ __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double
 template <typename F, int LOGN, int M, int PRIO = 0, typename TW>
 __device__ __forceinline__ void ntt_forward_digits(double (&x)[M][Geo<LOGN>::E], double *xbuf, const TW &tw, int lane)
 {
-    ntt_forward<F, LOGN, M, TW, PRIO, NoHook, HELM_SHORT_ROOT_STAGES != 0>(x, xbuf, tw, lane);
+    ntt_forward<F, LOGN, M, TW, PRIO, NoHook, HELM_SHORT_ROOT_STAGES != 0 ? 2 : 0>(x, xbuf, tw, lane);
 }
 
 // Inverse (without the 1/N factor, which is folded into the bootstrapping key).
