@@ -91,7 +91,7 @@ def test_shortint_parameter_validation_needs_no_device():
         assert nv.hip.helm_si_ctx_create(0, C.byref(bad), C.byref(h)) == -1, field
         assert msg in nv.hip.helm_hip_last_error(), (field, nv.hip.helm_hip_last_error())
     bad = helm_amd.SiParams.from_buffer_copy(p)
-    bad.pbs_l, bad.pbs_logB = 1, 26  # 2 * 2048 * 2^25 * 2^63 = 2^100 exceeds the two-prime CRT range (2^97.3)
+    bad.pbs_l, bad.pbs_logB = 1, 24  # 2 * 2048 * 2^23 * 2^63 = 2^98 exceeds the two-prime CRT range (2^97.5); 25 and up: "decomposition"
     assert nv.hip.helm_si_ctx_create(0, C.byref(bad), C.byref(h)) == -1
     assert b"capacity" in nv.hip.helm_hip_last_error()
 
