@@ -60,7 +60,9 @@ typedef struct helm_si_wires helm_si_wires;
  * n/g group steps; the key holds, per group, 2^g GGSWs of the indicators
  * prod_{i in S} s_i * prod_{i not in S} (1 - s_i), S a subset of the group (bit i of the subset
  * index = member i), and a step is acc <- (sum_S X^(sum_{i in S} a~_i) * GGSW_S) (x) acc.
- * n must be a multiple of g. */
+ * n must be a multiple of g.
+ * Accepted: pbs_logB <= 24 and pbs_logB * pbs_l <= 31 (every tfhe shortint set; the kernels multiply decomposition digits by
+ * a 25-bit root of unity without a modular reduction), exact products below the CRT pair's range (2^97.5). */
 typedef struct {
     int32_t n, k, N;
     int32_t pbs_l, pbs_logB;
