@@ -1,0 +1,107 @@
+"""Worst-case magnitudes of the boolean kernels' fp64 arithmetic in the round-4 fields (interval arithmetic, CPU only).
+
+Every value in the kernels is an integer held in a double; exactness needs |v| < 2^53 at every addition and at the inputs
+of `mulmod` (helm_amd/csrc/ntt_fp64.h).  Random parity tests cannot see a worst-case overflow, so the bounds the code
+comments state are recomputed here from the structure of a CMUX step, for the primes the engine uses now:
+
+  FpG  p = 5072^4 + 1 (lazy: no recentring in the forward transform, the products or their hand-over sums)
+  FpH  p = 6432^4 + 1 (recentred at every block boundary)
+
+mulmod(a, w), |w| <= p/2:  |r| <= (0.5 + 0.75 |a| 2^-52) p   (ntt_fp64.h)
+fwd_top2_digits:           |x| <= D (1 + b^2) + D (b + b^3),  D = 2^(logB-1)   - exact terms, no reduction
+a Cooley-Tukey stage:      |x'| <= |u| + |mulmod(v, w)|
+a Gentleman-Sande stage:   |u + v| <= 2 m;  |mulmod(u - v, w)| with |u - v| <= 2 m
+"""
+import pytest
+
+P = {"FpG": 5072 ** 4 + 1, "FpH": 6432 ** 4 + 1}
+B = {"FpG": 5072, "FpH": 6432}
+LIMIT = 2.0 ** 53
+
+
+def mulmod_bound(a, p):
+    assert a < LIMIT, "mulmod input not exact"
+    return (0.5 + 0.75 * a / 2.0 ** 52) * p
+
+
+def forward_bound(field, logn, logB, lazy, ba):
+    """max |x| after the forward transform of digits: top two stages plain, the rest Cooley-Tukey; the non-lazy field
+    recentres (|x| <= p/2 + 1) after block A (ba stages) and block B (logn - ba - 3 stages)"""
+    p, b = P[field], B[field]
+    d = 2.0 ** (logB - 1)
+    m = d * (1 + b * b) + d * (b + b ** 3)
+    worst = m
+    for stage in range(3, logn + 1):
+        m = m + mulmod_bound(m, p)
+        worst = max(worst, m)
+        assert m < LIMIT
+        if not lazy and stage in (ba, logn - 3):
+            m = p / 2 + 1
+    return m, worst
+
+
+def inverse_ok(field, logn, ba):
+    """inverse from |x| <= p/2: blocks of 3 (or 4, recentred after two stages in the 51-bit field) Gentleman-Sande stages,
+    recentred at the transposes"""
+    p = P[field]
+    for block in (3, logn - ba - 3, ba):
+        m = p / 2 + 1
+        for s in range(block):
+            if block == 4 and s == 2 and field == "FpH":
+                m = p / 2 + 1
+            assert 2 * m < LIMIT
+            mulmod_bound(2 * m, p)
+            m = 2 * m  # the pure-sum path; the multiplied path is smaller
+    return True
+
+
+@pytest.mark.parametrize("name,field,logn,k,l,logB", [
+    ("boolean_default", "FpG", 9, 2, 3, 6),
+    ("toy_k2", "FpG", 9, 2, 3, 6),
+    ("boolean_default in the 51-bit field (HELM_HIP_FIELD=51)", "FpH", 9, 2, 3, 6),
+    ("toy (k = 1, l = 2, logB = 8)", "FpH", 9, 1, 2, 8),
+    ("helm_cuda", "FpH", 10, 1, 3, 7),
+    ("largest digits the lazy field is chosen for", "FpG", 9, 1, 2, 12),
+])
+def test_every_sum_of_a_cmux_step_stays_exact(name, field, logn, k, l, logB):
+    p = P[field]
+    lazy = field == "FpG"
+    ba = 3 if logn == 9 else 4
+    # the set's exact products fit the field (helm_hip_ctx_create's own check, restated)
+    exact = (k + 1) * l * (1 << logn) * 2.0 ** (logB - 1) * 2.0 ** 31
+    if name != "largest digits the lazy field is chosen for":
+        assert exact * 1.0001 < p / 2
+    out, worst = forward_bound(field, logn, logB, lazy, ba)
+    prod = mulmod_bound(out, p)                       # one product spectrum x key
+    if lazy:
+        column = (k + 1) * l * prod                   # all (k+1) l products of a column summed raw (hand-over / ds_add_f64)
+    else:
+        column = max(l * prod, (k + 1) * l * (p / 2 + 1))  # a wave sums its l raw, the hand-over recentres each first
+    assert column < LIMIT, (name, column / p)
+    assert inverse_ok(field, logn, ba)
+    print(f"\n{name} [{field}]: forward <= {out / p:.2f} p (largest intermediate {worst / p:.2f} p), product <= {prod / p:.2f} p, "
+          f"column sum <= {column / p:.2f} p of 2^53 = {LIMIT / p:.2f} p")
+    if field == "FpG" and logB == 6:
+        assert out / p < 5.0 and column / p < 9.5     # the figures DESIGN.md 4.2 "The field" quotes
+
+
+def test_top2_terms_are_exact_and_tiny():
+    """digit x b^k for k <= 3 stays far below 2^53 and, for the lazy field's sets, below p/2 (no reduction needed)"""
+    for field in P:
+        b, p = B[field], P[field]
+        assert b ** 4 + 1 == p and (p - 1) % (2 * 1024 if field == "FpG" else 2 * 2048) == 0
+        for logB in (6, 7, 8, 12):
+            d = 2 ** (logB - 1)
+            total = d * (1 + b * b) + d * (b + b ** 3)
+            assert total < 2 ** 53
+            if logB <= 8:
+                assert total < 0.05 * p
+
+
+def test_shortint_stage1_product_is_exact_and_centred():
+    """64-bit engine: digit (|d| <= 2^23, pbs_logB <= 24) x psi^(N/2) = +-b^2 is exact and inside (-p/2, p/2)"""
+    for b in (5072, 5096):
+        p = b ** 4 + 1
+        assert (p - 1) % 4096 == 0                    # N = 2048
+        assert 2 ** 23 * b * b < p / 2 < 2 ** 53
+    assert (5072 ** 4 + 1) * (5096 ** 4 + 1) / 2 > 2.0 ** 97.35   # the range rounds 1-3 had
