@@ -24,40 +24,23 @@
 
 namespace helm {
 
-// Fields.  The boolean kernels (helm_hip.hip) compute in FpG / FpH below - primes b^4 + 1 whose eighth roots of unity are
-// short - since round 4; Fp<51>, Fp<49> and Fp49b remain the fields of the 64-bit-torus kernels (helm_shortint.hip: Fp<49>
-// and Fp49b as a CRT pair) and document the bounds the b^4 + 1 primes inherit:
-//   Fp51: p = 0x6060002B00001 = 1695446975119361 (p-1 = 2^20 * 5 * 323380847, generator 3).
-//         p/2 = 0.7529 * 2^50 exceeds the largest exact coefficient of every supported set
-//         ((k+1) * l * N * B/2 * 2^31 <= 0.75 * 2^50); 2^53 / p = 5.3 of headroom for lazy
-//         additions, so values are recentred at every block boundary.
-//   Fp49: p = 0x2424DD2F20001 = 635851972411393 (generator 5), for sets whose exact
-//         coefficients stay below p/2 = 0.565 * 2^49 (tfhe boolean DEFAULT: 2^48.17).
-//         2^53 / p = 14.2: a whole forward transform (digits in, <= 7.1p out), the
-//         pointwise sums (<= 3.8p) and their (k+1)-way hand-over sum (<= 11.4p) need no
-//         recentring at all (LAZY) - 11 % fewer fp64 operations per bootstrap.
-template <int ID> struct Fp;
-template <> struct Fp<51> {
-    static constexpr double P = 1695446975119361.0;
-    static constexpr uint64_t P_U64 = 1695446975119361ull;
-    static constexpr uint64_t GEN = 3;
-    static constexpr bool LAZY = false;
-};
-template <> struct Fp<49> {
-    static constexpr double P = 635851972411393.0;
-    static constexpr uint64_t P_U64 = 635851972411393ull;
-    static constexpr uint64_t GEN = 5;
-    static constexpr bool LAZY = true;
-};
+// Fields: primes p = b^4 + 1 (round 4).  b is then a primitive eighth root of unity, so the roots of unity of the first
+// two transform stages are the short integers b^2, b, b^3, and stages on decomposition digits lose their modular
+// reductions.  Rounds 1-3 used arbitrary primes of the same sizes (0x6060002B00001, 2^50.6, recentred at every block
+// boundary: 2^53 / p = 5.3; 0x2424DD2F20001 and 0x24007A8500001, 2^49.2, lazy: 2^53 / p = 14.2, forward outputs <= 7.1 p,
+// hand-over sums <= 11.4 p); the bounds of the present fields are recomputed in tests/test_lazy_bounds.py.
+//   FpG   5072^4 + 1 = 2^49.23  lazy    boolean kernels (N = 512 sets whose exact products fit) and CRT prime 0 of the 64-bit ones
+//   FpG2  5096^4 + 1 = 2^49.26  lazy    CRT prime 1 of the 64-bit kernels
+//   FpH   6432^4 + 1 = 2^50.60  strict  boolean kernels at N = 1024 and for larger N = 512 sets
 
-// The lazy field of the BOOLEAN kernels (round 4): p = b^4 + 1 with b = 5072 = 2^12.3 (generator 3; 2^11 | p - 1).
+// The lazy field of the BOOLEAN kernels (round 4): p = b^4 + 1 with b = 5072 = 2^12.3 (generator 3; 2^16 | p - 1).
 // b is a primitive EIGHTH root of unity, so the twiddles of a transform's first two stages - psi^(N/2) and psi^(N/4),
 // psi^(3N/4), with psi chosen such that psi^(N/4) = b (helm_hip_ctx_create) - are b^2, b, b^3: 25, 12 and 37 bits.
 // On decomposition digits (|d| <= 2^(logB-1)) every product of those two stages is an exact double far inside (-p/2, p/2):
 // the radix-4 butterfly on four digits is 10 plain operations instead of 6 modular multiplications and 8 additions
 // (fwd_top2_digits: 20 instead of 56 per transform and polynomial at N = 512).  p / 2 = 2^48.23 still covers tfhe boolean
-// DEFAULT's exact products (2^48.17); 2^53 / p = 13.6: the lazy bounds of Fp<49> (hand-over sums <= 11.4 p, inverse
-// sums <= 8 p) hold with room, the forward outputs being smaller than there (two stages add nothing to them).
+// DEFAULT's exact products (2^48.17); 2^53 / p = 13.6 against forward outputs <= 4.9 p, hand-over sums <= 9.4 p, inverse
+// sums <= 8 p (tests/test_lazy_bounds.py).
 struct FpG {
     static constexpr double P = 661785091833857.0;
     static constexpr uint64_t P_U64 = 661785091833857ull;
@@ -89,25 +72,6 @@ template <typename F> struct has_short_roots : std::false_type {};
 template <> struct has_short_roots<FpG> : std::true_type {};
 template <> struct has_short_roots<FpG2> : std::true_type {};
 template <> struct has_short_roots<FpH> : std::true_type {};
-
-// A second lazy 49-bit prime (0x24007A8500001, generator 5): with Fp<49> it forms the CRT pair
-// of the 64-bit-torus kernels (p * q / 2 = 2^97.35 covers their exact products); an 11-stage
-// forward transform of digits below 2^23 stays under 9.6 q < 2^53 without recentring.
-struct Fp49b {
-    static constexpr double P = 633351586185217.0;
-    static constexpr uint64_t P_U64 = 633351586185217ull;
-    static constexpr uint64_t GEN = 5;
-    static constexpr bool LAZY = true;
-};
-
-// The 49-bit prime with recentring kept (transforms of more than 9 stages, or inputs
-// larger than boolean digits, would outgrow the lazy bound).
-struct Fp49Strict {
-    static constexpr double P = Fp<49>::P;
-    static constexpr uint64_t P_U64 = Fp<49>::P_U64;
-    static constexpr uint64_t GEN = Fp<49>::GEN;
-    static constexpr bool LAZY = false;
-};
 
 // a*w mod p for integers |a| < 2^53, |w| <= p/2.  Result r == a*w (mod p) exactly,
 // |r| <= (0.5 + 0.75 * |a| * 2^-52) * p  (<= 2p for any admissible a).
