@@ -149,6 +149,20 @@ def test_two_ranks_through_the_library_communicator(tmp_path):
         assert 0 < sharded <= nl
 
 
+def test_three_ranks_through_the_library_communicator(tmp_path):
+    """The same with THREE ranks on the one GPU: launch sizes that three does not divide - padded last chunks, rank 2's
+    slot behind two others - through helm_hip_program_run_sharded_comm."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(3, port, 4, str(tmp_path), "gloo", "comm"), nprocs=3, join=True)
+    for r in range(3):
+        same, sharded, nl = np.load(tmp_path / f"rank{r}.npy")
+        assert same == 1, f"rank {r}: the three-rank pass through the library's communicator differs from the single-process one"
+        assert 0 < sharded <= nl
+
+
 def test_two_ranks_over_rccl(tmp_path):
     """The same run over the real `nccl` backend (RCCL over xGMI), one GPU per rank.  Needs two GPUs: on a one-GPU
     box this is reported as an expected failure - RCCL NOT exercised - rather than passing silently."""
