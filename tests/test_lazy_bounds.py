@@ -105,3 +105,25 @@ def test_shortint_stage1_product_is_exact_and_centred():
         assert (p - 1) % 4096 == 0                    # N = 2048
         assert 2 ** 23 * b * b < p / 2 < 2 ** 53
     assert (5072 ** 4 + 1) * (5096 ** 4 + 1) / 2 > 2.0 ** 97.35   # the range rounds 1-3 had
+
+
+def test_top2_formulas_equal_two_cooley_tukey_stages():
+    """fwd_top2_digits (ntt_fp64.h) restated in integers: the radix-4 butterfly on (d0, d2, d4, d6) with the constants b, b^2,
+    b^3 gives the same residues as stage 1 (twiddle psi^(N/2) = b^2) followed by stage 2 (twiddles psi^(N/4) = b for the
+    first half, psi^(3N/4) = b^3 for the second) of the merged negacyclic transform."""
+    import random
+    rnd = random.Random(5)
+    for field in P:
+        p, b = P[field], B[field]
+        assert pow(b, 4, p) == p - 1 and pow(b, 8, p) == 1          # a primitive eighth root of unity
+        for _ in range(200):
+            d0, d2, d4, d6 = (rnd.randint(-64, 64) for _ in range(4))
+            # two Cooley-Tukey stages
+            a0, a4 = d0 + b * b * d4, d0 - b * b * d4
+            a2, a6 = d2 + b * b * d6, d2 - b * b * d6
+            want = (a0 + b * a2, a0 - b * a2, a4 + b ** 3 * a6, a4 - b ** 3 * a6)
+            # the kernel's form: every term digit x (b, b^2, b^3); b^5 = -b
+            u, v = d2 * b + d6 * b ** 3, d2 * b ** 3 + d6 * b
+            got = (a0 + u, a0 - u, a4 + v, a4 - v)
+            assert all((g - w) % p == 0 for g, w in zip(got, want))
+            assert all(abs(g) < 2 ** 53 and abs(g) < p // 2 for g in got)   # exact doubles, already centred
