@@ -576,12 +576,22 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *x
                                             const HOOK &before_write = HOOK())
 {
     using G = Geo<LOGN>;
+    // LEAN (lazy fields, three blocks of three stages, centred output): after a three-stage Gentleman-Sande block on inputs
+    // <= m, slot e holds at most 8 m (e = 0: the pure sum), 4 x a product (e = 1), 2 x (e = 2, 3) or a fresh product
+    // (e >= 4) - from m = p/2: 4.0, 2.4, 1.4, 1.3, 0.9, 0.8, 0.7, 0.6 p.  A transpose gives a lane eight values of ONE
+    // slot class, so the next block's bound is eight times the largest value left unreduced: recentring slots 0-2 at
+    // the first transpose (the rest <= 1.27 p) and 0-4 at the second (<= 0.8 p) keeps every sum below 0.75 x 2^53
+    // (tests/test_lazy_bounds.py) and saves 8 of the 16 recentrings of the two transposes (24 instructions).
+#ifndef HELM_LEAN_INVERSE
+#define HELM_LEAN_INVERSE 1
+#endif
+    constexpr bool LEAN = HELM_LEAN_INVERSE != 0 && F::LAZY && CENTRE && LOGN == 9 && G::BA == 3 && G::BB == 3 && G::BC == 3;
     inv_block<F, LOGN, 0, 0, G::BC - 1, 0>(x, tw, G::jC(lane, 0));
     before_write();
     if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);
     double *pA = xbuf + G::baseA(lane), *pB = xbuf + G::baseB(lane), *pC = xbuf + G::baseC(lane);
 #pragma unroll
-    for (int e = 0; e < G::E; e++) pC[e] = reduce<F>(x[e]);
+    for (int e = 0; e < G::E; e++) pC[e] = (LEAN && e >= 3) ? x[e] : reduce<F>(x[e]);
     lds_wave_sync();
 #pragma unroll
     for (int e = 0; e < G::E; e++) x[e] = pB[G::offB2(e)];
@@ -589,7 +599,7 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *x
     inv_block<F, LOGN, G::BC, G::BC, G::BC + G::BB - 1, G::TWC>(x, tw, G::jB(lane, 0));
     if constexpr (PRIO > 1) __builtin_amdgcn_s_setprio(PRIO - 2);
 #pragma unroll
-    for (int e = 0; e < G::E; e++) pB[G::offB1(e)] = reduce<F>(x[e]);
+    for (int e = 0; e < G::E; e++) pB[G::offB1(e)] = (LEAN && e >= 5) ? x[e] : reduce<F>(x[e]);
     lds_wave_sync();
 #pragma unroll
     for (int e = 0; e < G::E; e++) x[e] = pA[G::offA1(e)];

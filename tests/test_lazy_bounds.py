@@ -127,3 +127,34 @@ def test_top2_formulas_equal_two_cooley_tukey_stages():
             got = (a0 + u, a0 - u, a4 + v, a4 - v)
             assert all((g - w) % p == 0 for g, w in zip(got, want))
             assert all(abs(g) < 2 ** 53 and abs(g) < p // 2 for g in got)   # exact doubles, already centred
+
+
+def test_lean_inverse_transform_bounds():
+    """ntt_inverse's LEAN form (lazy fields, N = 512): recentre slots 0-2 at the first transpose and 0-4 at the second.  A
+    three-stage Gentleman-Sande block leaves slot e with the sum of everything (e = 0), products followed by two, one or no
+    additions (e = 1; 2, 3; 4-7); after a transpose a lane holds eight values of one slot class, so every slot of the next
+    block is bounded by the largest value left unreduced."""
+    for p in (5072 ** 4 + 1, 5096 ** 4 + 1):
+
+        def block(m):
+            m, peak = list(m), 0.0
+            for eb in range(3):
+                new = m[:]
+                for e0 in range(8):
+                    if (e0 >> eb) & 1:
+                        continue
+                    e1 = e0 | (1 << eb)
+                    s = m[e0] + m[e1]
+                    assert s < LIMIT
+                    peak = max(peak, s)
+                    new[e0], new[e1] = s, mulmod_bound(s, p)
+                m = new
+            return m, peak
+
+        half = p / 2 + 1
+        m1, pk1 = block([half] * 8)
+        assert [round(v / p, 1) for v in m1[:4]] == [4.0, 2.4, 1.4, 1.3]
+        m2, pk2 = block([max(half if e < 3 else m1[e] for e in range(8))] * 8)
+        m3, pk3 = block([max(half if e < 5 else m2[e] for e in range(8))] * 8)
+        assert max(pk1, pk2, pk3) < 0.78 * LIMIT          # 0.75 (FpG), 0.76 (FpG2)
+        assert max(m3) < 7 * p                             # the final recentring sees at most 6.7 p
