@@ -528,10 +528,13 @@ __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double
         fwd_block<F, LOGN, M, 6, LOGN - 1, LOGN - G::BA, 0>(x, tw, G::jA(lane, 0));
     if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);
     double *pA = xbuf + G::baseA(lane), *pB = xbuf + G::baseB(lane), *pC = xbuf + G::baseC(lane);
+    // the recentring fields: after fwd_top2_digits block A ends below 1.2 p (its first two stages add almost nothing), so
+    // block B (three stages) stays below 4.5 p of 2^53 = 5.26 p without a recentring here (tests/test_lazy_bounds.py)
+    constexpr bool SKIP_T1 = DIGITS == 2 && has_short_roots<F>::value && G::BB == 3;
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
-        for (int e = 0; e < G::E; e++) pA[m * G::XPAD + G::offA1(e)] = reduce_unless_lazy<F>(x[m][e]);
+        for (int e = 0; e < G::E; e++) pA[m * G::XPAD + G::offA1(e)] = SKIP_T1 ? x[m][e] : reduce_unless_lazy<F>(x[m][e]);
     lds_wave_sync();
 #pragma unroll
     for (int m = 0; m < M; m++)

@@ -35,7 +35,7 @@ def forward_bound(field, logn, logB, lazy, ba):
         m = m + mulmod_bound(m, p)
         worst = max(worst, m)
         assert m < LIMIT
-        if not lazy and stage in (ba, logn - 3):
+        if not lazy and stage == logn - 3:   # (no recentring after block A since round 4: SKIP_T1 in ntt_forward)
             m = p / 2 + 1
     return m, worst
 
