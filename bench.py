@@ -42,6 +42,8 @@ HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md
 # measured fabric traffic of the dominant kernels (tools/pmc_traffic.sh: separate --pmc passes); the file is
 # rewritten by every round's profiling run, the per-round copies live under profiles/rNN/
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+# SQ_INSTS_VALU / SQ_WAVES of the lockstep k_pbs (tools/pmc_issue.py over a --pmc pass of tools/prof_pbs.py)
+PMC_ISSUE = os.path.join(ROOT, "profiles", "pmc_issue.json")
 METRIC = "encrypted gate-bootstraps/sec on AES-128 gates-mode netlist"
 RESULT_FILE_ENV = "HELM_BENCH_RESULT_FILE"
 
@@ -57,10 +59,16 @@ def parse_args(argv=None):
     ap.add_argument("--no-pack", action="store_true", help="level-synchronous launches (the round-1 schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the LUT-mode / arithmetic-mode side measurements")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration wall-clock lines (BASELINE.json configs 1-3)")
     ap.add_argument("--no-side-legs", action="store_true", help="N > 1: only the headline run")
     ap.add_argument("--overlap", action="store_true",
-                    help="N > 1, sharded runs: launches cut to one lockstep round per rank, each launch's all-gather + scatter on "
-                         "a side stream while the next launch's bootstraps run (off until a SCALE run has measured it)")
+                    help="sharded runs: the library's overlapped exchange (helm_hip_program_run_sharded_comm, overlap = 1): a launch's "
+                         "all-gather + scatter on the engine's exchange stream while the launches that do not need its outputs run; "
+                         "off until a SCALE run has measured it")
+    ap.add_argument("--allow-host-fallback", action="store_true",
+                    help="N > 1: if the RCCL communicator cannot be created on every rank, carry the exchange over the control plane "
+                         "(gloo through host memory) instead of failing; the line then says so - such a number is NOT a measurement "
+                         "of the RCCL path.  Without this flag the run ends with value null, the error and a non-zero exit code")
     ap.add_argument("--force-comm", action="store_true",
                     help="N = 1: run the headline through the sharded path anyway - a world-size-1 RCCL communicator inside the library, "
                          "every launch stage -> ncclAllGather -> scatter (what the exchange machinery itself costs; rccl_ranks is filled)")
@@ -155,6 +163,19 @@ def launch_workers(args, argv):
 # ----------------------------------------------------------------------------------------------------------------
 # worker
 # ----------------------------------------------------------------------------------------------------------------
+def _load_profile(path):
+    """-> (the committed counter summary, {"file", "sha256_16", "round"}) or (None, None): figures that come from a profile
+    are labelled as such in the line - this run did not measure them."""
+    import hashlib
+    if not os.path.exists(path):
+        return None, None
+    with open(path, "rb") as f:
+        raw = f.read()
+    data = json.loads(raw)
+    return data, {"file": os.path.relpath(path, ROOT), "sha256_16": hashlib.sha256(raw).hexdigest()[:16],
+                  "copy_of": data.get("copy_of"), "measured_by_this_run": False}
+
+
 def build_program_arrays(circuit, wire_names, blocks):
     """Tile the one-block level schedule over `blocks` copies of the wire table."""
     import numpy as np
@@ -172,20 +193,18 @@ def build_program_arrays(circuit, wire_names, blocks):
 
 
 def make_program(sk, circuit, wire_names, blocks, quantum, pack=True, overlap_split=0):
-    """-> (Program, launches, levels, depends_on): the batch's level schedule, launch-packed to `quantum` bootstraps.
-    overlap_split > 0: every launch cut into sub-launches of at most that many bootstraps and the launch dependencies
-    computed, for the overlapped sharded schedule (helm_amd/distributed.py); depends_on is None otherwise."""
+    """-> (Program, launches, levels, None): the batch's level schedule, launch-packed to `quantum` bootstraps.
+    overlap_split > 0: every launch cut into sub-launches of at most that many bootstraps, for the overlapped sharded
+    schedule (the library computes the launch dependencies itself: helm_hip_program_run_sharded_comm, overlap = 1)."""
     import helm_amd
-    from helm_amd.distributed import launch_dependencies, pack_levels, split_launches
+    from helm_amd.distributed import pack_levels, split_launches
     ops, i0, i1, i2, out, off, _ = build_program_arrays(circuit, wire_names, blocks)
     levels = len(off) - 1
     if pack:  # cost-aware: launches narrower than a round take the engine's most efficient width (wide / duo / lockstep)
         ops, i0, i1, i2, out, off, _ = pack_levels(ops, i0, i1, i2, out, off, quantum, quarter_cost=sk.launch_costs())
-    deps = None
     if overlap_split > 0:
         off = split_launches(ops, off, overlap_split)
-        deps = launch_dependencies(i0, i1, i2, out, off, len(wire_names) * blocks)
-    return helm_amd.Program(sk, ops, i0, i1, i2, out, off), len(off) - 1, levels, deps
+    return helm_amd.Program(sk, ops, i0, i1, i2, out, off), len(off) - 1, levels, None
 
 
 def upload_inputs(ck, wires, index, nw, keys_pt, first_block=0):
@@ -212,6 +231,20 @@ def check_outputs(ck, wires, index, nw, keys_pt, what):
         got = sum(int(dec[b, i]) << i for i in range(128)).to_bytes(16, "big")
         if got != aes128_reference_encrypt(key, pt):
             raise WrongResult(f"{what}: decrypted AES output of block {b} is WRONG")
+
+
+class RcclUnavailable(RuntimeError):
+    pass
+
+
+def _injected_failure():
+    """HELM_BENCH_INJECT_COMM_FAILURE=<step>:<rank> (id | precheck | create): the handshake's failure paths, for
+    tests/test_bench_launcher.py; never set otherwise."""
+    v = os.environ.get("HELM_BENCH_INJECT_COMM_FAILURE")
+    if not v:
+        return None
+    step, rank = v.split(":")
+    return step, int(rank)
 
 
 class _StdoutToStderr:
@@ -252,36 +285,24 @@ class Bench:
         torch.cuda.set_device(local_rank)
         self.comm, self.comm_error = None, None
         if self.world > 1:
-            # control plane (barrier, maximum over the ranks, the communicator's unique id): torch.distributed over gloo;
-            # --overlap drives the collectives from Python on torch's streams and needs torch's own nccl backend instead
-            if self.rehearse or not args.overlap:
-                dist.init_process_group("gloo")
-            else:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            # data path: the library's own RCCL communicator, one rank per GPU (include/helm_comm.h)
-            if not self.rehearse and not args.overlap:
-                from helm_amd import comm as hc
-                ok = torch.tensor([1 if hc.available() else 0])
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank can bind RCCL, or nobody tries
-                if int(ok.item()):
-                    try:
-                        with _StdoutToStderr():
-                            self.comm = hc.Comm.from_torch_dist(dist, local_rank)
-                    except Exception as e:                          # reported in the line; the data path falls back to gloo
-                        self.comm_error = repr(e)
-                else:
-                    self.comm_error = "librccl could not be loaded on every rank"
-                ok = torch.tensor([1 if self.comm is not None else 0])
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if not int(ok.item()) and self.comm is not None:
-                    self.comm.destroy()
-                    self.comm = None
-                    self.comm_error = self.comm_error or "another rank could not create its communicator"
-            if self.rehearse and not args.overlap:
+            from helm_amd import comm as hc
+            # control plane (barrier, maximum over the ranks, the communicator's unique id): torch.distributed over gloo
+            dist.init_process_group("gloo")
+            if self.rehearse and _injected_failure() is None:
                 # the same code path as the real run (helm_hip_program_run_sharded_comm, helm_si_set_exchange_comm), the
                 # library's communicator carried by a host transport because the ranks share the GPU
-                from helm_amd import comm as hc
                 self.comm = hc.Comm.over_torch_dist(dist, local_rank)
+            else:
+                # data path: the library's own RCCL communicator, one rank per GPU (include/helm_comm.h).  Comm.agree: id
+                # from rank 0 (or its error) broadcast unconditionally, local pre-checks agreed on BEFORE anybody enters
+                # ncclCommInitRank (which has no timeout), the outcome agreed on afterwards - every rank gets the same answer
+                with _StdoutToStderr():
+                    self.comm, self.comm_error = hc.Comm.agree(dist, local_rank, _inject=_injected_failure())
+                if self.comm is None:
+                    if not args.allow_host_fallback:
+                        raise RcclUnavailable(f"the RCCL communicator could not be created on every rank ({self.comm_error}); "
+                                              "--allow-host-fallback carries the exchange over gloo instead (not a measurement of the RCCL path)")
+                    self.comm = hc.Comm.over_torch_dist(dist, local_rank)
         elif args.force_comm:
             from helm_amd import comm as hc
             with _StdoutToStderr():
@@ -315,9 +336,13 @@ class Bench:
         a, np, torch, dist = self.args, self.np, self.torch, self.dist
         sharded = kind != "weak" and (self.world > 1 or self.comm is not None)
         blocks = a.blocks * (self.world if kind == "sharded_weak" else 1)   # blocks in this rank's wire table
-        prog, launches, levels, deps = make_program(self.sk, self.circuit, self.wire_names, blocks,
-                                                    self.quantum * (self.world if sharded else 1), pack=not a.no_pack,
-                                                    overlap_split=self.quantum * self.world if (sharded and a.overlap) else 0)
+        # --overlap: launches cut to one lockstep round per rank (the gates of a launch are independent, so any cut is
+        # valid): the sub-launches of one packed launch do not depend on each other, the exchange of one travels while the
+        # next one's bootstraps run
+        prog, launches, levels, _ = make_program(self.sk, self.circuit, self.wire_names, blocks,
+                                                 self.quantum * (self.world if sharded else 1), pack=not a.no_pack,
+                                                 overlap_split=self.quantum * self.world if (sharded and a.overlap) else 0)
+        overlapped = bool(sharded and a.overlap and prog.overlap_applies())
         rng = np.random.default_rng(0x48454C4D + (0 if sharded else self.rank))
         keys_pt = [(bytes(rng.integers(0, 256, 16, dtype=np.uint8)), bytes(rng.integers(0, 256, 16, dtype=np.uint8)))
                    for _ in range(blocks)]
@@ -327,8 +352,8 @@ class Bench:
         wires = self.sk.wires(self.nw * blocks)
         upload_inputs(self.ck, wires, self.index, self.nw, keys_pt)
         runner = ShardedRunner(GpuLevelExecutor(prog, wires), self.rank, self.world if sharded else 1,
-                               dist if sharded else None, time_collective=sharded, depends_on=deps,
-                               comm=self.comm if sharded else None)
+                               dist if sharded else None, time_collective=sharded,
+                               comm=self.comm if sharded else None, overlap=overlapped)
         for _ in range(warmup):
             runner.run()
         self.sync_all()
@@ -344,7 +369,7 @@ class Bench:
         self.sk.timing_enable(False)
         clock_ghz = self.sk.kernel_clock_ghz()
         if self.world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         # correctness of what was timed: every block of this rank's table decrypts to AES(key, pt)
@@ -361,7 +386,7 @@ class Bench:
                                         if sharded else 0.0),
              "collectives_per_step": (int(tm.exchange_count) // steps if (sharded and self.comm is not None)
                                       else len(runner.sharded_levels) if sharded else 0),
-             "overlapped": bool(deps is not None),
+             "overlapped": overlapped,
              "tm": tm, "clock_ghz": clock_ghz}
         if keep:
             r.update(prog=prog, wires=wires, keys_pt=keys_pt)
@@ -413,20 +438,20 @@ def emit(result):
     sys.stdout.flush()
 
 
-def guarded(bench, result, what, fn):
+def watched(world, rank, timeout, result, what, fn):
     """Run one leg under a watchdog: a collective that never comes back must not pass for a finished run.
     On timeout rank 0 prints the line with what it has and the error, and EVERY rank leaves with exit code 3."""
     import threading
-    if bench.world == 1:
+    if world == 1:
         return fn()
     finished = threading.Event()
 
     def watchdog():
-        if not finished.wait(bench.args.leg_timeout):
-            if bench.rank == 0:
-                result["error"] = f"{what}: no answer within {bench.args.leg_timeout:.0f} s (hung collective?)"
+        if not finished.wait(timeout):
+            if rank == 0:
+                result["error"] = f"{what}: no answer within {timeout:.0f} s (hung collective?)"
                 emit(result)
-            sys.stderr.write(f"[bench rank {bench.rank}] {what}: timed out, leaving with exit code 3\n")
+            sys.stderr.write(f"[bench rank {rank}] {what}: timed out, leaving with exit code 3\n")
             sys.stderr.flush()
             os._exit(3)
     threading.Thread(target=watchdog, daemon=True).start()
@@ -434,6 +459,10 @@ def guarded(bench, result, what, fn):
         return fn()
     finally:
         finished.set()
+
+
+def guarded(bench, result, what, fn):
+    return watched(bench.world, bench.rank, bench.args.leg_timeout, result, what, fn)
 
 
 def worker(args):
@@ -450,7 +479,8 @@ def worker(args):
     rc = 0
     bench = None
     try:
-        bench = Bench(args)
+        # the set-up has collectives of its own (process group, the communicator's handshake, ncclCommInitRank)
+        bench = watched(result["n_gpus"], rank, args.leg_timeout, result, "set-up (process group, communicator, keys)", lambda: Bench(args))
         fill_result(bench, result)
     except BaseException as e:  # incl. SystemExit / KeyboardInterrupt: the line carries the error, rc != 0
         import traceback
@@ -493,23 +523,41 @@ def fill_result(bench, result):
     bfly = p.n * (K1 * p.pbs_l + K1) * (p.N // 2) * logN
     macs = p.n * K1 * K1 * p.pbs_l * p.N
     algo_ops = bfly * 8 + macs * 7
-    # What the kernels themselves need at least since round 4 (NOT what `achieved` is priced with): in the lazy field
-    # p = 5072^4 + 1 the first two stages of every forward transform on decomposition digits are a radix-4 butterfly of 10
-    # plain operations per four values (no modular reduction) instead of 4 butterflies x 8
-    machine_ops = algo_ops
-    if bench.sk.field_bits() == 49 and p.N == 512:
-        machine_ops = algo_ops - p.n * (K1 * p.pbs_l) * (2 * (p.N // 2) * 8 - (p.N // 4) * 10)
+    survey_ops = algo_ops
+    # What the algorithm needs on this engine since round 4, and what `achieved` / `frac` are priced with since round 5: in
+    # the fields p = b^4 + 1 the first two stages of every forward transform on decomposition digits are ONE radix-4
+    # butterfly of 10 plain operations per four values (no modular reduction) instead of two stages of N/2 butterflies x 8.
+    # Pricing the kernel with operations it no longer executes (the survey's count, kept as `frac_survey_priced`) would
+    # overstate its fp64 utilisation.
+    if bench.sk.short_root_stages() == 2:
+        algo_ops = survey_ops - p.n * (K1 * p.pbs_l) * (2 * (p.N // 2) * 8 - (p.N // 4) * 10)
     n_cus = quantum // 4
     peak_tops = n_cus * 64 * PEAK_CLOCK_GHZ * 1e9 / 1e12
     achieved_tops = algo_ops * avg_pbs_per_launch / avg_launch_s / 1e12
-    traffic = None
-    if os.path.exists(PMC_TRAFFIC):
-        with open(PMC_TRAFFIC) as f:
-            traffic = json.load(f)
+    survey_tops = survey_ops * avg_pbs_per_launch / avg_launch_s / 1e12
+    # counters of the committed profile (separate rocprofv3 --pmc passes; this run did not collect them): fabric traffic of
+    # the lockstep launches, and the vector instructions a wave issues
+    traffic, traffic_from = _load_profile(PMC_TRAFFIC)
+    issue, issue_from = _load_profile(PMC_ISSUE)
     traffic_bytes = None
     if traffic:
         # bytes per bootstrap measured at the launch size of the committed profile, scaled to this run's average launch
         traffic_bytes = int(traffic["bytes_per_launch"] * avg_pbs_per_launch / traffic["bootstraps_per_launch"])
+    valu_issue = None
+    if issue and tm.pbs_main_launches > 0 and issue.get("params", args.params) == args.params:
+        # lane-instructions the kernel issues per bootstrap (every wave64 vector instruction occupies its SIMD for four
+        # cycles = 64 lane-slots) against the chip's issue capacity = the same 256 x 64 lanes per cycle the fp64 peak counts
+        lane_insts = issue["valu_insts_per_wave"] * issue["waves_per_bootstrap"] * 64
+        issued_tops = lane_insts * avg_pbs_per_launch / avg_launch_s / 1e12
+        valu_issue = {"frac": round(issued_tops / peak_tops, 4),
+                      "frac_at_held_clock": round(issued_tops / (peak_tops * clock_ghz / PEAK_CLOCK_GHZ), 4) if clock_ghz else None,
+                      "valu_insts_per_wave_step": round(issue["valu_insts_per_wave"] / p.n, 1),
+                      "lane_insts_per_bootstrap": int(lane_insts),
+                      "over_algorithmic": round(lane_insts / algo_ops, 3),
+                      "what": "SQ_INSTS_VALU of the lockstep k_pbs x 64 lanes x this run's bootstraps per second over the chip's "
+                              "vector issue capacity (256 CUs x 4 SIMDs x 16 lanes per cycle): how full the issue slots are; "
+                              "the rest of the distance to the peak is instruction overhead (`over_algorithmic`) and clock",
+                      "from_profile": issue_from}
 
     if rank != 0:
         # the other ranks only take part in the remaining runs
@@ -541,9 +589,11 @@ def fill_result(bench, result):
                         "hold whole lockstep rounds); ONE evaluation, what helm.rs:256-262 runs, is `single_block` with its own roofline",
             "parallelism": ("single GPU" if world == 1 else
                             f"launch-shard x{world} + all-gather of launch outputs " +
-                            ("inside the library (ncclAllGather, RCCL)" if bench.comm is not None and bench.comm.info()["rccl_version"] else
-                             "through the library's communicator over a host transport (REHEARSAL on one GPU)" if bench.comm is not None else
-                             "through torch.distributed") + ", keys and wire table replicated" if sharded else
+                            ("inside the library (ncclAllGather, RCCL)" if bench.comm.info()["rccl_version"] else
+                             "through the library's communicator over a HOST TRANSPORT (gloo through host memory; RCCL not used: " +
+                             ("rehearsal on one GPU" if bench.rehearse else "--allow-host-fallback") + ")") +
+                            (", exchange overlapped with independent launches" if head["overlapped"] else "") +
+                            ", keys and wire table replicated" if sharded else
                             f"block-parallel x{world}: independent blocks per GPU, keys replicated, no data-path collective"),
             "sharded_launches": head["sharded_launches"],
             "exchanged_MB_per_step": round(head["exchanged_MB_per_step"], 2),
@@ -566,14 +616,18 @@ def fill_result(bench, result):
             "held_clock_ghz": round(clock_ghz, 3) if clock_ghz else None,
             "frac_at_held_clock": round(achieved_tops / (peak_tops * clock_ghz / PEAK_CLOCK_GHZ), 4) if clock_ghz else None,
             "algorithmic_lane_ops_per_bootstrap": int(algo_ops),
-            "lane_ops_per_bootstrap_the_kernel_needs": int(machine_ops),
-            "frac_priced_at_what_the_kernel_needs": round(achieved_tops * machine_ops / algo_ops / peak_tops, 4),
-            "note_on_the_count": ("`achieved` prices SURVEY 8(d)'s butterflies and multiply-accumulates at 8 / 7 lane-operations, as in every "
-                                  "round; since round 4 the kernel does two of a forward transform's nine stages in 10 operations per four "
-                                  "values (short roots of unity of p = 5072^4 + 1), so part of `frac` is operations it no longer executes"),
+            "frac_survey_priced": round(survey_tops / peak_tops, 4),
+            "survey_lane_ops_per_bootstrap": int(survey_ops),
+            "note_on_the_count": ("`achieved` and `frac` price what the algorithm needs on this engine: SURVEY 8(d)'s butterflies x 8 and "
+                                  "multiply-accumulates x 7 lane-operations, MINUS the two leading stages of every forward transform on digits, "
+                                  "which the b^4 + 1 fields do as one radix-4 butterfly of 10 plain operations per four values (round 4). "
+                                  "`frac_survey_priced` is the figure of rounds 1-4 (the survey's count unchanged): it credits operations the "
+                                  "kernel no longer executes"),
+            "valu_issue": valu_issue,
             "avg_launch_ms": round(avg_launch_s * 1e3, 4), "avg_bootstraps_per_launch": round(avg_pbs_per_launch, 1),
             "traffic": traffic_bytes,
             "traffic_over_algorithmic": round(traffic_bytes / algo_bytes, 2) if traffic_bytes else None,
+            "traffic_from_profile": traffic_from,
             "traffic_source": (traffic or {}).get("source"),
             "hbm": {"achieved": round(algo_bytes / avg_launch_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(algo_bytes / avg_launch_s / 1e9 / HBM_PEAK_GBS, 5),
@@ -583,23 +637,20 @@ def fill_result(bench, result):
         "setup_s": {"keygen_upload": round(bench.t_keys, 2)},
     })
     if world > 1 or bench.comm is not None:
-        if bench.comm is not None:
-            info = bench.comm.info()   # what RCCL itself reports for the library's communicator
-            result["rccl_ranks"] = {"world_size": info["world_size"], "rank_of_this_line": info["rank"], "rccl_version": info["rccl_version"],
-                                    "communicator": ("helm_comm: ncclCommInitRank / ncclAllGather inside libhelm_hip.so (include/helm_comm.h)"
-                                                     if info["rccl_version"] else
-                                                     "helm_comm over a HOST TRANSPORT (gloo through host memory): rehearsal on one GPU, RCCL NOT used"),
-                                    "collectives_issued_by_rank_0": bench.comm.stats()["collectives"],
-                                    "control_plane": (f"torch.distributed {bench.dist.get_backend()} (barrier, max over ranks, unique id)"
-                                                      if world > 1 else "none (one process)"),
-                                    "one_process_per_gpu": not bench.rehearse}
-        else:
-            result["rccl_ranks"] = {"world_size": bench.dist.get_world_size(), "backend": bench.dist.get_backend(),
-                                    "communicator": "torch.distributed (" + ("rehearsal on one GPU" if bench.rehearse else
-                                                    "--overlap" if args.overlap else f"FALLBACK, RCCL not used: {bench.comm_error}") + ")",
-                                    "one_process_per_gpu": not bench.rehearse}
-            if bench.comm_error:
-                result["rccl_error"] = bench.comm_error
+        info = bench.comm.info()   # what RCCL itself reports for the library's communicator
+        over_rccl = bool(info["rccl_version"])
+        result["rccl_ranks"] = {"world_size": info["world_size"], "rank_of_this_line": info["rank"], "rccl_version": info["rccl_version"],
+                                "communicator": ("helm_comm: ncclCommInitRank / ncclAllGather inside libhelm_hip.so (include/helm_comm.h)"
+                                                 if over_rccl else
+                                                 "helm_comm over a HOST TRANSPORT (gloo through host memory), RCCL NOT used: " +
+                                                 ("rehearsal on one GPU" if bench.rehearse else f"--allow-host-fallback after: {bench.comm_error}")),
+                                "collectives_issued_by_rank_0": bench.comm.stats()["collectives"],
+                                "control_plane": (f"torch.distributed {bench.dist.get_backend()} (barrier, max over ranks, unique id)"
+                                                  if world > 1 else "none (one process)"),
+                                "one_process_per_gpu": not bench.rehearse}
+        if bench.comm_error:
+            result["rccl_error"] = bench.comm_error
+            result["not_a_measurement_of_the_rccl_path"] = True
         result[head_kind] = bench.describe(head)   # the headline under its own name as well
     checkpoint(result)
 
@@ -657,6 +708,14 @@ def fill_result(bench, result):
         prog1.destroy()
         checkpoint(result)
 
+    # ---- every BASELINE.json configuration as a wall-clock line (each one circuit, outside the timed region) ----
+    if world == 1 and not args.no_configs:
+        try:
+            result["configs"] = baseline_configs(bench, result)
+        except Exception as e:  # the headline line must survive a failure here
+            result["configs"] = {"error": repr(e)}
+        checkpoint(result)
+
     # ---- CPU baseline: the oracle (a port, not tfhe-rs) on this box's host cores --------
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, bench.ck, bench.circuit, bench.wire_names, bench.index, bench.nw,
@@ -670,6 +729,61 @@ def fill_result(bench, result):
             result["other_modes"] = other_modes(bench.local_rank)
         except Exception as e:  # the headline line must survive a failure here
             result["other_modes"] = {"error": repr(e)}
+        om, cfg = result["other_modes"], result.get("configs")
+        if isinstance(cfg, dict) and "error" not in om:
+            cfg["3_lut_adder_8bit"] = om.pop("lut_adder_8bit", None)
+            am = om["arith_mode_multibit3"]
+            cfg["5_chi_squared_u32"] = {"what": "config 5: chi_squared_arith.v, arithmetic mode u32 under the reference's own multi-bit set (helm.rs:83); "
+                                                "details under other_modes.arith_mode_multibit3 (classical set: other_modes.arith_mode)",
+                                        "wall_s": am["wall_s"], "bootstraps": am["bootstraps"], "rounds_in_a_row": am["rounds_in_a_row"],
+                                        "decrypt_ok": am["decrypt_ok"], "wall_s_classical_set": om["arith_mode"]["wall_s"]}
+
+
+def _one_gates_circuit(bench, path, seed):
+    """One gates-mode circuit through the evaluator API (GateCircuit: encrypt_inputs -> evaluate_encrypted, what
+    helm.rs:242-262 runs): wall-clock of the evaluation, every OUTPUT wire checked against the plaintext evaluator."""
+    from helm_amd import Circuit, GateCircuit, PtxtType, verilog_parser
+    gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_file(path, False)
+    c = Circuit(gates, inputs, outputs, dffs)
+    c.sort_circuit()
+    c.compute_levels()
+    rng = np.random.default_rng(seed)
+    vals = {w: PtxtType.Bool(int(rng.integers(0, 2))) for w in inputs}
+    ptxt = {w: PtxtType.None_() for w in wire_set}
+    ptxt.update(vals)
+    ptxt = c.evaluate(ptxt)
+    gc = GateCircuit(bench.ck, bench.sk, c)
+    enc = gc.encrypt_inputs(wire_set, vals)
+    gc.evaluate_encrypted(enc, 1, "bool")          # warm-up: plans and uploads the program
+    bench.sk.sync()
+    t0 = time.perf_counter()
+    enc = gc.evaluate_encrypted(enc, 2, "bool")    # a new cycle: the same-cycle memo must not answer
+    bench.sk.sync()
+    dt = time.perf_counter() - t0
+    ok = all(bench.ck.decrypt(enc[w]) == bool(ptxt[w].value) for w in outputs)
+    pbs = gc.pbs_per_cycle()
+    return {"netlist": os.path.relpath(path, ROOT), "gates": len(gates), "levels": len(c.level_map()), "bootstraps": int(pbs),
+            "wall_s": round(dt, 5), "gate_bootstraps_per_s": round(pbs / dt, 1), "decrypt_ok": bool(ok)}
+
+
+def baseline_configs(bench, result):
+    """BASELINE.json `configs`, each as ONE circuit evaluation with its wall-clock (config 4 is the headline and
+    `single_block`, config 5 `other_modes.arith_mode`; config 3 is filled in by other_modes(), which owns the 64-bit keys)."""
+    nets = os.path.join(ROOT, "tests", "netlists")
+    res = {}
+    c1 = _one_gates_circuit(bench, os.path.join(nets, "2-bit-adder.v"), 1)
+    c1["what"] = "config 1: 2-bit adder, gates mode (the reference's own CPU-runnable case, here on the GPU path; K-1's netlist)"
+    res["1_2bit_adder_gates"] = c1
+    c2 = _one_gates_circuit(bench, os.path.join(nets, "alu-c880-class.v"), 0x48454C4D)
+    c2["what"] = ("config 2: c880-CLASS STAND-IN (a generated 8-bit ALU netlist of ISCAS'85 c880's size; c880.v itself is not "
+                  "obtainable offline), gates mode, one circuit: its levels are narrower than one bootstrap per CU, so the wall-clock "
+                  "is levels x the latency of one bootstrap chain (k_pbs_wide)")
+    res["2_c880_class_gates"] = c2
+    res["4_aes128_gates"] = {"see": "value (32-block batch) and single_block (ONE evaluation)",
+                             "wall_s": result.get("single_block", {}).get("wall_s"),
+                             "gate_bootstraps_per_s": result.get("single_block", {}).get("gate_bootstraps_per_s"),
+                             "decrypt_ok": True}
+    return res
 
 
 def side_kinds(head_kind):
@@ -882,6 +996,34 @@ def _wide_lut_leg(device):
     return res
 
 
+def _lut_adder_leg(ck, sk):
+    """BASELINE config 3: 8-bit-adder-lut-3-1.v (the reference's LUT test, circuit_test.rs:266-311) as ONE circuit through
+    LutCircuit, wall-clock of the evaluation; every wire must decrypt to the plaintext evaluator's value."""
+    from helm_amd import Circuit, EvalCircuit, LutCircuit, PtxtType, verilog_parser
+    gs, ws, ins, outs, d, _, _ = verilog_parser.read_verilog_file(os.path.join(ROOT, "tests", "netlists", "8-bit-adder-lut-3-1.v"), False)
+    c = Circuit(gs, ins, outs, d)
+    c.sort_circuit()
+    c.compute_levels()
+    a, b, cin = 0xB7, 0x6E, 1
+    inputs = {f"a[{i}]": PtxtType.Bool((a >> i) & 1) for i in range(8)}
+    inputs.update({f"b[{i}]": PtxtType.Bool((b >> i) & 1) for i in range(8)})
+    inputs["cin"] = PtxtType.Bool(cin)
+    ptxt = c.evaluate(c.initialize_wire_map(ws, inputs, "bool"))
+    lc = LutCircuit(ck, sk, c)
+    enc = EvalCircuit.encrypt_inputs(lc, ws, inputs)
+    EvalCircuit.evaluate_encrypted(lc, enc, 1, "bool")
+    sk.sync()
+    t0 = time.perf_counter()
+    out = EvalCircuit.evaluate_encrypted(lc, enc, 2, "bool")
+    sk.sync()
+    dt = time.perf_counter() - t0
+    ok = all(ck.decrypt(out[w]) == int(bool(v)) for w, v in ptxt.items())
+    return {"what": "config 3: 8-bit-adder-lut-3-1.v, LUT mode (3-input look-ups = keyswitch + programmable bootstrap on the 64-bit torus), "
+                    "one circuit: a carry chain of 8 levels x 2 look-ups, so the wall-clock is 8 x the latency of one bootstrap (k_pbs64s)",
+            "netlist": "tests/netlists/8-bit-adder-lut-3-1.v", "luts": int(lc.pbs_per_cycle()), "levels": len(c.level_map()),
+            "wall_s": round(dt, 5), "luts_per_s": round(lc.pbs_per_cycle() / dt, 1), "decrypt_ok": bool(ok)}
+
+
 def _other_modes_set(device, set_name, tfhe_name):
     import helm_amd
     from helm_amd import ArithCircuit, Circuit, PtxtType, verilog_parser
@@ -916,6 +1058,8 @@ def _other_modes_set(device, set_name, tfhe_name):
                         "roofline": si_roofline("k_pbs64s" + (f" (multi-bit, g = {g})" if g > 1 else ""),
                                                 si_algo_ops(p.n, p.k, p.N, p.pbs_l, g), tm.pbs_count, tm.pbs_ms,
                                                 tm.pbs_launches, n_cus, bsk_bytes, io_bytes)}}
+    if set_name == "shortint_m2c2":
+        res["lut_adder_8bit"] = _lut_adder_leg(ck, sk)
     gs, ws, i, o, d, _, _ = verilog_parser.read_verilog_file(os.path.join(ROOT, "tests", "netlists", "chi_squared_arith.v"), True)
     c = Circuit(gs, i, o, d)
     c.sort_circuit()

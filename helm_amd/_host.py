@@ -31,6 +31,7 @@ HOST_API = {
                               [C.POINTER(C.c_int64)] * 3),
     "helm_host_pack_levels_costed": (C.c_int, [C.POINTER(C.c_int32)] * 5 + [C.POINTER(C.c_int64), C.c_int64, C.c_int64,
                                                 C.POINTER(C.c_double)] + [C.POINTER(C.c_int64)] * 3),
+    "helm_host_shard_bounds": (C.c_int64, [C.POINTER(C.c_int32), C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
     "helm_host_enc_map_new": (C.c_int, [vp, C.POINTER(vp)]),
     "helm_host_enc_map_free": (None, [vp]),
     "helm_host_enc_map_insert": (C.c_int, [vp, cp, u32p]),
@@ -48,6 +49,7 @@ HOST_API = {
     "helm_host_gate_circuit_pbs_per_cycle": (C.c_int64, [vp]),
     "helm_host_gate_circuit_memo_hits": (C.c_int64, [vp]),
     "helm_host_gate_circuit_shard_over": (C.c_int, [vp, vp, C.c_int64]),
+    "helm_host_gate_circuit_set_exchange_overlap": (C.c_int, [vp, C.c_int]),
     "helm_host_si_circuit_new": (C.c_int, [C.c_int, vp, vp, vp, C.POINTER(vp)]),
     "helm_host_si_circuit_free": (None, [vp]),
     "helm_host_si_circuit_encrypt_inputs": (C.c_int, [vp, cp, cp, C.POINTER(vp)]),

@@ -107,6 +107,7 @@ HIP_API = {
     "helm_hip_launch_quantum": (C.c_int64, [vp]),
     "helm_hip_launch_costs": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "helm_hip_field_bits": (C.c_int, [vp]),
+    "helm_hip_short_root_stages": (C.c_int, [vp]),
     "helm_hip_load_bootstrap_key": (C.c_int, [vp, u32p, C.c_size_t]),
     "helm_hip_load_keyswitch_key": (C.c_int, [vp, u32p, C.c_size_t]),
     "helm_hip_wires_alloc": (C.c_int, [vp, C.c_int64, C.POINTER(vp)]),
@@ -116,7 +117,9 @@ HIP_API = {
     "helm_hip_wires_set_trivial": (C.c_int, [vp, vp, i32p, u8p, C.c_int64]),
     "helm_hip_wires_copy": (C.c_int, [vp, vp, i32p, vp, i32p, C.c_int64]),
     "helm_hip_program_run_sharded": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp, vp, C.c_int64, HIP_EXCHANGE_FN, vp]),
-    "helm_hip_program_run_sharded_comm": (C.c_int, [vp, vp, vp, vp, C.c_int64]),
+    "helm_hip_program_run_sharded_comm": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int]),
+    "helm_hip_program_overlap_applies": (C.c_int, [vp]),
+    "helm_hip_program_chunk_bounds": (C.c_int, [vp, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
     "helm_hip_wires_device_ptr": (C.c_int, [vp, vp, C.POINTER(vp), i64p]),
     "helm_hip_eval_gate_level": (C.c_int, [vp, vp, i32p, i32p, i32p, i32p, i32p, C.c_int64]),
     "helm_hip_program_create": (C.c_int, [vp, i32p, i32p, i32p, i32p, i32p, i64p, C.c_int64, C.POINTER(vp)]),
@@ -174,6 +177,7 @@ SI_API = {
 COMM_ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp, C.c_size_t, vp)  # helm_comm_all_gather_fn
 COMM_API = {
     "helm_comm_available": (C.c_int, []),
+    "helm_comm_precheck": (C.c_int, [C.c_int]),
     "helm_comm_get_unique_id": (C.c_int, [u8p]),
     "helm_comm_create": (C.c_int, [C.c_int, u8p, C.c_int, C.c_int, C.POINTER(vp)]),
     "helm_comm_create_with_transport": (C.c_int, [C.c_int, C.c_int, C.c_int, COMM_ALL_GATHER_FN, vp, C.POINTER(vp)]),

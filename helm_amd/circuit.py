@@ -151,12 +151,14 @@ class GateCircuit(EvalCircuit):
         """evaluate_encrypted calls answered from the same-cycle memo (reference src/gates.rs:55-59)."""
         return int(H.host.helm_host_gate_circuit_memo_hits(self._h))
 
-    def shard_over(self, comm, replicate_below=256):
+    def shard_over(self, comm, replicate_below=256, overlap=False):
         """Multi-GPU (one process per GPU): split every launch of more than `replicate_below` bootstraps over the ranks of
         `comm` (helm_amd.comm.Comm, the engine's own RCCL communicator) and all-gather the output ciphertexts inside the
         engine - the level of reference src/circuit.rs:531 is the sharded unit.  Same keys, circuit and inputs on every
-        rank; every rank gets the wire map of a one-GPU evaluation.  comm = None: back to one GPU."""
+        rank; every rank gets the wire map of a one-GPU evaluation.  comm = None: back to one GPU.  overlap: the exchange
+        of a launch runs beside the launches that do not need its outputs."""
         H.check(H.host.helm_host_gate_circuit_shard_over(self._h, comm._h if comm is not None else None, int(replicate_below)))
+        H.check(H.host.helm_host_gate_circuit_set_exchange_overlap(self._h, 1 if overlap else 0))
         self._comm = comm  # keep alive
 
 

@@ -23,6 +23,31 @@ def available():
     return bool(hip.helm_comm_available())
 
 
+def precheck(device):
+    """What helm_comm_create needs from this process alone (RCCL bound, the device exists), without entering a
+    collective; raises with the library's message otherwise (include/helm_comm.h: helm_comm_precheck)."""
+    hip_check(hip.helm_comm_precheck(int(device)))
+
+
+_RT = None
+
+
+def _hip_runtime():
+    """The HIP runtime the engine itself is linked against, for the in-process group's device-to-device copies."""
+    global _RT
+    if _RT is None:
+        _RT = C.CDLL("libamdhip64.so")
+        _RT.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        _RT.hipStreamSynchronize.argtypes = [C.c_void_p]
+        _RT.hipSetDevice.argtypes = [C.c_int]
+    return _RT
+
+
+def _rt_check(rc):
+    if rc != 0:
+        raise RuntimeError(f"HIP runtime error {rc}")
+
+
 def unique_id():
     buf = np.zeros(ID_BYTES, dtype=np.uint8)
     hip_check(hip.helm_comm_get_unique_id(nv.as_u8p(buf)))
@@ -49,6 +74,63 @@ class Comm:
         box = [unique_id().tobytes() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         return cls(device, np.frombuffer(box[0], dtype=np.uint8).copy(), rank, world)
+
+    @classmethod
+    def agree(cls, dist, device, _inject=None, _hooks=None):
+        """The RCCL communicator over torch.distributed's control plane, in three steps that EVERY rank finishes whatever
+        fails on one of them - ncclCommInitRank has no timeout, so nobody may enter it unless everybody will:
+          1. rank 0 draws the unique id inside a try and broadcasts (id | error) unconditionally;
+          2. every rank runs its local pre-checks (helm_comm_precheck: RCCL bound, device usable) and the ranks exchange
+             the outcomes; one failure anywhere and nobody goes on;
+          3. ncclCommInitRank (helm_comm_create), the outcomes exchanged once more; a rank that has a communicator while
+             another has none destroys it.
+        -> (Comm, None) on every rank, or (None, reason) on every rank.  `_inject` = (step, rank) makes that rank fail
+        at that step ("id", "precheck", "create"); `_hooks` replaces the three device-touching calls (unique_id, precheck,
+        create): the CPU tests of the handshake (tests/test_comm_handshake.py)."""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        hooks = {"unique_id": unique_id, "precheck": precheck, "create": cls}
+        hooks.update(_hooks or {})
+
+        def fails(step):
+            return _inject is not None and _inject == (step, rank)
+
+        box = [None]
+        if rank == 0:
+            try:
+                if fails("id"):
+                    raise RuntimeError("injected failure: unique id")
+                box = [("id", hooks["unique_id"]().tobytes())]
+            except Exception as e:  # noqa: BLE001 - travels to the other ranks instead of leaving them in the broadcast
+                box = [("error", f"rank 0 could not draw the communicator's id: {e!r}")]
+        dist.broadcast_object_list(box, src=0)
+        kind, payload = box[0]
+        err = payload if kind == "error" else None
+        if err is None:
+            try:
+                if fails("precheck"):
+                    raise RuntimeError("injected failure: precheck")
+                hooks["precheck"](device)
+            except Exception as e:  # noqa: BLE001
+                err = f"rank {rank}: {e!r}"
+        outcomes = [None] * world
+        dist.all_gather_object(outcomes, err)
+        bad = [o for o in outcomes if o]
+        if bad:
+            return None, "; ".join(sorted(set(bad)))
+        comm = None
+        try:
+            if fails("create"):
+                raise RuntimeError("injected failure: create")
+            comm = hooks["create"](device, np.frombuffer(payload, dtype=np.uint8).copy(), rank, world)
+        except Exception as e:  # noqa: BLE001
+            err = f"rank {rank}: {e!r}"
+        dist.all_gather_object(outcomes, err)
+        bad = [o for o in outcomes if o]
+        if bad:
+            if comm is not None:
+                comm.destroy()
+            return None, "; ".join(sorted(set(bad)))
+        return comm, None
 
     @classmethod
     def with_transport(cls, device, rank, world, all_gather):
@@ -96,6 +178,47 @@ class Comm:
                 s.synchronize()
 
         return cls.with_transport(device, rank, world, all_gather)
+
+    @classmethod
+    def in_process_group(cls, devices, timeout=600.0):
+        """One communicator per entry of `devices` for ranks that are THREADS of this process (a host that drives its GPUs
+        from one process, one thread and one engine context per rank; several ranks may share a device): the transport form
+        with an all-gather made of device-to-device copies between the ranks' buffers, a threading.Barrier on either side.
+        Every rank must call the collectives from its own thread.  No RCCL, no torch.  A rank that fails breaks the
+        barrier (`abort_group`), so the others get an error instead of waiting; `timeout` seconds bound every wait.
+        -> [Comm] in rank order."""
+        import threading
+        world = len(devices)
+        rt = _hip_runtime()
+        barrier = threading.Barrier(world, timeout=timeout)
+        sends = [0] * world
+
+        def make(rank, device):
+            def all_gather(send, recv, nbytes, stream):
+                try:
+                    _rt_check(rt.hipSetDevice(int(device)))
+                    _rt_check(rt.hipStreamSynchronize(C.c_void_p(stream)))      # my chunk is complete
+                    sends[rank] = send
+                    barrier.wait()                                             # ... and so is everybody's
+                    for p in range(world):
+                        if sends[p] != recv + p * nbytes:                      # in place: nothing to move for my own slot
+                            _rt_check(rt.hipMemcpyAsync(C.c_void_p(recv + p * nbytes), C.c_void_p(sends[p]), C.c_size_t(nbytes),
+                                                        C.c_int(4), C.c_void_p(stream)))  # hipMemcpyDefault
+                    _rt_check(rt.hipStreamSynchronize(C.c_void_p(stream)))
+                    barrier.wait()                                             # nobody reuses its buffer before all have pulled
+                except BaseException:
+                    barrier.abort()                                            # the other ranks fail instead of waiting for ever
+                    raise
+            c = cls.with_transport(device, rank, world, all_gather)
+            c._group_barrier = barrier
+            return c
+        return [make(r, d) for r, d in enumerate(devices)]
+
+    def abort_group(self):
+        """in_process_group: break the group's barrier so that no other rank thread waits for this one any more."""
+        b = getattr(self, "_group_barrier", None)
+        if b is not None:
+            b.abort()
 
     def info(self):
         """What RCCL reports: rank, world size, device, library version."""

@@ -127,6 +127,17 @@ int helm_comm_available(void)
     return g_rccl.handle ? 1 : 0;
 }
 
+int helm_comm_precheck(int device_id)
+{
+    if (int rc = need_rccl()) return rc;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device_id < 0 || device_id >= n_dev)
+        return helm_hip_fail_(HELM_ERR_NO_DEVICE, "helm_comm_precheck: no such device (" + std::to_string(device_id) + " of " +
+                                                      std::to_string(n_dev) + ")");
+    HIPC_TRY(hipSetDevice(device_id));
+    return 0;
+}
+
 int helm_comm_get_unique_id(uint8_t id[HELM_COMM_ID_BYTES])
 {
     if (!id) return helm_hip_fail_(HELM_ERR_INVALID, "null id");

@@ -14,6 +14,7 @@
 #include "../../include/helm_hip.h"
 #include "../../include/helm_comm.h"
 #include "ntt_fp64.h"
+#include "shard_rule.h"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -2100,6 +2101,7 @@ struct helm_hip_ctx {
     helm_hip_params P{};
     int logN = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t xchg_stream = nullptr; // overlapped exchange: all-gather + scatter of a launch run here (created at first use)
     double *tw_fwd = nullptr, *tw_inv = nullptr;
     double n_inv = 0;
     double *bsk = nullptr;
@@ -2160,7 +2162,26 @@ struct helm_hip_program {
     DevBuf<int32_t> s_rows;
     std::vector<int64_t> sh_pbs_off, sh_ks_off, sh_lin_off, sh_rows_off;
     DevBuf<uint32_t> x_gather; // helm_hip_program_run_sharded_comm: the launches' gather buffer (chunk rows x world)
+    // chunk boundaries of (sh_world): level l's rank r owns gates [sh_bounds[l (world+1) + r], sh_bounds[l (world+1) + r + 1]),
+    // cut by bootstrap weight (shard_rule.h); sh_rows[l] = the largest chunk = rows of one rank's slot in the all-gather
+    std::vector<int64_t> sh_bounds, sh_rows;
+    // overlapped exchange (run_sharded_comm, overlap = 1): for every launch the last EARLIER launch that writes one of
+    // its input rows (-1: none), whether every row is written at most once per pass (otherwise the overlapped schedule
+    // does not apply), a ring of gather buffers and one event per sharded launch recorded behind its scatter
+    std::vector<int64_t> dep;
+    int dep_state = 0; // 0 not computed, 1 usable, -1 a row is written twice per pass
+    DevBuf<uint32_t> x_ring[3];
+    std::vector<hipEvent_t> x_done, x_comp; // per sharded launch: recorded behind its scatter / behind its chunk's kernels
 };
+
+static void release_overlap(helm_hip_program *pr)
+{
+    for (auto &b : pr->x_ring) b.release();
+    for (auto *v : {&pr->x_done, &pr->x_comp}) {
+        for (hipEvent_t e : *v) (void)hipEventDestroy(e);
+        v->clear();
+    }
+}
 
 static bool needs_pbs(int op)
 {
@@ -2253,18 +2274,20 @@ struct TimedScope {
     helm_hip_ctx *ctx;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> *list;
     hipEvent_t a = nullptr, b = nullptr;
-    TimedScope(helm_hip_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> *l) : ctx(c), list(l)
+    hipStream_t on;
+    TimedScope(helm_hip_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> *l) : TimedScope(c, l, c->stream) {}
+    TimedScope(helm_hip_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> *l, hipStream_t s) : ctx(c), list(l), on(s)
     {
         if (ctx->timing) {
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&b);
-            (void)hipEventRecord(a, ctx->stream);
+            (void)hipEventRecord(a, on);
         }
     }
     ~TimedScope()
     {
         if (ctx->timing) {
-            (void)hipEventRecord(b, ctx->stream);
+            (void)hipEventRecord(b, on);
             list->push_back({a, b});
         }
     }
@@ -2817,7 +2840,8 @@ int helm_hip_ctx_destroy(helm_hip_ctx *ctx)
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream || !ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto *l : {&ctx->ev_pbs, &ctx->ev_pbs_main, &ctx->ev_ks, &ctx->ev_lin})
+    if (ctx->xchg_stream) (void)hipStreamSynchronize(ctx->xchg_stream);
+    for (auto *l : {&ctx->ev_pbs, &ctx->ev_pbs_main, &ctx->ev_ks, &ctx->ev_lin, &ctx->ev_xchg})
         for (auto &p : *l) {
             (void)hipEventDestroy(p.first);
             (void)hipEventDestroy(p.second);
@@ -2839,6 +2863,7 @@ int helm_hip_ctx_destroy(helm_hip_ctx *ctx)
         pr->s_lin.release();
         pr->s_rows.release();
         pr->x_gather.release();
+        release_overlap(pr);
         pr->owner = nullptr;
     }
     (void)hipFree(ctx->tw_fwd);
@@ -2854,6 +2879,7 @@ int helm_hip_ctx_destroy(helm_hip_ctx *ctx)
     ctx->d_ks.release();
     ctx->d_lin.release();
     ctx->d_big.release();
+    if (ctx->xchg_stream) (void)hipStreamDestroy(ctx->xchg_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return 0;
@@ -2894,6 +2920,12 @@ int helm_hip_field_bits(const helm_hip_ctx *ctx)
 {
     if (!ctx) return fail(HELM_ERR_INVALID, "null argument");
     return ctx->field;
+}
+
+int helm_hip_short_root_stages(const helm_hip_ctx *ctx)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null argument");
+    return HELM_SHORT_ROOT_STAGES != 0 ? 2 : 0; // both fields of this engine (5072^4 + 1, 6432^4 + 1) have short eighth roots
 }
 
 int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4])
@@ -3300,6 +3332,7 @@ int helm_hip_program_destroy(helm_hip_ctx *ctx, helm_hip_program *prog)
     ctx->child_progs.erase(std::remove(ctx->child_progs.begin(), ctx->child_progs.end(), prog), ctx->child_progs.end());
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->xchg_stream) (void)hipStreamSynchronize(ctx->xchg_stream);
     (void)hipFree(prog->d_pbs);
     (void)hipFree(prog->d_ks);
     (void)hipFree(prog->d_lin);
@@ -3308,6 +3341,7 @@ int helm_hip_program_destroy(helm_hip_ctx *ctx, helm_hip_program *prog)
     prog->s_lin.release();
     prog->s_rows.release();
     prog->x_gather.release();
+    release_overlap(prog);
     delete prog;
     return 0;
 }
@@ -3339,11 +3373,20 @@ int helm_hip_program_run(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wir
     return 0;
 }
 
+// The cut of a level for `world` ranks: shard_rule.h (by bootstrap weight).
 int64_t helm_hip_program_chunk_rows(helm_hip_program *prog, int64_t level, int world)
 {
     if (!prog || level < 0 || level >= prog->n_levels || world <= 0) return -1;
-    const int64_t cnt = prog->off[level + 1] - prog->off[level];
-    return (cnt + world - 1) / world;
+    if (prog->sh_world == world && !prog->sh_rows.empty()) return prog->sh_rows[(size_t)level];
+    std::vector<int64_t> b((size_t)world + 1);
+    return helm_shard::chunk_bounds(prog->op.data() + prog->off[level], prog->off[level + 1] - prog->off[level], world, b.data());
+}
+
+int helm_hip_program_chunk_bounds(helm_hip_program *prog, int64_t level, int world, int64_t *bounds)
+{
+    if (!prog || !bounds || level < 0 || level >= prog->n_levels || world <= 0) return fail(HELM_ERR_INVALID, "bad chunk_bounds arguments");
+    helm_shard::chunk_bounds(prog->op.data() + prog->off[level], prog->off[level + 1] - prog->off[level], world, bounds);
+    return 0;
 }
 
 int64_t helm_hip_program_level_pbs(helm_hip_program *prog, int64_t level)
@@ -3358,16 +3401,23 @@ int64_t helm_hip_program_level_pbs(helm_hip_program *prog, int64_t level)
 static int shard_prepare(helm_hip_ctx *ctx, helm_hip_program *prog, int rank, int world)
 {
     if (prog->sh_rank == rank && prog->sh_world == world) return 0;
+    if (prog->sh_world != world) {
+        prog->sh_rows.clear();
+        prog->sh_world = 0;
+    }
     std::vector<PbsJob> all_pbs;
     std::vector<KsJob> all_ks;
     std::vector<LinJob> all_lin;
     std::vector<int32_t> all_rows;
     std::vector<int64_t> po{0}, ko{0}, lo{0}, ro{0};
+    std::vector<int64_t> bounds((size_t)prog->n_levels * (world + 1)), rows_of((size_t)prog->n_levels);
     LevelPlan pl;
     for (int64_t level = 0; level < prog->n_levels; level++) {
         const int64_t b = prog->off[level], cnt = prog->off[level + 1] - b;
-        const int64_t chunk = (cnt + world - 1) / world;
-        const int64_t g0 = std::min(cnt, chunk * rank), g1 = std::min(cnt, g0 + chunk);
+        int64_t *bd = bounds.data() + (size_t)level * (world + 1);
+        const int64_t chunk = helm_shard::chunk_bounds(prog->op.data() + b, cnt, world, bd);
+        rows_of[(size_t)level] = chunk;
+        const int64_t g0 = bd[rank], g1 = bd[rank + 1];
         if (g1 > g0) {
             if (int rc = plan_level(prog->op.data() + b + g0, prog->in0.data() + b + g0, prog->in1.data() + b + g0,
                                     prog->in2.data() + b + g0, g1 - g0, [&](int64_t g) { return (int32_t)g; }, pl))
@@ -3376,8 +3426,10 @@ static int shard_prepare(helm_hip_ctx *ctx, helm_hip_program *prog, int rank, in
             all_ks.insert(all_ks.end(), pl.ks.begin(), pl.ks.end());
             all_lin.insert(all_lin.end(), pl.lin.begin(), pl.lin.end());
         }
-        // chunks are contiguous: gathered row g = gate g of the level; padding rows are skipped
-        for (int64_t g = 0; g < chunk * world; g++) all_rows.push_back(g < cnt ? prog->out[(size_t)(b + g)] : -1);
+        // rank r's slot of the gathered launch holds its chunk's outputs in gate order, then padding rows (skipped)
+        for (int r = 0; r < world; r++)
+            for (int64_t j = 0; j < chunk; j++)
+                all_rows.push_back(bd[r] + j < bd[r + 1] ? prog->out[(size_t)(b + bd[r] + j)] : -1);
         po.push_back((int64_t)all_pbs.size());
         ko.push_back((int64_t)all_ks.size());
         lo.push_back((int64_t)all_lin.size());
@@ -3385,6 +3437,7 @@ static int shard_prepare(helm_hip_ctx *ctx, helm_hip_program *prog, int rank, in
     }
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // an earlier (rank, world) table may still be in use
+    if (ctx->xchg_stream) HIP_TRY(hipStreamSynchronize(ctx->xchg_stream));
     if (prog->s_pbs.ensure(all_pbs.size()) || prog->s_ks.ensure(all_ks.size()) || prog->s_lin.ensure(all_lin.size()) ||
         prog->s_rows.ensure(all_rows.size()))
         return fail(HELM_ERR_OOM, "shard tables");
@@ -3396,6 +3449,8 @@ static int shard_prepare(helm_hip_ctx *ctx, helm_hip_program *prog, int rank, in
     prog->sh_ks_off.swap(ko);
     prog->sh_lin_off.swap(lo);
     prog->sh_rows_off.swap(ro);
+    prog->sh_bounds.swap(bounds);
+    prog->sh_rows.swap(rows_of);
     prog->sh_rank = rank;
     prog->sh_world = world;
     return 0;
@@ -3417,19 +3472,29 @@ int helm_hip_program_run_level_shard(helm_hip_ctx *ctx, helm_hip_program *prog, 
         return fail(HELM_ERR_INVALID, "bad shard arguments");
     if (int rc = shard_prepare(ctx, prog, rank, world)) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    const int64_t cnt = prog->off[level + 1] - prog->off[level];
-    const int64_t chunk = (cnt + world - 1) / world;
-    const int64_t g0 = std::min(cnt, chunk * rank), g1 = std::min(cnt, g0 + chunk);
+    const int64_t *bd = prog->sh_bounds.data() + (size_t)level * (world + 1);
+    const int64_t chunk = prog->sh_rows[(size_t)level], mine = bd[rank + 1] - bd[rank];
     const size_t row = (size_t)ctx->P.n + 1;
     // padding rows of the staging chunk must be defined (they travel through the all-gather)
-    if (g1 - g0 < chunk)
-        HIP_TRY(hipMemsetAsync(static_cast<uint32_t *>(staging_dev) + row * (size_t)(g1 - g0), 0,
-                               row * (size_t)(chunk - (g1 - g0)) * sizeof(uint32_t), ctx->stream));
-    if (g1 == g0) return 0;
+    if (mine < chunk)
+        HIP_TRY(hipMemsetAsync(static_cast<uint32_t *>(staging_dev) + row * (size_t)mine, 0,
+                               row * (size_t)(chunk - mine) * sizeof(uint32_t), ctx->stream));
+    if (mine == 0) return 0;
     const int64_t pb = prog->sh_pbs_off[level], kb = prog->sh_ks_off[level], lb = prog->sh_lin_off[level];
     return run_level_device(ctx, prog->s_pbs.p + pb, prog->sh_pbs_off[level + 1] - pb, prog->s_ks.p + kb,
                             prog->sh_ks_off[level + 1] - kb, prog->s_lin.p + lb, prog->sh_lin_off[level + 1] - lb, w->d,
                             static_cast<uint32_t *>(staging_dev));
+}
+
+static int scatter_level_on(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, int64_t level, const void *gathered_dev,
+                            hipStream_t stream)
+{
+    const int64_t rb = prog->sh_rows_off[level], rows = prog->sh_rows_off[level + 1] - rb;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)rows), dim3(256), 0, stream, static_cast<const uint32_t *>(gathered_dev),
+                       prog->s_rows.p + rb, w->d, ctx->P.n);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int helm_hip_program_scatter_level(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, int64_t level,
@@ -3441,12 +3506,7 @@ int helm_hip_program_scatter_level(helm_hip_ctx *ctx, helm_hip_program *prog, he
     if (prog->sh_world != world)
         return fail(HELM_ERR_STATE, "scatter_level: run_level_shard / shard_prepare with this world size first");
     HIP_TRY(hipSetDevice(ctx->device));
-    const int64_t rb = prog->sh_rows_off[level], rows = prog->sh_rows_off[level + 1] - rb;
-    if (rows == 0) return 0;
-    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)rows), dim3(256), 0, ctx->stream,
-                       static_cast<const uint32_t *>(gathered_dev), prog->s_rows.p + rb, w->d, ctx->P.n);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return scatter_level_on(ctx, prog, w, level, gathered_dev, ctx->stream);
 }
 
 int helm_hip_program_run_sharded(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, int rank, int world,
@@ -3457,12 +3517,14 @@ int helm_hip_program_run_sharded(helm_hip_ctx *ctx, helm_hip_program *prog, helm
     if (world <= 0 || rank < 0 || rank >= world) return fail(HELM_ERR_INVALID, "bad shard arguments");
     if ((world > 1 || fn) && (!stage_dev || !gather_dev || !fn || capacity_rows <= 0))
         return fail(HELM_ERR_INVALID, "run_sharded: staging buffers and the exchange callback are needed for world > 1");
+    if (world > 1 || fn)
+        if (int rc = shard_prepare(ctx, prog, rank, world)) return rc;
     for (int64_t l = 0; l < prog->n_levels; l++) {
         if ((world == 1 && !fn) || helm_hip_program_level_pbs(prog, l) <= replicate_below) { // one wave of workgroups absorbs it
             if (int rc = helm_hip_program_run(ctx, prog, w, l, l + 1)) return rc;
             continue;
         }
-        const int64_t rows = helm_hip_program_chunk_rows(prog, l, world);
+        const int64_t rows = prog->sh_rows[(size_t)l];
         if (rows > capacity_rows)
             return fail(HELM_ERR_INVALID, "run_sharded: a launch's chunk has " + std::to_string(rows) + " rows, the staging buffer " +
                                               std::to_string(capacity_rows));
@@ -3474,8 +3536,115 @@ int helm_hip_program_run_sharded(helm_hip_ctx *ctx, helm_hip_program *prog, helm
     return 0;
 }
 
+// For every launch the last EARLIER launch that writes one of its input rows (-1: none): what the overlapped exchange
+// waits for.  The overlapped schedule needs every row written at most once per pass (a second writer could overtake the
+// first one's scatter); netlists with state-writing gates fall back to the in-order exchange.
+static void launch_dependencies(helm_hip_program *prog)
+{
+    if (prog->dep_state != 0) return;
+    std::vector<int64_t> producer((size_t)prog->max_row + 1, -1);
+    prog->dep.assign((size_t)prog->n_levels, -1);
+    prog->dep_state = 1;
+    const std::vector<int32_t> *ins[3] = {&prog->in0, &prog->in1, &prog->in2};
+    for (int64_t l = 0; l < prog->n_levels; l++) {
+        int64_t d = -1;
+        for (int64_t g = prog->off[l]; g < prog->off[l + 1]; g++)
+            for (auto *in : ins) {
+                const int32_t r = (*in)[(size_t)g];
+                if (r >= 0) d = std::max(d, producer[(size_t)r]);
+            }
+        prog->dep[(size_t)l] = d;
+        for (int64_t g = prog->off[l]; g < prog->off[l + 1]; g++) {
+            int64_t &pr = producer[(size_t)prog->out[(size_t)g]];
+            if (pr >= 0) prog->dep_state = -1;
+            pr = l;
+        }
+    }
+}
+
+int helm_hip_program_overlap_applies(helm_hip_program *prog)
+{
+    if (!prog) return fail(HELM_ERR_INVALID, "null program");
+    launch_dependencies(prog);
+    return prog->dep_state == 1 ? 1 : 0;
+}
+
+// The overlapped form of the pass below: launch l's chunk is computed on the context's stream into a gather buffer of a
+// ring of three; its all-gather and the scatter into the wire table follow on the context's exchange stream while the
+// main stream goes on with launch l + 1.  A launch waits only for the scatter of the launch it depends on (the exchange
+// stream runs in order, so everything before that one is in the table too); a ring buffer is reused once the exchange
+// stream is through with it.  Replicated launches run on the main stream as before.  Every rank issues the same
+// collectives in the same order (the schedule depends on the program alone).
+static int run_sharded_comm_overlapped(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, helm_comm *comm, int rank,
+                                       int world, int64_t replicate_below, int64_t cap)
+{
+    const size_t row = (size_t)ctx->P.n + 1;
+    if (!ctx->xchg_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->xchg_stream, hipStreamNonBlocking));
+    for (auto &b : prog->x_ring)
+        if (b.ensure((size_t)cap * world * row)) return fail(HELM_ERR_OOM, "gather ring");
+    hipStream_t main = ctx->stream, side = ctx->xchg_stream;
+    std::vector<int64_t> sharded; // launches exchanged so far, in order; x_done[i] is recorded behind the scatter of sharded[i]
+    auto event_of = [&](std::vector<hipEvent_t> &v, size_t i, hipEvent_t *e) -> int {
+        while (v.size() <= i) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            v.push_back(ev);
+        }
+        *e = v[i];
+        return 0;
+    };
+    int rc = 0;
+    size_t waited = 0; // the main stream has already waited for x_done[0 .. waited)
+    for (int64_t l = 0; l < prog->n_levels && !rc; l++) {
+        const int64_t d = prog->dep[(size_t)l];
+        if (d >= 0 && !sharded.empty()) {
+            // the latest exchanged launch at or before d
+            const size_t i = (size_t)(std::upper_bound(sharded.begin(), sharded.end(), d) - sharded.begin());
+            if (i > waited) {
+                if (hipStreamWaitEvent(main, prog->x_done[i - 1], 0) != hipSuccess) rc = fail(HELM_ERR_HIP, "hipStreamWaitEvent");
+                waited = i;
+            }
+        }
+        if (rc) break;
+        if (helm_hip_program_level_pbs(prog, l) <= replicate_below) {
+            rc = helm_hip_program_run(ctx, prog, w, l, l + 1);
+            continue;
+        }
+        const size_t k = sharded.size();
+        if (k >= 3 && k - 3 >= waited) { // the exchange stream must be through with this ring buffer
+            if (hipStreamWaitEvent(main, prog->x_done[k - 3], 0) != hipSuccess) rc = fail(HELM_ERR_HIP, "hipStreamWaitEvent");
+            waited = k - 2;
+        }
+        if (rc) break;
+        uint32_t *gather = prog->x_ring[k % 3].p;
+        const int64_t rows = prog->sh_rows[(size_t)l];
+        uint32_t *slot = gather + (size_t)rank * rows * row;
+        if ((rc = helm_hip_program_run_level_shard(ctx, prog, w, l, rank, world, slot))) break;
+        hipEvent_t computed, ev;
+        if ((rc = event_of(prog->x_comp, k, &computed)) || (rc = event_of(prog->x_done, k, &ev))) break;
+        if (hipEventRecord(computed, main) != hipSuccess || hipStreamWaitEvent(side, computed, 0) != hipSuccess) {
+            rc = fail(HELM_ERR_HIP, "overlapped exchange: event hand-over");
+            break;
+        }
+        {
+            TimedScope t(ctx, &ctx->ev_xchg, side);
+            rc = helm_comm_all_gather(comm, slot, gather, (size_t)rows * row * sizeof(uint32_t), side);
+        }
+        if (rc) break;
+        ctx->tacc.exchange_count++;
+        ctx->tacc.exchange_bytes += rows * (int64_t)(row * sizeof(uint32_t));
+        if ((rc = scatter_level_on(ctx, prog, w, l, gather, side))) break;
+        if (hipEventRecord(ev, side) != hipSuccess) rc = fail(HELM_ERR_HIP, "hipEventRecord");
+        sharded.push_back(l);
+    }
+    // whatever follows on the context's stream sees the whole table; on an error nothing is left in flight either
+    if (!sharded.empty() && sharded.size() > waited) (void)hipStreamWaitEvent(main, prog->x_done[sharded.size() - 1], 0);
+    if (rc) (void)hipStreamSynchronize(side);
+    return rc;
+}
+
 int helm_hip_program_run_sharded_comm(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, helm_comm *comm,
-                                      int64_t replicate_below)
+                                      int64_t replicate_below, int overlap)
 {
     if (int rc = check_program(ctx, prog, w)) return rc;
     if (!comm) return fail(HELM_ERR_INVALID, "run_sharded_comm: null communicator");
@@ -3486,7 +3655,12 @@ int helm_hip_program_run_sharded_comm(helm_hip_ctx *ctx, helm_hip_program *prog,
     const size_t row = (size_t)ctx->P.n + 1;
     int64_t cap = 0;
     for (int64_t l = 0; l < prog->n_levels; l++)
-        if (helm_hip_program_level_pbs(prog, l) > replicate_below) cap = std::max(cap, helm_hip_program_chunk_rows(prog, l, world));
+        if (helm_hip_program_level_pbs(prog, l) > replicate_below) cap = std::max(cap, prog->sh_rows[(size_t)l]);
+    if (overlap && cap > 0) {
+        launch_dependencies(prog);
+        if (prog->dep_state == 1) return run_sharded_comm_overlapped(ctx, prog, w, comm, rank, world, replicate_below, cap);
+        // a row written twice per pass (state-writing gates): the in-order exchange below
+    }
     if (cap > 0 && prog->x_gather.ensure((size_t)cap * world * row)) return fail(HELM_ERR_OOM, "gather buffer");
     for (int64_t l = 0; l < prog->n_levels; l++) {
         if (helm_hip_program_level_pbs(prog, l) <= replicate_below) {
@@ -3494,7 +3668,7 @@ int helm_hip_program_run_sharded_comm(helm_hip_ctx *ctx, helm_hip_program *prog,
             continue;
         }
         // this rank's chunk goes straight into its slot of the gather buffer: ncclAllGather in place
-        const int64_t rows = helm_hip_program_chunk_rows(prog, l, world);
+        const int64_t rows = prog->sh_rows[(size_t)l];
         uint32_t *slot = prog->x_gather.p + (size_t)rank * rows * row;
         if (int rc = helm_hip_program_run_level_shard(ctx, prog, w, l, rank, world, slot)) return rc;
         {

@@ -2446,8 +2446,6 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
     if (P.message_modulus < 2 || P.carry_modulus < 1 || (t & (t - 1)) || t > P.N / 2)
         return fail(HELM_ERR_INVALID, "message_modulus * carry_modulus must be a power of two <= N/2");
     const int group = P.grouping_factor > 1 ? P.grouping_factor : 1;
-    if (group > 1 && P.pbs_logB > 24) // (the multi-bit build only exists as the split kernel, whose stage 1 multiplies digits by b^2 plainly)
-        return fail(HELM_ERR_INVALID, "multi-bit sets need pbs_logB <= 24");
     if (P.grouping_factor < 0 || group > 3 || P.n % group)
         return fail(HELM_ERR_INVALID, "grouping_factor must be 0..3 and divide n");
     if (group > 1 && !(P.pbs_l == 1 && P.N >= 1024))

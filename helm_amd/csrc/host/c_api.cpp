@@ -1,6 +1,7 @@
 // c_api.cpp — flat C view (include/helm_host.h) of the C++ host front end.
 #include "../../../include/helm_host.h"
 #include "helm_host.hpp"
+#include "../shard_rule.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -259,6 +260,15 @@ int helm_host_pack_levels_costed(const int32_t *opcode, const int32_t *in0, cons
     }
 }
 
+int64_t helm_host_shard_bounds(const int32_t *opcode, int64_t count, int world, int64_t *bounds)
+{
+    if ((!opcode && count > 0) || !bounds || count < 0 || world <= 0) {
+        g_err = "shard_bounds: bad argument";
+        return -1;
+    }
+    return helm_shard::chunk_bounds(opcode, count, world, bounds);
+}
+
 int helm_host_enc_map_new(helm_hip_ctx *server_key, helm_enc_map **out)
 {
     return guard([&] {
@@ -307,6 +317,10 @@ int64_t helm_host_gate_circuit_pbs_per_cycle(const helm_gate_circuit *gc) { retu
 int helm_host_gate_circuit_shard_over(helm_gate_circuit *gc, helm_comm *comm, int64_t replicate_below)
 {
     return guard([&] { gc->gc->shard_over(comm, replicate_below); });
+}
+int helm_host_gate_circuit_set_exchange_overlap(helm_gate_circuit *gc, int on)
+{
+    return guard([&] { gc->gc->set_exchange_overlap(on != 0); });
 }
 int64_t helm_host_gate_circuit_memo_hits(const helm_gate_circuit *gc) { return gc->gc->memo_hits(); }
 

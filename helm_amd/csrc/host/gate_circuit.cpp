@@ -382,7 +382,7 @@ std::unique_ptr<EncWireMap> GateCircuit::evaluate_encrypted(const EncWireMap &en
     std::ostringstream os;
     if (comm_) {
         // every launch of more than replicate_below_ bootstraps split over the ranks, outputs all-gathered inside the engine
-        hip_ok(helm_hip_program_run_sharded_comm(server_key_, prog_, eval_values->table(), comm_, replicate_below_), "program_run_sharded_comm");
+        hip_ok(helm_hip_program_run_sharded_comm(server_key_, prog_, eval_values->table(), comm_, replicate_below_, overlap_ ? 1 : 0), "program_run_sharded_comm");
         os << "  Evaluated gates of " << total_levels << " levels in " << prog_launches_ << " launches sharded over " << comm_world_
            << " rank(s)\n";
     } else if (!packed_) {

@@ -254,6 +254,8 @@ class GateCircuit : public EvalCircuit<EncWireMap> {
     // the engine (helm_hip_program_run_sharded_comm, include/helm_comm.h) - the level of circuit.rs:531 is the sharded
     // unit.  Every rank ends with the wire map of a one-GPU evaluation.  comm = nullptr: back to one GPU.
     void shard_over(helm_comm *comm, int64_t replicate_below);
+    // the exchange of a launch overlapped with the launches that do not need its outputs (run_sharded_comm, overlap = 1)
+    void set_exchange_overlap(bool on) { overlap_ = on; }
 
   private:
     helm_client_key *client_key_;
@@ -271,6 +273,7 @@ class GateCircuit : public EvalCircuit<EncWireMap> {
     helm_comm *comm_ = nullptr;      // shard_over(): the engine's RCCL communicator, or null
     int comm_world_ = 1;
     int64_t replicate_below_ = 256;
+    bool overlap_ = false;
     bool packed_ = false; // the program's launches are packed rounds, not the circuit's levels
     std::string log_;
     // Same cycle AND the very input map (unmodified): the cached wire map is returned without a launch.  The

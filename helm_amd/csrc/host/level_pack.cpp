@@ -124,7 +124,8 @@ int pack_levels(const int32_t *op, const int32_t *in0, const int32_t *in1, const
         if (!tail[(size_t)g]) unreleased += pbs_cost(op[g]);
     auto pick_target = [&](int64_t ready, int64_t waiting) -> int64_t {
         if (ready >= quantum) return ready / quantum * quantum;
-        if (!quarter_cost || quantum < 4 || waiting < quantum) return ready;
+        // (quantum < 8: a quarter step could be ONE bootstrap, below the two a ready MUX costs - the launch would be empty)
+        if (!quarter_cost || quantum < 8 || waiting < quantum) return ready;
         auto cost = [&](int64_t w) { return quarter_cost[std::min<int64_t>(3, (4 * w - 1) / quantum)]; };
         int64_t best = ready;
         double best_rate = (double)ready / cost(ready);

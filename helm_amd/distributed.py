@@ -37,6 +37,10 @@ class GpuLevelExecutor:
     def level_pbs(self, level):
         return self.program.level_pbs(level)
 
+    def chunk_rows(self, level, world):
+        """Rows of one rank's slot in the level's all-gather (the largest chunk of the weight-balanced cut)."""
+        return self.program.chunk_rows(level, world)
+
     def new_buffer(self, rows):
         return self.torch.empty((rows, self.row_words), dtype=self.torch.int32, device=self.device)
 
@@ -76,8 +80,8 @@ class GpuLevelExecutor:
         self.program.run_sharded(self.wires, rank, world, stage.data_ptr(), gather.data_ptr(), capacity_rows, exchange,
                                  replicate_below)
 
-    def run_sharded_comm(self, comm, replicate_below):
-        self.program.run_sharded_comm(self.wires, comm, replicate_below)
+    def run_sharded_comm(self, comm, replicate_below, overlap=False):
+        self.program.run_sharded_comm(self.wires, comm, replicate_below, overlap)
 
     def exchange_ms(self, reset=False):
         """Device time of the in-library all-gathers (helm_hip_timing.exchange_ms; needs timing_enable)."""
@@ -96,11 +100,14 @@ class ShardedRunner:
     stage -> all-gather -> scatter (the single-GPU test of the path over real RCCL)."""
 
     def __init__(self, executor, rank=0, world=1, dist=None, replicate_below=256, time_collective=False, depends_on=None,
-                 ring=3, in_library=False, comm=None, force=False):
+                 ring=3, in_library=False, comm=None, force=False, overlap=False):
         """depends_on (optional, one entry per launch: the last EARLIER launch whose outputs this one reads, -1 for
         none; `launch_dependencies`) switches the overlapped schedule on: a sharded launch's all-gather and scatter go
-        to a side stream and the next launches run meanwhile, each waiting only for the launch it depends on."""
+        to a side stream and the next launches run meanwhile, each waiting only for the launch it depends on.
+        With a `comm`, `overlap=True` asks the library for the same schedule natively (helm_hip_program_run_sharded_comm,
+        overlap = 1: dependency table, second stream and events all inside libhelm_hip.so)."""
         self.ex, self.rank, self.world, self.dist, self.comm = executor, rank, world, dist, comm
+        self.overlap = bool(overlap) and comm is not None
         self.replicate_below = replicate_below
         active = world > 1 or bool(force) or comm is not None
         self.active = active
@@ -126,7 +133,7 @@ class ShardedRunner:
                     self.sharded_levels.append(l)
             if hasattr(executor, "shard_prepare"):
                 executor.shard_prepare(rank, world)
-            rows = max([-(-executor.level_count(l) // world) for l in self.sharded_levels], default=0)
+            rows = max([self._rows(l) for l in self.sharded_levels], default=0)
             if rows:
                 self._stage = executor.new_buffer(rows)
                 self._gather = executor.new_buffer(rows * world)
@@ -137,8 +144,17 @@ class ShardedRunner:
                               for _ in range(self._ring_size)]
         self._sharded = set(self.sharded_levels)
 
+    def _rows(self, level):
+        """Rows one rank contributes to the level's all-gather: the executor's own cut when it has one (the engine cuts by
+        bootstrap weight, helm_amd/csrc/shard_rule.h), contiguous chunks by gate count otherwise."""
+        if hasattr(self.ex, "chunk_rows"):
+            return int(self.ex.chunk_rows(level, self.world))
+        return -(-self.ex.level_count(level) // self.world)
+
     def run(self):
         if self.comm is not None:
+            if self.overlap:
+                return self.ex.run_sharded_comm(self.comm, self.replicate_below, True)
             return self.ex.run_sharded_comm(self.comm, self.replicate_below)
         if self.in_library and self.sharded_levels:
             rows_cap = self._stage.shape[0]
@@ -154,7 +170,7 @@ class ShardedRunner:
             if l not in self._sharded:
                 ex.run_level(l)
                 continue
-            rows = -(-ex.level_count(l) // self.world)
+            rows = self._rows(l)
             stage = self._stage[:rows]
             gathered = self._gather[:rows * self.world]
             ex.run_level_shard(l, self.rank, self.world, stage)
@@ -189,7 +205,7 @@ class ShardedRunner:
             if l not in self._sharded:
                 ex.run_level(l)
                 continue
-            rows = -(-ex.level_count(l) // self.world)
+            rows = self._rows(l)
             stage_full, gather_full, free = self._ring[k % self._ring_size]
             if k >= self._ring_size:
                 main.wait_event(free)  # the side stream has finished with this pair
@@ -236,7 +252,7 @@ class ShardedRunner:
 
     def exchanged_bytes_per_pass(self):
         ex = self.ex
-        return sum(-(-ex.level_count(l) // self.world) * self.world * ex.row_words * 4 for l in self.sharded_levels)
+        return sum(self._rows(l) * self.world * ex.row_words * 4 for l in self.sharded_levels)
 
 
 def level_arrays(circuit, index):
@@ -290,6 +306,24 @@ def gate_pbs(opcode):
     w[op == 3] = 2                                   # HELM_GATE_MUX
     w[np.isin(op, (1, 6, 10, 11, 12))] = 0           # DFF, NOT, BUF, constants
     return w
+
+
+def shard_bounds(opcode, world):
+    """The engine's cut of one launch into `world` contiguous chunks (helm_amd/csrc/shard_rule.h, mirrored here for
+    hosts and executors outside the library): by BOOTSTRAP weight - bounds[r] is the first gate at which the bootstraps
+    before it reach r / world of the launch's total; a launch without bootstraps is cut by gate count.
+    -> (bounds[0 .. world], rows of the largest chunk)"""
+    w = gate_pbs(opcode)
+    cnt, total = len(w), int(w.sum())
+    if total == 0:
+        chunk = -(-cnt // world)
+        b = np.minimum(np.arange(world + 1, dtype=np.int64) * chunk, cnt)
+    else:
+        before = np.concatenate([[0], np.cumsum(w)])       # bootstraps of gates [0, g)
+        # the first g with before[g] * world >= total * r
+        b = np.searchsorted(before * world, total * np.arange(world + 1, dtype=np.int64), side="left").astype(np.int64)
+        b[0], b[world] = 0, cnt
+    return b, int(np.max(np.diff(b))) if world > 0 else 0
 
 
 def split_launches(opcode, launch_offsets, max_pbs):

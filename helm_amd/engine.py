@@ -180,6 +180,13 @@ class ServerKey:
             hip_check(v)
         return v
 
+    def short_root_stages(self):
+        """Leading forward-transform stages on digits done as one radix-4 butterfly of plain operations (helm_hip_short_root_stages)."""
+        v = int(hip.helm_hip_short_root_stages(self._h))
+        if v < 0:
+            hip_check(v)
+        return v
+
     def kernel_clock_ghz(self):
         """Shader clock held during the most recent k_pbs launch (None before the first one)."""
         g, ms = C.c_double(), C.c_double()
@@ -281,6 +288,15 @@ class Program:
     def chunk_rows(self, level, world):
         return int(hip.helm_hip_program_chunk_rows(self._h, level, world))
 
+    def chunk_bounds(self, level, world):
+        """The cut of a launch for `world` ranks, by bootstrap weight: rank r owns gates bounds[r] .. bounds[r+1]."""
+        b = np.zeros(world + 1, dtype=np.int64)
+        hip_check(hip.helm_hip_program_chunk_bounds(self._h, level, world, nv.as_i64p(b)))
+        return b
+
+    def overlap_applies(self):
+        return bool(hip.helm_hip_program_overlap_applies(self._h))
+
     def shard_prepare(self, rank, world):
         hip_check(hip.helm_hip_program_shard_prepare(self.sk._h, self._h, rank, world))
 
@@ -302,12 +318,14 @@ class Program:
         hip_check(hip.helm_hip_program_run_sharded(self.sk._h, self._h, wires._h, int(rank), int(world), int(replicate_below),
                                                    nv.vp(stage_ptr), nv.vp(gather_ptr), int(capacity_rows), fn, None))
 
-    def run_sharded_comm(self, wires, comm, replicate_below=256):
+    def run_sharded_comm(self, wires, comm, replicate_below=256, overlap=False):
         """The whole sharded pass with the collective inside the library too (helm_hip_program_run_sharded_comm): every
         launch of more than `replicate_below` bootstraps is computed into this rank's slot of the program's gather
         buffer, all-gathered in place with ncclAllGather through `comm` (helm_amd.comm.Comm) on the engine's stream and
-        scattered into the replicated wire table."""
-        hip_check(hip.helm_hip_program_run_sharded_comm(self.sk._h, self._h, wires._h, comm._h, int(replicate_below)))
+        scattered into the replicated wire table.  overlap: all-gather + scatter on the engine's exchange stream while the
+        launches that do not need them run (same wire table)."""
+        hip_check(hip.helm_hip_program_run_sharded_comm(self.sk._h, self._h, wires._h, comm._h, int(replicate_below),
+                                                        1 if overlap else 0))
 
     def scatter_level(self, wires, level, world, gathered_ptr):
         hip_check(hip.helm_hip_program_scatter_level(self.sk._h, self._h, wires._h, level, world,

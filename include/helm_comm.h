@@ -38,6 +38,12 @@ typedef struct helm_comm helm_comm;
 
 /* 1 when an RCCL library could be bound in this process, 0 otherwise (never touches a device). */
 int helm_comm_available(void);
+/* Everything helm_comm_create() needs from THIS process alone, checked without entering a collective: an RCCL library
+ * is bound, `device_id` exists and can be made current.  ncclCommInitRank blocks until every rank of the world has
+ * entered it and has no timeout, so a host must not let one rank fail locally while the others go in: every rank calls
+ * this first, the ranks agree on the results over their control plane (bench.py / helm_amd.comm.Comm.agree: a
+ * MIN-reduce), and only then does anybody call helm_comm_create().  0 when the rank is ready. */
+int helm_comm_precheck(int device_id);
 /* ncclGetUniqueId: rank 0 calls it and sends the 128 bytes to the other ranks by any means it has
  * (a file, a socket, MPI, a host framework's key-value store). */
 int helm_comm_get_unique_id(uint8_t id[HELM_COMM_ID_BYTES]);

@@ -127,6 +127,11 @@ int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4]);
  * the 51-bit field.  Results do not depend on it (exact integer arithmetic either way); reported by benchmarks because the
  * operation count of the kernels does.  Negative on error. */
 int helm_hip_field_bits(const helm_hip_ctx *ctx);
+/* Number of leading stages of every forward transform on decomposition digits that run as plain multiplications by short
+ * roots of unity (2 in both fields of this engine: one radix-4 butterfly of 10 operations per four values instead of two
+ * stages of modular butterflies; 0 when built with -DHELM_SHORT_ROOT_STAGES=0).  For benchmarks that count the operations
+ * the kernels execute; results do not depend on it. */
+int helm_hip_short_root_stages(const helm_hip_ctx *ctx);
 
 /* -- keys ------------------------------------------------------------------ */
 /* Replaces convert_lwe_bootstrap_key / convert_lwe_keyswitch_key (reference
@@ -182,6 +187,13 @@ int helm_hip_program_run(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wir
 /* Multi-GPU: this rank evaluates the contiguous slice `rank` of `world` of the
  * level's gates and packs the slice's output ciphertexts into `staging`
  * (device memory, chunk_rows(level, world) rows of n+1 words, zero padded).
+ * The level is cut by BOOTSTRAP WEIGHT, not by gate count (binary gate 1, MUX 2,
+ * NOT / BUF / DFF / constants 0: SURVEY 8(d)'s count), so that every rank gets
+ * the same number of bootstraps to within one gate whatever the mix of a level:
+ * helm_hip_program_chunk_bounds() returns the cut (bounds[r] .. bounds[r+1] are
+ * rank r's gates, world + 1 entries), chunk_rows() the largest chunk = the rows
+ * of one rank's slot in the all-gather.  rayon balances the same loop
+ * dynamically in the reference (circuit.rs:531).
  * After an all-gather of the staging buffers (RCCL, driven by the caller),
  * helm_hip_program_scatter_level() writes all `world` chunks into the wire
  * table.  Keys and the wire table are replicated on every rank.
@@ -190,6 +202,7 @@ int helm_hip_program_run(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wir
  * run_level_shard() - so that the per-level calls only launch kernels. */
 int helm_hip_program_shard_prepare(helm_hip_ctx *ctx, helm_hip_program *prog, int rank, int world);
 int64_t helm_hip_program_chunk_rows(helm_hip_program *prog, int64_t level, int world);
+int helm_hip_program_chunk_bounds(helm_hip_program *prog, int64_t level, int world, int64_t *bounds);
 int helm_hip_program_run_level_shard(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w,
                                      int64_t level, int rank, int world, void *staging_dev);
 int helm_hip_program_scatter_level(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w,
@@ -210,10 +223,17 @@ int helm_hip_program_run_sharded(helm_hip_ctx *ctx, helm_hip_program *prog, helm
  * (include/helm_comm.h: an RCCL communicator created by the library; rank and world are the communicator's) and scattered
  * into the replicated wire table.  No callback, no host framework: what a Rust host and bench.py call.  world = 1 is valid and still
  * sends every launch of more than replicate_below bootstraps through stage -> ncclAllGather -> scatter (the path's
- * single-GPU test).  With timing enabled the all-gathers are bracketed by events (helm_hip_timing.exchange_ms). */
+ * single-GPU test).  With timing enabled the all-gathers are bracketed by events (helm_hip_timing.exchange_ms).
+ * overlap != 0: the exchange of a launch overlaps the launches that do not need its outputs - the chunk is computed on
+ * the context's stream into one of three gather buffers, its ncclAllGather and the scatter run on a second stream of the
+ * context, and a later launch waits (an event) only for the scatter of the last launch that writes one of its inputs;
+ * the dependency table comes from the program itself.  Same wire table, bit for bit.  Needs every wire written at most
+ * once per pass (helm_hip_program_overlap_applies() == 1; otherwise the call falls back to the in-order exchange). */
 struct helm_comm;
 int helm_hip_program_run_sharded_comm(helm_hip_ctx *ctx, helm_hip_program *prog, helm_hip_wires *w, struct helm_comm *comm,
-                                      int64_t replicate_below);
+                                      int64_t replicate_below, int overlap);
+/* 1 when the overlapped exchange applies to this program (no wire written twice per pass), 0 otherwise. */
+int helm_hip_program_overlap_applies(helm_hip_program *prog);
 /* Number of programmable bootstraps a level costs (binary gate 1, MUX 2, others 0). */
 int64_t helm_hip_program_level_pbs(helm_hip_program *prog, int64_t level);
 

@@ -85,6 +85,13 @@ int helm_host_pack_levels_costed(const int32_t *opcode, const int32_t *in0, cons
                                  const int32_t *out, const int64_t *level_offsets, int64_t n_levels, int64_t quantum,
                                  const double *quarter_cost, int64_t *order, int64_t *new_offsets, int64_t *n_launches);
 
+/* The engine's cut of one launch into `world` contiguous chunks, one per GPU (helm_amd/csrc/shard_rule.h; what
+ * helm_hip_program_chunk_bounds() returns for an uploaded program): by BOOTSTRAP weight - binary gate 1, MUX 2, NOT / BUF /
+ * DFF / constants 0 - so that a sharded launch gives every rank the same number of bootstraps to within one gate
+ * (the reference balances the level dynamically, circuit.rs:531 `par_iter_mut`).  bounds has world + 1 entries;
+ * returns the largest chunk (rows of one rank's slot in the all-gather), -1 on bad arguments. */
+int64_t helm_host_shard_bounds(const int32_t *opcode, int64_t count, int world, int64_t *bounds);
+
 /* encrypted wire maps */
 int helm_host_enc_map_new(helm_hip_ctx *server_key, helm_enc_map **out);
 void helm_host_enc_map_free(helm_enc_map *m);
@@ -122,6 +129,9 @@ int64_t helm_host_gate_circuit_memo_hits(const helm_gate_circuit *gc);
  * comm = NULL: back to one GPU. */
 struct helm_comm;
 int helm_host_gate_circuit_shard_over(helm_gate_circuit *gc, struct helm_comm *comm, int64_t replicate_below);
+/* on != 0: a launch's all-gather + scatter run on the engine's exchange stream while the launches that do not need its
+ * outputs go on (helm_hip_program_run_sharded_comm, overlap = 1); same wire map. */
+int helm_host_gate_circuit_set_exchange_overlap(helm_gate_circuit *gc, int on);
 
 /* ---- LUT mode / arithmetic mode (include/helm_shortint.h) ------------------------------
  * LutCircuit (circuit.rs:969-1120) and ArithCircuit (circuit.rs:1112-1500); `mode` 0 = LUT,

@@ -101,6 +101,7 @@ extern "C" {
     pub fn helm_hip_sync(ctx: *mut helm_hip_ctx) -> c_int;
     pub fn helm_hip_launch_quantum(ctx: *const helm_hip_ctx) -> i64;
     pub fn helm_hip_launch_costs(ctx: *const helm_hip_ctx, cost: *mut f64) -> c_int;
+    pub fn helm_hip_short_root_stages(ctx: *const helm_hip_ctx) -> c_int;
     pub fn helm_hip_field_bits(ctx: *const helm_hip_ctx) -> c_int;
     pub fn helm_hip_load_bootstrap_key(ctx: *mut helm_hip_ctx, bsk_std: *const u32, n_words: usize) -> c_int;
     pub fn helm_hip_load_keyswitch_key(ctx: *mut helm_hip_ctx, ksk: *const u32, n_words: usize) -> c_int;
@@ -126,10 +127,13 @@ extern "C" {
 
     // the same pass with the collective inside the library: ncclAllGather through a communicator of include/helm_comm.h
     pub fn helm_hip_program_run_sharded_comm(ctx: *mut helm_hip_ctx, prog: *mut helm_hip_program, w: *mut helm_hip_wires,
-                                             comm: *mut helm_comm, replicate_below: i64) -> c_int;
+                                             comm: *mut helm_comm, replicate_below: i64, overlap: c_int) -> c_int;
+    pub fn helm_hip_program_overlap_applies(prog: *mut helm_hip_program) -> c_int;
+    pub fn helm_hip_program_chunk_bounds(prog: *mut helm_hip_program, level: i64, world: c_int, bounds: *mut i64) -> c_int;
 
     // ---- include/helm_comm.h: the library's own RCCL communicator (one process per GPU) --------
     pub fn helm_comm_available() -> c_int;
+    pub fn helm_comm_precheck(device_id: c_int) -> c_int;
     pub fn helm_comm_get_unique_id(id: *mut u8) -> c_int;
     pub fn helm_comm_create(device_id: c_int, id: *const u8, rank: c_int, world: c_int, out: *mut *mut helm_comm) -> c_int;
     // a communicator over a transport the host brings (MPI, ...) instead of RCCL

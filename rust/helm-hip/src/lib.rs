@@ -41,6 +41,7 @@ pub struct HipGateCircuit<'a> {
     pub(crate) comm: *mut sys::helm_comm,
     pub(crate) world: i32,
     pub(crate) replicate_below: i64,
+    pub(crate) overlap: bool, // a launch's all-gather + scatter beside the launches that do not need its outputs
 }
 
 pub(crate) fn check(rc: i32) {
@@ -91,7 +92,7 @@ impl<'a> HipGateCircuit<'a> {
         HipGateCircuit {
             circuit, client_key, ctx, wires: std::ptr::null_mut(), prog: std::ptr::null_mut(),
             row_of: HashMap::new(), n_launches: 0, lwe_words: std_keys.params.n as usize + 1,
-            comm: std::ptr::null_mut(), world: 1, replicate_below: 256,
+            comm: std::ptr::null_mut(), world: 1, replicate_below: 256, overlap: false,
         }
     }
 
@@ -184,7 +185,7 @@ impl<'a> EvalCircuit<DeviceWire> for HipGateCircuit<'a> {
             check(unsafe { sys::helm_hip_program_run(self.ctx, self.prog, self.wires, 0, self.n_launches) });
         } else {
             // launches split over the ranks, outputs all-gathered with ncclAllGather inside the library (multi_gpu.rs)
-            check(unsafe { sys::helm_hip_program_run_sharded_comm(self.ctx, self.prog, self.wires, self.comm, self.replicate_below) });
+            check(unsafe { sys::helm_hip_program_run_sharded_comm(self.ctx, self.prog, self.wires, self.comm, self.replicate_below, self.overlap as std::os::raw::c_int) });
         }
         check(unsafe { sys::helm_hip_sync(self.ctx) });
         enc_wire_map.clone() // rows are stable; the values changed in HBM

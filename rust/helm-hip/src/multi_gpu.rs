@@ -67,6 +67,12 @@ impl<'a> crate::HipGateCircuit<'a> {
         self.world = comm.rank_and_world().1;
         self.replicate_below = replicate_below;
     }
+
+    /// Overlap a launch's exchange with the launches that do not read its outputs (helm_hip_program_run_sharded_comm,
+    /// overlap = 1: second stream, ring of gather buffers and dependency events inside the engine).  Same wire table.
+    pub fn set_exchange_overlap(&mut self, on: bool) {
+        self.overlap = on;
+    }
 }
 
 impl<'a> crate::lut::HipLutCircuit<'a> {

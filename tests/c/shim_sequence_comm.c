@@ -106,7 +106,7 @@ int main(int argc, char **argv)
 
     /* evaluate_encrypted, sharded: every launch through the communicator; and the one-GPU pass next to it */
     CHECK(helm_hip_timing_enable(ctx, 1), "helm_hip_timing_enable");
-    CHECK(helm_hip_program_run_sharded_comm(ctx, prog, wires[0], comm, 0), "helm_hip_program_run_sharded_comm");
+    CHECK(helm_hip_program_run_sharded_comm(ctx, prog, wires[0], comm, 0, 0), "helm_hip_program_run_sharded_comm");
     CHECK(helm_hip_program_run(ctx, prog, wires[1], 0, n_launch), "helm_hip_program_run");
     CHECK(helm_hip_sync(ctx), "helm_hip_sync");
     helm_hip_timing tm;

@@ -84,3 +84,23 @@ def test_rehearsal_two_ranks_on_one_gpu_reports_every_named_result():
     assert line["strong"]["value"] == line["value"]
     assert line["weak"]["exchanged_MB_per_step"] == 0 and line["sharded_weak"]["sharded_launches"] > 0
     assert line["sharded_weak"]["bootstraps_per_step"] == 2 * line["strong"]["bootstraps_per_step"]
+
+
+@pytest.mark.gpu
+def test_rccl_unavailable_on_one_rank_fails_loudly_unless_the_host_fallback_is_allowed():
+    """A rank that cannot get its RCCL communicator (here: an injected pre-check failure on rank 1; nobody enters
+    ncclCommInitRank) must not turn into a run over gloo that looks like a result: value null, the error, rc != 0 -
+    every rank leaves, nobody hangs.  --allow-host-fallback: the run goes through over the host transport, rc 0, and the
+    line says what it is."""
+    env = {"HELM_BENCH_REHEARSE": "1", "HELM_BENCH_INJECT_COMM_FAILURE": "precheck:1"}
+    args = ["--gpus", "2", "--steps", "1", "--warmup", "0", "--blocks", "1", "--no-side-legs", "--leg-timeout", "300"]
+    rc, lines, err = run_bench(args, env, timeout=600)
+    assert rc != 0, err[-2000:]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["value"] is None and "RCCL communicator could not be created" in line["error"] and "injected failure: precheck" in line["error"]
+    rc, lines, err = run_bench(args + ["--allow-host-fallback"], env, timeout=900)
+    assert rc == 0, err[-3000:]
+    line = json.loads(lines[0])
+    assert line["value"] > 0 and "injected failure: precheck" in line["rccl_error"] and line["not_a_measurement_of_the_rccl_path"] is True
+    assert line["rccl_ranks"]["rccl_version"] == 0 and "--allow-host-fallback" in line["rccl_ranks"]["communicator"]

@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 import helm_amd
 import oracle
 from helm_amd import Circuit, verilog_parser
-from helm_amd.distributed import ShardedRunner, level_arrays
+from helm_amd.distributed import ShardedRunner, level_arrays, shard_bounds
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -43,11 +43,16 @@ class OracleExecutor:
         s = slice(self.off[l], self.off[l + 1])
         self.orc.eval_level(self.wires, self.ops[s], self.i0[s], self.i1[s], self.i2[s], self.out[s], nthreads=1)
 
+    def _bounds(self, l, world):
+        """The engine's cut: by bootstrap weight (helm_amd/csrc/shard_rule.h, mirrored by distributed.shard_bounds)."""
+        return shard_bounds(self.ops[self.off[l]:self.off[l + 1]], world)
+
+    def chunk_rows(self, l, world):
+        return self._bounds(l, world)[1]
+
     def run_level_shard(self, l, rank, world, staging):
-        cnt = self.level_count(l)
-        chunk = -(-cnt // world)
-        g0 = min(cnt, chunk * rank)
-        g1 = min(cnt, g0 + chunk)
+        b, _ = self._bounds(l, world)
+        g0, g1 = int(b[rank]), int(b[rank + 1])
         staging.zero_()
         if g1 > g0:
             s = slice(self.off[l] + g0, self.off[l] + g1)
@@ -56,9 +61,11 @@ class OracleExecutor:
             staging[:g1 - g0] = torch.from_numpy(tmp[self.out[s]].view(np.int32))
 
     def scatter_level(self, l, world, gathered):
-        cnt = self.level_count(l)
+        b, rows_per_rank = self._bounds(l, world)
         rows = gathered.numpy().view(np.uint32)
-        self.wires[self.out[self.off[l]:self.off[l] + cnt]] = rows[:cnt]  # chunks are contiguous
+        for r in range(world):  # rank r's slot: its chunk's outputs in gate order, then padding
+            g0, g1 = int(b[r]), int(b[r + 1])
+            self.wires[self.out[self.off[l] + g0:self.off[l] + g1]] = rows[r * rows_per_rank:r * rows_per_rank + (g1 - g0)]
 
 
 def _setup():

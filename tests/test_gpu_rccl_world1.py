@@ -43,9 +43,10 @@ def _aes_program(helm_amd, sk, blocks):
                                                      for b in range(blocks)]) for l in range(nl)]).astype(np.int32)
     opsT = np.concatenate([np.tile(ops[off[l]:off[l + 1]], blocks) for l in range(nl)]).astype(np.int32)
     offT = (off[:nl + 1] * blocks).astype(np.int64)
-    prog = helm_amd.Program(sk, opsT, tile(i0), tile(i1), tile(i2), tile(out), offT)
+    arrays = (opsT, tile(i0), tile(i1), tile(i2), tile(out), offT)
+    prog = helm_amd.Program(sk, *arrays)
     rows = np.concatenate([b * nw + np.arange(len(inputs)) for b in range(blocks)]).astype(np.int32)
-    return prog, nw * blocks, rows, len(inputs)
+    return prog, nw * blocks, rows, len(inputs), arrays
 
 
 def _worker(_rank, port, result_path):
@@ -58,7 +59,7 @@ def _worker(_rank, port, result_path):
     ck = helm_amd.ClientKey.generate("toy_k2", seed=5)
     sk = helm_amd.ServerKey(ck, device=0)
     blocks = 3
-    prog, n_rows, in_rows, n_in = _aes_program(helm_amd, sk, blocks)
+    prog, n_rows, in_rows, n_in, prog_arrays = _aes_program(helm_amd, sk, blocks)
     bits = np.random.default_rng(3).integers(0, 2, size=blocks * n_in).astype(bool)
     enc = ck.encrypt(bits)
     ref = sk.wires(n_rows)
@@ -94,6 +95,30 @@ def _worker(_rank, port, result_path):
     res["comm_exchange_ms"] = float(tm.exchange_ms)
     res["comm_exchange_bytes"] = int(tm.exchange_bytes)
     res["comm_bytes_per_pass"] = int(runner.exchanged_bytes_per_pass())
+    # ---- (1a) the overlapped exchange inside the library: the all-gather + scatter of a launch on the engine's exchange
+    #      stream, later launches waiting (events) only for the launch they depend on; the launches cut into sub-launches
+    #      so that consecutive ones ARE independent; two passes back to back (ring buffers and events reused) ------------
+    from helm_amd.distributed import split_launches
+    cut = split_launches(prog_arrays[0], prog_arrays[5], 40)
+    prog_cut = helm_amd.Program(sk, *prog_arrays[:5], cut)
+    res["overlap_applies"] = prog_cut.overlap_applies()
+    res["overlap_launches"] = [int(prog.n_levels), int(prog_cut.n_levels)]
+    w = fresh()
+    before = c.stats()["collectives"]
+    sk.timing_enable(True)
+    sk.timing(reset=True)
+    runner = ShardedRunner(GpuLevelExecutor(prog_cut, w), 0, 1, comm=c, replicate_below=0, overlap=True)
+    runner.run()
+    runner.run()
+    sk.sync()
+    tmo = sk.timing(reset=True)
+    sk.timing_enable(False)
+    res["overlap_same"] = bool(np.array_equal(w.download(), want))
+    res["overlap_collectives"] = c.stats()["collectives"] - before
+    res["overlap_sharded_levels"] = len(runner.sharded_levels)
+    res["overlap_exchange_count"] = int(tmo.exchange_count)
+    res["overlap_exchange_ms"] = float(tmo.exchange_ms)
+    prog_cut.destroy()
     res["comm_allreduce_max"] = c.all_reduce(41.5, "max")
     res["comm_allreduce_sum"] = c.all_reduce(2.25, "sum")
     c.barrier()
@@ -197,9 +222,14 @@ def test_in_library_communicator_carries_every_launch(world1):
     assert r["comm_sharded_levels"] == r["levels_with_bootstraps"] > 0
     assert r["comm_exchange_count"] == 2 * r["comm_sharded_levels"]
     assert r["comm_exchange_bytes"] == 2 * r["comm_bytes_per_pass"] > 0
-    assert r["comm_stats"]["collectives"] == r["comm_exchange_count"]  # (read before the evaluator test below issues more)
+    assert r["comm_stats"]["collectives"] == r["comm_exchange_count"]  # (read before the later parts issue more)
     assert r["comm_exchange_ms"] > 0.0
     assert r["comm_allreduce_max"] == 41.5 and r["comm_allreduce_sum"] == 2.25
+    # the overlapped exchange (run_sharded_comm, overlap = 1) over real RCCL: same table, every sub-launch exchanged
+    assert r["overlap_applies"] and r["overlap_launches"][1] > r["overlap_launches"][0]
+    assert r["overlap_same"], "overlapped sharded pass over RCCL differs from helm_hip_program_run"
+    assert r["overlap_collectives"] == r["overlap_exchange_count"] == 2 * r["overlap_sharded_levels"] > 2 * r["comm_sharded_levels"]
+    assert r["overlap_exchange_ms"] > 0.0
     # the evaluator API on top of it: GateCircuit.shard_over
     assert r["gc_same"] and r["gc_back"] and r["gc_collectives"] > 0
     assert "sharded over 1 rank(s)" in r["gc_log"]

@@ -2,7 +2,7 @@
 #   bash tools/prof_r04.sh            -> gpurun_out/prof_r04/*   (copy the summaries into profiles/r04/)
 # Every rocprofv3 call has the program itself after `--`; --pmc passes carry --kernel-trace only.
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 O=gpurun_out/prof_r04; mkdir -p $O
 BENCH="--steps 1 --warmup 1 --no-cpu-baseline --no-other-modes"
 SMALL="--steps 1 --warmup 0 --blocks 4 --no-cpu-baseline --no-other-modes"
