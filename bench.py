@@ -265,7 +265,7 @@ class _StdoutToStderr:
 class Bench:
     """State shared by the runs of one worker."""
 
-    def __init__(self, args):
+    def __init__(self, args, thread_rank=None):
         import numpy as np
         import torch
         import torch.distributed as dist
@@ -276,15 +276,23 @@ class Bench:
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.threads = thread_rank is not None
+        if self.threads:
+            # HELM_BENCH_REHEARSE=threads: the ranks are THREADS of this one process (a one-GPU box allows six GPU
+            # processes, the scaling run has eight ranks); control plane and transport are in-process
+            self.dist = dist = thread_rank
+            self.rank, self.world, local_rank = dist.get_rank(), dist.get_world_size(), 0
         # rehearsal of the N > 1 path on a one-GPU box: HELM_BENCH_REHEARSE=1 puts every rank on cuda:0 and
         # carries the collectives over gloo (RCCL needs one GPU per rank); never used for reported numbers
-        self.rehearse = os.environ.get("HELM_BENCH_REHEARSE") == "1"
+        self.rehearse = os.environ.get("HELM_BENCH_REHEARSE") in ("1", "threads")
         if self.rehearse:
             local_rank = 0
         self.local_rank = local_rank
         torch.cuda.set_device(local_rank)
         self.comm, self.comm_error = None, None
-        if self.world > 1:
+        if self.threads:
+            self.comm = dist.comm      # helm_amd.comm.Comm.in_process_group: device-to-device copies between the rank threads
+        elif self.world > 1:
             from helm_amd import comm as hc
             # control plane (barrier, maximum over the ranks, the communicator's unique id): torch.distributed over gloo
             dist.init_process_group("gloo")
@@ -311,7 +319,8 @@ class Bench:
         t0 = time.time()
         self.ck = helm_amd.ClientKey.generate(args.params, seed=1)
         self.sk = helm_amd.ServerKey(self.ck, device=local_rank)
-        self.sk.set_stream(torch.cuda.current_stream().cuda_stream)
+        if not self.threads:   # (rank threads keep the context's own stream: torch's current stream is the same null stream in every thread)
+            self.sk.set_stream(torch.cuda.current_stream().cuda_stream)
         self.t_keys = time.time() - t0
         self.quantum = self.sk.launch_quantum()
         gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_text(aes128(), False)
@@ -465,12 +474,75 @@ def guarded(bench, result, what, fn):
     return watched(bench.world, bench.rank, bench.args.leg_timeout, result, what, fn)
 
 
-def worker(args):
+class ThreadDist:
+    """What bench.py uses of torch.distributed, for ranks that are threads of one process (HELM_BENCH_REHEARSE=threads)."""
+
+    class ReduceOp:
+        MAX, MIN = "max", "min"
+
+    def __init__(self, rank, shared):
+        self.rank, self.shared = rank, shared
+        self.comm = shared["comms"][rank]
+
+    def get_rank(self):
+        return self.rank
+
+    def get_world_size(self):
+        return len(self.shared["slots"])
+
+    def get_backend(self):
+        return "threads"
+
+    def barrier(self):
+        self.shared["barrier"].wait()
+
+    def all_reduce(self, t, op="max"):
+        s = self.shared
+        s["slots"][self.rank] = float(t.item())
+        s["barrier"].wait()
+        v = (max if op == "max" else min)(s["slots"])
+        s["barrier"].wait()
+        t.fill_(v)
+
+    def destroy_process_group(self):
+        pass
+
+
+def thread_workers(args):
+    """HELM_BENCH_REHEARSE=threads python3 bench.py --gpus N: N rank threads in THIS process, all on cuda:0, each with its own
+    engine context; the library's communicator over helm_amd.comm.Comm.in_process_group.  Everything else - programs packed
+    for N ranks, helm_hip_program_run_sharded_comm, the three runs, the decryption checks on every rank - is the real run's."""
+    import threading
+    from helm_amd.comm import Comm
+    n = args.gpus
+    shared = {"slots": [0.0] * n, "barrier": threading.Barrier(n, timeout=args.leg_timeout), "comms": Comm.in_process_group([0] * n)}
+    rcs = [1] * n
+
+    def main(r):
+        try:
+            rcs[r] = worker(args, ThreadDist(r, shared))
+        except BaseException:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+        finally:
+            if rcs[r] != 0:
+                shared["barrier"].abort()
+                shared["comms"][r].abort_group()
+    ts = [threading.Thread(target=main, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    return max(rcs)
+
+
+def worker(args, thread_rank=None):
     import signal
-    result = {"metric": METRIC, "value": None, "unit": "gate-bootstraps/s", "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
+    world0 = thread_rank.get_world_size() if thread_rank else int(os.environ.get("WORLD_SIZE", "1"))
+    result = {"metric": METRIC, "value": None, "unit": "gate-bootstraps/s", "n_gpus": world0,
               "steps": args.steps, "warmup": args.warmup}
-    rank = int(os.environ.get("RANK", "0"))
-    if rank == 0:
+    rank = thread_rank.get_rank() if thread_rank else int(os.environ.get("RANK", "0"))
+    if rank == 0 and thread_rank is None:
         def on_term(signum, _frame):  # torch.distributed.run stops the group when another rank dies
             result.setdefault("error", f"rank 0 stopped by signal {signum} (another rank failed?)")
             emit(result)
@@ -480,7 +552,7 @@ def worker(args):
     bench = None
     try:
         # the set-up has collectives of its own (process group, the communicator's handshake, ncclCommInitRank)
-        bench = watched(result["n_gpus"], rank, args.leg_timeout, result, "set-up (process group, communicator, keys)", lambda: Bench(args))
+        bench = watched(result["n_gpus"], rank, args.leg_timeout, result, "set-up (process group, communicator, keys)", lambda: Bench(args, thread_rank))
         fill_result(bench, result)
     except BaseException as e:  # incl. SystemExit / KeyboardInterrupt: the line carries the error, rc != 0
         import traceback
@@ -489,7 +561,7 @@ def worker(args):
         rc = 1
     if rank == 0:
         emit(result)
-    if bench is not None and bench.world > 1 and rc == 0:
+    if bench is not None and bench.world > 1 and rc == 0 and thread_rank is None:
         if bench.comm is not None:
             bench.comm.destroy()
         bench.dist.destroy_process_group()
@@ -575,7 +647,7 @@ def fill_result(bench, result):
         "vs_baseline": None,
         "dtype": "u32 torus (exact NTT in f64 FMA over a 49-bit prime)",
         "data": "synthetic: generated AES-128 netlist (stand-in for HELM's), seeded random keys/plaintexts, "
-                "fresh encryptions resident in HBM" + (" [REHEARSAL: all ranks on one GPU, gloo]" if bench.rehearse else ""),
+                "fresh encryptions resident in HBM" + (" [REHEARSAL: all ranks on one GPU, " + ("rank THREADS of one process, in-process transport]" if bench.threads else "gloo]") if bench.rehearse else ""),
         "config": {
             "workload": (f"AES-128 gates-mode netlist, fixed job of {head['blocks_total']} block(s)"
                          + (f", every launch sharded over {world} GPUs" if sharded else "") if head_kind != "weak" else
@@ -590,8 +662,8 @@ def fill_result(bench, result):
             "parallelism": ("single GPU" if world == 1 else
                             f"launch-shard x{world} + all-gather of launch outputs " +
                             ("inside the library (ncclAllGather, RCCL)" if bench.comm.info()["rccl_version"] else
-                             "through the library's communicator over a HOST TRANSPORT (gloo through host memory; RCCL not used: " +
-                             ("rehearsal on one GPU" if bench.rehearse else "--allow-host-fallback") + ")") +
+                             "through the library's communicator over a HOST TRANSPORT (" + ("in-process copies" if bench.threads else "gloo through host memory") + "; RCCL not used: " +
+                             ("rehearsal on one GPU" if bench.rehearse and not bench.comm_error else "--allow-host-fallback") + ")") +
                             (", exchange overlapped with independent launches" if head["overlapped"] else "") +
                             ", keys and wire table replicated" if sharded else
                             f"block-parallel x{world}: independent blocks per GPU, keys replicated, no data-path collective"),
@@ -642,10 +714,12 @@ def fill_result(bench, result):
         result["rccl_ranks"] = {"world_size": info["world_size"], "rank_of_this_line": info["rank"], "rccl_version": info["rccl_version"],
                                 "communicator": ("helm_comm: ncclCommInitRank / ncclAllGather inside libhelm_hip.so (include/helm_comm.h)"
                                                  if over_rccl else
-                                                 "helm_comm over a HOST TRANSPORT (gloo through host memory), RCCL NOT used: " +
-                                                 ("rehearsal on one GPU" if bench.rehearse else f"--allow-host-fallback after: {bench.comm_error}")),
+                                                 "helm_comm over a HOST TRANSPORT (" + ("device-to-device copies between rank threads of one process" if bench.threads
+                                                                                    else "gloo through host memory") + "), RCCL NOT used: " +
+                                                 ("rehearsal on one GPU" if bench.rehearse and not bench.comm_error else f"--allow-host-fallback after: {bench.comm_error}")),
                                 "collectives_issued_by_rank_0": bench.comm.stats()["collectives"],
-                                "control_plane": (f"torch.distributed {bench.dist.get_backend()} (barrier, max over ranks, unique id)"
+                                "control_plane": ("in-process (threading.Barrier between the rank threads)" if bench.threads else
+                                                  f"torch.distributed {bench.dist.get_backend()} (barrier, max over ranks, unique id)"
                                                   if world > 1 else "none (one process)"),
                                 "one_process_per_gpu": not bench.rehearse}
         if bench.comm_error:
@@ -793,9 +867,12 @@ def side_kinds(head_kind):
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
-    if "RANK" not in os.environ and args.gpus > 1:
+    threads = os.environ.get("HELM_BENCH_REHEARSE") == "threads" and args.gpus > 1
+    if "RANK" not in os.environ and args.gpus > 1 and not threads:
         sys.exit(launch_workers(args, argv))
     globals()["np"] = __import__("numpy")  # workers only: the launcher stays on the standard library
+    if threads:
+        sys.exit(thread_workers(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         args.gpus = world

@@ -141,6 +141,16 @@ HIP_API = {
 # helm_si_exchange_fn: int (*)(void *user, int64_t rows_per_rank)
 SI_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int64)
 
+
+class SiAuditRecord(C.Structure):  # helm_si_audit_record
+    _fields_ = [("kind", C.c_int32), ("terms", C.c_int32), ("count", C.c_int64), ("n_luts", C.c_int64),
+                ("in_rows", C.POINTER(C.c_uint64)), ("out_rows", C.POINTER(C.c_uint64)), ("lut_idx", C.POINTER(C.c_int32)),
+                ("luts", C.POINTER(C.c_uint64)), ("in_idx", C.POINTER(C.c_int32)), ("coef", C.POINTER(C.c_int64)),
+                ("const_add", C.POINTER(C.c_int64))]
+
+
+SI_AUDIT_FN = C.CFUNCTYPE(C.c_int, vp, C.POINTER(SiAuditRecord))  # helm_si_audit_fn
+
 # every symbol include/helm_shortint.h declares
 SI_API = {
     "helm_si_ctx_create": (C.c_int, [C.c_int, C.POINTER(SiParams), C.POINTER(vp)]),
@@ -163,6 +173,7 @@ SI_API = {
     "helm_si_eval_lut_level": (C.c_int, [vp, vp, i32p, i32p, C.c_int32, u64p, i32p, C.c_int64]),
     "helm_si_set_exchange": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_int64, SI_EXCHANGE_FN, vp]),
     "helm_si_set_exchange_comm": (C.c_int, [vp, vp, C.c_int64, C.c_int64]),
+    "helm_si_set_audit": (C.c_int, [vp, SI_AUDIT_FN, vp]),
     "helm_si_exchange_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "helm_si_exchange_world": (C.c_int, [vp]),
     "helm_si_round_capacity": (C.c_int64, [vp]),

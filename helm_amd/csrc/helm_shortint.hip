@@ -1908,6 +1908,9 @@ struct helm_si_ctx {
     // multi-GPU (helm_si_set_exchange): every bootstrap batch of at least x_min ciphertexts is split
     // into x_world contiguous chunks, this rank bootstraps chunk x_rank into x_stage, the caller's
     // collective fills x_gather with every rank's chunk and the rows are scattered into the table
+    // helm_si_set_audit: every helm_si_lincomb / helm_si_apply_luts call hands its operand rows and results to the host
+    helm_si_audit_fn audit_fn = nullptr;
+    void *audit_user = nullptr;
     int x_rank = 0, x_world = 1;
     int64_t x_min = 0, x_cap = 0;
     uint64_t *x_stage = nullptr, *x_gather = nullptr;
@@ -2562,6 +2565,8 @@ int helm_si_ctx_fork(helm_si_ctx *primary, helm_si_ctx **out)
     ctx->have_bsk = ctx->have_ksk = true;
     ctx->delta = primary->delta;
     ctx->n_cus = primary->n_cus;
+    ctx->audit_fn = primary->audit_fn; // a lane is audited like its primary
+    ctx->audit_user = primary->audit_user;
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
@@ -2875,8 +2880,57 @@ int helm_si_wires_set_trivial(helm_si_ctx *ctx, helm_si_wires *w, const int32_t 
     return 0;
 }
 
+int helm_si_set_audit(helm_si_ctx *ctx, helm_si_audit_fn fn, void *user)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null context");
+    ctx->audit_fn = fn;
+    ctx->audit_user = fn ? user : nullptr;
+    return 0;
+}
+
+// rows idx[0 .. count) of the table on the host (idx < 0: a zero row), for the audit
+static int audit_fetch(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *idx, int64_t count, std::vector<uint64_t> &rows)
+{
+    const size_t brow = (size_t)ctx->P.k * ctx->P.N + 1;
+    std::vector<int32_t> safe((size_t)count);
+    for (int64_t g = 0; g < count; g++) safe[(size_t)g] = idx[g] < 0 ? 0 : idx[g];
+    rows.assign((size_t)count * brow, 0);
+    if (int rc = helm_si_wires_download(ctx, w, safe.data(), rows.data(), count)) return rc;
+    for (int64_t g = 0; g < count; g++)
+        if (idx[g] < 0) std::fill(rows.begin() + (size_t)g * brow, rows.begin() + (size_t)(g + 1) * brow, 0);
+    return 0;
+}
+
+static int lincomb_impl(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, const int64_t *coef,
+                        const int64_t *const_add, const int32_t *out_idx, int32_t terms, int64_t count);
+
 int helm_si_lincomb(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, const int64_t *coef,
                     const int64_t *const_add, const int32_t *out_idx, int32_t terms, int64_t count)
+{
+    if (!ctx || !ctx->audit_fn || count <= 0) return lincomb_impl(ctx, w, in_idx, coef, const_add, out_idx, terms, count);
+    if (!w || !in_idx || !coef || !out_idx || terms < 1) return fail(HELM_ERR_INVALID, "bad argument");
+    if (!owns(ctx, w)) return fail(HELM_ERR_STATE, "table belongs to another context");
+    if (int rc = check_rows(w, in_idx, count * terms, true)) return rc;
+    std::vector<uint64_t> in_rows, out_rows;
+    if (int rc = audit_fetch(ctx, w, in_idx, count * terms, in_rows)) return rc;
+    if (int rc = lincomb_impl(ctx, w, in_idx, coef, const_add, out_idx, terms, count)) return rc;
+    if (int rc = audit_fetch(ctx, w, out_idx, count, out_rows)) return rc;
+    helm_si_audit_record rec{};
+    rec.kind = 1;
+    rec.count = count;
+    rec.terms = terms;
+    rec.in_rows = in_rows.data();
+    rec.out_rows = out_rows.data();
+    rec.in_idx = in_idx;
+    rec.coef = coef;
+    rec.const_add = const_add;
+    if (int rc = ctx->audit_fn(ctx->audit_user, &rec))
+        return fail(HELM_ERR_STATE, "helm_si_lincomb: the audit callback rejected the batch (" + std::to_string(rc) + ")");
+    return 0;
+}
+
+static int lincomb_impl(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx, const int64_t *coef,
+                        const int64_t *const_add, const int32_t *out_idx, int32_t terms, int64_t count)
 {
     if (!ctx || !w || !in_idx || !coef || !out_idx || terms < 1 || count < 0) return fail(HELM_ERR_INVALID, "bad argument");
     if (!owns(ctx, w)) return fail(HELM_ERR_STATE, "table belongs to another context");
@@ -2943,10 +2997,27 @@ int helm_si_apply_luts(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx
         ks[(size_t)g] = Ks64Job{in_idx[g], (int32_t)g};
         pbs[(size_t)g] = Pbs64Job{(int32_t)g, lut_idx[g], out_idx[g], 0};
     }
+    std::vector<uint64_t> audit_in, audit_out;
+    if (ctx->audit_fn)
+        if (int rc = audit_fetch(ctx, w, in_idx, count, audit_in)) return rc;
+    int rc = 0;
     if (ctx->x_on && count >= ctx->x_min)
-        return apply_luts_sharded(ctx, w, in_idx, lut_idx, out_idx, count, luts, n_luts);
-    // every keyswitch finishes (kernel boundary) before any bootstrap writes its output row
-    return apply_luts_device(ctx, w->d, w->d, ks, pbs, luts, n_luts);
+        rc = apply_luts_sharded(ctx, w, in_idx, lut_idx, out_idx, count, luts, n_luts);
+    else // every keyswitch finishes (kernel boundary) before any bootstrap writes its output row
+        rc = apply_luts_device(ctx, w->d, w->d, ks, pbs, luts, n_luts);
+    if (rc || !ctx->audit_fn) return rc;
+    if ((rc = audit_fetch(ctx, w, out_idx, count, audit_out))) return rc;
+    helm_si_audit_record rec{};
+    rec.kind = 0;
+    rec.count = count;
+    rec.n_luts = n_luts;
+    rec.in_rows = audit_in.data();
+    rec.out_rows = audit_out.data();
+    rec.lut_idx = lut_idx;
+    rec.luts = luts;
+    if ((rc = ctx->audit_fn(ctx->audit_user, &rec)))
+        return fail(HELM_ERR_STATE, "helm_si_apply_luts: the audit callback rejected the batch (" + std::to_string(rc) + ")");
+    return 0;
 }
 
 int helm_si_set_exchange(helm_si_ctx *ctx, int32_t rank, int32_t world, int64_t min_batch, void *stage_dev,

@@ -150,8 +150,50 @@ class SiServerKey:
     def sync(self):
         hip_check(hip.helm_si_sync(self._h))
 
+    def round_capacity(self):
+        """Bootstraps the device holds at once under this set (helm_si_round_capacity): CUs x resident workgroups per CU."""
+        v = int(hip.helm_si_round_capacity(self._h))
+        if v < 0:
+            hip_check(v)
+        return v
+
     def set_stream(self, stream_ptr):
         hip_check(hip.helm_si_set_stream(self._h, nv.vp(stream_ptr)))
+
+    def set_audit(self, fn):
+        """helm_si_set_audit: while set, every linear step and every look-up batch of this key - LUT levels, the radix
+        operators of arithmetic mode - hands `fn` a dict with its operand rows (read before the call ran), its result rows
+        and its arguments: kind "luts" -> in_rows, out_rows, lut_idx, luts; kind "lincomb" -> in_rows [count, terms, row],
+        out_rows, in_idx, coef, const_add (or None).  fn returning False (or raising) fails the call.  fn = None: off.
+        Set it BEFORE the evaluators fork their lanes."""
+        if fn is None:
+            hip_check(hip.helm_si_set_audit(self._h, nv.SI_AUDIT_FN(0), None))
+            self._audit = None
+            return
+        brow = self.params.k * self.params.N + 1
+        N = self.params.N
+
+        def trampoline(_user, recp):
+            try:
+                r = recp.contents
+                cnt = int(r.count)
+                arr = lambda p, shape, dt: np.ctypeslib.as_array(p, shape=shape).astype(dt, copy=True)
+                if r.kind == 0:
+                    rec = {"kind": "luts", "in_rows": arr(r.in_rows, (cnt, brow), np.uint64), "out_rows": arr(r.out_rows, (cnt, brow), np.uint64),
+                           "lut_idx": arr(r.lut_idx, (cnt,), np.int32), "luts": arr(r.luts, (int(r.n_luts), N), np.uint64)}
+                else:
+                    t = int(r.terms)
+                    rec = {"kind": "lincomb", "in_rows": arr(r.in_rows, (cnt, t, brow), np.uint64), "out_rows": arr(r.out_rows, (cnt, brow), np.uint64),
+                           "in_idx": arr(r.in_idx, (cnt, t), np.int32), "coef": arr(r.coef, (cnt, t), np.int64),
+                           "const_add": arr(r.const_add, (cnt,), np.int64) if r.const_add else None}
+                return 0 if fn(rec) is not False else 1
+            except BaseException:  # noqa: BLE001 - reported through the status code
+                import traceback
+                traceback.print_exc()
+                return 2
+        cb = nv.SI_AUDIT_FN(trampoline)
+        hip_check(hip.helm_si_set_audit(self._h, cb, None))
+        self._audit = cb  # kept alive as long as it is set
 
     def set_exchange_comm(self, comm, min_batch=None, capacity_rows=4096):
         """Shard every bootstrap batch of at least `min_batch` ciphertexts over the ranks of `comm`

@@ -162,6 +162,27 @@ int helm_si_exchange_stats(const helm_si_ctx *ctx, int64_t *batches, int64_t *ro
  * that shard keep to the primary context (the host library's ArithCircuit does not fork its default lane then). */
 int helm_si_exchange_world(const helm_si_ctx *ctx);
 
+/* Audit (tracing): while a callback is set, every helm_si_lincomb() and helm_si_apply_luts() call - and with them everything
+ * built on the two: helm_si_eval_lut_level(), the LUT-mode and arithmetic-mode evaluators of the host library - copies its
+ * operand rows (read BEFORE the call runs: a batch may work in place) and its result rows to the host and hands them to
+ * `fn` together with the call's arguments; a non-zero return fails the call.  How tests/test_gpu_audit.py checks whole
+ * evaluations at the full parameter sets against the CPU oracle, operation by operation (each batch's outputs == the
+ * oracle's on the GPU's own inputs, hence every wire).  Slow by construction (two synchronous copies per call); lanes
+ * forked AFTER this call inherit it.  fn = NULL switches it off. */
+typedef struct {
+    int32_t kind;             /* 0 = helm_si_apply_luts, 1 = helm_si_lincomb */
+    int32_t terms;            /* lincomb: operands per output */
+    int64_t count, n_luts;
+    const uint64_t *in_rows;  /* apply_luts: count rows of k*N+1 words; lincomb: count * terms (a skipped operand: zeros) */
+    const uint64_t *out_rows; /* count rows */
+    const int32_t *lut_idx;   /* apply_luts */
+    const uint64_t *luts;     /* apply_luts: n_luts test polynomials of N words */
+    const int32_t *in_idx;    /* lincomb: the call's own arrays */
+    const int64_t *coef, *const_add;
+} helm_si_audit_record;
+typedef int (*helm_si_audit_fn)(void *user, const helm_si_audit_record *rec);
+int helm_si_set_audit(helm_si_ctx *ctx, helm_si_audit_fn fn, void *user);
+
 /* Programmable bootstraps the device holds at once under this parameter set: CUs x workgroups of the set's bootstrap kernel
  * per CU (1 at N = 2048, 2 for k_pbs64k).  A batch of at most this many ciphertexts takes one bootstrap's time whatever its
  * size; the host library merges the look-up rounds of concurrent operators into launches of at most this size. */

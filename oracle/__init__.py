@@ -219,6 +219,15 @@ def lib64():
         L.orc64_modswitch.restype = C.c_uint64
         L.orc64_modswitch.argtypes = [C.c_uint64, C.c_int]
         L.orc64_decompose.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+        # the key behind a handle: either exact route (schoolbook / Goldilocks NTT on the key split into parts)
+        L.orc64_key_new.restype = C.c_void_p
+        L.orc64_key_new.argtypes = [P, u64p, C.c_int]
+        L.orc64_key_free.argtypes = [C.c_void_p]
+        L.orc64_key_part_bits.argtypes = [C.c_void_p]
+        L.orc64_bootstrap_k.argtypes = [C.c_void_p, u64p, u64p, u64p]
+        L.orc64_apply_lut_k.argtypes = [C.c_void_p, u64p, u64p, u64p, u64p]
+        L.orc64_eval_lut_rows_k.argtypes = [C.c_void_p, u64p, u64p, i32p, i32p, C.c_int, u64p, i32p, C.c_int, u64p]
+        L.orc64_apply_luts_k.argtypes = [C.c_void_p, u64p, u64p, u64p, i32p, C.c_int, u64p]
         _LIB64 = L
     return _LIB64
 
@@ -232,13 +241,24 @@ class Oracle64:
     """Server-side shortint evaluation with a given (bsk, ksk) in the standard-domain
     layouts documented in include/helm_shortint.h."""
 
-    def __init__(self, params9, bsk_std, ksk):
+    def __init__(self, params9, bsk_std, ksk, use_ntt=False):
+        """use_ntt: negacyclic products by the Goldilocks NTT on the key split into 32- / 16- / 8-bit parts (exact, the
+        route that makes whole levels at the full parameter sets checkable) instead of schoolbook convolution; the two
+        routes give identical ciphertexts (tests/test_oracle_shortint.py)."""
         self.p = Params64(*[int(x) for x in params9])
         self.bsk = np.ascontiguousarray(bsk_std, dtype=np.uint64)
         self.ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
         self.dim = self.p.k * self.p.N
         self.t = self.p.message_modulus * self.p.carry_modulus
         self.delta = (1 << 63) // self.t
+        self.use_ntt = bool(use_ntt)
+        self._key = lib64().orc64_key_new(C.byref(self.p), _u64(self.bsk), 1 if use_ntt else 0)
+        self.part_bits = int(lib64().orc64_key_part_bits(self._key))
+
+    def __del__(self):
+        k, self._key = getattr(self, "_key", None), None
+        if k:
+            lib64().orc64_key_free(k)
 
     def make_lut(self, f):
         vals = np.array([f(v) for v in range(self.t)] if callable(f) else list(f), dtype=np.uint64)
@@ -256,14 +276,38 @@ class Oracle64:
         small = np.ascontiguousarray(small, dtype=np.uint64)
         lut = np.ascontiguousarray(lut, dtype=np.uint64)
         out = np.zeros(self.dim + 1, dtype=np.uint64)
-        lib64().orc64_bootstrap(C.byref(self.p), _u64(self.bsk), _u64(small), _u64(lut), _u64(out))
+        lib64().orc64_bootstrap_k(self._key, _u64(small), _u64(lut), _u64(out))
         return out
 
     def apply_lut(self, big, lut):
         big = np.ascontiguousarray(big, dtype=np.uint64)
         lut = np.ascontiguousarray(lut, dtype=np.uint64)
         out = np.zeros(self.dim + 1, dtype=np.uint64)
-        lib64().orc64_apply_lut(C.byref(self.p), _u64(self.bsk), _u64(self.ksk), _u64(big), _u64(lut), _u64(out))
+        lib64().orc64_apply_lut_k(self._key, _u64(self.ksk), _u64(big), _u64(lut), _u64(out))
+        return out
+
+    def apply_luts(self, in_rows, luts, lut_index):
+        """A batch of independent look-ups (what helm_si_apply_luts does on the GPU): row q -> apply_lut(in_rows[q],
+        luts[lut_index[q]]); OpenMP over the rows."""
+        in_rows = np.ascontiguousarray(in_rows, dtype=np.uint64)
+        luts = np.ascontiguousarray(np.atleast_2d(luts), dtype=np.uint64)
+        idx = np.ascontiguousarray(lut_index, dtype=np.int32)
+        assert in_rows.shape == (len(idx), self.dim + 1) and luts.shape[1] == self.p.N
+        out = np.zeros_like(in_rows)
+        lib64().orc64_apply_luts_k(self._key, _u64(self.ksk), _u64(in_rows), _u64(luts), _i32(idx), len(idx), _u64(out))
+        return out
+
+    def eval_lut_rows(self, wires, arity, in_idx, table, gates):
+        """The output rows of the chosen `gates` of a LUT level over `wires` (not modified): lets a test check rows of a level
+        the GPU evaluated as a whole - first / last workgroup, tile edges - without paying for the others."""
+        assert wires.dtype == np.uint64 and wires.flags["C_CONTIGUOUS"]
+        arity = np.ascontiguousarray(arity, dtype=np.int32)
+        in_idx = np.ascontiguousarray(np.atleast_2d(in_idx), dtype=np.int32)
+        table = np.ascontiguousarray(table, dtype=np.uint64)
+        gates = np.ascontiguousarray(gates, dtype=np.int32)
+        out = np.zeros((len(gates), self.dim + 1), dtype=np.uint64)
+        lib64().orc64_eval_lut_rows_k(self._key, _u64(self.ksk), _u64(wires), _i32(arity), _i32(in_idx), in_idx.shape[1],
+                                      _u64(table), _i32(gates), len(gates), _u64(out))
         return out
 
     def eval_lut_level(self, wires, arity, in_idx, table, out_idx):
@@ -273,6 +317,9 @@ class Oracle64:
         in_idx = np.ascontiguousarray(np.atleast_2d(in_idx), dtype=np.int32)
         table = np.ascontiguousarray(table, dtype=np.uint64)
         out_idx = np.ascontiguousarray(out_idx, dtype=np.int32)
+        if self.use_ntt:
+            wires[out_idx] = self.eval_lut_rows(wires, arity, in_idx, table, np.arange(len(arity), dtype=np.int32))
+            return
         lib64().orc64_eval_lut_level(C.byref(self.p), _u64(self.bsk), _u64(self.ksk), _u64(wires), _i32(arity),
                                      _i32(in_idx), in_idx.shape[1], _u64(table), _i32(out_idx), len(arity))
 

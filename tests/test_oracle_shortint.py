@@ -282,3 +282,62 @@ def test_multibit_golden_vectors_two_routes():
         want = ((tb >> sum(b << (ar - 1 - q) for q, b in enumerate(x))) & 1) if ar >= 2 else \
             (x[0] if (ar == 0 or tb == 0) else (-x[0]) % t)
         assert orc.decrypt(g["glwe_sk"], g["expected"][gi]) == want, gi
+
+
+# ---- round 5: the second exact route (Goldilocks NTT on the key split into parts) --------------------------------
+TOY_SETS = ["si_toy_512", "si_toy_1024", "si_toy_2048", "si_toy_2048_l2", "si_toy_512_k2", "si_toy_512_k3", "si_toy_1024_mb2",
+            "si_toy_2048_mb3"]
+
+
+@pytest.mark.parametrize("name", TOY_SETS)
+def test_ntt_route_equals_schoolbook_on_every_toy_set(name):
+    """Every kernel class of the 64-bit engine has a toy set (one / two levels, k = 1, 2, 3, multi-bit g = 2, 3): on each,
+    keyswitch + bootstrap through the NTT route give the schoolbook route's ciphertexts bit for bit - independent
+    arithmetic (wrapping u64 convolution vs exact integers below 2^63 recombined mod 2^64), same algorithm."""
+    ck = helm_amd.SiClientKey.generate(name, seed=3)
+    a = oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk)
+    b = oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk, use_ntt=True)
+    assert a.part_bits == 0 and b.part_bits in (8, 16, 32)
+    rng = np.random.default_rng(5)
+    vals = rng.integers(0, ck.t, size=4).astype(np.uint64)
+    cts = ck.encrypt(vals)
+    lut = a.make_lut(lambda v: (3 * v + 1) % ck.t)
+    for v, ct in zip(vals, cts):
+        want = a.apply_lut(ct, lut)
+        assert np.array_equal(b.apply_lut(ct, lut), want), name
+        assert ck.decrypt_message_and_carry(want) == (3 * int(v) + 1) % ck.t
+    # the batch forms (OpenMP over rows) and the level form
+    luts = np.stack([lut, a.make_lut(lambda v: v & 1)])
+    idx = np.array([0, 1, 1, 0], dtype=np.int32)
+    got = b.apply_luts(cts, luts, idx)
+    for q in range(4):
+        assert np.array_equal(got[q], a.apply_lut(cts[q], luts[idx[q]]))
+    bits = rng.integers(0, 2, size=6).astype(np.uint64)
+    wires_a = np.zeros((8, ck.dim + 1), dtype=np.uint64)
+    wires_a[:6] = ck.encrypt(bits)
+    wires_b = wires_a.copy()
+    args = ([3, 2], [[0, 1, 2], [3, 4, -1]] if False else [[0, 1, 2], [3, 4, 5]], [0x96, 0x6], [6, 7])
+    a.eval_lut_level(wires_a, *args)
+    b.eval_lut_level(wires_b, *args)
+    assert np.array_equal(wires_a, wires_b)
+    rows = b.eval_lut_rows(wires_b, *args[:3], [1])
+    assert np.array_equal(rows[0], wires_a[7])
+
+
+def test_ntt_route_at_a_full_parameter_set_matches_schoolbook_and_decrypts():
+    """PARAM_MESSAGE_1_CARRY_1_KS_PBS's dimensions (k = 3, N = 512: the cheapest full set for the O(N^2) route): one
+    bootstrap both ways, identical; and the NTT route alone on a row of PARAM_MESSAGE_2_CARRY_2 (N = 2048, 16-bit parts)
+    decrypts to the look-up's value."""
+    ck = helm_amd.SiClientKey.generate("shortint_m1c1", seed=4)
+    a = oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk)
+    b = oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk, use_ntt=True)
+    assert b.part_bits == 32
+    ct = ck.encrypt(np.array([3], dtype=np.uint64))[0]
+    lut = a.make_lut(lambda v: (v + 2) % ck.t)
+    want = a.apply_lut(ct, lut)
+    assert np.array_equal(b.apply_lut(ct, lut), want) and ck.decrypt_message_and_carry(want) == (3 + 2) % ck.t
+    ck2 = helm_amd.SiClientKey.generate("shortint_m2c2", seed=4)
+    c = oracle.Oracle64(ck2.params.as_tuple(), ck2.bsk, ck2.ksk, use_ntt=True)
+    assert c.part_bits == 16
+    out = c.apply_lut(ck2.encrypt(np.array([11], dtype=np.uint64))[0], c.make_lut(lambda v: (5 * v + 3) % ck2.t))
+    assert ck2.decrypt_message_and_carry(out) == (5 * 11 + 3) % ck2.t
