@@ -57,6 +57,10 @@ def parse_headers():
                 decl = decl.strip()
                 if not decl:
                     continue
+                if "*" in decl:  # pointer fields (helm_si_audit_record): `const T *a, *b`
+                    for n in decl.split("*")[1:]:
+                        fields.append((n.strip(" ,"), ("ptr", 64)))
+                    continue
                 ty, names = decl.split(None, 1)
                 for n in names.split(","):
                     fields.append((n.strip(), C_SCALARS[ty]))
