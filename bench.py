@@ -318,9 +318,11 @@ class Bench:
         # keys (identical on every rank: same deterministic benchmark seed) and engine
         t0 = time.time()
         self.ck = helm_amd.ClientKey.generate(args.params, seed=1)
-        self.sk = helm_amd.ServerKey(self.ck, device=local_rank)
-        if not self.threads:   # (rank threads keep the context's own stream: torch's current stream is the same null stream in every thread)
-            self.sk.set_stream(torch.cuda.current_stream().cuda_stream)
+        with self.setup_lock():
+            self.sk = helm_amd.ServerKey(self.ck, device=local_rank)
+            if not self.threads:   # (rank threads keep the context's own stream: torch's current stream is the same null stream in every thread)
+                self.sk.set_stream(torch.cuda.current_stream().cuda_stream)
+            self.sk.sync()
         self.t_keys = time.time() - t0
         self.quantum = self.sk.launch_quantum()
         gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_text(aes128(), False)
@@ -330,6 +332,13 @@ class Bench:
         self.wire_names = list(inputs) + sorted(wire_set)
         self.nw = len(self.wire_names)
         self.index = {w: i for i, w in enumerate(self.wire_names)}
+
+    def setup_lock(self):
+        """Rank THREADS of one process allocate, upload and download one at a time (the HIP runtime of this image threw
+        std::bad_variant_access when eight threads did that while others synchronised streams; launches and copies inside the
+        passes run concurrently).  Processes: no lock."""
+        import contextlib
+        return self.dist.lock if self.threads else contextlib.nullcontext()
 
     def sync_all(self):
         if self.world > 1:
@@ -348,9 +357,10 @@ class Bench:
         # --overlap: launches cut to one lockstep round per rank (the gates of a launch are independent, so any cut is
         # valid): the sub-launches of one packed launch do not depend on each other, the exchange of one travels while the
         # next one's bootstraps run
-        prog, launches, levels, _ = make_program(self.sk, self.circuit, self.wire_names, blocks,
-                                                 self.quantum * (self.world if sharded else 1), pack=not a.no_pack,
-                                                 overlap_split=self.quantum * self.world if (sharded and a.overlap) else 0)
+        with self.setup_lock():
+            prog, launches, levels, _ = make_program(self.sk, self.circuit, self.wire_names, blocks,
+                                                     self.quantum * (self.world if sharded else 1), pack=not a.no_pack,
+                                                     overlap_split=self.quantum * self.world if (sharded and a.overlap) else 0)
         overlapped = bool(sharded and a.overlap and prog.overlap_applies())
         rng = np.random.default_rng(0x48454C4D + (0 if sharded else self.rank))
         keys_pt = [(bytes(rng.integers(0, 256, 16, dtype=np.uint8)), bytes(rng.integers(0, 256, 16, dtype=np.uint8)))
@@ -358,11 +368,14 @@ class Bench:
         if self.rank == 0 or sharded:
             keys_pt[0] = (bytes(range(16)), bytes.fromhex("00112233445566778899aabbccddeeff"))  # FIPS-197 C.1
         # synthetic inputs: encrypted on the host, uploaded once: resident in HBM before the timed region
-        wires = self.sk.wires(self.nw * blocks)
-        upload_inputs(self.ck, wires, self.index, self.nw, keys_pt)
-        runner = ShardedRunner(GpuLevelExecutor(prog, wires), self.rank, self.world if sharded else 1,
-                               dist if sharded else None, time_collective=sharded,
-                               comm=self.comm if sharded else None, overlap=overlapped)
+        with self.setup_lock():
+            wires = self.sk.wires(self.nw * blocks)
+            upload_inputs(self.ck, wires, self.index, self.nw, keys_pt)
+            runner = ShardedRunner(GpuLevelExecutor(prog, wires), self.rank, self.world if sharded else 1,
+                                   dist if sharded else None, time_collective=sharded,
+                                   comm=self.comm if sharded else None, overlap=overlapped)
+            self.sk.sync()
+        self.sync_all()
         for _ in range(warmup):
             runner.run()
         self.sync_all()
@@ -382,7 +395,8 @@ class Bench:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         # correctness of what was timed: every block of this rank's table decrypts to AES(key, pt)
-        check_outputs(self.ck, wires, self.index, self.nw, keys_pt, f"{kind} run, rank {self.rank}")
+        with self.setup_lock():
+            check_outputs(self.ck, wires, self.index, self.nw, keys_pt, f"{kind} run, rank {self.rank}")
         pbs = prog.total_pbs()
         job_pbs = pbs * (self.world if kind == "weak" else 1)
         r = {"kind": kind, "elapsed": elapsed, "steps": steps, "warmup": warmup, "job_pbs": int(job_pbs),
@@ -400,8 +414,11 @@ class Bench:
         if keep:
             r.update(prog=prog, wires=wires, keys_pt=keys_pt)
         else:
-            prog.destroy()
-            wires.free()
+            with self.setup_lock():
+                prog.destroy()
+                wires.free()
+        if self.threads:
+            dist.barrier()   # nobody frees while another rank still runs
         return r
 
     def describe(self, r):
@@ -483,6 +500,7 @@ class ThreadDist:
     def __init__(self, rank, shared):
         self.rank, self.shared = rank, shared
         self.comm = shared["comms"][rank]
+        self.lock = shared["lock"]
 
     def get_rank(self):
         return self.rank
@@ -515,7 +533,8 @@ def thread_workers(args):
     import threading
     from helm_amd.comm import Comm
     n = args.gpus
-    shared = {"slots": [0.0] * n, "barrier": threading.Barrier(n, timeout=args.leg_timeout), "comms": Comm.in_process_group([0] * n)}
+    shared = {"slots": [0.0] * n, "barrier": threading.Barrier(n, timeout=args.leg_timeout), "comms": Comm.in_process_group([0] * n),
+              "lock": threading.Lock()}
     rcs = [1] * n
 
     def main(r):

@@ -70,26 +70,27 @@ def _run_world(world, arrays, n_rows, in_rows, enc, ck, replicate_below, overlap
     from helm_amd.comm import Comm
     comms = Comm.in_process_group([0] * world)
     tables, stats, errors, sharded = [None] * world, [None] * world, [], [None] * world
+    # Contexts, programs and tables are made one after the other on this thread; the rank threads only run the passes.
+    # (Eight threads allocating, uploading keys and synchronising streams at the same time made the HIP runtime of this
+    # image throw std::bad_variant_access from inside libamdhip64 - a runtime race, not a kernel fault; concurrent kernel
+    # launches and copies, which is what eight ranks do in the passes, are fine.)
+    ranks = []
+    for r in range(world):
+        sk = helm_amd.ServerKey(ck, device=0)
+        prog = helm_amd.Program(sk, *arrays)
+        w = sk.wires(n_rows)
+        w.upload(in_rows, enc)
+        prog.shard_prepare(r, world)
+        sk.sync()
+        ranks.append((sk, prog, w))
 
     def rank_main(r):
         try:
-            sk = helm_amd.ServerKey(ck, device=0)
-            prog = helm_amd.Program(sk, *arrays)
-            w = sk.wires(n_rows)
-            w.upload(in_rows, enc)
+            sk, prog, w = ranks[r]
             assert comms[r].info() == {"rank": r, "world_size": world, "device": 0, "rccl_version": 0}
             for _ in range(passes):
                 prog.run_sharded_comm(w, comms[r], replicate_below, overlap)
             sk.sync()
-            tables[r] = w.download()
-            stats[r] = comms[r].stats()["collectives"]
-            sharded[r] = sum(1 for l in range(prog.n_levels) if prog.level_pbs(l) > replicate_below)
-            # the cut the engine made: within one gate of an even share of the bootstraps, the same on every rank
-            for l in range(prog.n_levels):
-                b = prog.chunk_bounds(l, world)
-                assert b[0] == 0 and b[-1] == arrays[5][l + 1] - arrays[5][l] and prog.chunk_rows(l, world) == int(np.max(np.diff(b)))
-            prog.destroy()
-            sk.close()
         except BaseException as e:  # noqa: BLE001 - reported by the test; the group's barrier is broken so nobody waits for ever
             errors.append((r, repr(e)))
             comms[r].abort_group()
@@ -100,6 +101,16 @@ def _run_world(world, arrays, n_rows, in_rows, enc, ck, replicate_below, overlap
         t.join(timeout=600)
         assert not t.is_alive(), "a rank thread is stuck"
     assert not errors, errors
+    for r, (sk, prog, w) in enumerate(ranks):
+        tables[r] = w.download()
+        stats[r] = comms[r].stats()["collectives"]
+        sharded[r] = sum(1 for l in range(prog.n_levels) if prog.level_pbs(l) > replicate_below)
+        # the cut the engine made: within one gate of an even share of the bootstraps, the same on every rank
+        for l in range(prog.n_levels):
+            b = prog.chunk_bounds(l, world)
+            assert b[0] == 0 and b[-1] == arrays[5][l + 1] - arrays[5][l] and prog.chunk_rows(l, world) == int(np.max(np.diff(b)))
+        prog.destroy()
+        sk.close()
     for c in comms:
         c.destroy()
     return tables, stats, sharded[0]
