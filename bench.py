@@ -334,9 +334,9 @@ class Bench:
         self.index = {w: i for i, w in enumerate(self.wire_names)}
 
     def setup_lock(self):
-        """Rank THREADS of one process allocate, upload and download one at a time (the HIP runtime of this image threw
-        std::bad_variant_access when eight threads did that while others synchronised streams; launches and copies inside the
-        passes run concurrently).  Processes: no lock."""
+        """Rank THREADS of one process plan, allocate, upload and download one at a time (eight ranks' set-up at once would only
+        compete for the same host cores and the one GPU's copy engines); the passes themselves run concurrently.  Processes:
+        no lock."""
         import contextlib
         return self.dist.lock if self.threads else contextlib.nullcontext()
 

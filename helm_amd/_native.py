@@ -189,6 +189,8 @@ COMM_ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp, C.c_size_t, vp)  # helm_co
 COMM_API = {
     "helm_comm_available": (C.c_int, []),
     "helm_comm_precheck": (C.c_int, [C.c_int]),
+    "helm_comm_create_in_process": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_double, C.POINTER(vp)]),
+    "helm_comm_abort_group": (C.c_int, [vp]),
     "helm_comm_get_unique_id": (C.c_int, [u8p]),
     "helm_comm_create": (C.c_int, [C.c_int, u8p, C.c_int, C.c_int, C.POINTER(vp)]),
     "helm_comm_create_with_transport": (C.c_int, [C.c_int, C.c_int, C.c_int, COMM_ALL_GATHER_FN, vp, C.POINTER(vp)]),

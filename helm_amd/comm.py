@@ -29,25 +29,6 @@ def precheck(device):
     hip_check(hip.helm_comm_precheck(int(device)))
 
 
-_RT = None
-
-
-def _hip_runtime():
-    """The HIP runtime the engine itself is linked against, for the in-process group's device-to-device copies."""
-    global _RT
-    if _RT is None:
-        _RT = C.CDLL("libamdhip64.so")
-        _RT.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-        _RT.hipStreamSynchronize.argtypes = [C.c_void_p]
-        _RT.hipSetDevice.argtypes = [C.c_int]
-    return _RT
-
-
-def _rt_check(rc):
-    if rc != 0:
-        raise RuntimeError(f"HIP runtime error {rc}")
-
-
 def unique_id():
     buf = np.zeros(ID_BYTES, dtype=np.uint8)
     hip_check(hip.helm_comm_get_unique_id(nv.as_u8p(buf)))
@@ -182,43 +163,27 @@ class Comm:
     @classmethod
     def in_process_group(cls, devices, timeout=600.0):
         """One communicator per entry of `devices` for ranks that are THREADS of this process (a host that drives its GPUs
-        from one process, one thread and one engine context per rank; several ranks may share a device): the transport form
-        with an all-gather made of device-to-device copies between the ranks' buffers, a threading.Barrier on either side.
-        Every rank must call the collectives from its own thread.  No RCCL, no torch.  A rank that fails breaks the
-        barrier (`abort_group`), so the others get an error instead of waiting; `timeout` seconds bound every wait.
-        -> [Comm] in rank order."""
-        import threading
+        from one process, one thread and one engine context per rank; several ranks may share a device):
+        helm_comm_create_in_process - the all-gather is device-to-device copies between the ranks' buffers inside the library,
+        a barrier on either side.  Every rank must call the collectives from its own thread.  No RCCL, no torch.  A rank that
+        fails breaks the group (`abort_group`), so the others get an error instead of waiting; `timeout` seconds bound every
+        wait.  -> [Comm] in rank order."""
         world = len(devices)
-        rt = _hip_runtime()
-        barrier = threading.Barrier(world, timeout=timeout)
-        sends = [0] * world
-
-        def make(rank, device):
-            def all_gather(send, recv, nbytes, stream):
-                try:
-                    _rt_check(rt.hipSetDevice(int(device)))
-                    _rt_check(rt.hipStreamSynchronize(C.c_void_p(stream)))      # my chunk is complete
-                    sends[rank] = send
-                    barrier.wait()                                             # ... and so is everybody's
-                    for p in range(world):
-                        if sends[p] != recv + p * nbytes:                      # in place: nothing to move for my own slot
-                            _rt_check(rt.hipMemcpyAsync(C.c_void_p(recv + p * nbytes), C.c_void_p(sends[p]), C.c_size_t(nbytes),
-                                                        C.c_int(4), C.c_void_p(stream)))  # hipMemcpyDefault
-                    _rt_check(rt.hipStreamSynchronize(C.c_void_p(stream)))
-                    barrier.wait()                                             # nobody reuses its buffer before all have pulled
-                except BaseException:
-                    barrier.abort()                                            # the other ranks fail instead of waiting for ever
-                    raise
-            c = cls.with_transport(device, rank, world, all_gather)
-            c._group_barrier = barrier
-            return c
-        return [make(r, d) for r, d in enumerate(devices)]
+        devs = (C.c_int * world)(*[int(d) for d in devices])
+        outs = (nv.vp * world)()
+        hip_check(hip.helm_comm_create_in_process(devs, world, float(timeout), outs))
+        comms = []
+        for r in range(world):
+            c = cls.__new__(cls)
+            c._h = nv.vp(outs[r])
+            c.device = int(devices[r])
+            comms.append(c)
+        return comms
 
     def abort_group(self):
         """in_process_group: break the group's barrier so that no other rank thread waits for this one any more."""
-        b = getattr(self, "_group_barrier", None)
-        if b is not None:
-            b.abort()
+        if getattr(self, "_h", None):
+            hip.helm_comm_abort_group(self._h)
 
     def info(self):
         """What RCCL reports: rank, world size, device, library version."""

@@ -14,8 +14,11 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -109,7 +112,47 @@ int need_rccl()
 
 } // namespace
 
+// helm_comm_create_in_process: the ranks are threads of this process.  A reusable barrier that can be broken (a rank that
+// fails must not leave the others waiting) and the ranks' send pointers of the collective in flight.
+struct InProcessGroup {
+    int world = 0;
+    double timeout_s = 600.0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool broken = false;
+    std::vector<const void *> sends;
+    // 0 on success, 1 when the barrier is broken or the wait timed out (which breaks it for everybody)
+    int wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (broken) return 1;
+        const uint64_t gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            generation++;
+            cv.notify_all();
+            return 0;
+        }
+        const bool ok = cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return generation != gen || broken; });
+        if (!ok || broken) {
+            broken = true;
+            cv.notify_all();
+            return 1;
+        }
+        return 0;
+    }
+    void abort()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        broken = true;
+        cv.notify_all();
+    }
+};
+
 struct helm_comm {
+    std::shared_ptr<InProcessGroup> group; // helm_comm_create_in_process
     ncclComm_t comm = nullptr;
     int device = 0, rank = 0, world = 1;
     hipStream_t side = nullptr; // the host-side helpers' own stream
@@ -207,6 +250,86 @@ int helm_comm_create_with_transport(int device_id, int rank, int world, helm_com
     return 0;
 }
 
+int helm_comm_create_in_process(const int *device_ids, int world, double timeout_s, helm_comm **out)
+{
+    if (!device_ids || !out || world < 1) return helm_hip_fail_(HELM_ERR_INVALID, "helm_comm_create_in_process: bad argument");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess) return helm_hip_fail_(HELM_ERR_NO_DEVICE, "helm_comm_create_in_process: no device");
+    for (int r = 0; r < world; r++) {
+        out[r] = nullptr;
+        if (device_ids[r] < 0 || device_ids[r] >= n_dev)
+            return helm_hip_fail_(HELM_ERR_NO_DEVICE, "helm_comm_create_in_process: no such device");
+    }
+    auto group = std::make_shared<InProcessGroup>();
+    group->world = world;
+    if (timeout_s > 0) group->timeout_s = timeout_s;
+    group->sends.assign((size_t)world, nullptr);
+    for (int r = 0; r < world; r++) {
+        helm_comm *c = new (std::nothrow) helm_comm();
+        bool ok = c != nullptr;
+        if (ok) {
+            c->device = device_ids[r];
+            c->rank = r;
+            c->world = world;
+            c->group = group;
+            ok = hipSetDevice(c->device) == hipSuccess && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
+                 hipMalloc(&c->scratch, sizeof(double) * (size_t)world) == hipSuccess;
+        }
+        if (!ok) {
+            if (c) helm_comm_destroy(c);
+            for (int q = 0; q < r; q++) {
+                helm_comm_destroy(out[q]);
+                out[q] = nullptr;
+            }
+            return helm_hip_fail_(HELM_ERR_HIP, "helm_comm_create_in_process: side stream / scratch");
+        }
+        out[r] = c;
+    }
+    return 0;
+}
+
+int helm_comm_abort_group(helm_comm *c)
+{
+    if (!c) return helm_hip_fail_(HELM_ERR_INVALID, "null communicator");
+    if (c->group) c->group->abort();
+    return 0;
+}
+
+// the in-process all-gather: every rank thread calls it for the same collective; device-to-device copies between the
+// ranks' buffers (peer copies when the ranks sit on different devices), a barrier on either side
+static int in_process_all_gather(helm_comm *c, const void *send_dev, void *recv_dev, size_t bytes, hipStream_t stream)
+{
+    InProcessGroup &g = *c->group;
+    auto broken = [&]() { return helm_hip_fail_(HELM_ERR_STATE, "in-process all-gather: another rank failed or did not arrive in time"); };
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream); // my chunk is complete
+    if (e != hipSuccess) {
+        g.abort();
+        return helm_hip_fail_(HELM_ERR_HIP, std::string("in-process all-gather: ") + hipGetErrorString(e));
+    }
+    {
+        std::lock_guard<std::mutex> lk(g.m);
+        g.sends[(size_t)c->rank] = send_dev;
+    }
+    if (g.wait()) return broken(); // ... and so is everybody's
+    for (int p = 0; p < c->world && e == hipSuccess; p++) {
+        const void *src;
+        {
+            std::lock_guard<std::mutex> lk(g.m);
+            src = g.sends[(size_t)p];
+        }
+        char *dst = static_cast<char *>(recv_dev) + (size_t)p * bytes;
+        if (src != dst) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream); // (in place: nothing to move for my own slot)
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        g.abort();
+        return helm_hip_fail_(HELM_ERR_HIP, std::string("in-process all-gather: ") + hipGetErrorString(e));
+    }
+    if (g.wait()) return broken(); // nobody reuses its buffer before everybody has pulled
+    return 0;
+}
+
 int helm_comm_destroy(helm_comm *c)
 {
     if (!c) return 0;
@@ -227,7 +350,7 @@ int helm_comm_info(const helm_comm *c, int *rank, int *world, int *device, int *
 {
     if (!c) return helm_hip_fail_(HELM_ERR_INVALID, "null communicator");
     int v = 0;
-    if (c->transport) {
+    if (c->transport || c->group) {
         if (rank) *rank = c->rank;
         if (world) *world = c->world;
         if (device) *device = c->device;
@@ -256,6 +379,12 @@ int helm_comm_all_gather(helm_comm *c, const void *send_dev, void *recv_dev, siz
 {
     if (!c || !send_dev || !recv_dev) return helm_hip_fail_(HELM_ERR_INVALID, "helm_comm_all_gather: null argument");
     if (bytes_per_rank == 0) return 0;
+    if (c->group) {
+        if (int rc = in_process_all_gather(c, send_dev, recv_dev, bytes_per_rank, static_cast<hipStream_t>(hip_stream))) return rc;
+        c->collectives++;
+        c->bytes_sent += (int64_t)bytes_per_rank;
+        return 0;
+    }
     if (c->transport) {
         if (int rc = c->transport(c->transport_user, send_dev, recv_dev, bytes_per_rank, hip_stream))
             return helm_hip_fail_(HELM_ERR_STATE, "helm_comm_all_gather: the host's transport failed (" + std::to_string(rc) + ")");
@@ -277,9 +406,11 @@ int helm_comm_all_reduce_f64(helm_comm *c, double *value, int op)
 {
     if (!c || !value || (op != 0 && op != 1)) return helm_hip_fail_(HELM_ERR_INVALID, "helm_comm_all_reduce_f64: bad argument");
     HIPC_TRY(hipSetDevice(c->device));
-    if (c->transport) { // one double per rank through the host's all-gather, reduced here
+    if (c->transport || c->group) { // one double per rank through the host's (or the in-process) all-gather, reduced here
         HIPC_TRY(hipMemcpyAsync(c->scratch + c->rank, value, sizeof(double), hipMemcpyHostToDevice, c->side));
-        if (int rc = c->transport(c->transport_user, c->scratch + c->rank, c->scratch, sizeof(double), c->side))
+        if (c->group) {
+            if (int rc = in_process_all_gather(c, c->scratch + c->rank, c->scratch, sizeof(double), c->side)) return rc;
+        } else if (int rc = c->transport(c->transport_user, c->scratch + c->rank, c->scratch, sizeof(double), c->side))
             return helm_hip_fail_(HELM_ERR_STATE, "helm_comm_all_reduce_f64: the host's transport failed (" + std::to_string(rc) + ")");
         std::vector<double> all((size_t)c->world);
         HIPC_TRY(hipMemcpyAsync(all.data(), c->scratch, sizeof(double) * all.size(), hipMemcpyDeviceToHost, c->side));

@@ -60,6 +60,15 @@ int helm_comm_create(int device_id, const uint8_t id[HELM_COMM_ID_BYTES], int ra
 typedef int (*helm_comm_all_gather_fn)(void *user, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *hip_stream);
 int helm_comm_create_with_transport(int device_id, int rank, int world, helm_comm_all_gather_fn all_gather, void *user,
                                     helm_comm **out);
+/* Communicators for ranks that are THREADS of this process (a host that drives its GPUs - or several contexts on one GPU -
+ * from one process, one thread and one engine context per rank): out[r] is rank r's communicator on device device_ids[r].
+ * The all-gather is device-to-device copies between the ranks' buffers (peer copies across devices) between two barriers;
+ * every rank must call each collective from its own thread.  No RCCL is needed or touched (rccl_version 0).  A rank that
+ * fails, or does not arrive within timeout_s seconds (<= 0: 600), breaks the group: every other rank's collective then
+ * returns an error instead of waiting; helm_comm_abort_group() breaks it from outside a collective.  Also how the sharded
+ * paths are tested at world size 8 on a box that allows six GPU processes (tests/test_gpu_eight_ranks.py). */
+int helm_comm_create_in_process(const int *device_ids, int world, double timeout_s, helm_comm **out);
+int helm_comm_abort_group(helm_comm *comm);
 /* ncclCommDestroy.  NULL is accepted. */
 int helm_comm_destroy(helm_comm *comm);
 /* What RCCL itself reports for the communicator (ncclCommUserRank / ncclCommCount / ncclCommCuDevice /

@@ -70,10 +70,7 @@ def _run_world(world, arrays, n_rows, in_rows, enc, ck, replicate_below, overlap
     from helm_amd.comm import Comm
     comms = Comm.in_process_group([0] * world)
     tables, stats, errors, sharded = [None] * world, [None] * world, [], [None] * world
-    # Contexts, programs and tables are made one after the other on this thread; the rank threads only run the passes.
-    # (Eight threads allocating, uploading keys and synchronising streams at the same time made the HIP runtime of this
-    # image throw std::bad_variant_access from inside libamdhip64 - a runtime race, not a kernel fault; concurrent kernel
-    # launches and copies, which is what eight ranks do in the passes, are fine.)
+    # contexts, programs and tables are made one after the other on this thread; the rank threads run the passes
     ranks = []
     for r in range(world):
         sk = helm_amd.ServerKey(ck, device=0)
