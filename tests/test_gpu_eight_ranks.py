@@ -172,3 +172,59 @@ def test_state_writing_program_falls_back_to_the_in_order_exchange(setup):
     tables, _, _ = _run_world(3, arr2, n_rows, in_rows, enc, ck, 0, True)
     for r, t in enumerate(tables):
         assert np.array_equal(t, want), f"rank {r}"
+
+
+@pytest.mark.parametrize("world,capacity_rows", [(8, 4), (3, 16)])
+def test_lut_level_sharded_over_eight_rank_threads(world, capacity_rows):
+    """The 64-bit-torus engine's sharded bootstrap batch (helm_si_set_exchange_comm: LUT mode, the radix operators and WoP
+    gates all go through it) at world size 8: 41 three-input LUTs in chunks of ceil(41 / 8) rows per rank, a gather buffer of
+    4 rows per rank (several exchange rounds per batch, the last one padded), every rank's table == the unsharded level."""
+    import helm_amd
+    from helm_amd.comm import Comm
+    ck = helm_amd.SiClientKey.generate("si_toy_1024", seed=1)
+    B = 41
+    bits = np.random.default_rng(4).integers(0, 2, size=3 * B).astype(np.uint64)
+    enc = ck.encrypt(bits)
+    in_idx = np.arange(3 * B, dtype=np.int32).reshape(3, B).T.copy()
+    ar, tb, out = np.full(B, 3, np.int32), np.full(B, 0x96, np.uint64), np.arange(3 * B, 4 * B, dtype=np.int32)
+    sk0 = helm_amd.SiServerKey(ck, device=0)
+    w0 = sk0.wires(4 * B)
+    w0.upload(np.arange(3 * B), enc)
+    w0.eval_lut_level(ar, in_idx, tb, out)
+    sk0.sync()
+    want = w0.download()
+    assert np.array_equal(ck.decrypt(want[3 * B:]), bits[:B] ^ bits[B:2 * B] ^ bits[2 * B:])
+    sk0.close()
+    comms = Comm.in_process_group([0] * world)
+    ranks, errors = [], []
+    for r in range(world):
+        sk = helm_amd.SiServerKey(ck, device=0)
+        w = sk.wires(4 * B)
+        w.upload(np.arange(3 * B), enc)
+        sk.set_exchange_comm(comms[r], min_batch=1, capacity_rows=capacity_rows)
+        sk.sync()
+        ranks.append((sk, w))
+
+    def rank_main(r):
+        try:
+            sk, w = ranks[r]
+            w.eval_lut_level(ar, in_idx, tb, out)
+            sk.sync()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            comms[r].abort_group()
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+        assert not t.is_alive(), "a rank thread is stuck"
+    assert not errors, errors
+    for r, (sk, w) in enumerate(ranks):
+        assert np.array_equal(w.download(), want), f"world {world}: rank {r}'s table differs from the unsharded level"
+        batches, rows = sk.exchange_stats()
+        assert batches == -(-B // (capacity_rows * world)) and B <= rows < B + world * batches, (batches, rows)
+        sk.set_exchange_comm(None)
+        sk.close()
+    for c in comms:
+        c.destroy()
