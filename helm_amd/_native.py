@@ -108,6 +108,7 @@ HIP_API = {
     "helm_hip_launch_costs": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "helm_hip_field_bits": (C.c_int, [vp]),
     "helm_hip_short_root_stages": (C.c_int, [vp]),
+    "helm_hip_bound_violations": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_int, C.c_int]),
     "helm_hip_load_bootstrap_key": (C.c_int, [vp, u32p, C.c_size_t]),
     "helm_hip_load_keyswitch_key": (C.c_int, [vp, u32p, C.c_size_t]),
     "helm_hip_wires_alloc": (C.c_int, [vp, C.c_int64, C.POINTER(vp)]),

@@ -2922,6 +2922,39 @@ int helm_hip_field_bits(const helm_hip_ctx *ctx)
     return ctx->field;
 }
 
+#ifdef HELM_CHECK_BOUNDS
+// the check build's self-test: one contract broken on purpose (mulmod with |a| = 2^53), so that a test can see the counter move
+__global__ void k_bounds_selftest(double *out)
+{
+    out[threadIdx.x] = mulmod<FpG>(threadIdx.x == 0 ? 0x1p53 : 3.0, 5.0);
+}
+#endif
+
+int helm_hip_bound_violations(helm_hip_ctx *ctx, uint32_t counts[8], int reset, int selftest)
+{
+    if (!ctx || !counts) return fail(HELM_ERR_INVALID, "null argument");
+#ifdef HELM_CHECK_BOUNDS
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (selftest) {
+        Scratch<double> d;
+        HIP_TRY(d.alloc(64));
+        hipLaunchKernelGGL(k_bounds_selftest, dim3(1), dim3(64), 0, ctx->stream, d.p);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_helm_bound_violations), 8 * sizeof(uint32_t)));
+    if (reset) {
+        const uint32_t zero[8] = {0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_helm_bound_violations), zero, sizeof(zero)));
+    }
+    return 0;
+#else
+    (void)reset;
+    (void)selftest;
+    return fail(HELM_ERR_STATE, "this library was not built with -DHELM_CHECK_BOUNDS (make libhelm_hip_check.so, HELM_HIP_LIB)");
+#endif
+}
+
 int helm_hip_short_root_stages(const helm_hip_ctx *ctx)
 {
     if (!ctx) return fail(HELM_ERR_INVALID, "null argument");

@@ -73,12 +73,29 @@ template <> struct has_short_roots<FpG> : std::true_type {};
 template <> struct has_short_roots<FpG2> : std::true_type {};
 template <> struct has_short_roots<FpH> : std::true_type {};
 
+// -DHELM_CHECK_BOUNDS: the contracts the lazy arithmetic rests on, checked at run time (a debug build, one translation unit:
+// `make libhelm_hip_check.so`, tests/test_gpu_bounds_check.py).  Every value is an exact integer held in a double, which is
+// only true below 2^53; the lean inverse transform additionally wants its inputs recentred (|x| <= p/2).  A violation is
+// COUNTED (helm_hip_bound_violations), never trapped: a trap would take the GPU context down.
+//   slot 0  mulmod: |a| >= 2^53        1  reduce: |a| >= 2^53        2  a butterfly sum or difference >= 2^53
+//   slot 3  ntt_inverse (lean form) entered with |x| > p/2           4  a lifted value outside to_torus32's range (2^51)
+#ifdef HELM_CHECK_BOUNDS
+static __device__ unsigned int g_helm_bound_violations[8];
+#define HELM_BOUND(cond, slot)                                                           \
+    do {                                                                                 \
+        if (!(cond)) atomicAdd(&g_helm_bound_violations[slot], 1u);                      \
+    } while (0)
+#else
+#define HELM_BOUND(cond, slot) ((void)0)
+#endif
+
 // a*w mod p for integers |a| < 2^53, |w| <= p/2.  Result r == a*w (mod p) exactly,
 // |r| <= (0.5 + 0.75 * |a| * 2^-52) * p  (<= 2p for any admissible a).
 template <typename F>
 __device__ __forceinline__ double mulmod(double a, double w)
 {
     constexpr double PINV = 1.0 / F::P;
+    HELM_BOUND(__builtin_fabs(a) < 0x1p53, 0);
     double h = a * w;
     double l = __builtin_fma(a, w, -h);
     double q = __builtin_rint(h * PINV);
@@ -91,6 +108,7 @@ template <typename F>
 __device__ __forceinline__ double reduce(double a)
 {
     constexpr double PINV = 1.0 / F::P;
+    HELM_BOUND(__builtin_fabs(a) < 0x1p53, 1);
     double q = __builtin_rint(a * PINV);
     return __builtin_fma(-q, F::P, a);
 }
@@ -105,6 +123,7 @@ __device__ __forceinline__ double reduce_unless_lazy(double a)
 // Exact integer in a double (|v| < 2^51) -> v mod 2^32.
 __device__ __forceinline__ uint32_t to_torus32(double v)
 {
+    HELM_BOUND(__builtin_fabs(v) < 0x1p51, 4);
     return (uint32_t)__double2loint(v + 6755399441055744.0 /* 1.5 * 2^52 */);
 }
 
@@ -436,6 +455,7 @@ __device__ __forceinline__ void fwd_block(double (&x)[M][Geo<LOGN>::E], const TW
                     double U = x[m][e0], V = (PLAIN_TOP && sb == SB_HI) ? x[m][e1] * w : mulmod<F>(x[m][e1], w);
                     x[m][e0] = U + V;
                     x[m][e1] = U - V;
+                    HELM_BOUND(__builtin_fabs(x[m][e0]) < 0x1p53 && __builtin_fabs(x[m][e1]) < 0x1p53, 2);
                 }
             }
         }
@@ -467,6 +487,7 @@ __device__ __forceinline__ void inv_block(double (&x)[Geo<LOGN>::E], const TW &t
                 const int e0 = (hi << (eb + 1)) | lo, e1 = e0 | (1 << eb);
                 double U = x[e0], V = x[e1];
                 x[e0] = U + V;
+                HELM_BOUND(__builtin_fabs(x[e0]) < 0x1p53 && __builtin_fabs(U - V) < 0x1p53, 2);
                 x[e1] = mulmod<F>(TW::MIRROR ? V - U : U - V, w);
             }
         }
@@ -507,6 +528,9 @@ __device__ __forceinline__ void fwd_top2_digits(double (&x)[M][E])
             x[m][e + Q] = a0 - u;
             x[m][e + 2 * Q] = a4 + v;
             x[m][e + 3 * Q] = a4 - v;
+            // every term is digit x (at most 38 bits): exact and far inside (-p/2, p/2) - the premise of the plain stages
+            HELM_BOUND(__builtin_fabs(x[m][e]) < F::P * 0.5 && __builtin_fabs(x[m][e + Q]) < F::P * 0.5 &&
+                           __builtin_fabs(x[m][e + 2 * Q]) < F::P * 0.5 && __builtin_fabs(x[m][e + 3 * Q]) < F::P * 0.5, 2);
         }
 }
 
@@ -531,6 +555,7 @@ __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double
     // the recentring fields: after fwd_top2_digits block A ends below 1.2 p (its first two stages add almost nothing), so
     // block B (three stages) stays below 4.5 p of 2^53 = 5.26 p without a recentring here (tests/test_lazy_bounds.py)
     constexpr bool SKIP_T1 = DIGITS == 2 && has_short_roots<F>::value && G::BB == 3;
+    static_assert(!SKIP_T1 || (G::BA >= 3 && G::BB == 3), "SKIP_T1: block A ends below 1.2 p only behind fwd_top2_digits, and block B must be three stages");
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
@@ -589,6 +614,13 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *x
 #define HELM_LEAN_INVERSE 1
 #endif
     constexpr bool LEAN = HELM_LEAN_INVERSE != 0 && F::LAZY && CENTRE && LOGN == 9 && G::BA == 3 && G::BB == 3 && G::BC == 3;
+    // what the slot classes above assume of the layout: eight values per lane, three blocks of three stages, so that a
+    // transpose hands a lane eight values of ONE slot of the block before (tests/test_lazy_bounds.py recomputes the bounds)
+    static_assert(!LEAN || (G::E == 8 && G::BA + G::BB + G::BC == LOGN), "LEAN inverse: slot-class bounds are derived for Geo<9>");
+    if constexpr (LEAN) {
+#pragma unroll
+        for (int e = 0; e < G::E; e++) HELM_BOUND(__builtin_fabs(x[e]) <= F::P * 0.5000001, 3);
+    }
     inv_block<F, LOGN, 0, 0, G::BC - 1, 0>(x, tw, G::jC(lane, 0));
     before_write();
     if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);

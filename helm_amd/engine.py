@@ -180,6 +180,13 @@ class ServerKey:
             hip_check(v)
         return v
 
+    def bound_violations(self, reset=True, selftest=False):
+        """Check build only (HELM_HIP_LIB=libhelm_hip_check.so): violations of the lazy arithmetic's contracts counted by the
+        kernels since the last reset -> [mulmod, reduce, butterfly, lean-inverse input, lift, 0, 0, 0]."""
+        c = (C.c_uint32 * 8)()
+        hip_check(hip.helm_hip_bound_violations(self._h, c, 1 if reset else 0, 1 if selftest else 0))
+        return [int(v) for v in c]
+
     def short_root_stages(self):
         """Leading forward-transform stages on digits done as one radix-4 butterfly of plain operations (helm_hip_short_root_stages)."""
         v = int(hip.helm_hip_short_root_stages(self._h))

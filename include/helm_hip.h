@@ -133,6 +133,13 @@ int helm_hip_field_bits(const helm_hip_ctx *ctx);
  * the kernels execute; results do not depend on it. */
 int helm_hip_short_root_stages(const helm_hip_ctx *ctx);
 
+/* Debug build only (-DHELM_CHECK_BOUNDS: csrc/libhelm_hip_check.so, loaded through HELM_HIP_LIB): the kernels of the boolean
+ * engine count every violation of the contracts their lazy modular arithmetic rests on - counts[0] a modular multiplication
+ * fed |a| >= 2^53, [1] a recentring fed the same, [2] a butterfly sum or difference that left 2^53 (or a plain short-root stage
+ * that left (-p/2, p/2)), [3] the lean inverse transform entered with |x| > p/2, [4] a lifted value outside 2^51 - since the
+ * last reset.  selftest != 0 first runs a kernel that breaks contract 0 once.  The regular build returns HELM_ERR_STATE. */
+int helm_hip_bound_violations(helm_hip_ctx *ctx, uint32_t counts[8], int reset, int selftest);
+
 /* -- keys ------------------------------------------------------------------ */
 /* Replaces convert_lwe_bootstrap_key / convert_lwe_keyswitch_key (reference
  * src/bin/helm.rs:187-192): standard-domain keys from the host are uploaded and
