@@ -867,22 +867,28 @@ struct DuoCfg {
     static constexpr bool STAG = STAG_;
     using G = Geo<LOGN>;
     static constexpr int MAX_SMALL_N = 1024;
-    static constexpr int ACC3 = (3 * G::N - 64 + 1) / 2 * 2; // u32 entries per polynomial (see PbsCfg)
+    // COMPACT (N = 1024, round 5): two bootstraps of the N = 512 layout scaled up would need 2 x 91.5 KB.  The lane twiddle
+    // table is shared by the workgroup's two bootstraps (it is the same table) and the accumulator copy holds the polynomial
+    // and its negation only (2 N entries; the third, wrap-free part of the N = 512 layout becomes an index mask per read):
+    // 2 x 69.6 KB + 14.3 KB = 153.6 KB.
+    static constexpr bool COMPACT = LOGN >= 10;
+    static constexpr int ACC3 = COMPACT ? 2 * G::N : (3 * G::N - 64 + 1) / 2 * 2; // u32 entries per polynomial (see PbsCfg)
     static constexpr int TW_ROWS = G::TWB + G::TWC;
     static_assert(L >= 2, "part A needs at least one level");
     static_assert(K1 == 2 || K1 == 3, "wave maps are written for k = 1 and k = 2");
+    static constexpr size_t TW_SHARED = COMPACT ? sizeof(double) * TW_ROWS * 64 : 0; // at the workgroup's base, before the bootstraps
     // per bootstrap
     static constexpr size_t X_OFF = 0;                                              // double [NWB][XPAD]
     static constexpr size_t COL_OFF = X_OFF + sizeof(double) * NWB * G::XPAD;       // double [K1][N]
-    static constexpr size_t TW_OFF = COL_OFF + sizeof(double) * K1 * G::N;          // double [TW_ROWS][64]
-    static constexpr size_t ACC_OFF = TW_OFF + sizeof(double) * TW_ROWS * 64;       // u32 [K1][ACC3]
+    static constexpr size_t TW_OFF = COL_OFF + sizeof(double) * K1 * G::N;          // double [TW_ROWS][64] (not COMPACT)
+    static constexpr size_t ACC_OFF = TW_OFF + (COMPACT ? 0 : sizeof(double) * TW_ROWS * 64); // u32 [K1][ACC3]
     static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint32_t) * K1 * ACC3;        // u16 [n+1]
     static constexpr size_t BOOT_BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
-    static constexpr size_t BYTES = BOOT_BYTES * NB;
+    static constexpr size_t BYTES = TW_SHARED + BOOT_BYTES * NB;
 };
 
 template <typename C>
-__global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restrict__ jobs, const uint32_t *__restrict__ wires,
+__global__ __launch_bounds__(64 * C::NW, C::NW / 4) void k_pbs_duo(const PbsJob *__restrict__ jobs, const uint32_t *__restrict__ wires,
                                                            const uint32_t *__restrict__ raw_in, const uint32_t *__restrict__ tvs,
                                                            const double *__restrict__ bsk, const double *__restrict__ tw_fwd,
                                                            uint32_t *__restrict__ out_big, int n, int logB, int flags, int count)
@@ -920,10 +926,12 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
     }
     const int jix = (int)blockIdx.x * NB + b;
     if (jix >= count) return; // the hardware barrier counts the surviving waves only
-    unsigned char *smem = smem_wg + (size_t)b * C::BOOT_BYTES;
+    unsigned char *smem = smem_wg + C::TW_SHARED + (size_t)b * C::BOOT_BYTES;
     double *X = reinterpret_cast<double *>(smem + C::X_OFF);
     double *COL = reinterpret_cast<double *>(smem + C::COL_OFF);
-    double *TW = reinterpret_cast<double *>(smem + C::TW_OFF);
+    // COMPACT: one table for the workgroup; each bootstrap's waves fill ALL of it (the same values: the other bootstrap's
+    // waves may have left already, and nobody reads before the barrier below)
+    double *TW = C::COMPACT ? reinterpret_cast<double *>(smem_wg) : reinterpret_cast<double *>(smem + C::TW_OFF);
     uint32_t *ACC = reinterpret_cast<uint32_t *>(smem + C::ACC_OFF);
     uint16_t *MS = reinterpret_cast<uint16_t *>(smem + C::MS_OFF);
     const int wb = r * 2 + g;            // wave index within the bootstrap
@@ -971,7 +979,7 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
         for (int e = 0; e < E; e++) {
             aw[64 * e] = accr[e];
             aw[64 * e + N] = 0u - accr[e];
-            if (e < E - 1) aw[64 * e + 2 * N] = accr[e];
+            if (!C::COMPACT && e < E - 1) aw[64 * e + 2 * N] = accr[e];
         }
     };
     if (g == 1) {
@@ -1034,10 +1042,17 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_duo(const PbsJob *__restr
             const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
             uint32_t st[E];
             {
-                const uint32_t *ar = acc_r + ((lane - a) & (2 * N - 1));
                 const uint32_t *ac = acc_r + lane;
+                if constexpr (C::COMPACT) { // [acc, -acc]: the rotated index wraps at 2 N
+                    const int base = lane - a;
 #pragma unroll
-                for (int e = 0; e < E; e++) st[e] = ((ar[64 * e] - ac[64 * e]) + (1u << (31 - rep))) >> (32 - rep);
+                    for (int e = 0; e < E; e++)
+                        st[e] = ((acc_r[(base + 64 * e) & (2 * N - 1)] - ac[64 * e]) + (1u << (31 - rep))) >> (32 - rep);
+                } else {
+                    const uint32_t *ar = acc_r + ((lane - a) & (2 * N - 1));
+#pragma unroll
+                    for (int e = 0; e < E; e++) st[e] = ((ar[64 * e] - ac[64 * e]) + (1u << (31 - rep))) >> (32 - rep);
+                }
             }
             double x[1][E];
             if (g == 1) {
@@ -2122,6 +2137,10 @@ struct helm_hip_ctx {
     int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput, 4 wide, 5 lockstep, 6 duo (the two
                              // bootstraps of a workgroup in step), 7 duo staggered, 8 sym, 9 trio (HELM_HIP_PBS_VARIANT)
     int duo_build = 2;       // the two-per-CU build the size dispatch uses: 1 k_pbs_duo in step, 2 staggered, 3 k_pbs_sym, 0 none (HELM_HIP_DUO)
+    int duo1024 = 1;         // N = 1024: launches of more than one and at most two bootstraps per CU on k_pbs_duo's compact layout (1 in step,
+                             // 2 staggered, 0: the two-wave build of rounds 1-4; HELM_HIP_DUO1024).  Round 5, same process, alternating,
+                             // helm_cuda, 512 bootstraps: two-wave 6.04 ms, in step 5.50 - 5.55 (stepping priorities), staggered 5.75
+    int duo1024_flags = 1;   // its issue priorities (HELM_HIP_DUO1024_FLAGS; bits as duo_flags): on, stepping down - flat (5) and off (0) measured 5 % slower
     int trio = 1;            // remainders of two to three bootstraps per CU on k_pbs_trio (HELM_HIP_TRIO=0: a partial lockstep round, round 3's choice)
     int trio_flags = 1;      // bit 0: issue-priority staging (HELM_HIP_TRIO_FLAGS)
     int duo_flags = 7;       // k_pbs_duo's issue priorities (HELM_HIP_DUO_FLAGS): bit 0 on at all; bit 1 staggered build: the inverse
@@ -2394,7 +2413,8 @@ static hipError_t launch_pbs_duo(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t 
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((count + C::NB - 1) / C::NB)), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, wires,
-                       raw, tvs, ctx->bsk, ctx->tw_fwd, out_big, ctx->P.n, ctx->P.pbs_logB, ctx->duo_flags, (int)count);
+                       raw, tvs, ctx->bsk, ctx->tw_fwd, out_big, ctx->P.n, ctx->P.pbs_logB,
+                       C::LOGN >= 10 ? ctx->duo1024_flags : ctx->duo_flags, (int)count);
     print_stamps(ctx, C::NW, "duo: forward | barriers | inverse | - | - | -");
     return hipGetLastError();
 }
@@ -2478,11 +2498,17 @@ hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int
     WIDE_CASE(49, 9, 2, 3) WIDE_CASE(49, 9, 1, 3) WIDE_CASE(49, 9, 1, 2)
     WIDE_CASE(51, 9, 2, 3) WIDE_CASE(51, 9, 1, 3) WIDE_CASE(51, 9, 1, 2)
 #undef WIDE_CASE
-    // N = 1024: two bootstraps of k_pbs_duo do not fit a CU's LDS (91 KB each): the wide build only
-    if (build == 0 && field == 51 && logn == 10 && k == 1 && l == 3)
-        return launch_pbs_wide<WideCfg<FpH, 10, 1, 3>>(ctx, jobs, count, wires, raw, tvs, out_big);
-    if (build == 0 && field == 51 && logn == 10 && k == 1 && l == 2)
-        return launch_pbs_wide<WideCfg<FpH, 10, 1, 2>>(ctx, jobs, count, wires, raw, tvs, out_big);
+    // N = 1024: the wide build, and (round 5) k_pbs_duo in its compact LDS layout (DuoCfg::COMPACT: 153.6 KB for two bootstraps)
+    if (field == 51 && logn == 10 && k == 1 && l == 3) {
+        if (build == 1) return launch_pbs_duo<DuoCfg<FpH, 10, 1, 3, false>>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if (build == 2) return launch_pbs_duo<DuoCfg<FpH, 10, 1, 3, true>>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if (build == 0) return launch_pbs_wide<WideCfg<FpH, 10, 1, 3>>(ctx, jobs, count, wires, raw, tvs, out_big);
+    }
+    if (field == 51 && logn == 10 && k == 1 && l == 2) {
+        if (build == 1) return launch_pbs_duo<DuoCfg<FpH, 10, 1, 2, false>>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if (build == 2) return launch_pbs_duo<DuoCfg<FpH, 10, 1, 2, true>>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if (build == 0) return launch_pbs_wide<WideCfg<FpH, 10, 1, 2>>(ctx, jobs, count, wires, raw, tvs, out_big);
+    }
     return hipErrorInvalidValue;
 }
 #endif
@@ -2495,9 +2521,9 @@ static hipError_t wide_launch(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t cou
     return helm_hip_tu1_launch_wide(ctx, build, std::is_same<F, FpG>::value ? 49 : 51, LOGN, K, L, jobs, count, wires, raw, tvs,
                                     out_big);
 #else
+    if (build == 1) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, false>>(ctx, jobs, count, wires, raw, tvs, out_big);
+    if (build == 2) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, true>>(ctx, jobs, count, wires, raw, tvs, out_big);
     if constexpr (LOGN == 9) {
-        if (build == 1) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, false>>(ctx, jobs, count, wires, raw, tvs, out_big);
-        if (build == 2) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, true>>(ctx, jobs, count, wires, raw, tvs, out_big);
         if (build == 3) return launch_pbs_sym<SymCfg<F, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
     }
     if (build) return hipErrorInvalidValue;
@@ -2583,6 +2609,12 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
         // HELM_HIP_NARROW=1 keeps the two-wave build)
         if (ctx->pbs_variant == 4 || (ctx->pbs_variant == 0 && count <= ctx->n_cus && ctx->narrow_variant == 4))
             return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
+        // round 5: two bootstraps per CU on k_pbs_duo's compact layout - the size dispatch's choice for launches of more than one
+        // and at most two per CU (HELM_HIP_DUO1024=0: the two-wave build as before); HELM_HIP_PBS_VARIANT=6 | 7 forces it
+        if (ctx->pbs_variant == 6 || ctx->pbs_variant == 7)
+            return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big, ctx->pbs_variant - 5);
+        if (ctx->pbs_variant == 0 && ctx->duo1024 && count > ctx->n_cus && count <= 2 * (int64_t)ctx->n_cus)
+            return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big, ctx->duo1024);
         if (ctx->pbs_variant != 1) {
             const int64_t round = 4 * (int64_t)ctx->n_cus;
             int64_t full = ctx->pbs_variant == 5 ? count : count / round * round;
@@ -2773,6 +2805,8 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) ctx->pbs_variant = atoi(v);
         if (const char *v = getenv("HELM_HIP_NARROW")) ctx->narrow_variant = atoi(v) == 4 ? 4 : 1;
         if (const char *v = getenv("HELM_HIP_DUO")) ctx->duo_build = atoi(v) >= 0 && atoi(v) <= 3 ? atoi(v) : 2;
+        if (const char *v = getenv("HELM_HIP_DUO1024")) ctx->duo1024 = atoi(v) == 1 || atoi(v) == 2 ? atoi(v) : 0;
+        if (const char *v = getenv("HELM_HIP_DUO1024_FLAGS")) ctx->duo1024_flags = atoi(v);
         if (const char *v = getenv("HELM_HIP_DUO_FLAGS")) ctx->duo_flags = atoi(v);
         if (const char *v = getenv("HELM_HIP_TRIO")) ctx->trio = atoi(v) != 0;
         if (const char *v = getenv("HELM_HIP_TRIO_FLAGS")) ctx->trio_flags = atoi(v);
@@ -2972,10 +3006,10 @@ int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4])
         cost[0] = ctx->narrow_variant == 4 ? 0.42 : 0.50;
         cost[1] = ctx->duo_build ? 0.66 : 0.80;
         cost[2] = ctx->P.k == 2 && ctx->trio ? 0.86 : 0.89;
-    } else { // N = 1024 (helm_cuda: 3.9 / 6.2 / 8.5 / 8.7 ms - wide, two all-levels workgroups per CU, lockstep rounds)
+    } else { // N = 1024 (helm_cuda, round 5: 3.9 / 5.5 / 8.0 / 8.6 ms - wide, k_pbs_duo's compact layout (two-wave build: 6.05), lockstep rounds)
         cost[0] = ctx->narrow_variant == 4 ? 0.45 : 0.64;
-        cost[1] = 0.71;
-        cost[2] = 0.98;
+        cost[1] = ctx->duo1024 ? 0.64 : 0.71;
+        cost[2] = 0.93;
     }
     cost[3] = 1.0;
     return 0;

@@ -203,7 +203,8 @@ def test_upload_rejects_duplicate_rows():
                                           (9, "toy_k2"),                                   # trio: three per workgroup, four waves each
                                           (1, "toy"), (3, "toy"), (4, "toy"), (5, "toy"),  # k = 2, l = 3 and k = 1, l = 2
                                           (6, "toy"), (7, "toy"), (8, "toy"),
-                                          (1, "toy_1024"), (4, "toy_1024"), (5, "toy_1024")])  # N = 1024: two-wave, wide, lockstep
+                                          (1, "toy_1024"), (4, "toy_1024"), (5, "toy_1024"),   # N = 1024: two-wave, wide, lockstep
+                                          (6, "toy_1024"), (7, "toy_1024")])                   # ... and k_pbs_duo's compact layout
 def test_every_build_of_k_pbs_bit_exact(variant, name, monkeypatch):
     """HELM_HIP_PBS_VARIANT forces one build of the blind-rotate kernel for a whole launch (latency,
     balanced, throughput, wide, lockstep, duo); each must reproduce the oracle bit for bit.  Nine
@@ -280,7 +281,8 @@ def test_full_size_lockstep_rounds_bit_exact(name):
     and at the reference's cited CUDA set (helm.rs:141-146), through one eval_gate_level per dispatch shape:
       4 CU + 7        one full lockstep round + a remainder that goes to the wide (N = 512) / all-levels
                       (N = 1024) build
-      5 CU + 5        lockstep round + a remainder of more than one bootstrap per CU (throughput build)
+      5 CU + 5        lockstep round + a remainder of more than one bootstrap per CU (k_pbs_duo: staggered at N = 512, the
+                      compact layout in step at N = 1024)
       6 CU + CU/2 + 2 between two and three per CU left over: k_pbs_trio (three bootstraps per workgroup, four waves each;
                       k = 2 only - at N = 1024 the whole launch runs in lockstep, last workgroup partial)
       7 CU + CU/2 + 2 more than three per CU left over: the whole launch in lockstep, last workgroup partial
