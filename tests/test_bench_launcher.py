@@ -104,3 +104,23 @@ def test_rccl_unavailable_on_one_rank_fails_loudly_unless_the_host_fallback_is_a
     line = json.loads(lines[0])
     assert line["value"] > 0 and "injected failure: precheck" in line["rccl_error"] and line["not_a_measurement_of_the_rccl_path"] is True
     assert line["rccl_ranks"]["rccl_version"] == 0 and "--allow-host-fallback" in line["rccl_ranks"]["communicator"]
+
+
+@pytest.mark.gpu
+def test_rehearsal_with_rank_threads_reports_every_named_result():
+    """HELM_BENCH_REHEARSE=threads: the ranks are threads of ONE process (the box allows six GPU processes, the scaling run
+    has eight ranks - profiles/r05/rehearse_n8.json is this command at --gpus 8): the library's in-process communicator
+    (helm_comm_create_in_process) under the real run's programs, sharded passes, three named runs and decryption checks."""
+    rc, lines, err = run_bench(["--gpus", "3", "--steps", "1", "--warmup", "0", "--blocks", "3", "--side-steps", "1"],
+                               {"HELM_BENCH_REHEARSE": "threads"}, timeout=900)
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert "error" not in line, line.get("error")
+    assert line["n_gpus"] == 3 and line["scaling"] == "strong" and line["value"] > 0
+    rr = line["rccl_ranks"]
+    assert rr["world_size"] == 3 and rr["rccl_version"] == 0 and "rank threads" in rr["communicator"] and rr["one_process_per_gpu"] is False
+    assert "THREADS" in line["data"]
+    for kind in ("strong", "weak", "sharded_weak"):
+        assert line[kind]["value"] > 0 and "every rank" in line[kind]["decrypt_check"], kind
+    assert line["sharded_weak"]["bootstraps_per_step"] == 3 * line["strong"]["bootstraps_per_step"]
