@@ -363,3 +363,44 @@ def test_vector_alu_keyswitch_fallback_bit_exact(name, monkeypatch):
             assert np.array_equal(got[g], orc.keyswitch(big[g])), (name, count, g)
     sk.close()
     sk_mfma.close()
+
+
+@pytest.mark.parametrize("name", ["boolean_default", "helm_cuda"])
+def test_whole_launch_every_row_bit_exact(name):
+    """EVERY output row of one launch that takes the size dispatch through a full lockstep round AND a two-per-CU remainder
+    (4 CU + CU + 5 gates: lockstep k_pbs + k_pbs_duo - staggered at N = 512, the compact layout at N = 1024) and of one that
+    ends in a one-per-CU remainder (4 CU + 7: k_pbs_wide), all gate types incl. MUX, NOT and constants, against the oracle's
+    SIMD route (oracle/fp_route.inc: exact fp64 NTT over a different prime than the GPU's, the route bench.py's cpu_baseline
+    times) - not a sample: the matrix-core keyswitch's tiles, every workgroup position and both kernels of the launch."""
+    import torch
+    cu = torch.cuda.get_device_properties(0).multi_processor_count
+    ck = helm_amd.ClientKey.generate(name, seed=9)
+    p = ck.params
+    sk = helm_amd.ServerKey(ck)
+    orc = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk, use_ntt=False, use_fp=True)
+    rng = np.random.default_rng(0xA11)
+    n_in = 32
+    bits = rng.integers(0, 2, n_in)
+    ct = ck.encrypt(bits.astype(bool))
+    kinds = [oracle.AND, oracle.OR, oracle.NAND, oracle.NOR, oracle.XOR, oracle.XNOR, oracle.MUX, oracle.NOT]
+    for count in (5 * cu + 5, 4 * cu + 7):
+        ops = rng.choice(kinds, size=count, p=[.16, .12, .16, .12, .16, .12, .1, .06]).astype(np.int32)
+        i0 = rng.integers(0, n_in, count).astype(np.int32)
+        i1 = np.where(ops == oracle.NOT, -1, rng.integers(0, n_in, count)).astype(np.int32)
+        i2 = np.where(ops == oracle.MUX, rng.integers(0, n_in, count), -1).astype(np.int32)
+        outs = np.arange(n_in, n_in + count, dtype=np.int32)
+        w = sk.wires(n_in + count)
+        w.upload(np.arange(n_in), ct)
+        w.eval_gate_level(ops, i0, i1, i2, outs)
+        got = w.download()
+        w.free()
+        ref = np.zeros_like(got)
+        ref[:n_in] = ct
+        orc.eval_level_fp(ref, ops, i0, i1, i2, outs)
+        bad = np.nonzero(np.any(got != ref, axis=1))[0]
+        assert len(bad) == 0, f"{name}: launch of {count}: rows {bad[:8]} differ from the oracle"
+        f2 = dict(GATES2)
+        want = [(int(bits[a]) if int(bits[c]) else int(bits[b])) if o == oracle.MUX else (1 - int(bits[a])) if o == oracle.NOT
+                else f2[int(o)](int(bits[a]), int(bits[b])) for o, a, b, c in zip(ops, i0, i1, i2)]
+        assert list(ck.decrypt(got[n_in:]).astype(int)) == want
+    sk.close()
