@@ -17,7 +17,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from helm_amd import Circuit, verilog_parser  # noqa: E402
-from helm_amd.distributed import gate_pbs, level_arrays, pack_levels  # noqa: E402
+from helm_amd.distributed import gate_pbs, level_arrays, pack_levels, shard_bounds  # noqa: E402
 from helm_amd.netlists import aes128  # noqa: E402
 
 TABLES = {  # ms for <= 1/4, 2/4, 3/4, 4/4 of a round of 4 x CUs bootstraps
@@ -25,6 +25,7 @@ TABLES = {  # ms for <= 1/4, 2/4, 3/4, 4/4 of a round of 4 x CUs bootstraps
     "r04": (3.55, 5.50, 7.50, 8.67),  # profiles/r04/microbench.jsonl (one box: 256 / 512 / 768 / 1,024)
     "r04b": (3.26, 5.40, 7.13, 8.25),  # with k_pbs_trio and the twiddle registers (profiles/r04/trio_experiments.txt, one box)
     "r04c": (3.33, 5.20, 6.65, 7.74),  # final build of round 4: + the short-root field (profiles/r04/microbench.jsonl)
+    "r05": (3.33, 5.34, 6.89, 8.32),   # round 5, same kernels on the round's profiling box (profiles/r05/microbench.jsonl)
 }
 
 
@@ -33,6 +34,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=32)
     ap.add_argument("--table", default="r04c", choices=sorted(TABLES))
     ap.add_argument("--costed", action="store_true", help="cost-aware launch packing (helm_host_pack_levels_costed)")
+    ap.add_argument("--by-count", action="store_true", help="cut launches by gate count (rounds 1-4) instead of by bootstrap weight")
     ap.add_argument("--json", action="store_true")
     a = ap.parse_args()
     blocks, CUS = a.blocks, 256
@@ -69,9 +71,13 @@ def main():
             if n == 1 or pbs <= CUS:
                 total_ms += chunk_ms(pbs)
                 continue
-            gates_per_rank = -(-(hi - lo) // n)
-            # the heaviest chunk: contiguous gates, bootstraps by the running count
-            worst = max(int(cs[min(hi, lo + (r + 1) * gates_per_rank)] - cs[min(hi, lo + r * gates_per_rank)]) for r in range(n))
+            if a.by_count:
+                gates_per_rank = -(-(hi - lo) // n)
+                # the heaviest chunk: contiguous gates, bootstraps by the running count
+                worst = max(int(cs[min(hi, lo + (r + 1) * gates_per_rank)] - cs[min(hi, lo + r * gates_per_rank)]) for r in range(n))
+            else:  # the engine's cut since round 5 (helm_amd/csrc/shard_rule.h): by bootstrap weight
+                b, gates_per_rank = shard_bounds(p_ops[lo:hi], n)
+                worst = max(int(cs[lo + b[r + 1]] - cs[lo + b[r]]) for r in range(n))
             total_ms += chunk_ms(worst)
             xchg_ms += gates_per_rank * n * 2892 / 50e9 * 1e3 + 0.04
         step = total_ms + xchg_ms
