@@ -58,6 +58,7 @@ echo "== 7 which memory-side counters gfx950 offers (is there one that separates
 rocprofv3 -L > $O/counters_available.txt 2>&1
 grep -i -E "mall|dram|hbm|TCC_EA|TCC_HIT|TCC_MISS|TCC_REQ\b|TCC_READ\b" $O/counters_available.txt | cut -c1-200 > $O/counters_memory_side.txt
 wc -l $O/counters_memory_side.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_HIT_sum TCC_MISS_sum -d $O/tcc_dram -o t -- python3 tools/prof_pbs.py boolean_default 4096 3 > $O/tcc_dram.log 2>&1 || tail -5 $O/tcc_dram.log
 fi
 echo "== summaries"
 python3 tools/prof_r03_summary.py $O > $O/summary.txt 2>&1; cat $O/summary.txt | cut -c1-260 | head -150
