@@ -260,6 +260,17 @@ int helm_comm_create_in_process(const int *device_ids, int world, double timeout
         if (device_ids[r] < 0 || device_ids[r] >= n_dev)
             return helm_hip_fail_(HELM_ERR_NO_DEVICE, "helm_comm_create_in_process: no such device");
     }
+    // ranks on different devices copy from each other's buffers: peer access where the topology offers it (without it the
+    // runtime stages the copies; an error here - no peer path, already enabled - is not one for the group)
+    for (int r = 0; r < world; r++)
+        for (int q = 0; q < world; q++)
+            if (device_ids[r] != device_ids[q]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, device_ids[r], device_ids[q]) == hipSuccess && can &&
+                    hipSetDevice(device_ids[r]) == hipSuccess)
+                    (void)hipDeviceEnablePeerAccess(device_ids[q], 0);
+            }
+    (void)hipGetLastError(); // (hipErrorPeerAccessAlreadyEnabled is sticky until read)
     auto group = std::make_shared<InProcessGroup>();
     group->world = world;
     if (timeout_s > 0) group->timeout_s = timeout_s;
