@@ -1,0 +1,28 @@
+import json, os, subprocess, sys
+ROOT = os.getcwd()
+CHILD = r'''
+import json, time, numpy as np, sys, hashlib
+sys.path.insert(0, %r)
+import helm_amd
+ck = helm_amd.ClientKey.generate("boolean_default", seed=1)
+sk = helm_amd.ServerKey(ck)
+B = 4096
+bits = np.random.default_rng(0).integers(0, 2, size=2 * B).astype(bool)
+w = sk.wires(3 * B)
+w.upload(np.arange(2 * B), ck.encrypt(bits))
+prog = helm_amd.Program(sk, np.full(B, 4, np.int32), np.arange(B), np.arange(B, 2 * B), np.full(B, -1), np.arange(2 * B, 3 * B), [0, B])
+for _ in range(3): prog.run(w)
+sk.sync()
+ts = []
+for _ in range(6):
+    t0 = time.perf_counter(); prog.run(w); sk.sync(); ts.append(time.perf_counter() - t0)
+out = w.download(np.arange(2 * B, 3 * B))
+print(json.dumps({"best_ms": round(min(ts) * 1e3, 3), "median_ms": round(sorted(ts)[3] * 1e3, 3), "sha": hashlib.sha256(out.tobytes()).hexdigest()[:12]}))
+'''
+libs = ["libhelm_hip.so", "variants/libhelm_hip_max-memory-clause.so", "variants/libhelm_hip_iterative-minreg.so"]
+for rnd in range(3):
+    for lib in libs:
+        env = dict(os.environ, HELM_HIP_LIB=lib)
+        p = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        print(rnd, lib, line[-1] if line else p.stderr[-300:], flush=True)
