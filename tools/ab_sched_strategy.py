@@ -19,7 +19,7 @@ for _ in range(6):
 out = w.download(np.arange(2 * B, 3 * B))
 print(json.dumps({"best_ms": round(min(ts) * 1e3, 3), "median_ms": round(sorted(ts)[3] * 1e3, 3), "sha": hashlib.sha256(out.tobytes()).hexdigest()[:12]}))
 '''
-libs = ["libhelm_hip.so", "variants/libhelm_hip_max-memory-clause.so", "variants/libhelm_hip_iterative-minreg.so"]
+libs = ["libhelm_hip.so"] + [a for a in sys.argv[1:]]
 for rnd in range(3):
     for lib in libs:
         env = dict(os.environ, HELM_HIP_LIB=lib)
