@@ -228,3 +228,67 @@ def test_lut_level_sharded_over_eight_rank_threads(world, capacity_rows):
         sk.close()
     for c in comms:
         c.destroy()
+
+
+@pytest.mark.parametrize("world,overlap", [(3, True), (8, False)])
+def test_gate_circuit_shard_over_rank_threads(world, overlap):
+    """The evaluator API on top of it (helm_host_gate_circuit_shard_over / _set_exchange_overlap; reference GateCircuit::
+    evaluate_encrypted, src/circuit.rs:506-549): every rank thread owns a GateCircuit on its own context, shards it over the
+    group's communicator and evaluates the c880-class netlist; every wire of every rank == the one-GPU evaluation."""
+    import os
+    import helm_amd
+    from helm_amd import Circuit, GateCircuit, PtxtType, verilog_parser
+    from helm_amd.comm import Comm
+    here = os.path.dirname(os.path.abspath(__file__))
+    gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_file(os.path.join(here, "netlists", "alu-c880-class.v"), False)
+    ck = helm_amd.ClientKey.generate("toy_k2", seed=5)
+    vals = {w: PtxtType.Bool(bool(v)) for w, v in zip(inputs, np.random.default_rng(8).integers(0, 2, len(inputs)))}
+
+    def circuit():
+        c = Circuit(gates, inputs, outputs, dffs)
+        c.sort_circuit()
+        c.compute_levels()
+        return c
+    sk0 = helm_amd.ServerKey(ck, device=0)
+    gc0 = GateCircuit(ck, sk0, circuit())
+    enc0 = gc0.encrypt_inputs(wire_set, vals)
+    one = gc0.evaluate_encrypted(enc0, 1, "bool")
+    want = {w: np.array(one[w]).copy() for w in one.keys()}
+    in_cts = {w: np.array(enc0[w]).copy() for w in inputs}
+    comms = Comm.in_process_group([0] * world)
+    ranks, errors, results = [], [], [None] * world
+    for r in range(world):
+        sk = helm_amd.ServerKey(ck, device=0)
+        gc = GateCircuit(ck, sk, circuit())
+        enc = gc.encrypt_inputs(wire_set, vals)
+        for w in inputs:  # the same input ciphertexts on every rank (fresh encryptions differ)
+            enc[w] = in_cts[w]
+        gc.shard_over(comms[r], 0, overlap=overlap)
+        ranks.append((sk, gc, enc))
+
+    def rank_main(r):
+        try:
+            sk, gc, enc = ranks[r]
+            out = gc.evaluate_encrypted(enc, 1, "bool")
+            results[r] = {w: np.array(out[w]).copy() for w in out.keys()}
+        except BaseException as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            comms[r].abort_group()
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+        assert not t.is_alive(), "a rank thread is stuck"
+    assert not errors, errors
+    for r in range(world):
+        assert set(results[r]) == set(want)
+        for w in want:
+            assert np.array_equal(results[r][w], want[w]), f"world {world}: rank {r}, wire {w}"
+        assert comms[r].stats()["collectives"] > 0
+    for sk, gc, _ in ranks:
+        gc.shard_over(None)
+        sk.close()
+    sk0.close()
+    for c in comms:
+        c.destroy()
