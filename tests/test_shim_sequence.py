@@ -15,7 +15,7 @@ def _build(tmp_path, name="shim_sequence"):
     exe = str(tmp_path / name)
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "c", name + ".c"), "-o", exe, "-L", CSRC, "-lhelm_host", "-lhelm_hip",
-                           f"-Wl,-rpath,{CSRC}"])
+                           "-lpthread", f"-Wl,-rpath,{CSRC}"])
     return exe
 
 
@@ -80,3 +80,24 @@ def test_communicator_sequence_on_the_gpu(tmp_path, params):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([exe, params], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "ok:" in r.stdout, r.stdout + r.stderr
+
+
+def test_rank_thread_sequence_builds_and_refuses_to_run_without_a_gpu(tmp_path):
+    """tests/c/shim_sequence_threads.c: a C host that drives its ranks from pthreads over helm_comm_create_in_process."""
+    from helm_amd import _native
+    exe = _build(tmp_path, "shim_sequence_threads")
+    if _native.hip.helm_hip_device_count() > 0:
+        pytest.skip("a GPU is present: the run is covered by the gpu test")
+    r = subprocess.run([exe, "toy"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "helm_hip_ctx_create failed" in r.stderr and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("params,world,overlap", [("toy_k2", 8, 0), ("toy_k2", 5, 1), ("boolean_default", 3, 0)])
+def test_rank_thread_sequence_on_the_gpu(tmp_path, params, world, overlap):
+    """Eight (five, three) rank threads of ONE C process, one engine context each: helm_hip_program_run_sharded_comm over the
+    library's in-process group - launches of 1..4 gates cut over up to eight ranks (most chunks empty and padded) - leaves
+    every rank the wire table of helm_hip_program_run; the reference's known answer (tests/circuit_test.rs:17-45) decrypts."""
+    exe = _build(tmp_path, "shim_sequence_threads")
+    r = subprocess.run([exe, params, str(world), str(overlap)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
