@@ -159,3 +159,32 @@ def test_chi_squared_u32_every_batch_bit_exact_under_the_references_set():
     assert aud.luts_checked == aud.luts_seen or os.environ.get("HELM_TEST_SAMPLED_AUDIT") == "1"
     assert aud.luts_checked >= aud.luts_seen // 8 and aud.lin_checked > 0
     sk.close()
+
+
+def test_fheuint16_known_answers_every_operation_bit_exact():
+    """K-7 (reference tests/gates_test.rs:127-310: FheUint16 10 + 20, 20 - 10, 10 x 20 and the scalar forms) under
+    PARAM_MESSAGE_2_CARRY_2's full dimensions: every linear step and every look-up of the evaluation against the oracle."""
+    ck, sk = helm_amd.gen_keys_shortint("shortint_m2c2", seed=1)
+    orc = oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk, use_ntt=True)
+    aud = Auditor(ck, orc)
+    sk.set_audit(aud)
+    text = """input [15:0] A, B;
+output [15:0] S, D, P, Q, R;
+add g0(A, B, S);
+sub g1(B, A, D);
+mult g2(A, B, P);
+add g3(A, 7, Q);
+sub g4(B, 3, R);
+"""
+    gs, ws, ins, outs, d, _, _ = verilog_parser.read_verilog_text(text, True)
+    c = Circuit(gs, ins, outs, d)
+    c.sort_circuit()
+    c.compute_levels()
+    ac = ArithCircuit(ck, sk, c)
+    out = ac.decrypt_outputs(ac.evaluate_encrypted(ac.encrypt_inputs(ws, {"A": PtxtType.U16(10), "B": PtxtType.U16(20)}), 1, "u16"), True)
+    sk.set_audit(None)
+    assert (out["S"], out["D"], out["P"], out["Q"], out["R"]) == (PtxtType.U16(30), PtxtType.U16(10), PtxtType.U16(200), PtxtType.U16(17),
+                                                                 PtxtType.U16(17))
+    assert not aud.bad, aud.bad[:5]
+    assert aud.luts_checked == aud.luts_seen == ac.pbs_per_cycle() > 100 and aud.lin_checked > 0
+    sk.close()
