@@ -188,3 +188,42 @@ sub g4(B, 3, R);
     assert not aud.bad, aud.bad[:5]
     assert aud.luts_checked == aud.luts_seen == ac.pbs_per_cycle() > 100 and aud.lin_checked > 0
     sk.close()
+
+
+def test_every_radix_operator_u8_every_operation_bit_exact():
+    """All thirteen FheUintN operators of arithmetic mode (reference src/gates.rs:331-701: + - * / << >> with encrypted and plain
+    right-hand sides, copy) on FheUint8 operands at PARAM_MESSAGE_2_CARRY_2's full dimensions - the restoring division and the
+    shifts by an encrypted amount have round structures of their own - every linear step and every look-up against the oracle."""
+    ck, sk = helm_amd.gen_keys_shortint("shortint_m2c2", seed=1)
+    orc = oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk, use_ntt=True)
+    aud = Auditor(ck, orc)
+    sk.set_audit(aud)
+    text = """input [7:0] A, B;
+output [7:0] S, D, P, Q, L, R, SA, SS, SM, SQ, SL, SR, C;
+add g0(A, B, S);
+sub g1(A, B, D);
+mult g2(A, B, P);
+div g3(A, B, Q);
+shl g4(A, B, L);
+shr g5(A, B, R);
+add g6(A, 77, SA);
+sub g7(A, 77, SS);
+mult g8(A, 77, SM);
+div g9(A, 11, SQ);
+shl g10(A, 5, SL);
+shr g11(A, 5, SR);
+copy g12(A, C);
+"""
+    gs, ws, ins, outs, d, _, _ = verilog_parser.read_verilog_text(text, True)
+    c = Circuit(gs, ins, outs, d)
+    c.sort_circuit()
+    c.compute_levels()
+    ac = ArithCircuit(ck, sk, c)
+    a, b = 201, 6
+    out = {k: v.value for k, v in ac.decrypt_outputs(ac.evaluate_encrypted(ac.encrypt_inputs(ws, {"A": PtxtType.U8(a), "B": PtxtType.U8(b)}), 1, "u8"), True).items()}
+    sk.set_audit(None)
+    assert out == {"S": (a + b) % 256, "D": (a - b) % 256, "P": a * b % 256, "Q": a // b, "L": (a << b) % 256, "R": a >> b,
+                   "SA": (a + 77) % 256, "SS": (a - 77) % 256, "SM": a * 77 % 256, "SQ": a // 11, "SL": (a << 5) % 256, "SR": a >> 5, "C": a}, out
+    assert not aud.bad, aud.bad[:5]
+    assert aud.luts_checked == aud.luts_seen == ac.pbs_per_cycle() > 200 and aud.lin_checked > 0
+    sk.close()
