@@ -404,3 +404,50 @@ def test_whole_launch_every_row_bit_exact(name):
                 else f2[int(o)](int(bits[a]), int(bits[b])) for o, a, b, c in zip(ops, i0, i1, i2)]
         assert list(ck.decrypt(got[n_in:]).astype(int)) == want
     sk.close()
+
+
+def test_one_aes128_evaluation_every_wire_bit_exact():
+    """BASELINE config 4 as ONE circuit at the full parameter set (what reference src/bin/helm.rs:256-262 runs): the 207 levels of
+    the AES-128 netlist (FIPS-197 C.1 key and plaintext) on the GPU - launches of 80-256 bootstraps: k_pbs_wide, the
+    single-circuit kernel, and the keyswitch's narrow-launch form - and the first 64 levels (three S-box layers, 10 k gates; all
+    207 with HELM_TEST_FULL_AES=1: one more minute of oracle time) on the oracle's SIMD route from the same input ciphertexts:
+    EVERY wire of those levels bit for bit, and the 128 output bits decrypt to the FIPS-197 ciphertext."""
+    import os
+    from helm_amd import Circuit, verilog_parser
+    from helm_amd.distributed import level_arrays
+    from helm_amd.netlists import aes128, aes128_reference_encrypt
+    ck = helm_amd.ClientKey.generate("boolean_default", seed=4)
+    p = ck.params
+    sk = helm_amd.ServerKey(ck)
+    orc = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk, use_ntt=False, use_fp=True)
+    gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_text(aes128(), False)
+    c = Circuit(gates, inputs, outputs, dffs)
+    c.sort_circuit()
+    c.compute_levels()
+    names = list(inputs) + sorted(wire_set)
+    index = {w: i for i, w in enumerate(names)}
+    ops, i0, i1, i2, out, off = level_arrays(c, index)
+    key, pt = bytes(range(16)), bytes.fromhex("00112233445566778899aabbccddeeff")
+    kv, pv = int.from_bytes(key, "big"), int.from_bytes(pt, "big")
+    rows = np.array([index[f"{w}[{i}]"] for w in ("key", "pt") for i in range(128)], np.int32)
+    bits = np.array([(v >> i) & 1 for v in (kv, pv) for i in range(128)], dtype=bool)
+    cts = ck.encrypt(bits)
+    w = sk.wires(len(names))
+    w.upload(rows, cts)
+    prog = helm_amd.Program(sk, ops, i0, i1, i2, out, off)
+    prog.run(w)
+    sk.sync()
+    got = w.download()
+    host = np.zeros_like(got)
+    host[rows] = cts
+    n_check = len(off) - 1 if os.environ.get("HELM_TEST_FULL_AES") == "1" else 64
+    for l in range(n_check):
+        s = slice(off[l], off[l + 1])
+        orc.eval_level_fp(host, ops[s], i0[s], i1[s], i2[s], out[s])
+    written = np.concatenate([rows, out[:off[n_check]]])
+    bad = [names[r] for r in written if not np.array_equal(got[r], host[r])]
+    assert not bad, f"{len(bad)} wires differ from the oracle, first: {bad[:5]}"
+    dec = ck.decrypt(got[[index[f"ct[{i}]"] for i in range(128)]])
+    assert sum(int(dec[i]) << i for i in range(128)).to_bytes(16, "big") == aes128_reference_encrypt(key, pt)
+    assert prog.total_pbs() > 30000 and len(off) - 1 > 200
+    sk.close()
