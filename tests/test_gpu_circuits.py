@@ -111,6 +111,19 @@ def test_c880_class_every_wire(keys):  # config 2 (stand-in netlist)
     for w in sorted(ptxt):
         assert client_key.decrypt(enc[w]) == bool(ptxt[w].value), w
     assert gc.pbs_per_cycle() > 330
+    # ... and bit for bit: the oracle's SIMD route from the evaluator's own input ciphertexts, level by level, every wire
+    orc = oracle.Oracle(client_key.params.as_tuple7(), client_key.bsk, client_key.ksk, use_ntt=False, use_fp=True)
+    names = list(input_wires) + sorted(wire_set)
+    index = {w: i for i, w in enumerate(names)}
+    ops, i0, i1, i2, out, off = level_arrays(circuit, index)
+    host = np.zeros((len(names), client_key.params.n + 1), dtype=np.uint32)
+    for w in input_wires:
+        host[index[w]] = enc[w]
+    for l in range(len(off) - 1):
+        s = slice(off[l], off[l + 1])
+        orc.eval_level_fp(host, ops[s], i0[s], i1[s], i2[s], out[s])
+    for w in sorted(wire_set):
+        assert np.array_equal(enc[w], host[index[w]]), f"{w}: the evaluator's ciphertext differs from the oracle's"
 
 
 def test_golden_vectors_on_gpu():
