@@ -140,6 +140,9 @@ extern "C" {
     pub fn helm_comm_create_with_transport(device_id: c_int, rank: c_int, world: c_int,
                                            all_gather: extern "C" fn(*mut c_void, *const c_void, *mut c_void, usize, *mut c_void) -> c_int,
                                            user: *mut c_void, out: *mut *mut helm_comm) -> c_int;
+    // ranks as threads of one process: device-to-device copies inside the library instead of RCCL
+    pub fn helm_comm_create_in_process(device_ids: *const c_int, world: c_int, timeout_s: f64, out: *mut *mut helm_comm) -> c_int;
+    pub fn helm_comm_abort_group(comm: *mut helm_comm) -> c_int;
     pub fn helm_comm_destroy(comm: *mut helm_comm) -> c_int;
     pub fn helm_comm_info(comm: *const helm_comm, rank: *mut c_int, world: *mut c_int, device: *mut c_int,
                           rccl_version: *mut c_int) -> c_int;

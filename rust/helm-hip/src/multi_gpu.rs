@@ -23,6 +23,30 @@ impl HipComm {
         id
     }
 
+    /// What `new` needs from THIS process alone (an RCCL library is bound, the device can be made current), without entering
+    /// a collective.  `ncclCommInitRank` blocks until every rank has entered it and has no timeout: a host calls this on every
+    /// rank first, agrees on the results over its control plane, and only then lets anybody call `new`.
+    pub fn precheck(device_id: i32) -> Result<(), String> {
+        if unsafe { sys::helm_comm_precheck(device_id) } == 0 {
+            Ok(())
+        } else {
+            Err(unsafe { std::ffi::CStr::from_ptr(sys::helm_hip_last_error()) }.to_string_lossy().into_owned())
+        }
+    }
+
+    /// Communicators for ranks that are THREADS of this process (one thread and one engine context per rank, on
+    /// `device_ids[rank]`): the all-gather is device-to-device copies inside the library, no RCCL involved.  Every rank calls
+    /// each collective from its own thread; a rank that fails should `abort_group` so that the others return instead of waiting.
+    pub fn in_process_group(device_ids: &[i32], timeout_s: f64) -> Vec<HipComm> {
+        let mut raw: Vec<*mut sys::helm_comm> = vec![std::ptr::null_mut(); device_ids.len()];
+        check(unsafe { sys::helm_comm_create_in_process(device_ids.as_ptr(), device_ids.len() as i32, timeout_s, raw.as_mut_ptr()) });
+        raw.into_iter().map(|raw| HipComm { raw }).collect()
+    }
+
+    pub fn abort_group(&self) {
+        unsafe { sys::helm_comm_abort_group(self.raw) };
+    }
+
     /// ncclCommInitRank on `device_id`; blocks until all `world` processes holding `id` have called it.
     pub fn new(device_id: i32, id: &[u8; sys::HELM_COMM_ID_BYTES], rank: i32, world: i32) -> Self {
         let mut raw = std::ptr::null_mut();
