@@ -173,7 +173,7 @@ def _load_profile(path):
         raw = f.read()
     data = json.loads(raw)
     return data, {"file": os.path.relpath(path, ROOT), "sha256_16": hashlib.sha256(raw).hexdigest()[:16],
-                  "copy_of": data.get("copy_of"), "measured_by_this_run": False}
+                  "copy_of": data.get("copy_of"), "copy_committed_in": data.get("copy_committed_in"), "measured_by_this_run": False}
 
 
 def build_program_arrays(circuit, wire_names, blocks):
