@@ -403,6 +403,7 @@ int helm_comm_all_gather(helm_comm *c, const void *send_dev, void *recv_dev, siz
         c->bytes_sent += (int64_t)bytes_per_rank;
         return 0;
     }
+    HIPC_TRY(hipSetDevice(c->device)); // a host thread that never selected a device must not enqueue on device 0
     // words where the size allows it (rows of u32 / u64 always do), bytes otherwise
     if (bytes_per_rank % 4 == 0)
         NCCL_TRY(g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank / 4, ncclUint32, c->comm, static_cast<hipStream_t>(hip_stream)));

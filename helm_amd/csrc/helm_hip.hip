@@ -3718,6 +3718,7 @@ int helm_hip_program_run_sharded_comm(helm_hip_ctx *ctx, helm_hip_program *prog,
     int rank = 0, world = 0, dev = -1;
     if (int rc = helm_comm_info(comm, &rank, &world, &dev, nullptr)) return rc;
     if (dev != ctx->device) return fail(HELM_ERR_STATE, "run_sharded_comm: the communicator lives on another device than the context");
+    HIP_TRY(hipSetDevice(ctx->device)); // the gather buffers and the exchange stream below belong to the context's device
     if (int rc = shard_prepare(ctx, prog, rank, world)) return rc;
     const size_t row = (size_t)ctx->P.n + 1;
     int64_t cap = 0;

@@ -2156,12 +2156,12 @@ hipError_t launch_ks64_key(helm_si_ctx *ctx, const KsKey &K, const Ks64Job *jobs
     }
 #define KS_CASE(LV)                                                                                                 \
     case LV: {                                                                                                      \
-        static bool done = false;                                                                                   \
-        if (!done) {                                                                                                \
+        static bool done[64] = {false}; /* per device: the attribute belongs to the device's code object */         \
+        if (!done[ctx->device & 63]) {                                                                              \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_keyswitch64<LV>),                   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);             \
             if (e != hipSuccess) return e;                                                                          \
-            done = true;                                                                                            \
+            done[ctx->device & 63] = true;                                                                          \
         }                                                                                                           \
         hipLaunchKernelGGL(k_keyswitch64<LV>, grid, dim3(256), lds, ctx->stream, jobs, big, K.key, out, P.n, kN,   \
                            P.ks_logB, (int)count, t_chunk);                                                         \
