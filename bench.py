@@ -14,16 +14,19 @@ CHILD process (never an exec), relays its ONE JSON line and leaves with its exit
 torch.distributed.run directly (RANK set), the process is a worker.
 
 One line, every result named:
-  value / scaling "strong"   the north star's per-level shard: a FIXED job of `--blocks` blocks, every packed launch
-                             split into N contiguous chunks, keys and wire table replicated, the launch's output
-                             ciphertexts all-gathered with ncclAllGather INSIDE libhelm_hip.so (include/helm_comm.h:
+  value / scaling "weak"     = `sharded_weak`: the north star's per-level shard at FIXED WORK PER GPU - ONE job of
+                             N x `--blocks` blocks (at N = 1 the 32-block job), every packed launch split into N chunks by
+                             bootstrap weight, keys and wire table replicated, the launch's output ciphertexts all-gathered
+                             with ncclAllGather INSIDE libhelm_hip.so (include/helm_comm.h:
                              helm_hip_program_run_sharded_comm - no torch in the data path); EXACTLY K timed steps
+  strong                     the same shard of a FIXED job of `--blocks` blocks whatever N (a 32-block level holds about
+                             5,000 bootstraps: at N = 8 a rank's chunk is two thirds of a lockstep round - the netlist's
+                             width, not the fabric, bounds it; modelled 0.72 of linear)
   weak                       independent blocks: every GPU evaluates its own `--blocks` blocks, no data-path collective
-  sharded_weak               the sharded path at fixed work per GPU: ONE job of N x `--blocks` blocks, every launch
-                             sharded and all-gathered (whole lockstep rounds per rank: what the exchange itself costs)
   rccl_ranks                 what the library's own RCCL communicator reports (ncclCommCount / ncclCommUserRank), the RCCL
                              version, and what carried the control plane (barrier, maximum over the ranks, the unique id)
-`--scaling weak` makes the independent-block run the headline instead (the strong run moves under "strong").
+`--scaling strong` / `--scaling weak` make one of the other two the headline instead; all three are always in the line
+under their own names (the runs that are not the headline with `--side-steps` timed steps).
 
 A worker that fails - an exception, a wrong decryption, a collective that does not come back within
 `--leg-timeout` seconds - ends with a non-zero exit code and its error in the line; nothing is retried.
@@ -54,7 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blocks", type=int, default=32, help="AES blocks of the fixed job (strong) / per GPU (weak)")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="which N > 1 run is the headline `value`")
+    ap.add_argument("--scaling", choices=["sharded_weak", "strong", "weak"], default="sharded_weak",
+                    help="which N > 1 run is the headline `value` (default: the per-level shard at fixed work per GPU)")
     ap.add_argument("--params", default="boolean_default")
     ap.add_argument("--no-pack", action="store_true", help="level-synchronous launches (the round-1 schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -661,14 +665,17 @@ def fill_result(bench, result):
         "value": round(head["value"], 1),
         "ms_per_step": round(head["ms_per_step"], 3),
         "higher_is_better": True,
-        # the job is `--blocks` blocks whatever N: total work fixed (N > 1 with --scaling weak: per-GPU work fixed)
-        "scaling": "weak" if head_kind == "weak" else "strong",
+        # N = 1: the `--blocks` job.  N > 1: per-GPU work fixed (sharded_weak: ONE job of N x `--blocks` blocks, every launch
+        # sharded; weak: independent blocks) unless --scaling strong (the `--blocks` job whatever N)
+        "scaling": "strong" if args.scaling == "strong" else "weak",
         "vs_baseline": None,
         "dtype": "u32 torus (exact NTT in f64 FMA over a 49-bit prime)",
         "data": "synthetic: generated AES-128 netlist (stand-in for HELM's), seeded random keys/plaintexts, "
                 "fresh encryptions resident in HBM" + (" [REHEARSAL: all ranks on one GPU, " + ("rank THREADS of one process, in-process transport]" if bench.threads else "gloo]") if bench.rehearse else ""),
         "config": {
-            "workload": (f"AES-128 gates-mode netlist, fixed job of {head['blocks_total']} block(s)"
+            "workload": (f"AES-128 gates-mode netlist, ONE job of {head['blocks_total']} blocks ({args.blocks} per GPU), every launch "
+                         f"sharded over {world} GPUs" if head_kind == "sharded_weak" else
+                         f"AES-128 gates-mode netlist, fixed job of {head['blocks_total']} block(s)"
                          + (f", every launch sharded over {world} GPUs" if sharded else "") if head_kind != "weak" else
                          f"AES-128 gates-mode netlist, {args.blocks} independent block(s) per GPU")
                         + (", launch-packed" if not args.no_pack else ", level-synchronous"),

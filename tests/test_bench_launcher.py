@@ -65,14 +65,15 @@ def test_hung_worker_group_is_stopped_and_reported():
 @pytest.mark.gpu
 def test_rehearsal_two_ranks_on_one_gpu_reports_every_named_result():
     """HELM_BENCH_REHEARSE=1: both ranks on cuda:0, the library's communicator over a host transport - the whole N > 1 path of bench.py, launcher
-    included: strong (headline), weak and sharded_weak each under its own name, rc 0."""
+    included: sharded_weak (the headline: the per-level shard at fixed work per GPU), strong and weak each under its own name, rc 0."""
     rc, lines, err = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "4", "--side-steps", "1"],
                                {"HELM_BENCH_REHEARSE": "1"}, timeout=1100)
     assert rc == 0, err[-3000:]
     assert len(lines) == 1, lines
     line = json.loads(lines[0])
     assert "error" not in line, line.get("error")
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2
+    assert line["config"]["blocks_total"] == 8 and "ONE job of 8 blocks (4 per GPU)" in line["config"]["workload"]
     # the data path is the real run's (the library's communicator: helm_hip_program_run_sharded_comm), carried by a host
     # transport in the rehearsal and labelled as such
     rr = line["rccl_ranks"]
@@ -81,7 +82,7 @@ def test_rehearsal_two_ranks_on_one_gpu_reports_every_named_result():
     assert line["config"]["sharded_launches"] > 0 and line["config"]["exchanged_MB_per_step"] > 0
     for kind in ("strong", "weak", "sharded_weak"):
         assert line[kind]["value"] > 0, kind
-    assert line["strong"]["value"] == line["value"]
+    assert line["sharded_weak"]["value"] == line["value"] and line["sharded_weak"]["steps"] == 2 and line["strong"]["steps"] == 1
     assert line["weak"]["exchanged_MB_per_step"] == 0 and line["sharded_weak"]["sharded_launches"] > 0
     assert line["sharded_weak"]["bootstraps_per_step"] == 2 * line["strong"]["bootstraps_per_step"]
 
@@ -111,13 +112,13 @@ def test_rehearsal_with_rank_threads_reports_every_named_result():
     """HELM_BENCH_REHEARSE=threads: the ranks are threads of ONE process (the box allows six GPU processes, the scaling run
     has eight ranks - profiles/r05/rehearse_n8.json is this command at --gpus 8): the library's in-process communicator
     (helm_comm_create_in_process) under the real run's programs, sharded passes, three named runs and decryption checks."""
-    rc, lines, err = run_bench(["--gpus", "3", "--steps", "1", "--warmup", "0", "--blocks", "3", "--side-steps", "1"],
+    rc, lines, err = run_bench(["--gpus", "3", "--steps", "1", "--warmup", "0", "--blocks", "3", "--side-steps", "1", "--scaling", "strong"],
                                {"HELM_BENCH_REHEARSE": "threads"}, timeout=900)
     assert rc == 0, err[-3000:]
     assert len(lines) == 1, lines
     line = json.loads(lines[0])
     assert "error" not in line, line.get("error")
-    assert line["n_gpus"] == 3 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["n_gpus"] == 3 and line["scaling"] == "strong" and line["value"] == line["strong"]["value"] > 0   # --scaling strong: the fixed job is the headline
     rr = line["rccl_ranks"]
     assert rr["world_size"] == 3 and rr["rccl_version"] == 0 and "rank threads" in rr["communicator"] and rr["one_process_per_gpu"] is False
     assert "THREADS" in line["data"]

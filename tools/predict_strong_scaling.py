@@ -7,7 +7,7 @@ MI355X (`--table r03|r04`; r04: profiles/r04/microbench.jsonl: whole lockstep ro
 <= 256 on the wide build 3.55 ms, <= 512 on k_pbs_duo 5.50 ms (r03: throughput build 7.4 ms), <= 768 in a partial lockstep
 round 7.50 ms (r03: 8.5)); launches of <= 256 bootstraps are computed on every rank.  The exchange is priced at bytes /
 50 GB/s + 40 us per all-gather.  Runs on the CPU (host library only).
-usage: predict_strong_scaling.py [--blocks 32] [--table r04] [--costed] [--json]"""
+usage: predict_strong_scaling.py [--blocks 32] [--table r04] [--costed] [--weak] [--json]"""
 import argparse
 import json
 import os
@@ -36,8 +36,33 @@ def main():
     ap.add_argument("--costed", action="store_true", help="cost-aware launch packing (helm_host_pack_levels_costed)")
     ap.add_argument("--by-count", action="store_true", help="cut launches by gate count (rounds 1-4) instead of by bootstrap weight")
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--weak", action="store_true", help="fixed work per GPU: the job at N ranks is N x --blocks blocks (bench.py's "
+                                                        "headline since round 5, `sharded_weak`) instead of --blocks whatever N")
     a = ap.parse_args()
-    blocks, CUS = a.blocks, 256
+    if a.weak:
+        return weak(a)
+    run(a, a.blocks, (1, 2, 4, 8))
+
+
+def weak(a):
+    rows = []
+    for n in (1, 2, 4, 8):
+        rows.append(run(a, a.blocks * n, (n,), quiet=True)[0])
+    base = rows[0]["k_gate_bootstraps_per_s"]
+    for r in rows:
+        r["of_linear"] = round(r["k_gate_bootstraps_per_s"] / base / r["n_gpus"], 3)
+        if not a.json:
+            print(f"N = {r['n_gpus']}: job of {a.blocks * r['n_gpus']:3d} blocks, {r['launches']:4d} launches, {r['ms_per_step']:8.1f} ms per step "
+                  f"(exchange {r['exchange_ms']:6.1f} ms) -> {r['k_gate_bootstraps_per_s']:8.1f} k gate-bootstraps/s, {r['of_linear']:5.2f} of linear")
+    if a.json:
+        print(json.dumps({"model": "launch lists priced with the kernel table; NOT a measurement", "blocks_per_gpu": a.blocks,
+                          "scaling": "weak (ONE job of N x blocks, every launch sharded)",
+                          "table_ms": dict(zip(("le_256", "le_512", "le_768", "le_1024"), TABLES[a.table])),
+                          "costed_packing": a.costed, "rows": rows}))
+
+
+def run(a, blocks, worlds, quiet=False):
+    CUS = 256
     T = TABLES[a.table]
     quarter_cost = [t / T[3] for t in T]
     gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_text(aes128(), False)
@@ -60,7 +85,7 @@ def main():
         return full * T[3] + tail
 
     base, rows = None, []
-    for n in (1, 2, 4, 8):
+    for n in worlds:
         p_ops, _, _, _, _, p_off, _ = pack_levels(*arrs, offT, 4 * CUS * n, quarter_cost if a.costed else None)
         w = gate_pbs(p_ops)
         cs = np.concatenate([[0], np.cumsum(w)])
@@ -85,9 +110,11 @@ def main():
             base = step
         rows.append({"n_gpus": n, "launches": launches, "ms_per_step": round(step, 1), "exchange_ms": round(xchg_ms, 1),
                      "k_gate_bootstraps_per_s": round(int(cs[-1]) / step, 1), "of_linear": round(base / step / n, 3)})
-        if not a.json:
+        if not a.json and not quiet:
             print(f"N = {n}: {launches:4d} launches, {step:8.1f} ms per step (exchange {xchg_ms:6.1f} ms) -> "
                   f"{int(cs[-1]) / step:8.1f} k gate-bootstraps/s, {base / step / n:5.2f} of linear")
+    if quiet:
+        return rows
     if a.json:
         print(json.dumps({"model": "launch lists priced with the kernel table; NOT a measurement", "blocks": blocks,
                           "table_ms": dict(zip(("le_256", "le_512", "le_768", "le_1024"), T)), "costed_packing": a.costed,
