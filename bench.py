@@ -331,6 +331,7 @@ class Bench:
         self.quantum = self.sk.launch_quantum()
         gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_text(aes128(), False)
         self.circuit = Circuit(gates, inputs, outputs, dffs)
+        self.n_gates = len(gates)
         self.circuit.sort_circuit()
         self.circuit.compute_levels()
         self.wire_names = list(inputs) + sorted(wire_set)
@@ -698,6 +699,8 @@ def fill_result(bench, result):
             "collective_ms_per_step": round(head["collective_ms_per_step"], 3),
         },
         "wall_s_per_step": round(head["elapsed"] / head["steps"], 4),
+        # all gates of the netlist (NOT included, which costs no bootstrap) over the same wall-clock
+        "netlist_gates_per_s": round(bench.n_gates * head["blocks_total"] * head["steps"] / head["elapsed"], 1),
         "decrypt_check": "all blocks == software AES (FIPS-197 C.1 vector in block 0)",
         "kernel_ms_per_step": {"k_pbs": round(tm.pbs_ms / args.steps, 3),
                                "k_pbs_lockstep_build": round(tm.pbs_main_ms / args.steps, 3),
@@ -722,6 +725,16 @@ def fill_result(bench, result):
                                   "`frac_survey_priced` is the figure of rounds 1-4 (the survey's count unchanged): it credits operations the "
                                   "kernel no longer executes"),
             "valu_issue": valu_issue,
+            # "achieved modmul/s against a measured integer-multiply micro-benchmark peak" - the micro-benchmark is
+            # tools/ubench_modmul.hip (profiles/r01_ubench_modmul.txt: one exact modular butterfly on the fp64 pipe, mulmod + add +
+            # sub, 33.6 SIMD-cycles per wave = 4,678 G butterflies/s on 256 CUs at 2.4 GHz; a 64-bit integer Goldilocks butterfly
+            # 137 cycles, two 31-bit Shoup primes 64); a multiply-accumulate of the external product is priced as one modmul too
+            "modmul": {"achieved_G_per_s": round((bfly + macs) * avg_pbs_per_launch / avg_launch_s / 1e9, 1),
+                       "ubench_peak_G_per_s": 4677.8, "unit": "exact modular multiplications (butterflies + multiply-accumulates) per second",
+                       "frac": round((bfly + macs) * avg_pbs_per_launch / avg_launch_s / 1e9 / 4677.8, 4),
+                       "peak_from": "profiles/r01_ubench_modmul.txt (fp_bfly, tools/ubench_modmul.hip)",
+                       "note": "above the butterfly micro-benchmark is possible: multiply-accumulates sum lazily (one reduction per "
+                               "column value) and the short-root stages multiply by small integers"},
             "avg_launch_ms": round(avg_launch_s * 1e3, 4), "avg_bootstraps_per_launch": round(avg_pbs_per_launch, 1),
             "traffic": traffic_bytes,
             "traffic_over_algorithmic": round(traffic_bytes / algo_bytes, 2) if traffic_bytes else None,
