@@ -39,6 +39,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the pool's host driver only supports dmabuf IPC: without this RCCL's peer mappings fail with `hipIpcGetMemHandle: invalid
+# argument`.  Exported on the boxes already; kept here so that a launcher with a scrubbed environment still gets it (it has to be
+# in place before the HIP runtime initialises, i.e. before the workers import torch)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PEAK_CLOCK_GHZ = 2.4          # MI355X engine clock the nominal peaks are quoted at
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md

@@ -175,6 +175,7 @@ SI_API = {
     "helm_si_set_exchange": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_int64, SI_EXCHANGE_FN, vp]),
     "helm_si_set_exchange_comm": (C.c_int, [vp, vp, C.c_int64, C.c_int64]),
     "helm_si_set_audit": (C.c_int, [vp, SI_AUDIT_FN, vp]),
+    "helm_si_bound_violations": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_int]),
     "helm_si_exchange_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "helm_si_exchange_world": (C.c_int, [vp]),
     "helm_si_round_capacity": (C.c_int64, [vp]),

@@ -2880,6 +2880,26 @@ int helm_si_wires_set_trivial(helm_si_ctx *ctx, helm_si_wires *w, const int32_t 
     return 0;
 }
 
+int helm_si_bound_violations(helm_si_ctx *ctx, uint32_t counts[8], int reset)
+{
+    if (!ctx || !counts) return fail(HELM_ERR_INVALID, "null argument");
+#ifdef HELM_CHECK_BOUNDS
+    // this translation unit's own copy of the counters (ntt_fp64.h): every kernel of the 64-bit engine and of the WoP-PBS
+    // path is compiled into it in the check build (one unit, no max-ILP split)
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_helm_bound_violations), 8 * sizeof(uint32_t)));
+    if (reset) {
+        const uint32_t zero[8] = {0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_helm_bound_violations), zero, sizeof(zero)));
+    }
+    return 0;
+#else
+    (void)reset;
+    return fail(HELM_ERR_STATE, "this library was not built with -DHELM_CHECK_BOUNDS (make libhelm_hip_check.so, HELM_HIP_LIB)");
+#endif
+}
+
 int helm_si_set_audit(helm_si_ctx *ctx, helm_si_audit_fn fn, void *user)
 {
     if (!ctx) return fail(HELM_ERR_INVALID, "null context");

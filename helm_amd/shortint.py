@@ -160,6 +160,13 @@ class SiServerKey:
     def set_stream(self, stream_ptr):
         hip_check(hip.helm_si_set_stream(self._h, nv.vp(stream_ptr)))
 
+    def bound_violations(self, reset=True):
+        """Check build only (HELM_HIP_LIB=libhelm_hip_check.so): violations of the lazy arithmetic's contracts counted by the
+        64-bit engine's kernels (and the WoP-PBS path's) since the last reset, slots as ServerKey.bound_violations."""
+        c = (C.c_uint32 * 8)()
+        hip_check(hip.helm_si_bound_violations(self._h, c, 1 if reset else 0))
+        return [int(v) for v in c]
+
     def set_audit(self, fn):
         """helm_si_set_audit: while set, every linear step and every look-up batch of this key - LUT levels, the radix
         operators of arithmetic mode - hands `fn` a dict with its operand rows (read before the call ran), its result rows

@@ -183,6 +183,12 @@ typedef struct {
 typedef int (*helm_si_audit_fn)(void *user, const helm_si_audit_record *rec);
 int helm_si_set_audit(helm_si_ctx *ctx, helm_si_audit_fn fn, void *user);
 
+/* Debug build only (-DHELM_CHECK_BOUNDS: csrc/libhelm_hip_check.so, loaded through HELM_HIP_LIB): the kernels of the 64-bit
+ * engine (and of the WoP-PBS path, which shares its translation unit) count every violation of the contracts of the lazy
+ * modular arithmetic, slots as in helm_hip_bound_violations (include/helm_hip.h).  The counters are per engine: the boolean
+ * engine's are read through its own entry point.  The regular build returns HELM_ERR_STATE. */
+int helm_si_bound_violations(helm_si_ctx *ctx, uint32_t counts[8], int reset);
+
 /* Programmable bootstraps the device holds at once under this parameter set: CUs x workgroups of the set's bootstrap kernel
  * per CU (1 at N = 2048, 2 for k_pbs64k).  A batch of at most this many ciphertexts takes one bootstrap's time whatever its
  * size; the host library merges the look-up rounds of concurrent operators into launches of at most this size. */
