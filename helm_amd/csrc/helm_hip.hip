@@ -2483,7 +2483,9 @@ __attribute__((visibility("hidden"))) hipError_t helm_hip_tu1_launch_wide(helm_h
 // field id of the engine context -> field type of the boolean kernels (49: the lazy FpG)
 template <int ID> struct BoolField;
 template <> struct BoolField<49> { using type = FpG; };
+template <> struct BoolField<50> { using type = FpI; }; // N = 1024, lazy, chosen per loaded key (helm_hip_load_bootstrap_key)
 template <> struct BoolField<51> { using type = FpH; };
+template <typename F> constexpr int bool_field_id() { return std::is_same<F, FpG>::value ? 49 : std::is_same<F, FpI>::value ? 50 : 51; }
 #if HELM_HIP_TU == 1
 hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int logn, int k, int l, const PbsJob *jobs, int64_t count,
                                     const uint32_t *wires, const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
@@ -2499,16 +2501,14 @@ hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int
     WIDE_CASE(51, 9, 2, 3) WIDE_CASE(51, 9, 1, 3) WIDE_CASE(51, 9, 1, 2)
 #undef WIDE_CASE
     // N = 1024: the wide build, and (round 5) k_pbs_duo in its compact LDS layout (DuoCfg::COMPACT: 153.6 KB for two bootstraps)
-    if (field == 51 && logn == 10 && k == 1 && l == 3) {
-        if (build == 1) return launch_pbs_duo<DuoCfg<FpH, 10, 1, 3, false>>(ctx, jobs, count, wires, raw, tvs, out_big);
-        if (build == 2) return launch_pbs_duo<DuoCfg<FpH, 10, 1, 3, true>>(ctx, jobs, count, wires, raw, tvs, out_big);
-        if (build == 0) return launch_pbs_wide<WideCfg<FpH, 10, 1, 3>>(ctx, jobs, count, wires, raw, tvs, out_big);
+#define WIDE1024_CASE(FB, LL)                                                                                               \
+    if (field == FB && logn == 10 && k == 1 && l == LL) {                                                                    \
+        if (build == 1) return launch_pbs_duo<DuoCfg<BoolField<FB>::type, 10, 1, LL, false>>(ctx, jobs, count, wires, raw, tvs, out_big); \
+        if (build == 2) return launch_pbs_duo<DuoCfg<BoolField<FB>::type, 10, 1, LL, true>>(ctx, jobs, count, wires, raw, tvs, out_big);  \
+        if (build == 0) return launch_pbs_wide<WideCfg<BoolField<FB>::type, 10, 1, LL>>(ctx, jobs, count, wires, raw, tvs, out_big);      \
     }
-    if (field == 51 && logn == 10 && k == 1 && l == 2) {
-        if (build == 1) return launch_pbs_duo<DuoCfg<FpH, 10, 1, 2, false>>(ctx, jobs, count, wires, raw, tvs, out_big);
-        if (build == 2) return launch_pbs_duo<DuoCfg<FpH, 10, 1, 2, true>>(ctx, jobs, count, wires, raw, tvs, out_big);
-        if (build == 0) return launch_pbs_wide<WideCfg<FpH, 10, 1, 2>>(ctx, jobs, count, wires, raw, tvs, out_big);
-    }
+    WIDE1024_CASE(51, 3) WIDE1024_CASE(51, 2) WIDE1024_CASE(50, 3) WIDE1024_CASE(50, 2)
+#undef WIDE1024_CASE
     return hipErrorInvalidValue;
 }
 #endif
@@ -2518,8 +2518,7 @@ static hipError_t wide_launch(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t cou
                               const uint32_t *tvs, uint32_t *out_big, int build = 0)
 {
 #if HELM_HIP_SPLIT_TU
-    return helm_hip_tu1_launch_wide(ctx, build, std::is_same<F, FpG>::value ? 49 : 51, LOGN, K, L, jobs, count, wires, raw, tvs,
-                                    out_big);
+    return helm_hip_tu1_launch_wide(ctx, build, bool_field_id<F>(), LOGN, K, L, jobs, count, wires, raw, tvs, out_big);
 #else
     if (build == 1) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, false>>(ctx, jobs, count, wires, raw, tvs, out_big);
     if (build == 2) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, true>>(ctx, jobs, count, wires, raw, tvs, out_big);
@@ -2645,6 +2644,8 @@ static hipError_t launch_pbs_t(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
 {
     if constexpr (LOGN == 9) {
         if (ctx->field == 49) return launch_pbs_f<FpG, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
+    } else {
+        if (ctx->field == 50) return launch_pbs_f<FpI, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
     }
     return launch_pbs_f<FpH, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
 }
@@ -2766,6 +2767,47 @@ int helm_hip_device_count(void)
     return n;
 }
 
+// The tables of the field the context computes in (ctx->field: 49 FpG, 50 FpI, 51 FpH): bit-reversed powers of psi and
+// psi^-1, 1/N.  Called by helm_hip_ctx_create and again by helm_hip_load_bootstrap_key when the key moves an N = 1024 set
+// into the lazy field.
+static int setup_field_tables(helm_hip_ctx *ctx)
+{
+    // twiddle tables: bit-reversed powers of psi (primitive 2N-th root) and of psi^-1
+    const int N = ctx->P.N, logN = ctx->logN;
+    const uint64_t pm = ctx->field == 49 ? FpG::P_U64 : ctx->field == 50 ? FpI::P_U64 : FpH::P_U64;
+    const uint64_t gen = ctx->field == 49 ? FpG::GEN : ctx->field == 50 ? FpI::GEN : FpH::GEN;
+    uint64_t psi = powmod_u64(gen, (pm - 1) / (2 * (uint64_t)N), pm);
+    const double b1 = ctx->field == 49 ? FpG::B1 : ctx->field == 50 ? FpI::B1 : FpH::B1,
+                 b2 = ctx->field == 49 ? FpG::B2 : ctx->field == 50 ? FpI::B2 : FpH::B2,
+                 b3 = ctx->field == 49 ? FpG::B3 : ctx->field == 50 ? FpI::B3 : FpH::B3;
+    {
+        // the kernels' first two forward stages assume psi^(N/4) = b (then psi^(N/2) = b^2, psi^(3N/4) = b^3): psi^(N/4) is
+        // one of the four primitive eighth roots b, b^3, -b, -b^3 - an odd power of psi puts it on b
+        uint64_t pick = 0;
+        for (uint64_t t = 1; t < 8 && !pick; t += 2)
+            if (powmod_u64(powmod_u64(psi, t, pm), (uint64_t)N / 4, pm) == (uint64_t)b1) pick = t;
+        if (!pick) return fail(HELM_ERR_STATE, "internal: no 2N-th root of unity with psi^(N/4) = b");
+        psi = powmod_u64(psi, pick, pm);
+    }
+    const uint64_t psi_inv = powmod_u64(psi, pm - 2, pm);
+    std::vector<double> tf(N), ti(N);
+    uint64_t a = 1, b = 1;
+    for (int i = 0; i < N; i++) {
+        tf[bitrev(i, logN)] = centred(a, pm);
+        ti[bitrev(i, logN)] = centred(b, pm);
+        a = mulmod_u64(a, psi, pm);
+        b = mulmod_u64(b, psi_inv, pm);
+    }
+    if (tf[1] != b2 || tf[2] != b1 || tf[3] != b3)
+        return fail(HELM_ERR_STATE, "internal: the first twiddles are not the constants the kernels assume");
+    ctx->n_inv = centred(powmod_u64((uint64_t)N, pm - 2, pm), pm);
+    if (!ctx->tw_fwd) HIP_TRY(hipMalloc(&ctx->tw_fwd, sizeof(double) * N));
+    if (!ctx->tw_inv) HIP_TRY(hipMalloc(&ctx->tw_inv, sizeof(double) * N));
+    HIP_TRY(hipMemcpy(ctx->tw_fwd, tf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->tw_inv, ti.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_ctx **out)
 {
     if (!params || !out) return fail(HELM_ERR_INVALID, "null argument");
@@ -2817,44 +2859,15 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
         ctx->stream = ctx->own_stream;
 
-        // twiddle tables: bit-reversed powers of psi (primitive 2N-th root) and of psi^-1
-        const int N = P.N, logN = ctx->logN;
         // the 49-bit prime (no recentring inside transforms) when the set's exact products fit
         // below its half and a lazy build exists (N = 512); HELM_HIP_FIELD=51 forces the other
         // ("49": the lazy field of the boolean kernels is FpG, p = 5072^4 + 1 = 2^49.23, ntt_fp64.h; its first two forward stages
-        // on digits need 2^(logB-1) b^3 far below p/2: any logB <= 12)
+        // on digits need 2^(logB-1) b^3 far below p/2: any logB <= 12).  N = 1024 starts in the 51-bit field; the key decides
+        // whether the lazy FpI serves (helm_hip_load_bootstrap_key)
+        const int N = P.N;
         ctx->field = (N == 512 && bound * 1.002 < FpG::P / 2 && P.pbs_logB <= 12) ? 49 : 51;
         if (const char *v = getenv("HELM_HIP_FIELD")) if (atoi(v) == 51) ctx->field = 51;
-        const uint64_t pm = ctx->field == 49 ? FpG::P_U64 : FpH::P_U64;
-        const uint64_t gen = ctx->field == 49 ? FpG::GEN : FpH::GEN;
-        uint64_t psi = powmod_u64(gen, (pm - 1) / (2 * (uint64_t)N), pm);
-        const double b1 = ctx->field == 49 ? FpG::B1 : FpH::B1, b2 = ctx->field == 49 ? FpG::B2 : FpH::B2,
-                     b3 = ctx->field == 49 ? FpG::B3 : FpH::B3;
-        {
-            // the kernels' first two forward stages assume psi^(N/4) = b (then psi^(N/2) = b^2, psi^(3N/4) = b^3): psi^(N/4) is
-            // one of the four primitive eighth roots b, b^3, -b, -b^3 - an odd power of psi puts it on b
-            uint64_t pick = 0;
-            for (uint64_t t = 1; t < 8 && !pick; t += 2)
-                if (powmod_u64(powmod_u64(psi, t, pm), (uint64_t)N / 4, pm) == (uint64_t)b1) pick = t;
-            if (!pick) return fail(HELM_ERR_STATE, "internal: no 2N-th root of unity with psi^(N/4) = b");
-            psi = powmod_u64(psi, pick, pm);
-        }
-        const uint64_t psi_inv = powmod_u64(psi, pm - 2, pm);
-        std::vector<double> tf(N), ti(N);
-        uint64_t a = 1, b = 1;
-        for (int i = 0; i < N; i++) {
-            tf[bitrev(i, logN)] = centred(a, pm);
-            ti[bitrev(i, logN)] = centred(b, pm);
-            a = mulmod_u64(a, psi, pm);
-            b = mulmod_u64(b, psi_inv, pm);
-        }
-        if (tf[1] != b2 || tf[2] != b1 || tf[3] != b3)
-            return fail(HELM_ERR_STATE, "internal: the first twiddles are not the constants the kernels assume");
-        ctx->n_inv = centred(powmod_u64((uint64_t)N, pm - 2, pm), pm);
-        HIP_TRY(hipMalloc(&ctx->tw_fwd, sizeof(double) * N));
-        HIP_TRY(hipMalloc(&ctx->tw_inv, sizeof(double) * N));
-        HIP_TRY(hipMemcpy(ctx->tw_fwd, tf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ctx->tw_inv, ti.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+        if (int rc = setup_field_tables(ctx)) return rc;
         std::vector<uint32_t> tv(N, PT_TRUE);
         HIP_TRY(hipMalloc(&ctx->tv_bool, sizeof(uint32_t) * N));
         HIP_TRY(hipMemcpy(ctx->tv_bool, tv.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
@@ -3025,12 +3038,54 @@ int helm_hip_load_bootstrap_key(helm_hip_ctx *ctx, const uint32_t *bsk_std, size
         return fail(HELM_ERR_INVALID, "bootstrapping key: expected " + std::to_string(polys * P.N) + " words, got " +
                                           std::to_string(n_words));
     HIP_TRY(hipSetDevice(ctx->device));
+    if (P.N == 1024) {
+        // Round 5: which field serves THIS key.  The exact sum an external product can reach is at most B/2 x the l1-norm of
+        // the key coefficients that meet in one output coefficient: the (k+1) l polynomials of one key column of one step (a
+        // negacyclic product's output coefficient is a signed sum over ALL coefficients of each factor).  Both groupings of
+        // the (k+1)^2 polynomials of a level are taken (row-wise and column-wise), so the bound does not depend on the
+        // container's order.  Below FpI's half (2^48.64; a key of uniform masks gives 2^48.58 under helm.rs:141-146's set)
+        // the lazy field is exact for every input under this key; otherwise the 51-bit field stays (worst case 2^49.58).
+        double worst = 0.0;
+        const size_t per_step = (size_t)P.pbs_l * K1 * K1;
+        std::vector<double> l1(per_step);
+        for (size_t i = 0; i < (size_t)P.n; i++) {
+            for (size_t q = 0; q < per_step; q++) {
+                const uint32_t *w = bsk_std + (i * per_step + q) * (size_t)P.N;
+                uint64_t acc = 0;
+                for (int j = 0; j < P.N; j++) {
+                    const int32_t v = (int32_t)w[j];
+                    acc += (uint64_t)(v < 0 ? -(int64_t)v : (int64_t)v);
+                }
+                l1[q] = (double)acc;
+            }
+            for (size_t c = 0; c < K1; c++) {
+                double by_col = 0.0, by_row = 0.0;
+                for (size_t q = 0; q < per_step; q++) {
+                    if (q % K1 == c) by_col += l1[q];
+                    if ((q / K1) % K1 == c) by_row += l1[q];
+                }
+                worst = std::max(worst, std::max(by_col, by_row));
+            }
+        }
+        const double key_bound = worst * (double)(1u << (P.pbs_logB - 1));
+        int want = (key_bound * 1.002 < FpI::P / 2 && P.pbs_logB <= 12) ? 50 : 51;
+        if (const char *v = getenv("HELM_HIP_FIELD")) if (atoi(v) == 51) want = 51;
+        if (want != ctx->field) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream)); // nothing in flight may still read the other field's tables
+            ctx->field = want;
+            ctx->have_bsk = false;
+            if (int rc = setup_field_tables(ctx)) return rc;
+        }
+    }
     Scratch<uint32_t> d_std;
     HIP_TRY(d_std.alloc(n_words));
     if (!ctx->bsk) HIP_TRY(hipMalloc(&ctx->bsk, n_words * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(d_std.p, bsk_std, n_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     if (P.N == 512 && ctx->field == 49)
         hipLaunchKernelGGL((k_bsk_convert<FpG, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
+                           ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
+    else if (P.N == 1024 && ctx->field == 50)
+        hipLaunchKernelGGL((k_bsk_convert<FpI, 10>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
                            ctx->tw_fwd, ctx->n_inv, (int)K1, P.pbs_l);
     else if (P.N == 512)
         hipLaunchKernelGGL((k_bsk_convert<FpH, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std.p, ctx->bsk,
@@ -3825,6 +3880,9 @@ int helm_hip_ntt_roundtrip(helm_hip_ctx *ctx, const uint32_t *poly_in, uint32_t 
     HIP_TRY(hipMemcpyAsync(d_in.p, poly_in, (size_t)count * N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     if (N == 512 && ctx->field == 49)
         hipLaunchKernelGGL((k_ntt_roundtrip<FpG, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,
+                           ctx->tw_fwd, ctx->tw_inv, ctx->n_inv);
+    else if (N == 1024 && ctx->field == 50)
+        hipLaunchKernelGGL((k_ntt_roundtrip<FpI, 10>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,
                            ctx->tw_fwd, ctx->tw_inv, ctx->n_inv);
     else if (N == 512)
         hipLaunchKernelGGL((k_ntt_roundtrip<FpH, 9>), dim3((unsigned)count), dim3(64), 0, ctx->stream, d_in.p, d_out.p,

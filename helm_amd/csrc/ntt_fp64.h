@@ -32,6 +32,7 @@ namespace helm {
 //   FpG   5072^4 + 1 = 2^49.23  lazy    boolean kernels (N = 512 sets whose exact products fit) and CRT prime 0 of the 64-bit ones
 //   FpG2  5096^4 + 1 = 2^49.26  lazy    CRT prime 1 of the 64-bit kernels
 //   FpH   6432^4 + 1 = 2^50.60  strict  boolean kernels at N = 1024 and for larger N = 512 sets
+//   FpI   5440^4 + 1 = 2^49.64  lazy    boolean kernels at N = 1024 when the loaded key's own bound fits (round 5)
 
 // The lazy field of the BOOLEAN kernels (round 4): p = b^4 + 1 with b = 5072 = 2^12.3 (generator 3; 2^16 | p - 1).
 // b is a primitive EIGHTH root of unity, so the twiddles of a transform's first two stages - psi^(N/2) and psi^(N/4),
@@ -68,7 +69,23 @@ struct FpH {
     static constexpr bool LAZY = false;
     static constexpr double B1 = 6432.0, B2 = 41370624.0, B3 = 266095853568.0;
 };
+// Round 5: a LAZY field for the N = 1024 sets (the reference's CUDA parameters, helm.rs:141-146): p = 5440^4 + 1 = 2^49.64
+// (generator 3; 2^24 | p - 1), 2^53 / p = 10.28.  Its half, 2^48.64, is BELOW the worst case of helm_cuda's exact products
+// ((k+1) l N B/2 2^31 = 2^49.58, every key coefficient at 2^31 with aligned signs) and ABOVE what a loaded key can produce:
+// |sum| <= B/2 x the largest l1-norm of a key column (about N (k+1) l 2^30 = 2^48.58 for a key of uniform masks), which
+// helm_hip_load_bootstrap_key computes for the key at hand - an exact guarantee for that key and every input; a key that
+// does not fit keeps FpH.  Bounds (tests/test_lazy_bounds.py): forward outputs <= 6.9 p, hand-over sums of the six products
+// <= 9.1 p, inverse sums <= 8 p, all below 10.28 p: no recentring in the forward transforms, the products, their sums or the
+// four-stage inverse block - 112 of FpH's 160 recentrings per wave-step (of 3,785 vector instructions) are gone.
+struct FpI {
+    static constexpr double P = 875781160960001.0;
+    static constexpr uint64_t P_U64 = 875781160960001ull;
+    static constexpr uint64_t GEN = 3;
+    static constexpr bool LAZY = true;
+    static constexpr double B1 = 5440.0, B2 = 29593600.0, B3 = 160989184000.0;
+};
 template <typename F> struct has_short_roots : std::false_type {};
+template <> struct has_short_roots<FpI> : std::true_type {};
 template <> struct has_short_roots<FpG> : std::true_type {};
 template <> struct has_short_roots<FpG2> : std::true_type {};
 template <> struct has_short_roots<FpH> : std::true_type {};

@@ -174,7 +174,8 @@ class ServerKey:
 
     def field_bits(self):
         """49: the blind-rotate kernels compute in the lazy field p = 5072^4 + 1 (short eighth roots of unity: two forward
-        stages on digits without modular reductions), 51: in the 51-bit field (helm_hip_field_bits)."""
+        stages on digits without modular reductions), 51: in the 51-bit field, 50: N = 1024 in the lazy field p = 5440^4 + 1,
+        chosen when the loaded key's own bound fits (helm_hip_field_bits)."""
         v = int(hip.helm_hip_field_bits(self._h))
         if v < 0:
             hip_check(v)

@@ -124,8 +124,12 @@ int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4]);
 /* The prime field the blind-rotate kernels of this context compute in, as its size class: 49 = the lazy field p = 5072^4 + 1
  * (2^49.2; N = 512 sets whose exact products fit below p/2: no recentring inside transforms, and the first two stages of
  * every forward transform on decomposition digits as plain multiplications by the short eighth roots of unity 5072^k), 51 =
- * the 51-bit field.  Results do not depend on it (exact integer arithmetic either way); reported by benchmarks because the
- * operation count of the kernels does.  Negative on error. */
+ * the 51-bit field p = 6432^4 + 1 (recentred at block boundaries), 50 = the lazy field p = 5440^4 + 1 (2^49.6) of N = 1024
+ * contexts: helm_hip_load_bootstrap_key takes it when B/2 x the largest l1-norm of a column of the LOADED key stays below
+ * p/2 - an exact guarantee for that key and every input (a generated key under helm.rs:141-146's set does; the worst case
+ * of the set does not, and a key that does not fit keeps 51), so the value may change when a key is loaded
+ * (HELM_HIP_FIELD=51 in the environment keeps the 51-bit field).  Results do not depend on it (exact integer arithmetic
+ * either way); reported by benchmarks because the operation count of the kernels does.  Negative on error. */
 int helm_hip_field_bits(const helm_hip_ctx *ctx);
 /* Number of leading stages of every forward transform on decomposition digits that run as plain multiplications by short
  * roots of unity (2 in both fields of this engine: one radix-4 butterfly of 10 operations per four values instead of two

@@ -275,6 +275,67 @@ def test_lockstep_build_n1024_bit_exact(monkeypatch):
     sk.close()
 
 
+def _nine_bootstraps_bit_exact(ck, sk, orc, seed):
+    p = ck.params
+    rng = np.random.default_rng(seed)
+    lwe = rng.integers(0, 2**32, size=(9, p.n + 1), dtype=np.uint32)
+    lwe[0] = ck.encrypt(True)
+    lwe[3, :] = 0
+    tvs = rng.integers(0, 2**32, size=(2, p.N), dtype=np.uint32)
+    idx = rng.integers(0, 2, size=9).astype(np.int32)
+    got = sk.pbs_batch(lwe, tvs, idx)
+    for g in range(len(lwe)):
+        assert np.array_equal(got[g], orc.bootstrap_noks(lwe[g], tvs[idx[g]])), g
+
+
+@pytest.mark.parametrize("variant", [1, 4, 5, 6, 7])
+def test_n1024_builds_bit_exact_in_the_51_bit_field_too(variant, monkeypatch):
+    """Round 5: N = 1024 sets run in the lazy field FpI (p = 5440^4 + 1) when the loaded key's own bound allows it - the toy and
+    the cited set do, so test_every_build_of_k_pbs_bit_exact[*-toy_1024] now covers FpI's kernels.  The 51-bit field stays
+    the fallback for keys that do not fit: its five N = 1024 builds (two-wave, wide, lockstep, duo in step / staggered)
+    against the oracle under HELM_HIP_FIELD=51.  Parameters: reference src/bin/helm.rs:141-146."""
+    monkeypatch.setenv("HELM_HIP_FIELD", "51")
+    monkeypatch.setenv("HELM_HIP_PBS_VARIANT", str(variant))
+    ck = helm_amd.ClientKey.generate("toy_1024", seed=11)
+    sk = helm_amd.ServerKey(ck)
+    assert sk.field_bits() == 51
+    _nine_bootstraps_bit_exact(ck, sk, oracle.Oracle(ck.params.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True), 40 + variant)
+    sk.close()
+
+
+def test_n1024_field_follows_the_loaded_key():
+    """helm_hip_load_bootstrap_key decides the field of an N = 1024 context from the key at hand: B/2 x the largest l1-norm of
+    a key column below FpI's half -> the lazy field (exact for every input under that key); a key whose norms are larger -
+    here every coefficient at the largest magnitude, and a real key with the polynomials of ONE step replaced - keeps the
+    51-bit field, whose half covers the worst case.  Bit-exact against the oracle under each key; loading another key into
+    the same context moves the field back and forth."""
+    ck = helm_amd.ClientKey.generate("toy_1024", seed=12)
+    p = ck.params
+    sk = helm_amd.ServerKey(ck)
+    assert sk.field_bits() == 50
+    _nine_bootstraps_bit_exact(ck, sk, oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True), 3)
+    per_step = p.pbs_l * (p.k + 1) ** 2 * p.N
+    worst = np.full_like(ck.bsk, 0x7FFFFFFF)
+    one_step = ck.bsk.copy().reshape(p.n, per_step)
+    one_step[5] = 0x80000000                      # -2^31 everywhere in step 5 only
+    for bsk in (worst, one_step.reshape(-1)):
+        from helm_amd._native import hip, hip_check, as_u32p
+        bsk = np.ascontiguousarray(bsk, dtype=np.uint32).reshape(-1)
+        hip_check(hip.helm_hip_load_bootstrap_key(sk._h, as_u32p(bsk), bsk.size))   # the same context: the tables follow the key
+        assert sk.field_bits() == 51
+        _nine_bootstraps_bit_exact(ck, sk, oracle.Oracle(p.as_tuple7(), bsk, ck.ksk, use_ntt=True), 4)
+    own = np.ascontiguousarray(ck.bsk, dtype=np.uint32).reshape(-1)
+    hip_check(hip.helm_hip_load_bootstrap_key(sk._h, as_u32p(own), own.size))
+    assert sk.field_bits() == 50
+    _nine_bootstraps_bit_exact(ck, sk, oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk, use_ntt=True), 5)
+    sk.close()
+    # the cited set at full size: its generated key fits the lazy field
+    ck = helm_amd.ClientKey.generate("helm_cuda", seed=7)
+    sk = helm_amd.ServerKey(ck)
+    assert sk.field_bits() == 50
+    sk.close()
+
+
 @pytest.mark.parametrize("name", ["boolean_default", "helm_cuda"])
 def test_full_size_lockstep_rounds_bit_exact(name):
     """The benchmark's dominant kernel at the benchmark's parameter set (tfhe boolean DEFAULT, helm.rs:241)
