@@ -21,7 +21,9 @@ import numpy as np
 sys.path.insert(0, %r)
 import helm_amd, oracle
 res = {}
-for name, B in (("toy_k2", 40), ("boolean_default", 300), ("helm_cuda", 40)):
+# helm_cuda (round 5: the lazy field FpI, bounds closer to 2^53 than FpG's): 40 -> the wide build, 1400 -> a lockstep round +
+# k_pbs_duo's compact layout, 1700 -> two lockstep rounds, the last workgroups partial
+for name, B in (("toy_k2", 40), ("boolean_default", 300), ("helm_cuda", 40), ("helm_cuda", 1400), ("helm_cuda", 1700)):
     ck = helm_amd.ClientKey.generate(name, seed=3)
     sk = helm_amd.ServerKey(ck, device=0)
     if name == "toy_k2":
@@ -47,7 +49,8 @@ for name, B in (("toy_k2", 40), ("boolean_default", 300), ("helm_cuda", 40)):
     host[:3 * B] = w.download(np.arange(3 * B))
     s = np.arange(0, B, max(1, B // 12))
     orc.eval_level(host, ops[s], i0[s], i1[s], i2[s], out[s])
-    res[name] = {"decrypt_ok": ok, "bit_exact_sample": bool(np.array_equal(host[out[s]], got[s])), "violations": sk.bound_violations()}
+    res[f"{name}:{B}"] = {"decrypt_ok": ok, "bit_exact_sample": bool(np.array_equal(host[out[s]], got[s])), "violations": sk.bound_violations(),
+                          "field": sk.field_bits()}
     sk.close()
 print("RESULT " + json.dumps(res))
 """
@@ -61,10 +64,11 @@ def test_no_contract_of_the_lazy_arithmetic_is_broken_and_the_check_can_fire():
     assert p.returncode == 0, p.stderr[-3000:]
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert res["selftest"][0] == 1 and sum(res["selftest"][1:]) == 0, res["selftest"]   # the one contract broken on purpose
-    for name in ("toy_k2", "boolean_default", "helm_cuda"):
+    for name in ("toy_k2:40", "boolean_default:300", "helm_cuda:40", "helm_cuda:1400", "helm_cuda:1700"):
         r = res[name]
         assert r["decrypt_ok"] and r["bit_exact_sample"], (name, r)
         assert r["violations"] == [0] * 8, (name, r["violations"])
+        assert r["field"] == (50 if name.startswith("helm_cuda") else 49), (name, r["field"])
 
 
 CHILD64 = r"""
