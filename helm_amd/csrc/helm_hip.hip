@@ -112,10 +112,13 @@ __device__ __forceinline__ uint32_t modswitch(uint32_t x, int log2_2N)
 // - five instructions per digit with the conversion (bit-field extract, three-operand add, shift,
 // 24-bit multiply-add, convert) instead of eight.  Needs state + B/2 < 2^32 (logB * L <= 31) and
 // next < 2^23; both follow from the field-size bound checked in helm_hip_ctx_create.
-__device__ __forceinline__ int decompose_step(uint32_t &state, int logB, uint32_t half_m1, int neg_B)
+// `last`: the most significant level.  There the state is at most B = 2^logB (it starts below 2^(L logB) and loses logB
+// bits per level, the rounding carry included), so its tie bit - bit 2 logB - 1 - is zero for logB >= 2, and for logB = 1
+// (s = 2: tie bit set) (s + tie) >> 1 == s >> 1: the bit never changes the digit and is not extracted.
+__device__ __forceinline__ int decompose_step(uint32_t &state, int logB, uint32_t half_m1, int neg_B, bool last = false)
 {
     const uint32_t s = state;
-    const uint32_t next = (s + half_m1 + __builtin_amdgcn_ubfe(s, 2 * logB - 1, 1)) >> logB;
+    const uint32_t next = last ? (s + half_m1) >> logB : (s + half_m1 + __builtin_amdgcn_ubfe(s, 2 * logB - 1, 1)) >> logB;
     state = next;
     return __mul24((int)next, neg_B) + (int)s;
 }
@@ -129,7 +132,7 @@ __device__ __forceinline__ void decompose(uint32_t x, int logB, int (&dig)[L])
     const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
     const int neg_B = -(1 << logB);
 #pragma unroll
-    for (int lev = L - 1; lev >= 0; lev--) dig[lev] = decompose_step(state, logB, half_m1, neg_B);
+    for (int lev = L - 1; lev >= 0; lev--) dig[lev] = decompose_step(state, logB, half_m1, neg_B, lev == 0);
 }
 
 // Diagnostic clock stamps (HELM_HIP_CLOCK_PROBE=1): workgroup 0 records s_memtime (shader
@@ -297,7 +300,9 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
     // ---- accumulator init: (0,...,0, X^{-b~} * tv) ------------------------------------
     double *xb = X + (size_t)p * C::WAVE_STRIDE; // this wave's exchange slots
     uint32_t *acc_p = reinterpret_cast<uint32_t *>(xb);
-    uint32_t accr[E];
+    // the wave's accumulator coefficients in registers, NEGATED: the rotated difference of a step is then one three-operand
+    // addition (rotated + (-acc) + rounding offset) instead of a subtraction and an addition
+    uint32_t nacc[E];
     {
         const int bt = (int)MS[n];
         const uint32_t *tv = tvs + (size_t)job.tv * N;
@@ -310,16 +315,17 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
                 v = tv[idx & (N - 1)];
                 if (idx >= N) v = 0u - v;
             }
-            accr[e] = v;
+            nacc[e] = 0u - v;
         }
     }
     auto acc_store = [&]() { // acc3[j] = v, acc3[j + N] = -v, acc3[j + 2N] = v (j < N - 64)
         uint32_t *aw = acc_p + lane;
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            aw[64 * e] = accr[e];
-            aw[64 * e + N] = 0u - accr[e];
-            if (e < E - 1) aw[64 * e + 2 * N] = accr[e];
+            const uint32_t v = 0u - nacc[e];
+            aw[64 * e] = v;
+            aw[64 * e + N] = nacc[e];
+            if (e < E - 1) aw[64 * e + 2 * N] = v;
         }
     };
     acc_store();
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
                 for (int e = 0; e < E; e++) {
                     const uint32_t v = rot[e];
                     int dig[L];
-                    decompose<L>(v - accr[e], logB, dig);
+                    decompose<L>(v + nacc[e], logB, dig);
 #pragma unroll
                     for (int lev = 0; lev < L; lev++) x[lev][e] = (double)dig[lev];
                 }
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
                 const int rep = logB * L;
                 const uint32_t *ar = acc_p + ((lane - a) & (2 * N - 1)); // (X^a acc)[jA(lane, e)] = ar[64 e]
 #pragma unroll
-                for (int e = 0; e < E; e++) state[e] = ((ar[64 * e] - accr[e]) + (1u << (31 - rep))) >> (32 - rep);
+                for (int e = 0; e < E; e++) state[e] = (ar[64 * e] + nacc[e] + (1u << (31 - rep))) >> (32 - rep);
             }
             // Key column (p + d) % K1 is handled at distance d: d = 0 is this wave's own sum
             // (registers), d = 1 stays in registers and is written to the transform scratch
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
             for (int lev = L - 1; lev >= 0; lev--) {
                 double x[1][E];
 #pragma unroll
-                for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(state[e], logB, half_m1, neg_B);
+                for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(state[e], logB, half_m1, neg_B, lev == 0);
                 // this level's key words: issued before the transform that hides their latency
                 // (the last column is fetched after the transform: during it the transform's own
                 // temporaries need the registers, and the first two products cover its latency)
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
         ntt_inverse<F, LOGN>(mine, xb, twi, lane);
         STAMP(4) // inverse transform
 #pragma unroll
-        for (int e = 0; e < E; e++) accr[e] += to_torus32(mine[e]);
+        for (int e = 0; e < E; e++) nacc[e] -= to_torus32(mine[e]);
         acc_store();
         lds_wave_sync();
         STAMP(5) // lift, accumulate, publish
@@ -563,13 +569,13 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
     if (p < K) {
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            const int j = G::jA(lane, e); // accr[e] = A_p[j]
+            const int j = G::jA(lane, e); // nacc[e] = -A_p[j]
             // out[p*N + t] = (t == 0) ? A[0] : -A[N - t]
-            if (j == 0) ob[p * N] = accr[e];
-            else ob[p * N + (N - j)] = 0u - accr[e];
+            if (j == 0) ob[p * N] = 0u - nacc[e];
+            else ob[p * N + (N - j)] = nacc[e];
         }
     } else if (lane == 0) {
-        ob[K * N] = accr[0]; // body = B[0]
+        ob[K * N] = 0u - nacc[0]; // body = B[0]
     }
 }
 
@@ -768,7 +774,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_wide(const PbsJob *__rest
             for (int l = L - 1; l >= 0; l--) {
                 if (l >= lev) {
 #pragma unroll
-                    for (int e = 0; e < E; e++) dig[e] = decompose_step(st[e], logB, half_m1, neg_B);
+                    for (int e = 0; e < E; e++) dig[e] = decompose_step(st[e], logB, half_m1, neg_B, l == 0);
                 }
             }
 #pragma unroll
@@ -1078,7 +1084,7 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void k_pbs_duo(const PbsJob 
 #pragma unroll
                 for (int lev = L - 2; lev >= 0; lev--) {
 #pragma unroll
-                    for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(st[e], logB, half_m1, neg_B);
+                    for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(st[e], logB, half_m1, neg_B, lev == 0);
                     if (lev != L - 2) load_keys(i, lev); // (the first level's words came an interval ahead)
                     ntt_forward_digits<F, LOGN, 1>(x, xb, twf, lane);
                     if (prio && !flat) { // a wave steps its priority down as it advances: whoever is behind goes first (see k_pbs)
@@ -1297,8 +1303,8 @@ __global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_sym(const PbsJob *__restr
             for (int lev = L - 1; lev >= 0; lev--) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const double U = (double)decompose_step(st[e], logB, half_m1, neg_B);
-                    const double V = mulmod<F>((double)decompose_step(st[e + 4], logB, half_m1, neg_B), w8);
+                    const double U = (double)decompose_step(st[e], logB, half_m1, neg_B, lev == 0);
+                    const double V = mulmod<F>((double)decompose_step(st[e + 4], logB, half_m1, neg_B, lev == 0), w8);
                     x[lev][e] = h ? U - V : U + V;
                 }
             }
@@ -1623,7 +1629,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_trio(const PbsJob *__rest
         for (int lev = L - 2; lev >= 0; lev--) {
             double x[1][E];
 #pragma unroll
-            for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(state[e], logB, half_m1, neg_B);
+            for (int e = 0; e < E; e++) x[0][e] = (double)decompose_step(state[e], logB, half_m1, neg_B, lev == 0);
             double2 bwl[K1][E / 2];
 #pragma unroll
             for (int d = 0; d < 2; d++)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-box A/B of builds of libhelm_hip.so: runs a micro-benchmark in a fresh process per build (HELM_HIP_LIB selects
 the library, helm_amd/_native.py), alternating the builds over several rounds.
-usage: ab_variants.py [--rounds R] [--bench lut|wop|m1c1] variant [variant ...]
+usage: ab_variants.py [--rounds R] [--bench lut|wop|m1c1|gates] variant [variant ...]
 A variant is a file name under helm_amd/csrc/ (e.g. variants/libhelm_hip_base.so) or `default` (the Makefile's)."""
 import argparse
 import json
@@ -57,6 +57,32 @@ for name, B in (("shortint_m1c1", 2048), ("shortint_m1c1", 512), ("si_toy_512_k2
 print(json.dumps(res))
 '''
 
+GATES = r'''
+import json, time, numpy as np, sys
+sys.path.insert(0, %r)
+import helm_amd
+res = {}
+for name, B in (("boolean_default", 4096), ("boolean_default", 1024), ("boolean_default", 256), ("helm_cuda", 4096)):
+    ck = helm_amd.ClientKey.generate(name, seed=1)
+    sk = helm_amd.ServerKey(ck)
+    bits = np.random.default_rng(0).integers(0, 2, size=2 * B).astype(bool)
+    w = sk.wires(3 * B)
+    w.upload(np.arange(2 * B), ck.encrypt(bits))
+    prog = helm_amd.Program(sk, np.full(B, 4, np.int32), np.arange(B), np.arange(B, 2 * B), np.full(B, -1), np.arange(2 * B, 3 * B), [0, B])
+    for _ in range(2):
+        prog.run(w)
+    sk.sync()
+    ts = []
+    for _ in range(6):
+        t0 = time.perf_counter(); prog.run(w); prog.run(w); sk.sync(); ts.append((time.perf_counter() - t0) / 2)
+    out = w.download(np.arange(2 * B, 3 * B))
+    ok = bool(np.array_equal(ck.decrypt(out), ~(bits[:B] & bits[B:])))
+    res[f"{name}:{B}"] = {"ms": round(min(ts) * 1e3, 3), "median_ms": round(sorted(ts)[len(ts) // 2] * 1e3, 3), "ok": ok,
+                          "sha": __import__("hashlib").sha256(out.tobytes()).hexdigest()[:12]}
+    sk.close()
+print(json.dumps(res))
+'''
+
 WOP = r'''
 import json, subprocess, sys
 out = subprocess.run([sys.executable, %r + "/tools/wop_bench.py", "256", "6", "1"], capture_output=True, text=True).stdout
@@ -70,7 +96,7 @@ def main():
     ap.add_argument("--bench", default="lut")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
-    code = {"lut": LUT, "wop": WOP, "m1c1": M1C1}[a.bench] % ROOT
+    code = {"lut": LUT, "wop": WOP, "m1c1": M1C1, "gates": GATES}[a.bench] % ROOT
     for r in range(a.rounds):
         for v in a.variants:
             env = dict(os.environ)
