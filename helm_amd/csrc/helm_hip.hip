@@ -3025,10 +3025,12 @@ int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4])
         cost[0] = ctx->narrow_variant == 4 ? 0.42 : 0.50;
         cost[1] = ctx->duo_build ? 0.66 : 0.80;
         cost[2] = ctx->P.k == 2 && ctx->trio ? 0.86 : 0.89;
-    } else { // N = 1024 (helm_cuda, round 5: 3.9 / 5.5 / 8.0 / 8.6 ms - wide, k_pbs_duo's compact layout (two-wave build: 6.05), lockstep rounds)
-        cost[0] = ctx->narrow_variant == 4 ? 0.45 : 0.64;
-        cost[1] = ctx->duo1024 ? 0.64 : 0.71;
-        cost[2] = 0.93;
+    } else { // N = 1024 (helm_cuda, round 5: 3.9 / 5.5 / 8.0 / 8.6 ms - wide, k_pbs_duo's compact layout (two-wave build: 6.05), lockstep rounds;
+             // in the lazy field FpI: 3.41 / 5.11 / 7.55 / 7.76 ms, profiles/r05/ab_field1024.jsonl)
+        const bool lazy = ctx->field == 50;
+        cost[0] = ctx->narrow_variant == 4 ? (lazy ? 0.44 : 0.45) : (lazy ? 0.70 : 0.64);
+        cost[1] = ctx->duo1024 ? (lazy ? 0.66 : 0.64) : (lazy ? 0.73 : 0.71);
+        cost[2] = lazy ? 0.97 : 0.93;
     }
     cost[3] = 1.0;
     return 0;
