@@ -3080,6 +3080,7 @@ int helm_hip_load_bootstrap_key(helm_hip_ctx *ctx, const uint32_t *bsk_std, size
         if (const char *v = getenv("HELM_HIP_FIELD")) if (atoi(v) == 51) want = 51;
         if (want != ctx->field) {
             HIP_TRY(hipStreamSynchronize(ctx->stream)); // nothing in flight may still read the other field's tables
+            if (ctx->xchg_stream) HIP_TRY(hipStreamSynchronize(ctx->xchg_stream));
             ctx->field = want;
             ctx->have_bsk = false;
             if (int rc = setup_field_tables(ctx)) return rc;

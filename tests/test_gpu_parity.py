@@ -318,8 +318,8 @@ def test_n1024_field_follows_the_loaded_key():
     worst = np.full_like(ck.bsk, 0x7FFFFFFF)
     one_step = ck.bsk.copy().reshape(p.n, per_step)
     one_step[5] = 0x80000000                      # -2^31 everywhere in step 5 only
+    from helm_amd._native import hip, hip_check, as_u32p
     for bsk in (worst, one_step.reshape(-1)):
-        from helm_amd._native import hip, hip_check, as_u32p
         bsk = np.ascontiguousarray(bsk, dtype=np.uint32).reshape(-1)
         hip_check(hip.helm_hip_load_bootstrap_key(sk._h, as_u32p(bsk), bsk.size))   # the same context: the tables follow the key
         assert sk.field_bits() == 51
