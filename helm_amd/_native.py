@@ -80,6 +80,68 @@ vp = C.c_void_p
 HIP_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp, C.c_int64)  # helm_hip_exchange_fn
 
 
+def mapped_hip_runtimes():
+    """Real paths of the libamdhip64 copies mapped into this process (Linux: /proc/self/maps)."""
+    found = []
+    try:
+        with open("/proc/self/maps") as maps:
+            for line in maps:
+                fields = line.split(None, 5)  # address perms offset dev inode [path]
+                path = fields[5].strip() if len(fields) == 6 else ""
+                if path.startswith("/") and os.path.basename(path).startswith("libamdhip64.so"):
+                    path = os.path.realpath(path)
+                    if path not in found:
+                        found.append(path)
+    except OSError:
+        pass
+    return found
+
+
+def _bind_one_hip_runtime():
+    """One HIP runtime per process, whatever the import order.
+
+    libhelm_hip.so NEEDs `libamdhip64.so.7` with a RUNPATH into the ROCm installation; PyTorch's libtorch_hip.so NEEDs
+    `libamdhip64.so` and finds the wheel's own copy next to itself.  Loaded in that order the process holds two runtimes,
+    and a torch stream handed to helm_hip_set_stream (or one of our device ranges wrapped in a torch tensor) crosses from
+    one to the other: round 5's `std::bad_variant_access` abort.  So, BEFORE libhelm_hip.so is opened:
+      * a runtime is already mapped (torch, or the host application's): open that very file RTLD_GLOBAL - its SONAME
+        `libamdhip64.so.7` then satisfies our NEEDED entry and the RUNPATH is never searched;
+      * none is mapped and PyTorch is installed (found without importing it): open the wheel's copy RTLD_GLOBAL - we run
+        on it, and a later `import torch` finds the file it looks for already mapped (same inode) and reuses it;
+      * neither: the RUNPATH's copy, as linked.
+    HELM_HIP_RUNTIME=<path> names the copy explicitly; HELM_HIP_RUNTIME=system keeps the RUNPATH's even when PyTorch is
+    installed (the caller then must not import torch afterwards and exchange handles: the guards raise HelmError)."""
+    forced = os.environ.get("HELM_HIP_RUNTIME", "")
+    if forced == "system":
+        return None
+    mapped = mapped_hip_runtimes()
+    if forced:
+        choice = forced
+    elif mapped:
+        choice = mapped[0]
+    else:
+        choice = None
+        try:
+            import importlib.util
+            spec = importlib.util.find_spec("torch")  # locates the package, does not import it
+        except (ImportError, ValueError):
+            spec = None
+        for root in (spec.submodule_search_locations or []) if spec is not None else []:
+            cand = os.path.join(root, "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                choice = cand
+                break
+    if choice is None:
+        return None
+    try:
+        C.CDLL(choice, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        if forced:
+            raise ImportError(f"HELM_HIP_RUNTIME={forced}: {e}")
+        return None  # the wheel's copy does not load here (a CPU-only torch build): the RUNPATH's copy it is
+    return os.path.realpath(choice)
+
+
 def _load(name):
     path = name if os.path.isabs(name) else os.path.join(_CSRC, name)
     if not os.path.exists(path):
@@ -88,6 +150,7 @@ def _load(name):
     return C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
+hip_runtime = _bind_one_hip_runtime()  # the libamdhip64 this process was bound to before libhelm_hip.so (None: as linked)
 # HELM_HIP_LIB: another build of libhelm_hip.so (same-box A/B of compile-time switches, tools/ab_variants.py) - a file
 # name under csrc/ or an absolute path; loaded first, so libhelm_host.so's references bind to it as well.  The
 # Makefile's library stays untouched (round 2's script copied the alternative over it).
@@ -99,6 +162,7 @@ host = _load("libhelm_host.so")
 HIP_API = {
     "helm_hip_last_error": (C.c_char_p, []),
     "helm_hip_device_count": (C.c_int, []),
+    "helm_hip_runtime_copies": (C.c_int, [C.c_char_p, C.c_size_t]),
     "helm_hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(Params), C.POINTER(vp)]),
     "helm_hip_ctx_destroy": (C.c_int, [vp]),
     "helm_hip_get_params": (C.c_int, [vp, C.POINTER(Params)]),
@@ -279,6 +343,19 @@ for _lib, _api in ((hip, HIP_API), (host, CLIENT_API), (hip, SI_API), (host, SI_
         _fn = getattr(_lib, _name)  # AttributeError here = header/library mismatch
         _fn.restype = _res
         _fn.argtypes = _args
+
+
+def require_one_hip_runtime(where):
+    """HelmError naming every copy when this process maps more than one libamdhip64 - called where a handle of another
+    framework (a torch stream, a torch tensor over our device memory) is about to cross into the library.  The library's
+    entry points check the same thing natively (helm_hip_runtime_copies); this is the early, Python-side message."""
+    buf = C.create_string_buffer(4096)
+    n = hip.helm_hip_runtime_copies(buf, len(buf))
+    if n > 1:
+        raise HelmError(f"{where}: this process maps {n} HIP runtimes ({buf.value.decode().replace(chr(10), ', ')}); a stream "
+                        "or device pointer of one is not valid in the other.  Import helm_amd before anything dlopens a "
+                        "second copy, or set HELM_HIP_RUNTIME to the copy the host framework uses (INTEGRATION.md, "
+                        "\"One HIP runtime per process\")")
 
 
 def hip_check(rc):

@@ -142,6 +142,7 @@ class Comm:
         hosts without RCCL and for rehearsing the rank > 0 paths with several ranks on one GPU.  Slow by construction
         (device -> host -> peers -> device per collective); `from_torch_dist` is the RCCL communicator."""
         import torch
+        nv.require_one_hip_runtime("Comm.over_torch_dist")  # torch tensors over the library's device ranges
         rank, world = dist.get_rank(), dist.get_world_size()
 
         class _Raw:  # a device range as something torch.as_tensor understands

@@ -14,6 +14,8 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <link.h>
+#include <limits.h>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -26,6 +28,60 @@
 #include <algorithm>
 
 int helm_hip_fail_(int code, const std::string &msg); // helm_hip.hip: sets helm_hip_last_error()
+
+// ------------------------------------------------------------------------------------------------------------------
+// One HIP runtime per process.  A hipStream_t, an event or a device pointer means something to the libamdhip64 that made it
+// and to no other copy: a process that maps two (PyTorch ships its own next to libtorch_hip.so, this library's RUNPATH names
+// the ROCm installation's) and hands a handle of one to the other does not get an error, it aborts inside the runtime
+// (std::bad_variant_access, round 5's diag.log).  helm_amd/_native.py makes the second copy impossible to get by import
+// order; the guard below is for every other way in (a host that links its own HIP, dlopen by a plug-in): every entry point
+// where a foreign handle crosses the ABI calls it and fails with both paths in the message instead.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+int collect_runtime(struct dl_phdr_info *info, size_t, void *data)
+{
+    const char *name = info->dlpi_name;
+    if (!name || !*name) return 0;
+    const char *base = strrchr(name, '/');
+    base = base ? base + 1 : name;
+    if (strncmp(base, "libamdhip64.so", 14) != 0) return 0;
+    char real[PATH_MAX];
+    std::string path = realpath(name, real) ? real : name;
+    auto &paths = *static_cast<std::vector<std::string> *>(data);
+    if (std::find(paths.begin(), paths.end(), path) == paths.end()) paths.push_back(path);
+    return 0;
+}
+std::vector<std::string> mapped_runtimes()
+{
+    std::vector<std::string> paths;
+    dl_iterate_phdr(collect_runtime, &paths);
+    return paths;
+}
+} // namespace
+
+int helm_hip_runtime_guard_(const char *where)
+{
+    const std::vector<std::string> paths = mapped_runtimes();
+    if (paths.size() <= 1) return 0;
+    std::string msg = std::string(where) + ": this process maps " + std::to_string(paths.size()) + " HIP runtimes (";
+    for (size_t i = 0; i < paths.size(); i++) msg += (i ? ", " : "") + paths[i];
+    msg += "); a stream or device pointer of one is not valid in the other - load libhelm_hip.so after the host's HIP runtime "
+           "(helm_amd/_native.py does; INTEGRATION.md \"One HIP runtime per process\")";
+    return helm_hip_fail_(HELM_ERR_STATE, msg);
+}
+
+extern "C" int helm_hip_runtime_copies(char *paths, size_t cap)
+{
+    const std::vector<std::string> found = mapped_runtimes();
+    if (paths && cap) {
+        std::string joined;
+        for (size_t i = 0; i < found.size(); i++) joined += (i ? "\n" : "") + found[i];
+        const size_t m = std::min(cap - 1, joined.size());
+        memcpy(paths, joined.data(), m);
+        paths[m] = 0;
+    }
+    return (int)found.size();
+}
 
 namespace {
 
@@ -64,10 +120,21 @@ void bind_rccl()
         const char *what;
     };
     const char *forced = getenv("HELM_RCCL_LIB");
+    // the RCCL of the distribution the process's HIP runtime comes from (PyTorch's wheel ships both side by side): the copy a
+    // later `import torch` would map anyway, built against that runtime
+    std::string beside, beside1;
+    const std::vector<std::string> rt = mapped_runtimes();
+    if (rt.size() == 1 && rt[0].find('/') != std::string::npos) {
+        const std::string dir = rt[0].substr(0, rt[0].rfind('/') + 1);
+        beside1 = dir + "librccl.so.1";
+        beside = dir + "librccl.so";
+    }
     const Try tries[] = {
         {forced, RTLD_NOW | RTLD_GLOBAL, "HELM_RCCL_LIB"},
         {"librccl.so.1", RTLD_NOW | RTLD_NOLOAD, "already loaded by the process"},
         {"librccl.so", RTLD_NOW | RTLD_NOLOAD, "already loaded by the process"},
+        {beside1.c_str(), RTLD_NOW | RTLD_GLOBAL, "next to the process's HIP runtime"},
+        {beside.c_str(), RTLD_NOW | RTLD_GLOBAL, "next to the process's HIP runtime"},
         {"librccl.so.1", RTLD_NOW | RTLD_GLOBAL, "loader search path"},
         {"/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL, "/opt/rocm/lib"},
     };
@@ -229,6 +296,8 @@ int helm_comm_create_with_transport(int device_id, int rank, int world, helm_com
     *out = nullptr;
     if (world < 1 || rank < 0 || rank >= world)
         return helm_hip_fail_(HELM_ERR_INVALID, "helm_comm_create_with_transport: bad rank / world");
+    // the host's all-gather is handed this library's device pointers and stream
+    if (int rc = helm_hip_runtime_guard_("helm_comm_create_with_transport")) return rc;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device_id < 0 || device_id >= n_dev)
         return helm_hip_fail_(HELM_ERR_NO_DEVICE, "helm_comm_create_with_transport: no such device");

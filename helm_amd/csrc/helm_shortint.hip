@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,6 +40,7 @@ using namespace helm;
 
 int helm_hip_fail_(int code, const std::string &msg); // helm_hip.hip: sets helm_hip_last_error()
 #define fail helm_hip_fail_
+int helm_hip_runtime_guard_(const char *where); // helm_comm.cpp: one HIP runtime per process, or HELM_ERR_STATE naming the copies
 #define HIP_TRY(expr)                                                                               \
     do {                                                                                            \
         hipError_t e__ = (expr);                                                                    \
@@ -1971,7 +1973,7 @@ template <typename C>
 hipError_t launch_pbs64k_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
                            const uint64_t *luts, uint64_t *out, int *per_cu = nullptr)
 {
-    static bool attr_done[64] = {false};
+    static std::atomic<bool> attr_done[64]; // (rank threads of one process launch concurrently)
     auto kern = k_pbs64k<C>;
     if (!attr_done[ctx->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -1990,7 +1992,7 @@ hipError_t launch_pbs64_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count,
                           const uint64_t *luts, uint64_t *out, const double *key = nullptr, int n_steps = -1,
                           int logB = 0, size_t key_stride = 0, int key_first = 0, int *per_cu = nullptr)
 {
-    static bool attr_done[64] = {false};
+    static std::atomic<bool> attr_done[64]; // (rank threads of one process launch concurrently)
     auto kern = k_pbs64<C, MODE>;
     if (!attr_done[ctx->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -2020,7 +2022,7 @@ template <typename C, bool MB>
 hipError_t launch_pbs64s_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count, const uint64_t *small,
                            const uint64_t *luts, uint64_t *out, int *per_cu = nullptr)
 {
-    static bool attr_done[64] = {false};
+    static std::atomic<bool> attr_done[64]; // (rank threads of one process launch concurrently)
     auto kern = k_pbs64s<C, MB>;
     if (!attr_done[ctx->device & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -2636,6 +2638,7 @@ int helm_si_get_params(const helm_si_ctx *ctx, helm_si_params *out)
 int helm_si_set_stream(helm_si_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");
+    if (int rc = helm_hip_runtime_guard_("helm_si_set_stream")) return rc; // the handle was made by the caller's HIP runtime
     // NULL is HIP's null (legacy default) stream - what torch.cuda.current_stream() is unless the caller
     // switched streams - NOT "back to the context's own stream": collectives the caller orders on that
     // stream must see the engine's kernels on it
@@ -3044,6 +3047,8 @@ int helm_si_set_exchange(helm_si_ctx *ctx, int32_t rank, int32_t world, int64_t 
                          void *gather_dev, int64_t capacity_rows, helm_si_exchange_fn fn, void *user)
 {
     if (!ctx) return fail(HELM_ERR_INVALID, "null context");
+    if (fn)
+        if (int rc = helm_hip_runtime_guard_("helm_si_set_exchange")) return rc; // the caller's buffers and collective
     if (ctx->x_own) {
         HIP_TRY(hipSetDevice(ctx->device));
         HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -18,6 +18,9 @@ class GpuLevelExecutor:
 
     def __init__(self, program, wires):
         import torch
+        from ._native import require_one_hip_runtime
+        # torch streams, events and tensors meet the engine's kernels and buffers from here on
+        require_one_hip_runtime("GpuLevelExecutor")
         self.torch = torch
         self.program, self.wires = program, wires
         self.n_levels = program.n_levels

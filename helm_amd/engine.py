@@ -124,6 +124,7 @@ class ServerKey:
         self.close()
 
     def set_stream(self, stream_ptr):
+        nv.require_one_hip_runtime(type(self).__name__ + ".set_stream")  # the handle is another framework's
         hip_check(hip.helm_hip_set_stream(self._h, nv.vp(stream_ptr)))
 
     def sync(self):

@@ -158,6 +158,7 @@ class SiServerKey:
         return v
 
     def set_stream(self, stream_ptr):
+        nv.require_one_hip_runtime(type(self).__name__ + ".set_stream")  # the handle is another framework's
         hip_check(hip.helm_si_set_stream(self._h, nv.vp(stream_ptr)))
 
     def bound_violations(self, reset=True):

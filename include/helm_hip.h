@@ -97,6 +97,16 @@ const char *helm_hip_last_error(void);
 /* Number of visible HIP devices (does not initialise a device context). */
 int helm_hip_device_count(void);
 
+/* One HIP runtime per process.  A hipStream_t or a device pointer is only valid in the copy of libamdhip64 that made it;
+ * a process that maps two copies (a host framework's bundled one next to the ROCm installation's this library's RUNPATH
+ * names) and passes a handle from one to the other aborts inside the runtime.  Returns the number of distinct libamdhip64
+ * objects mapped into the calling process and, when paths != NULL, their real paths separated by '\n' (truncated to cap).
+ * Every entry point where a handle of the caller's crosses this ABI - helm_hip_set_stream, helm_si_set_stream,
+ * helm_hip_wires_device_ptr, helm_hip_program_run_sharded and helm_si_set_exchange with a callback,
+ * helm_comm_create_with_transport - fails with HELM_ERR_STATE and both paths in helm_hip_last_error() when this is > 1.
+ * INTEGRATION.md "One HIP runtime per process" says how a host makes it 1. */
+int helm_hip_runtime_copies(char *paths, size_t cap);
+
 /* -- context --------------------------------------------------------------- */
 /* Replaces ServerKey construction (reference src/bin/helm.rs:241, 187-192). */
 int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_ctx **out);
