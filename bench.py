@@ -52,6 +52,9 @@ PMC_TRAFFIC = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 # SQ_INSTS_VALU / SQ_WAVES of the lockstep k_pbs (tools/pmc_issue.py over a --pmc pass of tools/prof_pbs.py)
 PMC_ISSUE = os.path.join(ROOT, "profiles", "pmc_issue.json")
 METRIC = "encrypted gate-bootstraps/sec on AES-128 gates-mode netlist"
+# gate-bootstraps per second ONE GPU held in the last round's driver runs (BENCH_r05.json; profiles/r05/bench_n1_helm_cuda.json):
+# only the prior of the printed plan of an N > 1 run - replaced by this run's own headline as soon as it is measured
+PRIOR_GPU_RATE = {"boolean_default": 134e3, "helm_cuda": 133e3}
 RESULT_FILE_ENV = "HELM_BENCH_RESULT_FILE"
 
 
@@ -81,6 +84,10 @@ def parse_args(argv=None):
                     help="N = 1: run the headline through the sharded path anyway - a world-size-1 RCCL communicator inside the library, "
                          "every launch stage -> ncclAllGather -> scatter (what the exchange machinery itself costs; rccl_ranks is filled)")
     ap.add_argument("--side-steps", type=int, default=3, help="N > 1: timed steps of the runs that are not the headline")
+    ap.add_argument("--wall-budget", type=float, default=450.0,
+                    help="N > 1: seconds the whole run should stay under; the planned wall time of every run is printed (stderr, "
+                         "and `planned_wall_s` in the line) before it starts, and the runs that are NOT the headline are cut to one "
+                         "timed step - then dropped - if the plan does not fit (the headline's K steps are never touched)")
     ap.add_argument("--leg-timeout", type=float, default=900.0,
                     help="N > 1: seconds one run may take before it counts as hung (the line is printed with the error, rc 3)")
     ap.add_argument("--launch-timeout", type=float, default=3300.0, help="launcher: seconds before the worker group is stopped")
@@ -245,6 +252,38 @@ class RcclUnavailable(RuntimeError):
     pass
 
 
+class RankLayoutError(RuntimeError):
+    pass
+
+
+def check_rank_devices(devices, world, n_gpus, rehearsal=False, host_fallback=False):
+    """What must hold before an N > 1 number means anything: as many ranks as --gpus, a communicator that reports that
+    world size and this rank on every rank, RCCL carrying it (unless the run is a labelled rehearsal / host fallback), and
+    no two ranks on the same device.  -> list of problems (empty: fine).  Pure function of the gathered records
+    (tests/test_bench_launcher.py feeds it by hand)."""
+    problems = []
+    if world != n_gpus:
+        problems.append(f"world size {world} != --gpus {n_gpus}")
+    if len(devices) != world or any(d is None for d in devices):
+        return problems + [f"{sum(d is not None for d in devices)} of {world} ranks reported their device"]
+    for d in devices:
+        if d["comm_world"] != world:
+            problems.append(f"rank {d['rank']}: its communicator reports world size {d['comm_world']}, not {world}")
+        if d["comm_rank"] != d["rank"]:
+            problems.append(f"rank {d['rank']}: its communicator reports rank {d['comm_rank']}")
+        if not d["rccl_version"] and not (rehearsal or host_fallback):
+            problems.append(f"rank {d['rank']}: the communicator is not RCCL's")
+    if not rehearsal:
+        seen = {}
+        for d in devices:
+            key = (d["pci"], d["uuid"])
+            if key in seen:
+                problems.append(f"ranks {seen[key]} and {d['rank']} share one device ({d['pci']}): one process per GPU needs "
+                                f"{world} different devices")
+            seen.setdefault(key, d["rank"])
+    return problems
+
+
 def _injected_failure():
     """HELM_BENCH_INJECT_COMM_FAILURE=<step>:<rank> (id | precheck | create): the handshake's failure paths, for
     tests/test_bench_launcher.py; never set otherwise."""
@@ -281,6 +320,7 @@ class Bench:
         from helm_amd import Circuit, verilog_parser
         from helm_amd.netlists import aes128
         self.args, self.np, self.torch, self.dist = args, np, torch, dist
+        self.t_start = time.time()
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -323,6 +363,21 @@ class Bench:
             from helm_amd import comm as hc
             with _StdoutToStderr():
                 self.comm = hc.Comm.single(local_rank)
+        self.devices = None
+        if self.world > 1 and not self.threads:
+            # one process per GPU means N DIFFERENT devices and a communicator of N ranks: checked, not assumed - every rank
+            # learns every rank's device (PCI address + uuid as torch reports them) and what its own communicator says, and
+            # every rank raises the same error (value null, rc != 0) if two ranks share a device or the world is not --gpus
+            pr = torch.cuda.get_device_properties(local_rank)
+            mine = {"rank": self.rank, "local_rank": local_rank, "pci": f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}",
+                    "uuid": str(getattr(pr, "uuid", "")), "comm_world": self.comm.info()["world_size"],
+                    "comm_rank": self.comm.info()["rank"], "rccl_version": self.comm.info()["rccl_version"]}
+            self.devices = [None] * self.world
+            dist.all_gather_object(self.devices, mine)
+            problems = check_rank_devices(self.devices, self.world, args.gpus, rehearsal=self.rehearse,
+                                          host_fallback=bool(self.comm_error) and args.allow_host_fallback)
+            if problems:
+                raise RankLayoutError("; ".join(problems))
         # keys (identical on every rank: same deterministic benchmark seed) and engine
         t0 = time.time()
         self.ck = helm_amd.ClientKey.generate(args.params, seed=1)
@@ -341,6 +396,32 @@ class Bench:
         self.wire_names = list(inputs) + sorted(wire_set)
         self.nw = len(self.wire_names)
         self.index = {w: i for i, w in enumerate(self.wire_names)}
+        from helm_amd.distributed import gate_pbs, level_arrays
+        self.pbs_per_block = int(gate_pbs(level_arrays(self.circuit, self.index)[0]).sum())
+
+    def agree_max(self, values):
+        """The maximum over the ranks of each value: identical on every rank afterwards (plans every rank must reach the same
+        way are made from such figures only)."""
+        out = []
+        for v in values:
+            t = self.torch.tensor([float(v)], dtype=self.torch.float64)
+            if self.world > 1:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            out.append(float(t.item()))
+        return out
+
+    def plan(self, kind, steps, warmup, gpu_rate, setup_s_per_block=None):
+        """Planned wall time of one run, from the rate one GPU holds (bootstraps per second: the last round's 134 k before
+        anything is measured, this run's own headline afterwards) and the measured set-up time per block of a wire table
+        (encryption and upload of the inputs, launch packing, the decryption check)."""
+        a, w = self.args, self.world
+        per_gpu_blocks = a.blocks / w if kind == "strong" else a.blocks
+        # the fixed job cut N ways fills N GPUs by about three quarters (chunks of two thirds of a lockstep round: DESIGN 7)
+        step_s = per_gpu_blocks * self.pbs_per_block / gpu_rate / (0.76 if kind == "strong" and w > 1 else 1.0)
+        table_blocks = a.blocks * (w if kind == "sharded_weak" else 1)
+        setup_s = 2.0 + table_blocks * (0.25 if setup_s_per_block is None else setup_s_per_block)
+        return {"steps": steps, "warmup": warmup, "s_per_step": round(step_s, 2), "setup_and_check_s": round(setup_s, 1),
+                "wall_s": round((steps + warmup) * step_s + setup_s, 1)}
 
     def setup_lock(self):
         """Rank THREADS of one process plan, allocate, upload and download one at a time (eight ranks' set-up at once would only
@@ -361,7 +442,16 @@ class Bench:
         synchronize on both sides; the elapsed time is the maximum over the ranks."""
         from helm_amd.distributed import GpuLevelExecutor, ShardedRunner
         a, np, torch, dist = self.args, self.np, self.torch, self.dist
-        sharded = kind != "weak" and (self.world > 1 or self.comm is not None)
+        # "solo" (N > 1 only): the N = 1 value of the SAME job shape, measured in this very run - rank 0 alone evaluates the
+        # `--blocks` job unsharded (what `python3 bench.py --gpus 1` times) while every other rank idles at the barrier, so
+        # that each N > 1 row carries its own baseline and a scaling efficiency is computable from ONE record
+        solo = kind == "solo"
+        if solo and self.rank != 0:
+            dist.barrier()
+            return None
+        sync = torch.cuda.synchronize if solo else self.sync_all
+        t_run0 = time.perf_counter()
+        sharded = kind not in ("weak", "solo") and (self.world > 1 or self.comm is not None)
         blocks = a.blocks * (self.world if kind == "sharded_weak" else 1)   # blocks in this rank's wire table
         # --overlap: launches cut to one lockstep round per rank (the gates of a launch are independent, so any cut is
         # valid): the sub-launches of one packed launch do not depend on each other, the exchange of one travels while the
@@ -384,28 +474,31 @@ class Bench:
                                    dist if sharded else None, time_collective=sharded,
                                    comm=self.comm if sharded else None, overlap=overlapped)
             self.sk.sync()
-        self.sync_all()
+        sync()
+        t_setup = time.perf_counter() - t_run0
         for _ in range(warmup):
             runner.run()
-        self.sync_all()
+        sync()
         runner.collective_ms(reset=True)
         self.sk.timing_enable(True)
         self.sk.timing(reset=True)
         t0 = time.perf_counter()
         for _ in range(steps):
             runner.run()
-        self.sync_all()
+        sync()
         elapsed = time.perf_counter() - t0
         tm = self.sk.timing(reset=True)
         self.sk.timing_enable(False)
         clock_ghz = self.sk.kernel_clock_ghz()
-        if self.world > 1:
+        if self.world > 1 and not solo:
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         # correctness of what was timed: every block of this rank's table decrypts to AES(key, pt)
+        t_chk0 = time.perf_counter()
         with self.setup_lock():
             check_outputs(self.ck, wires, self.index, self.nw, keys_pt, f"{kind} run, rank {self.rank}")
+        t_setup += time.perf_counter() - t_chk0
         pbs = prog.total_pbs()
         job_pbs = pbs * (self.world if kind == "weak" else 1)
         r = {"kind": kind, "elapsed": elapsed, "steps": steps, "warmup": warmup, "job_pbs": int(job_pbs),
@@ -418,7 +511,7 @@ class Bench:
                                         if sharded else 0.0),
              "collectives_per_step": (int(tm.exchange_count) // steps if (sharded and self.comm is not None)
                                       else len(runner.sharded_levels) if sharded else 0),
-             "overlapped": overlapped,
+             "overlapped": overlapped, "setup_s": t_setup,
              "tm": tm, "clock_ghz": clock_ghz}
         if keep:
             r.update(prog=prog, wires=wires, keys_pt=keys_pt)
@@ -426,7 +519,9 @@ class Bench:
             with self.setup_lock():
                 prog.destroy()
                 wires.free()
-        if self.threads:
+        if solo:
+            dist.barrier()   # releases the ranks that idled
+        elif self.threads:
             dist.barrier()   # nobody frees while another rank still runs
         return r
 
@@ -438,8 +533,10 @@ class Bench:
                 "weak": f"{self.args.blocks} independent AES-128 block(s) per GPU ({r['blocks_total']} in total), keys replicated, "
                         "no data-path collective",
                 "sharded_weak": f"ONE job of {r['blocks_total']} AES-128 blocks ({self.args.blocks} per GPU), every packed launch "
-                                f"sharded over {w} GPU(s), output ciphertexts all-gathered"}[r["kind"]]
-        return {"workload": what, "scaling": "strong" if r["kind"] == "strong" else "weak",
+                                f"sharded over {w} GPU(s), output ciphertexts all-gathered",
+                "solo": f"the N = 1 job measured inside this N = {w} run: rank 0 ALONE evaluates {r['blocks_total']} AES-128 block(s) "
+                        "unsharded (what `bench.py --gpus 1` times), the other ranks idle at a barrier"}[r["kind"]]
+        return {"workload": what, "scaling": {"strong": "strong", "solo": "none (one GPU)"}.get(r["kind"], "weak"),
                 "value": round(r["value"], 1), "unit": "gate-bootstraps/s", "steps": r["steps"], "warmup": r["warmup"],
                 "ms_per_step": round(r["ms_per_step"], 3), "bootstraps_per_step": r["job_pbs"],
                 "launches_per_step": r["launches"], "sharded_launches": r["sharded_launches"],
@@ -601,9 +698,42 @@ def fill_result(bench, result):
     world, rank = bench.world, bench.rank
     p = bench.ck.params
     head_kind = args.scaling if world > 1 else "strong"
+    say = (lambda msg: (sys.stderr.write("[bench] " + msg + "\n"), sys.stderr.flush())) if rank == 0 else (lambda msg: None)
+    planned = {}
+    if world > 1:
+        # before anything is measured: the rate one GPU held in the last round's driver run (BENCH_r05.json, boolean_default)
+        planned[head_kind] = bench.plan(head_kind, args.steps, args.warmup, PRIOR_GPU_RATE.get(args.params, 130e3))
+        say(f"plan: {head_kind} (headline) {args.warmup} + {args.steps} steps x ~{planned[head_kind]['s_per_step']} s + set-up and check "
+            f"~{planned[head_kind]['setup_and_check_s']} s = ~{planned[head_kind]['wall_s']} s; budget for the whole run {args.wall_budget:.0f} s")
     head = guarded(bench, result, f"{head_kind} run", lambda: bench.run(head_kind, args.steps, args.warmup, keep=True))
     tm, clock_ghz, quantum = head["tm"], head["clock_ghz"], bench.quantum
     sharded = head_kind != "weak" and world > 1
+
+    # ---- N > 1: which other runs follow, decided the same way on every rank from figures every rank holds ----
+    legs, dropped = [], []
+    if world > 1 and not args.no_side_legs:
+        used, setup_s = guarded(bench, result, "plan of the remaining runs",
+                                lambda: bench.agree_max([time.time() - bench.t_start, head["setup_s"]]))
+        gpu_rate = head["value"] / world / (0.76 if head_kind == "strong" else 1.0)
+        per_block = setup_s / head["blocks_per_table"]
+        planned[head_kind]["measured_wall_s"] = round(head["elapsed"] * (1 + args.warmup / max(1, args.steps)) + setup_s, 1)
+        # the N = 1 baseline first (it is what makes the record self-explanatory), then the two other shapes
+        for steps_each in (args.side_steps, 1):
+            legs = [(k, steps_each, 1) for k in ["solo"] + side_kinds(head_kind)]
+            if used + sum(bench.plan(k, st, wu, gpu_rate, per_block)["wall_s"] for k, st, wu in legs) <= args.wall_budget:
+                break
+        while len(legs) > 1 and used + sum(bench.plan(k, st, wu, gpu_rate, per_block)["wall_s"] for k, st, wu in legs) > args.wall_budget:
+            dropped.append(legs.pop()[0])
+        for k, st, wu in legs:
+            planned[k] = bench.plan(k, st, wu, gpu_rate, per_block)
+        say(f"plan: {used:.0f} s used so far (headline measured: {head['ms_per_step'] / 1e3:.2f} s per step); then " +
+            ", ".join(f"{k} {wu} + {st} steps = ~{planned[k]['wall_s']} s" for k, st, wu in legs) +
+            f"; total ~{used + sum(planned[k]['wall_s'] for k, _, _ in legs):.0f} s of {args.wall_budget:.0f} s" +
+            (f"; dropped to fit: {', '.join(dropped)}" if dropped else ""))
+    solo = None
+    if legs and legs[0][0] == "solo":
+        _, st, wu = legs.pop(0)
+        solo = guarded(bench, result, "solo run (the N = 1 job inside this run)", lambda: bench.run("solo", st, wu))
 
     # ---- roofline of the dominant kernel (lockstep build of k_pbs), HIP events on its own stream ----
     K1 = p.k + 1
@@ -661,15 +791,28 @@ def fill_result(bench, result):
 
     if rank != 0:
         # the other ranks only take part in the remaining runs
-        if world > 1 and not args.no_side_legs:
-            for kind in side_kinds(head_kind):
-                guarded(bench, result, f"{kind} run", lambda k=kind: bench.run(k, args.side_steps, 1))
+        for kind, st, wu in legs:
+            guarded(bench, result, f"{kind} run", lambda k=kind, st=st, wu=wu: bench.run(k, st, wu))
         return
+
+    def with_baseline(row):
+        """Every N > 1 row carries the N = 1 value of the same job shape (--blocks blocks on one GPU, unsharded: per-GPU work
+        of `weak` / `sharded_weak`, the whole job of `strong`), measured by rank 0 inside this run: value / (N x that) is the
+        row's distance to linear, from this one record."""
+        if solo is not None:
+            row["n1_same_job"] = {"value": round(solo["value"], 1), "ms_per_step": round(solo["ms_per_step"], 3), "steps": solo["steps"],
+                                  "blocks": solo["blocks_total"], "measured": "in this run, rank 0 alone, the other ranks idle"}
+            row["speedup_over_n1"] = round(row["value"] / solo["value"], 4)
+            row["linear_would_be"] = world
+        return row
 
     result.update({
         "value": round(head["value"], 1),
         "ms_per_step": round(head["ms_per_step"], 3),
         "higher_is_better": True,
+        # which of the named runs `value` is; at N = 1 there is only the fixed `--blocks` job on one GPU (the N = 1 point of
+        # every one of the three curves)
+        "headline_kind": head_kind if world > 1 else "fixed_job_single_gpu",
         # N = 1: the `--blocks` job.  N > 1: per-GPU work fixed (sharded_weak: ONE job of N x `--blocks` blocks, every launch
         # sharded; weak: independent blocks) unless --scaling strong (the `--blocks` job whatever N)
         "scaling": "strong" if args.scaling == "strong" else "weak",
@@ -765,18 +908,38 @@ def fill_result(bench, result):
                                                   f"torch.distributed {bench.dist.get_backend()} (barrier, max over ranks, unique id)"
                                                   if world > 1 else "none (one process)"),
                                 "one_process_per_gpu": not bench.rehearse}
+        if bench.threads:
+            # (advisor, round 5) helm_comm's in-process all-gather synchronises the rank's stream and waits at two barriers ON
+            # THE RANK'S HOST THREAD: with --overlap the exchange stream's collective stalls the thread that would feed the next
+            # launch, so this rehearsal serialises more than RCCL does and cannot show what the overlap is worth
+            result["rccl_ranks"]["in_process_exchange"] = ("blocks the rank's host thread (stream sync + two barriers per collective): "
+                                                           "overlap on / off must NOT be decided from rank-thread figures")
         if bench.comm_error:
             result["rccl_error"] = bench.comm_error
             result["not_a_measurement_of_the_rccl_path"] = True
-        result[head_kind] = bench.describe(head)   # the headline under its own name as well
+        if bench.devices:
+            result["rccl_ranks"]["devices"] = [{"rank": d["rank"], "local_rank": d["local_rank"], "pci": d["pci"], "uuid": d["uuid"]}
+                                               for d in bench.devices]
+            result["rccl_ranks"]["checked"] = ("world size == --gpus, every communicator reports that world and its rank, RCCL carries it, "
+                                               "no two ranks on one device - or the run ends with value null and rc != 0" if not bench.rehearse
+                                               else "world size and communicator ranks (rehearsal: the ranks share one device by design)")
+        result[head_kind] = with_baseline(bench.describe(head))   # the headline under its own name as well
+    if world > 1:
+        if solo is not None:
+            result["solo"] = bench.describe(solo)
+            result["n1_same_job_value"] = round(solo["value"], 1)
+        result["planned_wall_s"] = planned
+        if dropped:
+            result["dropped_for_wall_budget"] = dropped
     checkpoint(result)
 
     # ---- N > 1: the runs that are not the headline, each under its own name -----------------------------
-    if world > 1 and not args.no_side_legs:
-        for kind in side_kinds(head_kind):
-            r = guarded(bench, result, f"{kind} run", lambda k=kind: bench.run(k, args.side_steps, 1))
-            result[kind] = bench.describe(r)
-            checkpoint(result)
+    for kind, st, wu in legs:
+        r = guarded(bench, result, f"{kind} run", lambda k=kind, st=st, wu=wu: bench.run(k, st, wu))
+        result[kind] = with_baseline(bench.describe(r))
+        checkpoint(result)
+    if world > 1:
+        result["wall_s_total"] = round(time.time() - bench.t_start, 1)
 
     # ---- wall-clock of ONE AES-128 evaluation (latency; levels are 80-256 gates wide, so the
     #      GPU is far from full: this is the n-step blind-rotation chain, 207 levels deep) ------

@@ -85,6 +85,52 @@ def test_rehearsal_two_ranks_on_one_gpu_reports_every_named_result():
     assert line["sharded_weak"]["value"] == line["value"] and line["sharded_weak"]["steps"] == 2 and line["strong"]["steps"] == 1
     assert line["weak"]["exchanged_MB_per_step"] == 0 and line["sharded_weak"]["sharded_launches"] > 0
     assert line["sharded_weak"]["bootstraps_per_step"] == 2 * line["strong"]["bootstraps_per_step"]
+    # the record explains itself: which run the headline is, the N = 1 value of the same job shape measured inside this run
+    # (rank 0 alone, 4 blocks unsharded) on every row, the plan that was printed before the runs started, the rank layout
+    assert line["headline_kind"] == "sharded_weak"
+    assert line["solo"]["bootstraps_per_step"] == line["strong"]["bootstraps_per_step"] and line["solo"]["exchanged_MB_per_step"] == 0
+    for kind in ("strong", "weak", "sharded_weak"):
+        assert line[kind]["n1_same_job"]["value"] == line["n1_same_job_value"] == line["solo"]["value"] > 0
+        assert line[kind]["linear_would_be"] == 2
+        assert abs(line[kind]["speedup_over_n1"] - line[kind]["value"] / line["solo"]["value"]) < 1e-3
+    assert set(line["planned_wall_s"]) == {"sharded_weak", "solo", "strong", "weak"} and line["wall_s_total"] > 0
+    assert "plan: sharded_weak (headline)" in err and "plan:" in err.split("plan: sharded_weak (headline)")[1]
+    assert [d["rank"] for d in rr["devices"]] == [0, 1] and "rehearsal" in rr["checked"]
+
+
+def test_rank_layout_is_checked_not_assumed():
+    """bench.check_rank_devices: an N > 1 number needs N ranks on N different devices under an RCCL communicator of N ranks;
+    anything else is a list of problems (the worker raises it: value null, rc != 0)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    def rec(rank, pci, world=2, comm_rank=None, rccl=22705):
+        return {"rank": rank, "local_rank": rank, "pci": pci, "uuid": "u" + pci, "comm_world": world,
+                "comm_rank": rank if comm_rank is None else comm_rank, "rccl_version": rccl}
+    good = [rec(0, "0000:05:00"), rec(1, "0000:15:00")]
+    assert bench.check_rank_devices(good, 2, 2) == []
+    assert any("share one device" in p for p in bench.check_rank_devices([rec(0, "0000:05:00"), rec(1, "0000:05:00")], 2, 2))
+    assert bench.check_rank_devices([rec(0, "0000:05:00"), rec(1, "0000:05:00")], 2, 2, rehearsal=True) == []
+    assert any("world size 2 != --gpus 8" in p for p in bench.check_rank_devices(good, 2, 8))
+    assert any("reports world size 1" in p for p in bench.check_rank_devices([rec(0, "a", world=1), rec(1, "b")], 2, 2))
+    assert any("reports rank 0" in p for p in bench.check_rank_devices([rec(0, "a"), rec(1, "b", comm_rank=0)], 2, 2))
+    assert any("not RCCL's" in p for p in bench.check_rank_devices([rec(0, "a"), rec(1, "b", rccl=0)], 2, 2))
+    assert bench.check_rank_devices([rec(0, "a", rccl=0), rec(1, "b", rccl=0)], 2, 2, host_fallback=True) == []
+    assert any("1 of 2 ranks" in p for p in bench.check_rank_devices([rec(0, "a"), None], 2, 2))
+
+
+def test_the_plan_of_an_eight_gpu_run_fits_the_budget():
+    """The default N = 8 run (driver: --steps 20 --warmup 1 at most) is planned under --wall-budget = 450 s with the figures
+    one GPU holds; the arithmetic of Bench.plan without a GPU."""
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.parse_args(["--gpus", "8"])
+    assert args.wall_budget == 450.0
+    b = bench.Bench.__new__(bench.Bench)
+    b.args, b.world, b.pbs_per_block = args, 8, 32464
+    head = b.plan("sharded_weak", 2, 1, 134e3, 0.05)
+    side = [b.plan(k, args.side_steps, 1, 134e3, 0.05) for k in ("solo", "strong", "weak")]
+    assert 7.5 < head["s_per_step"] < 8.1 and head["wall_s"] + sum(p["wall_s"] for p in side) + 60 < args.wall_budget
+    assert side[1]["s_per_step"] < 1.5   # the fixed job cut eight ways
 
 
 @pytest.mark.gpu
@@ -125,3 +171,5 @@ def test_rehearsal_with_rank_threads_reports_every_named_result():
     for kind in ("strong", "weak", "sharded_weak"):
         assert line[kind]["value"] > 0 and "every rank" in line[kind]["decrypt_check"], kind
     assert line["sharded_weak"]["bootstraps_per_step"] == 3 * line["strong"]["bootstraps_per_step"]
+    assert line["headline_kind"] == "strong" and line["strong"]["n1_same_job"]["value"] == line["solo"]["value"] > 0
+    assert "must NOT be decided from rank-thread figures" in rr["in_process_exchange"]
