@@ -172,29 +172,23 @@ static __device__ unsigned long long g_wide_stamps[2 * 16 * 6];
 // other waves over through LDS (the only two workgroup barriers of the step),
 // inverse-transforms its own sum and accumulates.
 //
-// Builds (struct PbsCfg), picked per launch from the launch size (launch_pbs_f):
-//   latency    M = L: all levels of a polynomial transformed together, key words prefetched
-//              one step ahead into registers, twiddles in registers; ~330 registers -> one
-//              workgroup per CU.  Launches of at most one workgroup per CU.
-//   balanced   as above, twiddles from the LDS lane table; 256 registers -> two per CU.
-//   throughput M = 1: one level at a time (digits produced in the order the signed
-//              decomposition generates them), that level's key words fetched around its
-//              transform, only two partial sums in registers (the third accumulates in LDS),
-//              twiddles from the LDS lane table; 168 registers and 35 KB LDS -> up to four
-//              workgroups per CU.  Remainders of wide launches.
-//   lockstep   the throughput structure with NB = 4 bootstraps per workgroup of 12 waves, one
-//              bootstrap per SIMD (see NB below) and issue priorities that fall as a wave
-//              advances through the step; 132 registers, 138 KB LDS -> one workgroup per CU,
-//              three waves on every SIMD doing the same work at the same time.  The full rounds
-//              of every wide launch: the dominant kernel of the benchmark.
+// One build (struct PbsCfg): LOCKSTEP - one level at a time (digits produced in the order the signed decomposition generates
+// them), that level's key words fetched around its transform, only two partial sums in registers (the third accumulates in
+// LDS), twiddles from the LDS lane table (the forward direction's per-lane twiddles copied into registers once), NB = 4
+// bootstraps per workgroup, one bootstrap per SIMD (see NB below), issue priorities that fall as a wave advances through the
+// step; 162 registers, 138 KB LDS at N = 512 -> one workgroup per CU, three waves on every SIMD doing the same work at the same
+// time.  The full rounds of every wide launch: the dominant kernel of the benchmark.  (Rounds 1-5 also carried a latency, a
+// balanced and a throughput build of this kernel - all levels transformed together, key words prefetched a step ahead,
+// twiddles in registers - and k_pbs_sym; the size dispatch stopped selecting them in round 4 and they were removed in
+// round 6: profiles/README.md "retired builds".)
 // ------------------------------------------------------------------------------------
-enum { TW_REG = 0, TW_LANE = 1 /* lane-major LDS table of forward twiddles, inverse reads it mirrored */,
+enum { TW_LANE = 1 /* lane-major LDS table of forward twiddles, inverse reads it mirrored */,
        TW_LANE_FREG = 2 /* the same, the forward direction's per-lane twiddles copied into registers once */ };
 
-template <typename F_, int LOGN_, int K_, int L_, int M_, int TW_, bool PREFETCH_, int MINW_, int NB_ = 1>
+template <typename F_, int LOGN_, int K_, int L_, int TW_, int NB_ = 4>
 struct PbsCfg {
     using F = F_;
-    static constexpr int LOGN = LOGN_, K = K_, L = L_, M = M_, TW = TW_, MINW = MINW_;
+    static constexpr int LOGN = LOGN_, K = K_, L = L_, TW = TW_;
     // bootstraps per workgroup.  NB = 4: wave w serves bootstrap w % 4 as polynomial w / 4; the
     // hardware deals the waves of a workgroup round the four SIMDs (tools/ubench_placement.hip), so
     // the k+1 waves of a bootstrap share one SIMD, every SIMD carries the same work, and the
@@ -207,15 +201,12 @@ struct PbsCfg {
 #define HELM_PRIO_STAGES 1 /* 0: plain oldest-first issue (109 k instead of 116 k gates/s) */
 #endif
     static constexpr bool PRIO_STAGES = HELM_PRIO_STAGES != 0;
-    static constexpr bool PREFETCH = PREFETCH_;
     using G = Geo<LOGN>;
     static constexpr int K1 = K + 1;
-    static constexpr int SLOTS = M > K ? M : K; // exchange slots per wave (also carry the hand-over)
+    static constexpr int SLOTS = K > 1 ? K : 1; // exchange slots per wave (also carry the hand-over)
     static constexpr int MAX_SMALL_N = 1024;
-    static_assert(L % M == 0, "levels are transformed M at a time");
-    // slot 0 is the (padded) transform scratch; with M == 1 the other slots only carry the
-    // hand-over and need no padding
-    static constexpr int SLOT_STRIDE = M > 1 ? G::XPAD : G::N;
+    // slot 0 is the (padded) transform scratch; the other slots only carry the hand-over and need no padding
+    static constexpr int SLOT_STRIDE = G::N;
     // the u32 copy of a wave's accumulator polynomial lives in the wave's (then idle) exchange
     // slots, unrolled negacyclically over 3N - 64 entries (+acc, -acc, +acc) so that the rotated
     // read of slot e is one address register + 256 e bytes, sign included
@@ -223,7 +214,7 @@ struct PbsCfg {
     static constexpr int WAVE_STRIDE_X = G::XPAD + (SLOTS - 1) * SLOT_STRIDE;
     static constexpr int WAVE_STRIDE = WAVE_STRIDE_X > (ACC3 + 1) / 2 ? WAVE_STRIDE_X : (ACC3 + 1) / 2;
     static constexpr int slot_off(int s) { return s == 0 ? 0 : G::XPAD + (s - 1) * SLOT_STRIDE; }
-    static constexpr int TW_ROWS = TW != TW_REG ? G::TWB + G::TWC : 0;
+    static constexpr int TW_ROWS = G::TWB + G::TWC;
     static constexpr size_t X_OFF = 0;                                                // double [K1][WAVE_STRIDE]
     static constexpr size_t TW_OFF = X_OFF + sizeof(double) * K1 * WAVE_STRIDE;       // double [TW_ROWS][64]
     static constexpr size_t MS_OFF = TW_OFF + sizeof(double) * TW_ROWS * 64;          // u16 [n+1]
@@ -232,7 +223,7 @@ struct PbsCfg {
 };
 
 template <typename C>
-__global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const PbsJob *__restrict__ jobs,
+__global__ __launch_bounds__(64 * (C::K + 1) * C::NB, 1) void k_pbs(const PbsJob *__restrict__ jobs,
                                                                   const uint32_t *__restrict__ wires,  // rows of n+1
                                                                   const uint32_t *__restrict__ raw_in, // rows of n+1
                                                                   const uint32_t *__restrict__ tvs,    // rows of N
@@ -242,7 +233,7 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
                                                                   uint32_t *__restrict__ out_big, // rows of K*N+1
                                                                   int n, int logB, int probe, int count)
 {
-    constexpr int LOGN = C::LOGN, K = C::K, L = C::L, M = C::M, NB = C::NB;
+    constexpr int LOGN = C::LOGN, K = C::K, L = C::L, NB = C::NB;
     using F = typename C::F;
     using G = Geo<LOGN>;
     constexpr int N = G::N, E = G::E, K1 = K + 1;
@@ -277,17 +268,14 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
             MS[i] = (uint16_t)modswitch(v, LOGN + 1);
         }
     }
-    // ---- twiddles: registers, or the lane-major LDS table -----------------------------
-    using TwF0 = typename std::conditional<C::TW == TW_REG, TwReg<G::NTW>, TwLane<LOGN, false>>::type;
+    // ---- twiddles: the lane-major LDS table (block A: lane-uniform scalars) ---------------
+    using TwF0 = TwLane<LOGN, false>;
     using TwF = typename std::conditional<C::TW == TW_LANE_FREG, TwLaneFwdReg<LOGN>, TwF0>::type;
-    using TwI = typename std::conditional<C::TW == TW_REG, TwReg<G::NTW>, TwLane<LOGN, true>>::type;
+    using TwI = TwLane<LOGN, true>;
     TwF0 twf0;
     TwF twf;
     TwI twi;
-    if constexpr (C::TW == TW_REG) {
-        tw_fill_forward<LOGN>(twf, tw_fwd, lane);
-        tw_fill_inverse<LOGN>(twi, tw_inv, lane);
-    } else {
+    {
         double *TW = reinterpret_cast<double *>(smem + C::TW_OFF);
         for (int r = p; r < C::TW_ROWS; r += K1) TW[r * 64 + lane] = tw_fwd[tw_lane_index<LOGN>(r, lane)];
         twf0.base = TW + lane;
@@ -339,26 +327,8 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
     const unsigned row_off = (unsigned)(p * K1 * L) * poly_bytes;        // this wave's GGSW row
     KeyBuf kb;
     kb.init(bsk, (size_t)n * step_bytes, lane);
-    double2 bw[C::PREFETCH ? K1 : 1][C::PREFETCH ? L : 1][C::PREFETCH ? E / 2 : 1];
-    auto prefetch = [&](int i) {
-        if constexpr (C::PREFETCH) {
-            const unsigned so = (unsigned)i * step_bytes + row_off;
-#pragma unroll
-            for (int c = 0; c < K1; c++)
-#pragma unroll
-                for (int lev = 0; lev < L; lev++)
-#pragma unroll
-                    for (int e2 = 0; e2 < E / 2; e2++)
-                        bw[c][lev][e2] = kb.load(so + (unsigned)(c * L + lev) * poly_bytes, e2 * 1024);
-        }
-    };
-    auto next_nonzero = [&](int i) {
-        // a zero rotation contributes nothing; bootstraps that share a workgroup keep it (one step in
-        // 2N) so that they meet at the same barriers
-        if constexpr (NB == 1)
-            while (i < n && __builtin_amdgcn_readfirstlane((int)MS[i]) == 0) i++;
-        return i;
-    };
+    // (a zero rotation is not skipped - one step in 2N, its external product is exactly zero - so that the bootstraps that
+    // share a workgroup meet at the same barriers)
 
     // four scalar clock reads per launch that fills the chip (probe bit 1, set by the host), taken by the LAST
     // workgroup - it runs in the launch's last round, when the chip has been under this load for the whole launch
@@ -369,8 +339,7 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
         g_clock_probe[1] = __builtin_amdgcn_s_memrealtime();
     }
     // ---- blind rotation: acc += BSK_i (x) (X^{a_i} acc - acc) -------------------------
-    int i = next_nonzero(0);
-    if (i < n) prefetch(i);
+    int i = 0;
     // Lockstep build: the waves of a bootstrap share a SIMD, which issues oldest-first, so the youngest
     // would run the end of every step alone (and a lone wave cannot hide its own latencies).  Each wave
     // lowers its priority as it advances through the step - 3 from the second barrier through the
@@ -386,58 +355,10 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
         const unsigned so_i = (unsigned)i * step_bytes + row_off;
 
         double mine[E];
-        if constexpr (M == L) {
-            // ---- all L levels transformed together (latency / balanced builds) ----------
-            double x[L][E];
-            {
-                uint32_t rot[E];
-                const uint32_t *ar = acc_p + ((lane - a) & (2 * N - 1)); // (X^a acc)[jA(lane, e)] = ar[64 e]
-#pragma unroll
-                for (int e = 0; e < E; e++) rot[e] = ar[64 * e];
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    const uint32_t v = rot[e];
-                    int dig[L];
-                    decompose<L>(v + nacc[e], logB, dig);
-#pragma unroll
-                    for (int lev = 0; lev < L; lev++) x[lev][e] = (double)dig[lev];
-                }
-            }
-            ntt_forward_digits<F, LOGN, L>(x, xb, twf, lane);
-            // part[c] = sum_lev x[lev] * BSK_i[p][c][lev]; the partial sums of the other
-            // polynomials are handed over through this wave's exchange slots 0..K-1 (idle
-            // until the inverse transform, which starts after the second barrier)
-#pragma unroll
-            for (int c = 0; c < K1; c++) {
-                double part[E];
-#pragma unroll
-                for (int e2 = 0; e2 < E / 2; e2++) {
-                    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                    for (int lev = 0; lev < L; lev++) {
-                        double2 w;
-                        if constexpr (C::PREFETCH) w = bw[c][lev][e2];
-                        else w = kb.load(so_i + (unsigned)(c * L + lev) * poly_bytes, e2 * 1024);
-                        s0 += mulmod<F>(x[lev][2 * e2], w.x);
-                        s1 += mulmod<F>(x[lev][2 * e2 + 1], w.y);
-                    }
-                    part[2 * e2] = reduce_unless_lazy<F>(s0);
-                    part[2 * e2 + 1] = reduce_unless_lazy<F>(s1);
-                }
-                if (c == p) {
-#pragma unroll
-                    for (int e = 0; e < E; e++) mine[e] = part[e];
-                } else {
-                    double *dst = xb + C::slot_off(c < p ? c : c - 1);
-#pragma unroll
-                    for (int e = 0; e < E; e++) dst[e * 64 + lane] = part[e];
-                }
-            }
-        } else {
+        {
             // ---- one level at a time, least significant first (throughput build): the
             //      decomposition state is carried in registers, digits are produced in the
             //      order the signed decomposition generates them ---------------------------
-            static_assert(M == 1, "level-at-a-time path");
             uint32_t state[E];
             {
                 const int rep = logB * L;
@@ -514,23 +435,11 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
                 for (int e = 0; e < E; e++) dst[e * 64] = keep[e];
             }
         }
-        // key words of the next step: in flight during the exchange, the inverse
-        // transform and the next step's forward transforms
-        const int inext = next_nonzero(i + 1);
-        if (inext < n) prefetch(inext);
         STAMP(0) // rotation, decomposition, forward transforms, products, hand-over written
 
         lds_block_sync();
         STAMP(1) // barrier 1
-        if constexpr (M == L) {
-#pragma unroll
-            for (int q = 0; q < K1; q++) {
-                if (q == p) continue;
-                const double *src = X + (size_t)q * C::WAVE_STRIDE + C::slot_off(p < q ? p : p - 1);
-#pragma unroll
-                for (int e = 0; e < E; e++) mine[e] += src[e * 64 + lane];
-            }
-        } else {
+        {
             // the sum for this wave computed at distance d sits in wave (p - d) mod K1, slot d - 1
             if constexpr (!F::LAZY) {
 #pragma unroll
@@ -558,7 +467,7 @@ __global__ __launch_bounds__(64 * (C::K + 1) * C::NB, C::MINW) void k_pbs(const 
         acc_store();
         lds_wave_sync();
         STAMP(5) // lift, accumulate, publish
-        i = inext;
+        i++;
     }
     STAMP_END(p)
 
@@ -1146,251 +1055,6 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void k_pbs_duo(const PbsJob 
         } else if (lane == 0) {
             ob[K * N] = accr[0];
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// k_pbs_sym: two bootstraps per workgroup like k_pbs_duo, but every wave does THE SAME work: 2 (k+1) waves per bootstrap =
-// (polynomial r, transform half h).  A 512-point negacyclic transform splits after its first stage into two independent
-// 256-point transforms on the index halves (ntt_fp64.h: half transforms, four values per lane); wave (r, h)
-//   - rotates / subtracts / decomposes polynomial r (all of it: both waves of a polynomial do, 165 integer instructions),
-//     does the first stage for its half and the L half transforms of the digit polynomials together,
-//   - multiplies them with its half of the key words of row r (the key's layout is the full transform's: spectrum position
-//     (h << 8) | p), sums over the levels in registers, keeps column r and hands the k other column sums over through LDS,
-//   - after barrier 1 adds the k sums it receives, runs the inverse half transform of column r, publishes it, and after
-//     barrier 2 does its half of the joining stage (h = 0: z0 + z1 -> coefficients j; h = 1: (z0 - z1) psi^-(N/2) ->
-//     coefficients j + N/2), lifts and updates its half of the accumulator copy both waves read after barrier 3.
-// Twelve identical waves, three per SIMD: no SIMD waits for another inside an interval, and no wave waits while others
-// invert.  Measured (profiles/r04/duo_experiments.txt (7)): 1.3 % faster than k_pbs_duo on the same box - 78 % of the issue
-// slots instead of 72 %, but 1,150 vector instructions per wave-step instead of 1,059 (both waves of a polynomial run its
-// whole decomposition and the first stage's products; three transposes per half transform, three barriers per step).
-// Opt-in (HELM_HIP_DUO=3, HELM_HIP_PBS_VARIANT=8): k_pbs_duo stays the size dispatch's choice.
-// Same exact integers as every other build: identical ciphertexts.  N = 512 only.
-// ------------------------------------------------------------------------------------
-template <typename F_, int K_, int L_>
-struct SymCfg {
-    using F = F_;
-    static constexpr int LOGN = 9, K = K_, L = L_, K1 = K_ + 1, NB = 2, NWB = 2 * (K_ + 1), NW = 4 * (K_ + 1);
-    using G = Geo<9>;
-    using HG = HalfGeo9;
-    static constexpr int MAX_SMALL_N = 1024;
-    static constexpr int ACC3 = (3 * G::N - 64 + 1) / 2 * 2; // u32 entries per polynomial (see PbsCfg)
-    // per wave: forward scratch L x XPAD doubles (the inverse uses the first XPAD); the K hand-over slots of 256 doubles
-    // start behind the inverse's scratch (they are read while their owner already inverts); the published half inverse
-    // (256 doubles) behind them
-    static constexpr int HO_OFF = HG::XPAD, ZX_OFF = HG::XPAD + K * 256;
-    static constexpr int WAVE_DOUBLES = (L * HG::XPAD > ZX_OFF + 256 ? L * HG::XPAD : ZX_OFF + 256);
-    static constexpr size_t X_OFF = 0;                                                 // double [NWB][WAVE_DOUBLES]
-    static constexpr size_t ACC_OFF = X_OFF + sizeof(double) * NWB * WAVE_DOUBLES;     // u32 [K1][ACC3]
-    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint32_t) * K1 * ACC3;           // u16 [n+1]
-    static constexpr size_t BOOT_BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
-    static constexpr size_t BYTES = BOOT_BYTES * NB;
-};
-
-template <typename C>
-__global__ __launch_bounds__(64 * C::NW, 3) void k_pbs_sym(const PbsJob *__restrict__ jobs, const uint32_t *__restrict__ wires,
-                                                           const uint32_t *__restrict__ raw_in, const uint32_t *__restrict__ tvs,
-                                                           const double *__restrict__ bsk, const double *__restrict__ tw_fwd,
-                                                           const double *__restrict__ tw_inv, uint32_t *__restrict__ out_big, int n,
-                                                           int logB, int flags, int count)
-{
-    constexpr int K = C::K, L = C::L, K1 = C::K1, NB = C::NB, NWB = C::NWB;
-    using F = typename C::F;
-    using G = Geo<9>;
-    constexpr int N = G::N, E = G::E;
-    extern __shared__ __align__(16) unsigned char smem_wg[];
-
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int b = w / NWB, wb = w - b * NWB; // bootstrap of the workgroup, wave of the bootstrap
-    const int r = wb >> 1, h = wb & 1;       // polynomial, transform half
-    const int jix = (int)blockIdx.x * NB + b;
-    if (jix >= count) return; // the hardware barrier counts the surviving waves only
-    unsigned char *smem = smem_wg + (size_t)b * C::BOOT_BYTES;
-    double *X = reinterpret_cast<double *>(smem + C::X_OFF);
-    uint32_t *ACC = reinterpret_cast<uint32_t *>(smem + C::ACC_OFF);
-    uint16_t *MS = reinterpret_cast<uint16_t *>(smem + C::MS_OFF);
-    const int tid = wb * 64 + lane;
-    const PbsJob job = jobs[jix];
-    const size_t row = (size_t)n + 1;
-    {
-        const uint32_t *a0 = nullptr, *a1 = nullptr, *a2 = nullptr;
-        if (job.op < 0) a0 = raw_in + row * (size_t)job.in0;
-        else {
-            if (job.in0 >= 0) a0 = wires + row * (size_t)job.in0;
-            if (job.in1 >= 0) a1 = wires + row * (size_t)job.in1;
-            if (job.in2 >= 0) a2 = wires + row * (size_t)job.in2;
-        }
-        for (int i = tid; i <= n; i += 64 * NWB) {
-            uint32_t v;
-            if (job.op < 0) v = a0[i];
-            else v = gate_lincomb(job.op, job.which, a0 ? a0[i] : 0u, a1 ? a1[i] : 0u, a2 ? a2[i] : 0u, i == n);
-            MS[i] = (uint16_t)modswitch(v, 10);
-        }
-    }
-    HalfTw twf, twi;
-    twf.fill(tw_fwd, h, lane);
-    twi.fill(tw_inv, h, lane);
-    const double w8 = tw_fwd[1], w8i = tw_inv[1]; // the joining stage (stride bit 8): psi^(N/2) and its inverse
-    __syncthreads();
-
-    // accumulator (0, ..., 0, X^{-b~} tv): wave (r, h) owns the coefficients j0(lane, e) + 256 h = jA(lane, e + 4 h) of
-    // polynomial r and publishes them in the negacyclically unrolled u32 copy both waves of the polynomial read
-    uint32_t *acc_r = ACC + (size_t)r * C::ACC3;
-    uint32_t accr[4];
-    auto acc_store = [&]() {
-        uint32_t *aw = acc_r + lane + 256 * h;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            aw[64 * e] = accr[e];
-            aw[64 * e + N] = 0u - accr[e];
-            if (4 * h + e < E - 1) aw[64 * e + 2 * N] = accr[e];
-        }
-    };
-    {
-        const int bt = (int)MS[n];
-        const uint32_t *tv = tvs + (size_t)job.tv * N;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            uint32_t v = 0;
-            if (r == K) {
-                const int idx = (G::jA(lane, e + 4 * h) + bt) & (2 * N - 1);
-                v = tv[idx & (N - 1)];
-                if (idx >= N) v = 0u - v;
-            }
-            accr[e] = v;
-        }
-        acc_store();
-    }
-    __syncthreads();
-
-    double *xb = X + (size_t)wb * C::WAVE_DOUBLES;
-    const unsigned poly_bytes = (unsigned)(N / 2) * 16u;
-    const unsigned step_bytes = (unsigned)(K1 * K1 * L) * poly_bytes;
-    const unsigned row_off = (unsigned)(r * K1 * L) * poly_bytes; // + (c * L + lev) * poly_bytes
-    KeyBuf kb;
-    kb.init(bsk, (size_t)n * step_bytes, lane);
-    // this wave's four spectrum positions (h << 8) | (lane << 2 | e) sit in the full-transform layout [e_f / 2][lane_f][2]
-    // at lane_f = h * 32 + (lane >> 1), e_f = (lane & 1) * 4 + e: double2 number (lane & 1) * 2 + e / 2 of that lane
-    kb.lane16 = (lane & 1) * 2048 + (h * 32 + (lane >> 1)) * 16;
-    const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
-    const int neg_B = -(1 << logB);
-    const int rep = logB * L;
-    const bool prio = (flags & 1) != 0;
-
-    double2 kw[2][K1][2]; // the key words of two levels: one in use, one on its way
-    auto load_keys = [&](int buf, int ii, int lev) {
-        const unsigned so = (unsigned)ii * step_bytes + row_off + (unsigned)lev * poly_bytes;
-#pragma unroll
-        for (int c = 0; c < K1; c++)
-#pragma unroll
-            for (int e2 = 0; e2 < 2; e2++) kw[buf][c][e2] = kb.load(so + (unsigned)(c * L) * poly_bytes, e2 * 1024);
-    };
-    load_keys(0, 0, 0);
-    if (prio) __builtin_amdgcn_s_setprio(3);
-    STAMP_DECL
-    for (int i = 0; i < n; i++) {
-        STAMP_BEGIN
-        // a zero rotation is not skipped: the bootstraps of a workgroup meet at the same barriers (its product is exactly zero)
-        const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
-        // ---- rotation, digits, the first transform stage for this half ---------------------------------------------
-        double x[L][4];
-        {
-            uint32_t st[E];
-            const uint32_t *ar = acc_r + ((lane - a) & (2 * N - 1));
-            const uint32_t *ac = acc_r + lane;
-#pragma unroll
-            for (int e = 0; e < E; e++) st[e] = ((ar[64 * e] - ac[64 * e]) + (1u << (31 - rep))) >> (32 - rep);
-#pragma unroll
-            for (int lev = L - 1; lev >= 0; lev--) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const double U = (double)decompose_step(st[e], logB, half_m1, neg_B, lev == 0);
-                    const double V = mulmod<F>((double)decompose_step(st[e + 4], logB, half_m1, neg_B, lev == 0), w8);
-                    x[lev][e] = h ? U - V : U + V;
-                }
-            }
-        }
-        ntt_half_forward<F, L>(x, xb, twf, lane);
-        if (prio) __builtin_amdgcn_s_setprio(2);
-        // ---- products with this half of row r, summed over the levels; level lev's words were fetched during level lev - 1
-        double part[K1][4];
-#pragma unroll
-        for (int lev = 0; lev < L; lev++) {
-            if (lev + 1 < L) load_keys((lev + 1) & 1, i, lev + 1);
-#pragma unroll
-            for (int c = 0; c < K1; c++)
-#pragma unroll
-                for (int e2 = 0; e2 < 2; e2++) {
-                    const double2 q = kw[lev & 1][c][e2];
-                    const double t0 = reduce_unless_lazy<F>(mulmod<F>(x[lev][2 * e2], q.x));
-                    const double t1 = reduce_unless_lazy<F>(mulmod<F>(x[lev][2 * e2 + 1], q.y));
-                    part[c][2 * e2] = lev ? part[c][2 * e2] + t0 : t0;
-                    part[c][2 * e2 + 1] = lev ? part[c][2 * e2 + 1] + t1 : t1;
-                }
-        }
-        // hand-over: the sum for column c != r goes to wave (c, h), which reads slot (r < c ? r : r - 1) of this wave
-#pragma unroll
-        for (int c = 0; c < K1; c++) {
-            if (c == r) continue;
-            double *dst = xb + C::HO_OFF + (c < r ? c : c - 1) * 256 + lane;
-#pragma unroll
-            for (int e = 0; e < 4; e++) dst[64 * e] = part[c][e];
-        }
-        if (i + 1 < n) load_keys(0, i + 1, 0); // in flight during the inverse side of the step
-        STAMP(0) // rotation, digits, forward half transforms, products
-        lds_block_sync();
-        STAMP(1) // barrier 1
-        if (prio) __builtin_amdgcn_s_setprio(3);
-        double mine[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) mine[e] = part[r][e];
-#pragma unroll
-        for (int q = 0; q < K1; q++) {
-            if (q == r) continue;
-            const double *src = X + (size_t)(2 * q + h) * C::WAVE_DOUBLES + C::HO_OFF + (r < q ? r : r - 1) * 256 + lane;
-#pragma unroll
-            for (int e = 0; e < 4; e++) mine[e] += src[64 * e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; e++) mine[e] = reduce<F>(mine[e]);
-        ntt_half_inverse<F>(mine, xb, twi, lane);
-        {
-            double *zx = xb + C::ZX_OFF + lane;
-#pragma unroll
-            for (int e = 0; e < 4; e++) zx[64 * e] = mine[e];
-        }
-        STAMP(2) // hand-over summed, inverse half transform, published
-        lds_block_sync();
-        STAMP(3) // barrier 2
-        {
-            const double *zp = X + (size_t)(2 * r + (1 - h)) * C::WAVE_DOUBLES + C::ZX_OFF + lane;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const double o = zp[64 * e];
-                // h = 0: z0 + z1 -> coefficient j;  h = 1: (z0 - z1) psi^-(N/2) -> coefficient j + N / 2 (own = z1, other = z0)
-                const double v = h ? mulmod<F>(o - mine[e], w8i) : mine[e] + o;
-                accr[e] += to_torus32(reduce<F>(v));
-            }
-        }
-        acc_store();
-        STAMP(4) // joining stage, lift, accumulator update
-        lds_block_sync();
-        STAMP(5) // barrier 3
-    }
-    STAMP_END(w)
-
-    // ---- sample extract (coefficient 0): every wave writes its half of its polynomial -------------------------------
-    uint32_t *ob = out_big + (size_t)jix * ((size_t)K * N + 1);
-    if (r < K) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int j = G::jA(lane, e + 4 * h);
-            if (j == 0) ob[r * N] = accr[e];
-            else ob[r * N + (N - j)] = 0u - accr[e];
-        }
-    } else if (h == 0 && lane == 0) {
-        ob[K * N] = accr[0];
     }
 }
 
@@ -2140,14 +1804,13 @@ struct helm_hip_ctx {
     bool have_bsk = false, have_ksk = false;
     int field = 51; // 51: FpH, 49: FpG (lazy) - both with short eighth roots of unity -, chosen from the parameter set
     int n_cus = 256;
-    int narrow_variant = 4;  // build for launches of at most one workgroup per CU: 4 wide, 1 latency (HELM_HIP_NARROW)
     int clock_probe = 0;     // HELM_HIP_CLOCK_PROBE: print the in-kernel clock of every k_pbs launch
-    int pbs_variant = 0;     // 0 = by launch size, 1 latency, 2 balanced, 3 throughput, 4 wide, 5 lockstep, 6 duo (the two
-                             // bootstraps of a workgroup in step), 7 duo staggered, 8 sym, 9 trio (HELM_HIP_PBS_VARIANT)
-    int duo_build = 2;       // the two-per-CU build the size dispatch uses: 1 k_pbs_duo in step, 2 staggered, 3 k_pbs_sym, 0 none (HELM_HIP_DUO)
-    int duo1024 = 1;         // N = 1024: launches of more than one and at most two bootstraps per CU on k_pbs_duo's compact layout (1 in step,
-                             // 2 staggered, 0: the two-wave build of rounds 1-4; HELM_HIP_DUO1024).  Round 5, same process, alternating,
-                             // helm_cuda, 512 bootstraps: two-wave 6.04 ms, in step 5.50 - 5.55 (stepping priorities), staggered 5.75
+    int pbs_variant = 0;     // 0 = by launch size, 4 wide, 5 lockstep, 6 duo (the two bootstraps of a workgroup in step), 7 duo
+                             // staggered, 9 trio (HELM_HIP_PBS_VARIANT; 1, 2, 3, 8 named builds retired in round 6: refused)
+    int duo_build = 2;       // the two-per-CU build the size dispatch uses at N = 512: 1 k_pbs_duo in step, 2 staggered, 0 none (HELM_HIP_DUO)
+    int duo1024 = 1;         // N = 1024: more than one and at most two bootstraps per CU on k_pbs_duo's compact layout (1 in step, 2
+                             // staggered, 0: a lockstep round; HELM_HIP_DUO1024).  Round 5, same process, alternating, helm_cuda,
+                             // 512 bootstraps: the two-wave build of rounds 1-4 6.04 ms, in step 5.50 - 5.55 (stepping priorities), staggered 5.75
     int duo1024_flags = 1;   // its issue priorities (HELM_HIP_DUO1024_FLAGS; bits as duo_flags): on, stepping down - flat (5) and off (0) measured 5 % slower
     int trio = 1;            // remainders of two to three bootstraps per CU on k_pbs_trio (HELM_HIP_TRIO=0: a partial lockstep round, round 3's choice)
     int trio_flags = 1;      // bit 0: issue-priority staging (HELM_HIP_TRIO_FLAGS)
@@ -2337,8 +2000,8 @@ static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
                                                                64 * (C::K + 1) * C::NB, C::BYTES);
             hipFuncAttributes fa{};
             (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
-            fprintf(stderr, "[helm_hip] k_pbs M=%d TW=%d MINW=%d NB=%d: LDS %zu B, regs %d, scratch %zu B, max %d workgroups/CU\n",
-                    C::M, C::TW, C::MINW, C::NB, (size_t)C::BYTES, fa.numRegs, (size_t)fa.localSizeBytes, nb);
+            fprintf(stderr, "[helm_hip] k_pbs (lockstep) TW=%d NB=%d: LDS %zu B, regs %d, scratch %zu B, max %d workgroups/CU\n",
+                    C::TW, C::NB, (size_t)C::BYTES, fa.numRegs, (size_t)fa.localSizeBytes, nb);
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((count + C::NB - 1) / C::NB)), dim3(64 * (C::K + 1) * C::NB), C::BYTES,
@@ -2350,7 +2013,7 @@ static hipError_t launch_pbs_v(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
         unsigned long long v[4];
         (void)hipStreamSynchronize(ctx->stream);
         if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_clock_probe), sizeof(v)) == hipSuccess && v[3] > v[1])
-            fprintf(stderr, "[helm_hip] k_pbs M=%d x%lld: in-kernel clock %.3f GHz (%.3f ms of blind rotation)\n", C::M,
+            fprintf(stderr, "[helm_hip] k_pbs x%lld: in-kernel clock %.3f GHz (%.3f ms of blind rotation)\n",
                     (long long)count, (double)(v[2] - v[0]) / (double)(v[3] - v[1]) * 0.1, (double)(v[3] - v[1]) * 1e-5);
     }
     return e;
@@ -2453,37 +2116,11 @@ static hipError_t launch_pbs_trio(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t
     return hipGetLastError();
 }
 
-template <typename C>
-static hipError_t launch_pbs_sym(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
-                                 const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
-{
-    static std::atomic<bool> attr_done[64]; // (rank threads of one process launch concurrently)
-    auto kern = k_pbs_sym<C>;
-    if (!attr_done[ctx->device & 63]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
-        if (e != hipSuccess) return e;
-        attr_done[ctx->device & 63] = true;
-        if (getenv("HELM_HIP_VERBOSE")) {
-            int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), 64 * C::NW, C::BYTES);
-            hipFuncAttributes fa{};
-            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
-            fprintf(stderr, "[helm_hip] k_pbs_sym: %d waves, LDS %zu B, regs %d, scratch %zu B, max %d workgroups/CU\n", C::NW,
-                    (size_t)C::BYTES, fa.numRegs, (size_t)fa.localSizeBytes, nb);
-        }
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((count + C::NB - 1) / C::NB)), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, wires,
-                       raw, tvs, ctx->bsk, ctx->tw_fwd, ctx->tw_inv, out_big, ctx->P.n, ctx->P.pbs_logB, ctx->duo_flags, (int)count);
-    print_stamps(ctx, C::NW, "sym: forward | bar1 | inverse | bar2 | join | bar3");
-    return hipGetLastError();
-}
-
 // Two translation units from this one source (Makefile): the whole file is compiled under the compiler's max-ILP scheduling
 // strategy (-mllvm -amdgpu-sched-strategy=max-ilp: +1.9 % on the lockstep k_pbs, same box, alternating, identical
 // ciphertexts), except k_pbs_wide, which that strategy slows down by 0.9 % and which is therefore compiled a second time
 // with -DHELM_HIP_TU=1 under the default strategy - that unit holds this launcher and nothing else of the host side.
-// build: 0 = k_pbs_wide, 1 = k_pbs_duo with the two bootstraps of a workgroup in step, 2 = k_pbs_duo staggered, 3 = k_pbs_sym
+// build: 0 = k_pbs_wide, 1 = k_pbs_duo with the two bootstraps of a workgroup in step, 2 = k_pbs_duo staggered
 __attribute__((visibility("hidden"))) hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int logn, int k,
                                                                         int l, const PbsJob *jobs, int64_t count,
                                                                         const uint32_t *wires, const uint32_t *raw,
@@ -2502,7 +2139,6 @@ hipError_t helm_hip_tu1_launch_wide(helm_hip_ctx *ctx, int build, int field, int
     if (field == FB && logn == LN && k == KK && l == LL) {                                                               \
         if (build == 1) return launch_pbs_duo<DuoCfg<BoolField<FB>::type, LN, KK, LL, false>>(ctx, jobs, count, wires, raw, tvs, out_big); \
         if (build == 2) return launch_pbs_duo<DuoCfg<BoolField<FB>::type, LN, KK, LL, true>>(ctx, jobs, count, wires, raw, tvs, out_big); \
-        if (build == 3) return launch_pbs_sym<SymCfg<BoolField<FB>::type, KK, LL>>(ctx, jobs, count, wires, raw, tvs, out_big);            \
         return launch_pbs_wide<WideCfg<BoolField<FB>::type, LN, KK, LL>>(ctx, jobs, count, wires, raw, tvs, out_big);                  \
     }
     WIDE_CASE(49, 9, 2, 3) WIDE_CASE(49, 9, 1, 3) WIDE_CASE(49, 9, 1, 2)
@@ -2530,120 +2166,62 @@ static hipError_t wide_launch(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t cou
 #else
     if (build == 1) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, false>>(ctx, jobs, count, wires, raw, tvs, out_big);
     if (build == 2) return launch_pbs_duo<DuoCfg<F, LOGN, K, L, true>>(ctx, jobs, count, wires, raw, tvs, out_big);
-    if constexpr (LOGN == 9) {
-        if (build == 3) return launch_pbs_sym<SymCfg<F, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
-    }
     if (build) return hipErrorInvalidValue;
     return launch_pbs_wide<WideCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
 #endif
 }
 
-// Build choice.  Measured on MI355X, boolean_default (profiles/r01/microbench_*): one launch of B
-// bootstraps takes
-//   wide       3.7 - 4.0 ms per round of <= 256 ((k+1) L = 9 waves per bootstrap: k_pbs_wide)
-//   latency    4.4 ms per round of 256 (one workgroup per CU)
-//   balanced   4.8 (<= 256), 7.6 (<= 512) ms
-//   throughput 4.9, 7.4, 9.9, 12.4 ms for up to 1..4 workgroups per CU (12 waves per CU, three per
-//              SIMD), 10.6 ms per 1,024 in longer launches
-//   lockstep   9.0 - 9.2 ms per round of <= 1,024 (four bootstraps per workgroup, one per SIMD)
-// (round 1; round 4, profiles/r04: wide 3.0 - 3.5, duo 5.1 - 5.6 per <= 512, trio 7.0 - 7.15 per <= 768, lockstep 8.2 - 8.7)
-// so a launch runs its full rounds of 4 bootstraps per CU in lockstep and the remainder by size:
-// up to one per CU wide (HELM_HIP_NARROW=1: latency), up to two per CU duo (round 3: throughput), up to three per CU
-// trio (k = 2; round 3: a partial lockstep round), more another lockstep round.
-// HELM_HIP_PBS_VARIANT=1|2|3|4|5|6|7|8|9 forces latency | balanced | throughput | wide | lockstep | duo in step | duo
-// staggered | sym | trio for the whole launch.
+// Build choice by launch size (measured: profiles/r04/microbench.jsonl, profiles/r05/microbench*.jsonl; relative costs in
+// helm_hip_launch_costs).  A launch runs its full rounds of 4 bootstraps per CU on the lockstep k_pbs and the remainder by size:
+//   <= 1 per CU   k_pbs_wide   (k+1) L waves per bootstrap: the latency of ONE chain (a single netlist's levels)
+//   <= 2 per CU   k_pbs_duo    two bootstraps per workgroup, staggered by half a step (N = 1024: the compact LDS layout, in step)
+//   <= 3 per CU   k_pbs_trio   three bootstraps per workgroup, four waves each (k = 2, N = 512); other sets: a lockstep round
+//   more          another lockstep round
+// HELM_HIP_PBS_VARIANT=4|5|6|7|9 forces wide | lockstep | duo in step | duo staggered | trio for the whole launch (parity tests
+// and same-box A/B runs); every other value is refused by helm_hip_ctx_create.
 template <typename F, int LOGN, int K, int L>
 static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
                                const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
 {
-    if constexpr (LOGN == 9) {
-        using Lat = PbsCfg<F, LOGN, K, L, L, TW_REG, true, 1>;
-        using Bal = PbsCfg<F, LOGN, K, L, L, TW_LANE, true, 2>;
-        using Thr = PbsCfg<F, LOGN, K, L, 1, TW_LANE, false, 3>;
-        // Round 4: the lane's block-B / block-C twiddles of the FORWARD direction sit in registers (TW_LANE_FREG: 28 of them,
-        // 140 -> 162 registers, still three waves per SIMD) instead of being read from the LDS lane table in every one of the
-        // three forward transforms of a step: 42 LDS reads fewer per wave-step (of 145 LDS instructions), **+1.9 %** on the
-        // headline kernel (4,096 bootstraps: 33.49 -> 32.84 ms, same box, alternating, identical ciphertexts;
-        // profiles/r04/lockstep_twiddle_registers.txt).  -DHELM_LOCK_TW=TW_LANE is round 3's form.
+    // Round 4 (N = 512): the lane's block-B / block-C twiddles of the FORWARD direction sit in registers (TW_LANE_FREG: 28 of
+    // them, 140 -> 162 registers, still three waves per SIMD) instead of being read from the LDS lane table in every one of the
+    // three forward transforms of a step: +1.9 % (profiles/r04/lockstep_twiddle_registers.txt).  N = 1024 (two waves per
+    // bootstrap on one SIMD, 248 registers) reads the table.  -DHELM_LOCK_TW=TW_LANE is round 3's form at N = 512.
 #ifndef HELM_LOCK_TW
 #define HELM_LOCK_TW TW_LANE_FREG
 #endif
-        using Lock = PbsCfg<F, LOGN, K, L, 1, HELM_LOCK_TW, false, 1, 4>;
-        int v = ctx->pbs_variant;
-        if (v == 0) {
-            const int64_t round = 4 * (int64_t)ctx->n_cus;
-            int64_t full = count / round * round;
-            // a remainder of more than three per CU (two without k_pbs_trio) is another lockstep round
-            const bool trio = K == 2 && ctx->trio;
-            if (count - full > (trio ? 3 : 2) * (int64_t)ctx->n_cus) full = count;
-            if (full) {
-                hipError_t e;
-                {
-                    TimedScope t(ctx, &ctx->ev_pbs_main);
-                    e = launch_pbs_v<Lock>(ctx, jobs, full, wires, raw, tvs, out_big);
-                }
-                ctx->tacc.pbs_main_launches++;
-                ctx->tacc.pbs_main_count += full;
-                if (e != hipSuccess || full == count) return e;
-                jobs += full;
-                out_big += (size_t)full * ((size_t)K * (1 << LOGN) + 1);
-                count -= full;
+    using Lock = PbsCfg<F, LOGN, K, L, LOGN == 9 ? HELM_LOCK_TW : TW_LANE>;
+    constexpr bool HAS_TRIO = LOGN == 9 && K == 2;
+    const int64_t cus = ctx->n_cus;
+    int v = ctx->pbs_variant;
+    if (v == 0) {
+        const int64_t round = 4 * cus;
+        int64_t full = count / round * round;
+        // a remainder of more than three per CU (two where there is no three-per-CU build) is another lockstep round
+        const bool trio = HAS_TRIO && ctx->trio;
+        if (count - full > (trio ? 3 : 2) * cus) full = count;
+        if (full) {
+            hipError_t e;
+            {
+                TimedScope t(ctx, &ctx->ev_pbs_main);
+                e = launch_pbs_v<Lock>(ctx, jobs, full, wires, raw, tvs, out_big);
             }
-            // the remainder: up to one per CU wide, up to two per CU duo (each bootstrap on two SIMDs; HELM_HIP_DUO=0: the
-            // throughput build as in round 3), up to three per CU trio (four waves per bootstrap)
-            v = count <= ctx->n_cus ? ctx->narrow_variant : count > 2 * (int64_t)ctx->n_cus ? 9 : ctx->duo_build ? 5 + ctx->duo_build : 3;
+            ctx->tacc.pbs_main_launches++;
+            ctx->tacc.pbs_main_count += full;
+            if (e != hipSuccess || full == count) return e;
+            jobs += full;
+            out_big += (size_t)full * ((size_t)K * (1 << LOGN) + 1);
+            count -= full;
         }
-        if (v == 9) {
-            if constexpr (K == 2) return launch_pbs_trio<TrioCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
-            else return launch_pbs_v<Lock>(ctx, jobs, count, wires, raw, tvs, out_big);
-        }
-        if (v == 4) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
-        if (v == 6 || v == 7 || v == 8) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big, v - 5);
-        if (v == 1) return launch_pbs_v<Lat>(ctx, jobs, count, wires, raw, tvs, out_big);
-        if (v == 2) return launch_pbs_v<Bal>(ctx, jobs, count, wires, raw, tvs, out_big);
-        if (v == 5) return launch_pbs_v<Lock>(ctx, jobs, count, wires, raw, tvs, out_big);
-        return launch_pbs_v<Thr>(ctx, jobs, count, wires, raw, tvs, out_big);
-    } else {
-        // N = 1024 (k = 1): two waves per bootstrap, 422 registers: two workgroups per CU put one
-        // wave on every SIMD (82.6 k gates/s on helm_cuda; a one-level-at-a-time build with 256
-        // registers spilled and measured 73 k)
-        using Big = PbsCfg<F, LOGN, K, L, L, TW_LANE, true, 1>;
-        // lockstep build (level at a time, four bootstraps per workgroup, the two waves of a bootstrap on
-        // one SIMD): the full rounds of wide launches (HELM_HIP_PBS_VARIANT=1 keeps the build above)
-        using Lock = PbsCfg<F, LOGN, K, L, 1, TW_LANE, false, 1, 4>;
-        // launches of at most one bootstrap per CU (a single netlist's levels): the wide build, (k+1) L waves per
-        // bootstrap - 2.6 ms instead of 5.6 ms per bootstrap on helm_cuda (HELM_HIP_PBS_VARIANT=4 forces it,
-        // HELM_HIP_NARROW=1 keeps the two-wave build)
-        if (ctx->pbs_variant == 4 || (ctx->pbs_variant == 0 && count <= ctx->n_cus && ctx->narrow_variant == 4))
-            return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
-        // round 5: two bootstraps per CU on k_pbs_duo's compact layout - the size dispatch's choice for launches of more than one
-        // and at most two per CU (HELM_HIP_DUO1024=0: the two-wave build as before); HELM_HIP_PBS_VARIANT=6 | 7 forces it
-        if (ctx->pbs_variant == 6 || ctx->pbs_variant == 7)
-            return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big, ctx->pbs_variant - 5);
-        if (ctx->pbs_variant == 0 && ctx->duo1024 && count > ctx->n_cus && count <= 2 * (int64_t)ctx->n_cus)
-            return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big, ctx->duo1024);
-        if (ctx->pbs_variant != 1) {
-            const int64_t round = 4 * (int64_t)ctx->n_cus;
-            int64_t full = ctx->pbs_variant == 5 ? count : count / round * round;
-            if (ctx->pbs_variant != 5 && count - full > 2 * (int64_t)ctx->n_cus) full = count;
-            if (full) {
-                hipError_t e;
-                {
-                    TimedScope t(ctx, &ctx->ev_pbs_main);
-                    e = launch_pbs_v<Lock>(ctx, jobs, full, wires, raw, tvs, out_big);
-                }
-                ctx->tacc.pbs_main_launches++;
-                ctx->tacc.pbs_main_count += full;
-                if (e != hipSuccess || full == count) return e;
-                jobs += full;
-                out_big += (size_t)full * ((size_t)K * (1 << LOGN) + 1);
-                count -= full;
-            }
-        }
-        if (ctx->pbs_variant == 0 && count <= ctx->n_cus && ctx->narrow_variant == 4)
-            return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
-        return launch_pbs_v<Big>(ctx, jobs, count, wires, raw, tvs, out_big);
+        const int duo = LOGN == 9 ? ctx->duo_build : ctx->duo1024; // 0: no two-per-CU build (A/B): a lockstep round instead
+        v = count <= cus ? 4 : count > 2 * cus ? 9 : duo ? 5 + duo : 5;
     }
+    if (v == 4) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
+    if (v == 6 || v == 7) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big, v - 5);
+    if (v == 9) {
+        if constexpr (HAS_TRIO) return launch_pbs_trio<TrioCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
+    }
+    return launch_pbs_v<Lock>(ctx, jobs, count, wires, raw, tvs, out_big);
 }
 
 template <int LOGN, int K, int L>
@@ -2852,9 +2430,14 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         ctx->device = device_id;
         ctx->P = P;
         ctx->n_cus = prop.multiProcessorCount;
-        if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) ctx->pbs_variant = atoi(v);
-        if (const char *v = getenv("HELM_HIP_NARROW")) ctx->narrow_variant = atoi(v) == 4 ? 4 : 1;
-        if (const char *v = getenv("HELM_HIP_DUO")) ctx->duo_build = atoi(v) >= 0 && atoi(v) <= 3 ? atoi(v) : 2;
+        if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) {
+            ctx->pbs_variant = atoi(v);
+            const int pv = ctx->pbs_variant;
+            if (!(pv == 0 || pv == 4 || pv == 5 || pv == 6 || pv == 7 || pv == 9))
+                return fail(HELM_ERR_INVALID, std::string("HELM_HIP_PBS_VARIANT=") + v + ": builds are 4 wide, 5 lockstep, 6 / 7 duo in step / "
+                                              "staggered, 9 trio (1 latency, 2 balanced, 3 throughput, 8 sym were retired in round 6)");
+        }
+        if (const char *v = getenv("HELM_HIP_DUO")) ctx->duo_build = atoi(v) >= 0 && atoi(v) <= 2 ? atoi(v) : 2;
         if (const char *v = getenv("HELM_HIP_DUO1024")) ctx->duo1024 = atoi(v) == 1 || atoi(v) == 2 ? atoi(v) : 0;
         if (const char *v = getenv("HELM_HIP_DUO1024_FLAGS")) ctx->duo1024_flags = atoi(v);
         if (const char *v = getenv("HELM_HIP_DUO_FLAGS")) ctx->duo_flags = atoi(v);
@@ -3023,17 +2606,17 @@ int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4])
     if (!ctx || !cost) return fail(HELM_ERR_INVALID, "null argument");
     // launch_pbs_f's dispatch, measured (profiles/r04/microbench.jsonl and the other boxes of the round; boolean_default:
     // 3.2 - 3.3 / 5.0 - 5.3 / 6.6 - 6.7 / 7.6 - 8.0 ms for <= 256 / 512 / 768 / 1,024 bootstraps - wide, duo, trio and a full
-    // lockstep round, final build of round 4; without k_pbs_duo the throughput build is 0.80 of a round for <= 512, without
+    // lockstep round, final build of round 4; without k_pbs_duo (A/B switch) a launch of <= 512 is a lockstep round, without
     // k_pbs_trio a lockstep round of three per CU 0.89 - 0.90 for <= 768)
     if (ctx->P.N == 512) {
-        cost[0] = ctx->narrow_variant == 4 ? 0.42 : 0.50;
-        cost[1] = ctx->duo_build ? 0.66 : 0.80;
+        cost[0] = 0.42;
+        cost[1] = ctx->duo_build ? 0.66 : 1.0;
         cost[2] = ctx->P.k == 2 && ctx->trio ? 0.86 : 0.89;
     } else { // N = 1024 (helm_cuda, round 5: 3.9 / 5.5 / 8.0 / 8.6 ms - wide, k_pbs_duo's compact layout (two-wave build: 6.05), lockstep rounds;
              // in the lazy field FpI: 3.41 / 5.11 / 7.55 / 7.76 ms, profiles/r05/ab_field1024.jsonl)
         const bool lazy = ctx->field == 50;
-        cost[0] = ctx->narrow_variant == 4 ? (lazy ? 0.44 : 0.45) : (lazy ? 0.70 : 0.64);
-        cost[1] = ctx->duo1024 ? (lazy ? 0.66 : 0.64) : (lazy ? 0.73 : 0.71);
+        cost[0] = lazy ? 0.44 : 0.45;
+        cost[1] = ctx->duo1024 ? (lazy ? 0.66 : 0.64) : 1.0;
         cost[2] = lazy ? 0.97 : 0.93;
     }
     cost[3] = 1.0;

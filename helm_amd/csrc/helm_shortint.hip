@@ -698,32 +698,22 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 2) void k_pbs64k(const Pbs64Job
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-#ifndef HELM_SI_KEYBUF
-#define HELM_SI_KEYBUF 0 // classical k_pbs64s: key words through buffer loads (scalar offset + immediate) instead of pointers:
-                         // 7 vector instructions fewer per wave-step, measured +0.2 % (slower): off
-#endif
 #ifndef HELM_SI_MB_NESTED
 #define HELM_SI_MB_NESTED 1 // multi-bit: the group's key sum in nested form (2^g - 1 multiplications per position and column)
 #endif
-#ifndef HELM_SI_SWAP_NTT
-#define HELM_SI_SWAP_NTT 0 // N = 2048: half transforms with one LDS transpose (lane-bit stages through row swaps, ntt_fp64.h):
-                           // bit-identical, 13 % fewer LDS instructions, +2.5 % vector instructions - measured -0.4 % (m2c2) /
-                           // +0.7 % (multi-bit), and the two-level build spills: off (profiles/r03/si_kernel_experiments.txt)
-#endif
-// the half transforms of k_pbs64s: the one-transpose form where it exists (1,024 points), the two-transpose form otherwise
+// the half transforms of k_pbs64s (a one-transpose form of the 1,024-point half - lane-bit stages through row swaps - was
+// bit-identical and measured -0.4 % / +0.7 %: profiles/r03/si_kernel_experiments.txt; removed in round 6)
 template <typename F, int LOGH, typename TW, int PRIO, typename HOOK = NoHook>
 __device__ __forceinline__ void half_forward(double (&x)[1][Geo<LOGH>::E], double *xb, const TW &tw, int lane,
                                              const HOOK &hook = HOOK())
 {
-    if constexpr (LOGH == 10 && HELM_SI_SWAP_NTT) ntt_forward_sw10<F, TW, PRIO, HOOK>(x, xb, tw, lane, hook);
-    else ntt_forward<F, LOGH, 1, TW, PRIO, HOOK>(x, xb, tw, lane, hook);
+    ntt_forward<F, LOGH, 1, TW, PRIO, HOOK>(x, xb, tw, lane, hook);
 }
 template <typename F, int LOGH, typename TW, int PRIO, bool CENTRE, typename HOOK = NoHook>
 __device__ __forceinline__ void half_inverse(double (&x)[Geo<LOGH>::E], double *xb, const TW &tw, int lane,
                                              const HOOK &hook = HOOK())
 {
-    if constexpr (LOGH == 10 && HELM_SI_SWAP_NTT) ntt_inverse_sw10<F, TW, PRIO, CENTRE, HOOK>(x, xb, tw, lane, hook);
-    else ntt_inverse<F, LOGH, TW, PRIO, CENTRE, HOOK>(x, xb, tw, lane, hook);
+    ntt_inverse<F, LOGH, TW, PRIO, CENTRE, HOOK>(x, xb, tw, lane, hook);
 }
 
 template <int LOGN_, int L_ = 1>
@@ -741,26 +731,14 @@ struct Pbs64sCfg {
 #ifndef HELM_SI_KW1_EARLY
 #define HELM_SI_KW1_EARLY 1 // second key column fetched before the LAST block of the forward half transform
 #endif
-#ifndef HELM_SI_PAIR_FLAG
-#define HELM_SI_PAIR_FLAG 0 // hand-over between the two waves of a SIMD through LDS flags instead of two workgroup barriers:
-                            // measured 2.2 % SLOWER (profiles/r03/si_kernel_experiments.txt), kept as a switch
-#endif
 #ifndef HELM_SI_STAGE1_SRC
 #define HELM_SI_STAGE1_SRC 1 // k_pbs64s, one level: stage 1 of the full transform done by the wave that makes the digits
 #endif
 #ifndef HELM_SI_TWC_REGS
 #define HELM_SI_TWC_REGS 1 // classical k_pbs64s, one level: the lane's block-C twiddles of both half transforms in registers
 #endif
-#ifndef HELM_SI_STAGE1_SRC_MB
-#define HELM_SI_STAGE1_SRC_MB 0 // the same in the multi-bit body: measured -0.3 % (its digit phase has no rotated reads to hide
-                                // the extra LDS writes behind): off
-#endif
 #ifndef HELM_SI_PAIR_LIFT
 #define HELM_SI_PAIR_LIFT 1 // k_pbs64s: a wave lifts both outputs j and j + N/2 of a quarter of the slots (lift_pairs)
-#endif
-#ifndef HELM_SI_PRIO_SKEW
-#define HELM_SI_PRIO_SKEW 0 // k_pbs64s: the waves of polynomial 0 (the older wave of each SIMD pair) enter the transforms one
-                            // priority level below their partners
 #endif
 #ifndef HELM_SI_MIX_HALVES
 #define HELM_SI_MIX_HALVES 1 // k_pbs64s: one wave of either transform half per SIMD (the halves' last stages differ in cost)
@@ -771,7 +749,7 @@ struct Pbs64sCfg {
 #ifndef HELM_SI_LAZY_INV
 #define HELM_SI_LAZY_INV 1 // the half inverse leaves its outputs uncentred: the last stage recentres anyway
 #endif
-    static constexpr bool PRIO = HELM_SI_PRIO == 1; // 2: the waves of polynomial 1 above their SIMD partners throughout
+    static constexpr bool PRIO = HELM_SI_PRIO != 0;
     static constexpr int TW_IDX = GS::N >> GS::BC, TW_PART = TW_IDX + GS::TWC * 64; // per (field, half)
     static constexpr size_t X_OFF = 0;                                              // double [NW][GS::XPAD]
     static constexpr size_t TW_OFF = X_OFF + sizeof(double) * NW * GS::XPAD;        // double [2][2][TW_PART]
@@ -827,7 +805,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
     using GS = typename C::GS;
     constexpr int N = G::N, E = G::E, EH = GS::E, Q = E / 4, HC = EH / 2;
     // entry priority of the transforms (stepped down block by block inside them)
-    constexpr int PH = !C::PRIO ? 0 : (HELM_SI_PRIO_SKEW && P == 0) ? 2 : 3;
+    constexpr int PH = !C::PRIO ? 0 : 3;
     constexpr bool SRC1 = HELM_SI_STAGE1_SRC && L == 1; // stage 1 where the digits are made
     double *X = reinterpret_cast<double *>(smem + C::X_OFF);
     uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
@@ -856,11 +834,6 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         twi.base = tw_oth + C::TW_IDX + (63 - lane);
     }
     const int quarter = f * 2 + h; // which E/4 slots of the polynomial this wave decomposes
-#if HELM_SI_PAIR_FLAG
-    uint32_t *flags = reinterpret_cast<uint32_t *>(smem + C::FLAG_OFF); // zeroed by the kernel before the first barrier
-    uint32_t *flag_mine = flags + wave_of(p, f, h), *flag_partner = flags + wave_of(1 - p, f, h);
-    uint32_t seq = 0;
-#endif
 
     // key words of this wave: [i][row p][c][level][f][h][e/2][lane] as double2
     const size_t part = (size_t)(GS::N / 2);
@@ -868,12 +841,6 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
     const double2 *bsk_w = reinterpret_cast<const double2 *>(bsk) + ((size_t)p * K1 * L * 4 + f * 2 + h) * part + lane;
     const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
     [[maybe_unused]] const uint32_t bmask = (1u << logB) - 1u;
-#if HELM_SI_KEYBUF
-    const unsigned step_bytes = (unsigned)(bsk_step * 16), col_bytes = (unsigned)(4 * part * 16);
-    const unsigned wave_off = (unsigned)(((size_t)p * K1 * L * 4 + f * 2 + h) * part * 16);
-    KeyBuf kbuf;
-    kbuf.init(bsk, (size_t)n * step_bytes, lane);
-#endif
 
     STAMP_DECL
     for (int i = 0; i < n; i++) {
@@ -881,14 +848,7 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         if (a == 0) continue; // uniform over the workgroup
         STAMP_BEGIN
         [[maybe_unused]] const double2 *bp_i = bsk_w + (size_t)i * bsk_step;
-#if HELM_SI_KEYBUF
-        const unsigned so_i = (unsigned)i * step_bytes + wave_off;
-        auto key = [&](int col_lev, int u) { // double2 u of key polynomial (column, level) of this wave's row / field / half
-            return kbuf.load(so_i + (unsigned)col_lev * col_bytes + (unsigned)(u >> 2) * 4096u, (u & 3) * 1024);
-        };
-#else
         auto key = [&](int col_lev, int u) { return (bp_i + (size_t)col_lev * 4 * part)[u * 64]; };
-#endif
         // ---- (1) digits of this wave's quarter of polynomial p -------------------------------
         if constexpr (SRC1) {
             // L = 1: the quarter is Q/2 PAIRS (j, j + N/2); stage 1 of the full transform is done here, once per pair
@@ -1009,24 +969,6 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
 #pragma unroll
         for (int e = 0; e < EH; e++) xb[e * 64 + lane] = other[e];
         STAMP(3) // products
-#if HELM_SI_PAIR_FLAG
-        // The hand-over concerns two waves only: (p, f, h) and (1 - p, f, h), which share a SIMD and run the same
-        // instruction stream.  Two flags per wave in LDS (sequence numbers of the step) replace the two workgroup
-        // barriers: "my sums are written" (release after the writes; the partner acquires before it reads) and "I have
-        // read yours" (release after the reads; the partner acquires before its inverse transform first writes into
-        // its scratch).  The other six waves are not held up.
-        seq++;
-        lds_flag_set(flag_mine, seq);
-        lds_flag_wait(flag_partner, seq);
-#pragma unroll
-        for (int e = 0; e < EH; e++) mine[e] = reduce<F>(mine[e] + x_poly[e * 64 + lane]);
-        lds_flag_set(flag_mine + C::NW, seq);
-        STAMP(4) // flag 1, sum
-        auto partner_has_read = [&]() { lds_flag_wait(flag_partner + C::NW, seq); };
-        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(PH);
-        half_inverse<F, LOGN - 1, decltype(twi), PH, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane, partner_has_read);
-        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
-#else
         lds_block_sync();
 #pragma unroll
         for (int e = 0; e < EH; e++) mine[e] = reduce<F>(mine[e] + x_poly[e * 64 + lane]);
@@ -1036,7 +978,6 @@ __device__ __forceinline__ void pbs64s_body(unsigned char *smem, const double *_
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(PH);
         half_inverse<F, LOGN - 1, decltype(twi), PH, !(HELM_SI_LAZY_INV && HELM_SI_FUSED_XCHG)>(mine, xb, twi, lane); // a_h[e * 64 + lane], centred
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
-#endif
         STAMP(5) // half inverse
 #pragma unroll
         for (int e = 0; e < EH; e++)
@@ -1120,7 +1061,7 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
     constexpr int LOGN = C::LOGN, K1 = C::K1;
     using G = typename C::G;
     using GS = typename C::GS;
-    constexpr int PH = !C::PRIO ? 0 : (HELM_SI_PRIO_SKEW && P == 0) ? 2 : 3;
+    constexpr int PH = !C::PRIO ? 0 : 3;
     constexpr int N = G::N, E = G::E, EH = GS::E, Q = E / 4, HC = EH / 2;
     double *X = reinterpret_cast<double *>(smem + C::X_OFF);
     uint64_t *ACC = reinterpret_cast<uint64_t *>(smem + C::ACC_OFF);
@@ -1166,33 +1107,6 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
 #pragma unroll
         for (int q = 0; q < 3; q++) bq[q] = psi_pow[(c_lane * am[q]) & (2 * N - 1)];
         // ---- (1) digits of this wave's quarter of polynomial p ----------------------------------
-#if HELM_SI_STAGE1_SRC_MB
-        { // pairs (j, j + N/2), stage 1 in both fields, results into the consumers' scratches (see pbs64s_body)
-            using FO = std::conditional_t<std::is_same<F, F0>::value, F1, F0>;
-            double *x_f0 = X + (size_t)wave_of(p, f, 0) * GS::XPAD + lane, *x_f1 = X + (size_t)wave_of(p, f, 1) * GS::XPAD + lane;
-            double *x_o0 = X + (size_t)wave_of(p, 1 - f, 0) * GS::XPAD + lane, *x_o1 = X + (size_t)wave_of(p, 1 - f, 1) * GS::XPAD + lane;
-            auto digit = [&](int j) {
-                const uint64_t v = acc_p[j];
-                const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
-                return (double)((int)((st + half_m1) & bmask) - (int)half_m1); // st <= B/2 stays, above it st - B
-            };
-#pragma unroll
-            for (int u = 0; u < Q / 2; u++) {
-                const int e = quarter * (Q / 2) + u;
-                const double U = digit(G::jA(lane, e)), D1 = digit(G::jA(lane, e + EH));
-                const double Vf = stage1_digit_product<F>(D1, w1), Vo = stage1_digit_product<FO>(D1, w1o);
-                x_f0[e * 64] = U + Vf;
-                x_f1[e * 64] = U - Vf;
-                x_o0[e * 64] = U + Vo;
-                x_o1[e * 64] = U - Vo;
-            }
-        }
-        lds_block_sync(); // stage-1 outputs published
-        if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(PH);
-        double x[1][EH];
-#pragma unroll
-        for (int e = 0; e < EH; e++) x[0][e] = xb[e * 64 + lane];
-#else
         // ---- (1) digits of this wave's quarter of polynomial p ----------------------------------
 #pragma unroll
         for (int u = 0; u < Q; u++) {
@@ -1213,7 +1127,6 @@ __device__ __forceinline__ void pbs64s_mb_body(unsigned char *smem, const double
                 x[0][e] = h ? U - V : U + V;
             }
         }
-#endif
         half_forward<F, LOGN - 1, decltype(twf), PH>(x, xb, twf, lane);
         if constexpr (C::PRIO) __builtin_amdgcn_s_setprio(0);
 #if HELM_SI_MB_NESTED
@@ -1471,9 +1384,6 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs64s(const Pbs64Job *__rest
     __syncthreads();
     // psi^(N/2): entry 1 of the full forward table of this wave's field
     const double w1 = f == 0 ? tw0[1] : tw1[1], w1o = f == 0 ? tw1[1] : tw0[1];
-#if HELM_SI_PRIO == 2
-    if (p) __builtin_amdgcn_s_setprio(2);
-#endif
     // one specialisation per (field, transform half): both are uniform over the wave
     // (the polynomial as a literal too where HELM_SI_STATIC_P: the bodies are inlined, so `c == p` in the products and the
     // row offsets fold - 66 v_cndmask per wave-step gone from the classical kernel)

@@ -252,7 +252,6 @@ struct Geo {
 // asked with get(sb, hi, cnt, idx, slot): hi = which of the stage's cnt twiddles of this
 // lane, idx = table index, slot = running count in consumption order.
 //   TwMem    fetches table[idx] (LDS or global table)
-//   TwReg    one lane's twiddles of one direction in registers (filled once per kernel)
 //   TwLane   block A twiddles are the same for every lane (scalar registers); those of
 //            blocks B and C come from a lane-major LDS table [slot][64] of the FORWARD
 //            twiddles: one base address register + immediate offsets.  The inverse
@@ -264,22 +263,6 @@ struct TwMem {
     static constexpr bool MIRROR = false;
     const double *t;
     __device__ __forceinline__ double get(int, int, int, int idx, int) const { return t[idx]; }
-};
-// inverse twiddles read from the FORWARD index table (see TwLane for the identity)
-template <int LOGN>
-struct TwMemMirror {
-    static constexpr bool MIRROR = true;
-    const double *t;
-    __device__ __forceinline__ double get(int sb, int, int, int idx, int) const
-    {
-        return t[3 * ((1 << LOGN) >> (sb + 1)) - 1 - idx];
-    }
-};
-template <int NT>
-struct TwReg {
-    static constexpr bool MIRROR = false;
-    double v[NT];
-    __device__ __forceinline__ double get(int, int, int, int, int slot) const { return v[slot]; }
 };
 // forward-order slot of twiddle (sb, hi) among one lane's twiddles (block A, then B, then C)
 template <int LOGN>
@@ -412,40 +395,6 @@ struct TwHybridC {
         return t[MIRROR ? 3 * (G::N >> (sb + 1)) - 1 - idx : idx];
     }
 };
-
-// Enumerate (in consumption order) the table indices of a block's twiddles.
-template <int LOGN, int SHIFT, int SB_FIRST, int SB_LAST, int SLOT0, int NT>
-__device__ __forceinline__ void tw_fill_block(TwReg<NT> &r, const double *__restrict__ table, int jbase)
-{
-    constexpr int E = Geo<LOGN>::E, N = Geo<LOGN>::N;
-    constexpr int DIR = SB_FIRST <= SB_LAST ? 1 : -1;
-    int slot = SLOT0;
-#pragma unroll
-    for (int sb = SB_FIRST; sb != SB_LAST + DIR; sb += DIR) {
-        const int eb = sb - SHIFT;
-#pragma unroll
-        for (int hi = 0; hi < (E >> (eb + 1)); hi++) {
-            const int jh = jbase | (hi << (eb + 1 + SHIFT));
-            r.v[slot++] = table[(N >> (sb + 1)) + (jh >> (sb + 1))];
-        }
-    }
-}
-template <int LOGN>
-__device__ __forceinline__ void tw_fill_forward(TwReg<Geo<LOGN>::NTW> &r, const double *__restrict__ table, int lane)
-{
-    using G = Geo<LOGN>;
-    tw_fill_block<LOGN, 6, LOGN - 1, LOGN - G::BA, 0>(r, table, G::jA(lane, 0));
-    tw_fill_block<LOGN, G::BC, G::BC + G::BB - 1, G::BC, G::TWA>(r, table, G::jB(lane, 0));
-    tw_fill_block<LOGN, 0, G::BC - 1, 0, G::TWA + G::TWB>(r, table, G::jC(lane, 0));
-}
-template <int LOGN>
-__device__ __forceinline__ void tw_fill_inverse(TwReg<Geo<LOGN>::NTW> &r, const double *__restrict__ table, int lane)
-{
-    using G = Geo<LOGN>;
-    tw_fill_block<LOGN, 0, 0, G::BC - 1, 0>(r, table, G::jC(lane, 0));
-    tw_fill_block<LOGN, G::BC, G::BC, G::BC + G::BB - 1, G::TWC>(r, table, G::jB(lane, 0));
-    tw_fill_block<LOGN, 6, LOGN - G::BA, LOGN - 1, G::TWC + G::TWB>(r, table, G::jA(lane, 0));
-}
 
 // Fused radix-2 Cooley-Tukey stages on stride bits SB_HI..SB_LO (descending), all of
 // which are register-slot bits (slot bit = stride bit - SHIFT), for M polynomials.
@@ -666,296 +615,6 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *x
         static_assert(F::LAZY, "uncentred outputs need the headroom of the 49-bit fields");
         x[0] = reduce<F>(x[0]);
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// 1,024-point transforms (16 values per lane) with ONE LDS transpose instead of two.  Stride bits 9..6 are slot bits of
-// layout A, stride bits 3..0 slot bits of layout C; the two in between, 5 and 4, are LANE bits 5 and 4 and are done with
-// gfx950's row swaps: v_permlane32_swap / v_permlane16_swap exchange the upper (odd) 32- / 16-lane rows of one register
-// with the lower rows of another, so that after swapping the registers of slots e and e | 8 (e | 4) every lane holds
-// both ends (j, j ^ 32) (j, j ^ 16) of eight butterflies.  The swap is not undone: lane bit 5 (4) then stands for what
-// was slot bit 3 (2), and the transpose addresses absorb it.  Same butterflies, same twiddles, same stage order as
-// ntt_forward<F, 10> / ntt_inverse<F, 10>: identical results, 32 LDS operations fewer and 32 vector instructions more
-// per transform.  Holder of coefficient j after the swap stages: lane = (j9 j8 j3 j2 j1 j0), slot = (j5 j4 j7 j6).
-// ---------------------------------------------------------------------------------------------------------------------
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void swap32_f64(double &a, double &b)
-{
-    const u32x2_t lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const u32x2_t hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    a = __hiloint2double((int)hi.x, (int)lo.x);
-    b = __hiloint2double((int)hi.y, (int)lo.y);
-}
-__device__ __forceinline__ void swap16_f64(double &a, double &b)
-{
-    const u32x2_t lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const u32x2_t hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    a = __hiloint2double((int)hi.x, (int)lo.x);
-    b = __hiloint2double((int)hi.y, (int)lo.y);
-}
-
-struct GeoSw10 {
-    using G = Geo<10>;
-    // padded address of coefficient j: j + (j >> 4) (conflict-free for the 16-consecutive writes of the swapped layout and
-    // for layout C's stride-16 reads); writer (lane, slot e) holds j = (l5 l4 e1 e0 e3 e2 l3 l2 l1 l0)
-    __device__ static __forceinline__ int baseP(int lane) { return ((lane >> 4) << 8) + ((lane >> 4) << 4) + (lane & 15); }
-    static constexpr int offP(int e) { return ((e & 3) << 6) + ((e >> 2) << 4) + ((e & 3) << 2) + (e >> 2); }
-    __device__ static __forceinline__ int baseC(int lane) { return lane * 17; }
-    // twiddle table indices of the two swap stages for this lane: stride bit 5: 16 + (j >> 6), stride bit 4: 32 + (j >> 5)
-    __device__ static __forceinline__ int idx5(int lane, int e_lo) { return 16 + ((lane >> 5) << 3) + e_lo; }                       // e_lo < 8
-    __device__ static __forceinline__ int idx4(int lane, int e_c) { return 32 + ((lane >> 4) << 3) + ((e_c & 3) << 1) + (e_c >> 3); } // bit 2 of e_c clear
-};
-
-template <typename F, typename TW, int PRIO = 0, typename HOOK = NoHook>
-__device__ __forceinline__ void ntt_forward_sw10(double (&x)[1][16], double *xbuf, const TW &tw, int lane,
-                                                 const HOOK &before_last = HOOK())
-{
-    using G = Geo<10>;
-    static_assert(F::LAZY, "the swap-stage transform is written for the lazy 49-bit fields (no recentring on the way)");
-    fwd_block<F, 10, 1, 6, 9, 6, 0>(x, tw, G::jA(lane, 0)); // stride bits 9..6
-    if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);
-    // stride bit 5: slots e and e + 8 swap rows of 32 lanes
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        double u = x[0][e], v = x[0][e + 8];
-        swap32_f64(u, v);
-        const double w = tw.get(5, 0, 0, GeoSw10::idx5(lane, e), 0);
-        const double V = mulmod<F>(v, w);
-        x[0][e] = u + V;
-        x[0][e + 8] = u - V;
-    }
-    // stride bit 4: slots e and e + 4 (bit 2 clear) swap rows of 16 lanes
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int e = (q & 3) | ((q >> 2) << 3);
-        double u = x[0][e], v = x[0][e + 4];
-        swap16_f64(u, v);
-        const double w = tw.get(4, 0, 0, GeoSw10::idx4(lane, e), 0);
-        const double V = mulmod<F>(v, w);
-        x[0][e] = u + V;
-        x[0][e + 4] = u - V;
-    }
-    if constexpr (PRIO > 1) __builtin_amdgcn_s_setprio(PRIO - 2);
-    double *pP = xbuf + GeoSw10::baseP(lane), *pC = xbuf + GeoSw10::baseC(lane);
-#pragma unroll
-    for (int e = 0; e < 16; e++) pP[GeoSw10::offP(e)] = x[0][e];
-    lds_wave_sync();
-#pragma unroll
-    for (int e = 0; e < 16; e++) x[0][e] = pC[e];
-    lds_wave_sync();
-    before_last();
-    fwd_block<F, 10, 1, 0, 3, 0, 0>(x, tw, G::jC(lane, 0)); // stride bits 3..0
-}
-
-template <typename F, typename TW, int PRIO = 0, bool CENTRE = true, typename HOOK = NoHook>
-__device__ __forceinline__ void ntt_inverse_sw10(double (&x)[16], double *xbuf, const TW &tw, int lane,
-                                                 const HOOK &before_write = HOOK())
-{
-    using G = Geo<10>;
-    static_assert(F::LAZY, "the swap-stage transform is written for the lazy 49-bit fields");
-    inv_block<F, 10, 0, 0, 3, 0>(x, tw, G::jC(lane, 0)); // stride bits 0..3: four doublings from 0.5 p
-    before_write();
-    if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);
-    double *pP = xbuf + GeoSw10::baseP(lane), *pC = xbuf + GeoSw10::baseC(lane);
-#pragma unroll
-    for (int e = 0; e < 16; e++) pC[e] = reduce<F>(x[e]);
-    lds_wave_sync();
-#pragma unroll
-    for (int e = 0; e < 16; e++) x[e] = pP[GeoSw10::offP(e)];
-    lds_wave_sync();
-    // stride bit 4, then the rows of 16 lanes go back
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int e = (q & 3) | ((q >> 2) << 3);
-        const double U = x[e], V = x[e + 4];
-        const double w = tw.get(4, 0, 0, GeoSw10::idx4(lane, e), 0);
-        double s0 = U + V, s1 = mulmod<F>(TW::MIRROR ? V - U : U - V, w);
-        swap16_f64(s0, s1);
-        x[e] = s0;
-        x[e + 4] = s1;
-    }
-    // stride bit 5, rows of 32 lanes back
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const double U = x[e], V = x[e + 8];
-        const double w = tw.get(5, 0, 0, GeoSw10::idx5(lane, e), 0);
-        double s0 = U + V, s1 = mulmod<F>(TW::MIRROR ? V - U : U - V, w);
-        swap32_f64(s0, s1);
-        x[e] = s0;
-        x[e + 8] = s1;
-    }
-    if constexpr (PRIO > 1) __builtin_amdgcn_s_setprio(PRIO - 2);
-    // two doublings since the transpose (<= 2 p); four more follow: recentre here (where the second transpose did)
-#pragma unroll
-    for (int e = 0; e < 16; e++) x[e] = reduce<F>(x[e]);
-    inv_block<F, 10, 6, 6, 9, 0>(x, tw, G::jA(lane, 0)); // stride bits 6..9
-    if constexpr (CENTRE) {
-#pragma unroll
-        for (int e = 0; e < 16; e++) x[e] = reduce<F>(x[e]);
-    } else {
-        x[0] = reduce<F>(x[0]); // the pure-sum slot reaches 8 p (see ntt_inverse)
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Half transforms (N = 512).  After its first stage (stride bit 8: pairs j, j + 256, twiddle table[1]) a negacyclic
-// 512-point transform is two independent 256-point transforms on the index halves h = 0, 1 whose butterflies and twiddles
-// are exactly the full transform's stages 7 .. 0 restricted to indices with top bit h:
-//   twiddle of the butterfly on stride bit sb for half index j:  table[(512 >> (sb + 1)) + (((h << 8) | j) >> (sb + 1))]
-// so a half's values are the full transform's values at spectrum positions (h << 8) | p, p = 0 .. 255 - the bootstrapping
-// key needs no second layout.  One wave holds a half as FOUR values per lane; the eight stages run as four blocks of two
-// stages in four register layouts with three wave-private LDS transposes:
-//   L0: j = e << 6 | lane             (slot bits = index bits 7, 6)     stages 7, 6   (twiddles uniform over the wave)
-//   L1: j = (lane >> 4) << 6 | e << 4 | (lane & 15)        (5, 4)       stages 5, 4
-//   L2: j = (lane >> 2) << 4 | e << 2 | (lane & 3)         (3, 2)       stages 3, 2
-//   L3: j = lane << 2 | e                                  (1, 0)       stages 1, 0
-// LDS address of index j: j + (j >> 2) (320 doubles per polynomial), which is (per-lane base) + (constant) * e in every
-// layout and keeps the 32 lanes of a half-wave on all sixteen 8-byte bank pairs (L2, L3) or on thirteen of them (L0, L1).
-// The inverse runs the blocks backwards (Gentleman-Sande, inverse table, same indices).  Used by k_pbs_sym.
-// ---------------------------------------------------------------------------------------------------------------------
-struct HalfGeo9 {
-    static constexpr int N = 512, H = 256, E = 4, XPAD = 320;
-    __device__ static __forceinline__ int j0(int lane, int e) { return (e << 6) | lane; }
-    __device__ static __forceinline__ int j1(int lane, int e) { return ((lane >> 4) << 6) | (e << 4) | (lane & 15); }
-    __device__ static __forceinline__ int j2(int lane, int e) { return ((lane >> 2) << 4) | (e << 2) | (lane & 3); }
-    __device__ static __forceinline__ int j3(int lane, int e) { return (lane << 2) | e; }
-    // padded address = base(lane) + STEP * e
-    __device__ static __forceinline__ int base0(int lane) { return lane + (lane >> 2); }
-    __device__ static __forceinline__ int base1(int lane) { return 80 * (lane >> 4) + (lane & 15) + ((lane & 15) >> 2); }
-    __device__ static __forceinline__ int base2(int lane) { return 20 * (lane >> 2) + (lane & 3); }
-    __device__ static __forceinline__ int base3(int lane) { return 5 * lane; }
-    static constexpr int STEP0 = 80, STEP1 = 20, STEP2 = 5, STEP3 = 1;
-};
-
-// the twiddles one lane needs for the half transforms of half h, one direction: per block the twiddle of its first stage
-// (one per lane) and the two of its second stage (by the upper slot bit)
-struct HalfTw {
-    double hi[4], lo[4][2];
-    // table: tw_fwd (forward) or tw_inv (inverse), both indexed as above
-    __device__ __forceinline__ void fill(const double *__restrict__ table, int h, int lane)
-    {
-        const int jb[4] = {HalfGeo9::j0(lane, 0), HalfGeo9::j1(lane, 0), HalfGeo9::j2(lane, 0), HalfGeo9::j3(lane, 0)};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int sbhi = 7 - 2 * k, sblo = 6 - 2 * k;
-            const int jp = (h << 8) | jb[k];
-            hi[k] = table[(512 >> (sbhi + 1)) + (jp >> (sbhi + 1))];
-#pragma unroll
-            for (int t = 0; t < 2; t++) lo[k][t] = table[(512 >> (sblo + 1)) + ((jp | (t << sbhi)) >> (sblo + 1))];
-        }
-    }
-};
-
-// two Cooley-Tukey stages of block k on M half polynomials (slot bit 1 = the block's upper index bit)
-template <typename F, int M>
-__device__ __forceinline__ void half_fwd_block(double (&x)[M][4], const HalfTw &tw, int k)
-{
-#pragma unroll
-    for (int m = 0; m < M; m++) {
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const double U = x[m][e], V = mulmod<F>(x[m][e + 2], tw.hi[k]);
-            x[m][e] = U + V;
-            x[m][e + 2] = U - V;
-        }
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const double U = x[m][2 * t], V = mulmod<F>(x[m][2 * t + 1], tw.lo[k][t]);
-            x[m][2 * t] = U + V;
-            x[m][2 * t + 1] = U - V;
-        }
-    }
-}
-template <typename F>
-__device__ __forceinline__ void half_inv_block(double (&x)[4], const HalfTw &tw, int k)
-{
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const double U = x[2 * t], V = x[2 * t + 1];
-        x[2 * t] = U + V;
-        x[2 * t + 1] = mulmod<F>(U - V, tw.lo[k][t]);
-    }
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const double U = x[e], V = x[e + 2];
-        x[e] = U + V;
-        x[e + 2] = mulmod<F>(U - V, tw.hi[k]);
-    }
-}
-
-// Forward half transforms of M polynomials.  in: x[m][e] = value at half index j0(lane, e) (after the stride-8 stage);
-// out: x[m][e] = spectrum position (h << 8) | j3(lane, e).  xbuf: wave-private, M * XPAD doubles.
-template <typename F, int M>
-__device__ __forceinline__ void ntt_half_forward(double (&x)[M][4], double *xbuf, const HalfTw &tw, int lane)
-{
-    using G = HalfGeo9;
-    double *p0 = xbuf + G::base0(lane), *p1 = xbuf + G::base1(lane), *p2 = xbuf + G::base2(lane), *p3 = xbuf + G::base3(lane);
-    half_fwd_block<F, M>(x, tw, 0);
-#pragma unroll
-    for (int m = 0; m < M; m++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) p0[m * G::XPAD + G::STEP0 * e] = reduce_unless_lazy<F>(x[m][e]);
-    lds_wave_sync();
-#pragma unroll
-    for (int m = 0; m < M; m++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) x[m][e] = p1[m * G::XPAD + G::STEP1 * e];
-    lds_wave_sync();
-    half_fwd_block<F, M>(x, tw, 1);
-#pragma unroll
-    for (int m = 0; m < M; m++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) p1[m * G::XPAD + G::STEP1 * e] = reduce_unless_lazy<F>(x[m][e]);
-    lds_wave_sync();
-#pragma unroll
-    for (int m = 0; m < M; m++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) x[m][e] = p2[m * G::XPAD + G::STEP2 * e];
-    lds_wave_sync();
-    half_fwd_block<F, M>(x, tw, 2);
-#pragma unroll
-    for (int m = 0; m < M; m++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) p2[m * G::XPAD + G::STEP2 * e] = reduce_unless_lazy<F>(x[m][e]);
-    lds_wave_sync();
-#pragma unroll
-    for (int m = 0; m < M; m++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) x[m][e] = p3[m * G::XPAD + G::STEP3 * e];
-    lds_wave_sync();
-    half_fwd_block<F, M>(x, tw, 3);
-}
-
-// Inverse half transform (stages 0 .. 7; the joining stage on stride bit 8 and the 1/N factor are the caller's).
-// in: x[e] = spectrum position j3(lane, e), |x| <= 0.5 p; out: x[e] = half index j0(lane, e), not recentred
-// (|x| <= 4 * 0.5 p after the last two-stage block).
-template <typename F>
-__device__ __forceinline__ void ntt_half_inverse(double (&x)[4], double *xbuf, const HalfTw &tw, int lane)
-{
-    using G = HalfGeo9;
-    double *p0 = xbuf + G::base0(lane), *p1 = xbuf + G::base1(lane), *p2 = xbuf + G::base2(lane), *p3 = xbuf + G::base3(lane);
-    half_inv_block<F>(x, tw, 3);
-#pragma unroll
-    for (int e = 0; e < 4; e++) p3[G::STEP3 * e] = reduce<F>(x[e]);
-    lds_wave_sync();
-#pragma unroll
-    for (int e = 0; e < 4; e++) x[e] = p2[G::STEP2 * e];
-    lds_wave_sync();
-    half_inv_block<F>(x, tw, 2);
-#pragma unroll
-    for (int e = 0; e < 4; e++) p2[G::STEP2 * e] = reduce<F>(x[e]);
-    lds_wave_sync();
-#pragma unroll
-    for (int e = 0; e < 4; e++) x[e] = p1[G::STEP1 * e];
-    lds_wave_sync();
-    half_inv_block<F>(x, tw, 1);
-#pragma unroll
-    for (int e = 0; e < 4; e++) p1[G::STEP1 * e] = reduce<F>(x[e]);
-    lds_wave_sync();
-#pragma unroll
-    for (int e = 0; e < 4; e++) x[e] = p0[G::STEP0 * e];
-    lds_wave_sync();
-    half_inv_block<F>(x, tw, 0);
 }
 
 } // namespace helm

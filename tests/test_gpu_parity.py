@@ -198,16 +198,16 @@ def test_upload_rejects_duplicate_rows():
     ssk.close()
 
 
-@pytest.mark.parametrize("variant,name", [(1, "toy_k2"), (2, "toy_k2"), (3, "toy_k2"), (4, "toy_k2"), (5, "toy_k2"),
-                                          (6, "toy_k2"), (7, "toy_k2"), (8, "toy_k2"),     # duo in step / staggered, sym (transform halves)
+@pytest.mark.parametrize("variant,name", [(4, "toy_k2"), (5, "toy_k2"),
+                                          (6, "toy_k2"), (7, "toy_k2"),                    # duo in step / staggered
                                           (9, "toy_k2"),                                   # trio: three per workgroup, four waves each
-                                          (1, "toy"), (3, "toy"), (4, "toy"), (5, "toy"),  # k = 2, l = 3 and k = 1, l = 2
-                                          (6, "toy"), (7, "toy"), (8, "toy"),
-                                          (1, "toy_1024"), (4, "toy_1024"), (5, "toy_1024"),   # N = 1024: two-wave, wide, lockstep
-                                          (6, "toy_1024"), (7, "toy_1024")])                   # ... and k_pbs_duo's compact layout
+                                          (4, "toy"), (5, "toy"),                          # k = 1, l = 2
+                                          (6, "toy"), (7, "toy"),
+                                          (4, "toy_1024"), (5, "toy_1024"),                # N = 1024: wide, lockstep
+                                          (6, "toy_1024"), (7, "toy_1024")])               # ... and k_pbs_duo's compact layout
 def test_every_build_of_k_pbs_bit_exact(variant, name, monkeypatch):
-    """HELM_HIP_PBS_VARIANT forces one build of the blind-rotate kernel for a whole launch (latency,
-    balanced, throughput, wide, lockstep, duo); each must reproduce the oracle bit for bit.  Nine
+    """HELM_HIP_PBS_VARIANT forces one build of the blind-rotate kernel for a whole launch (wide, lockstep,
+    duo in step / staggered, trio - every build the size dispatch can select); each must reproduce the oracle bit for bit.  Nine
     ciphertexts: two full workgroups and one with a single bootstrap in the lockstep build, four full
     workgroups and a half-empty one in the two-per-workgroup duo build (the other waves leave before the
     first barrier); an all-zero mask keeps every rotation at zero."""
@@ -231,8 +231,8 @@ def test_every_build_of_k_pbs_bit_exact(variant, name, monkeypatch):
 
 def test_launch_split_over_builds_bit_exact(monkeypatch):
     """Default dispatch of a wide launch: the full rounds (4 bootstraps per CU) go to the lockstep
-    build, the remainder to the wide / throughput build.  Same ciphertexts as the throughput build
-    alone, and as the oracle on a sample."""
+    build, the remainder to the wide build.  Same ciphertexts as the lockstep build alone, and as the
+    oracle on a sample."""
     ck = helm_amd.ClientKey.generate("toy_k2", seed=12)
     p = ck.params
     rng = np.random.default_rng(5)
@@ -245,7 +245,7 @@ def test_launch_split_over_builds_bit_exact(monkeypatch):
     idx = rng.integers(0, 3, size=count).astype(np.int32)
     got = sk.pbs_batch(lwe, tvs, idx)
     sk.close()
-    monkeypatch.setenv("HELM_HIP_PBS_VARIANT", "3")
+    monkeypatch.setenv("HELM_HIP_PBS_VARIANT", "5")
     sk3 = helm_amd.ServerKey(ck)
     assert np.array_equal(got, sk3.pbs_batch(lwe, tvs, idx))
     sk3.close()
@@ -288,11 +288,21 @@ def _nine_bootstraps_bit_exact(ck, sk, orc, seed):
         assert np.array_equal(got[g], orc.bootstrap_noks(lwe[g], tvs[idx[g]])), g
 
 
-@pytest.mark.parametrize("variant", [1, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [1, 2, 3, 8])
+def test_retired_builds_are_refused_by_name(variant, monkeypatch):
+    """Round 6 removed the builds the size dispatch had stopped selecting (latency, balanced, throughput, sym); asking for
+    one is an error with the list of what exists, not a silent substitute."""
+    monkeypatch.setenv("HELM_HIP_PBS_VARIANT", str(variant))
+    ck = helm_amd.ClientKey.generate("toy_k2", seed=1)
+    with pytest.raises(helm_amd.HelmError, match="retired in round 6"):
+        helm_amd.ServerKey(ck)
+
+
+@pytest.mark.parametrize("variant", [4, 5, 6, 7])
 def test_n1024_builds_bit_exact_in_the_51_bit_field_too(variant, monkeypatch):
     """Round 5: N = 1024 sets run in the lazy field FpI (p = 5440^4 + 1) when the loaded key's own bound allows it - the toy and
     the cited set do, so test_every_build_of_k_pbs_bit_exact[*-toy_1024] now covers FpI's kernels.  The 51-bit field stays
-    the fallback for keys that do not fit: its five N = 1024 builds (two-wave, wide, lockstep, duo in step / staggered)
+    the fallback for keys that do not fit: its four N = 1024 builds (wide, lockstep, duo in step / staggered)
     against the oracle under HELM_HIP_FIELD=51.  Parameters: reference src/bin/helm.rs:141-146."""
     monkeypatch.setenv("HELM_HIP_FIELD", "51")
     monkeypatch.setenv("HELM_HIP_PBS_VARIANT", str(variant))
@@ -467,19 +477,23 @@ def test_whole_launch_every_row_bit_exact(name):
     sk.close()
 
 
-def test_one_aes128_evaluation_every_wire_bit_exact():
+@pytest.mark.parametrize("params,levels_checked", [("boolean_default", None), ("helm_cuda", 32)])
+def test_one_aes128_evaluation_every_wire_bit_exact(params, levels_checked):
     """BASELINE config 4 as ONE circuit at the full parameter set (what reference src/bin/helm.rs:256-262 runs): the 207 levels of
     the AES-128 netlist (FIPS-197 C.1 key and plaintext) on the GPU - launches of 80-256 bootstraps: k_pbs_wide, the
-    single-circuit kernel, and the keyswitch's narrow-launch form - and the first 64 levels (three S-box layers, 10 k gates; all
-    207 with HELM_TEST_FULL_AES=1: one more minute of oracle time) on the oracle's SIMD route from the same input ciphertexts:
-    EVERY wire of those levels bit for bit, and the 128 output bits decrypt to the FIPS-197 ciphertext."""
+    single-circuit kernel, and the keyswitch's narrow-launch form - and ALL 207 levels (32 k gates; HELM_TEST_SAMPLED_AES=1: the
+    first 64) on the oracle's SIMD route from the same input ciphertexts: EVERY wire bit for bit, and the 128 output bits
+    decrypt to the FIPS-197 ciphertext.  helm_cuda (the set reference src/bin/helm.rs:141-146 cites): the first 32 levels, so
+    that k_pbs_wide at N = 1024 in the lazy field the loaded key selects (FpI) meets the oracle on a real netlist as well."""
     import os
     from helm_amd import Circuit, verilog_parser
     from helm_amd.distributed import level_arrays
     from helm_amd.netlists import aes128, aes128_reference_encrypt
-    ck = helm_amd.ClientKey.generate("boolean_default", seed=4)
+    ck = helm_amd.ClientKey.generate(params, seed=4)
     p = ck.params
     sk = helm_amd.ServerKey(ck)
+    if params == "helm_cuda":
+        assert sk.field_bits() == 50   # the generated key fits the lazy field of N = 1024 contexts
     orc = oracle.Oracle(p.as_tuple7(), ck.bsk, ck.ksk, use_ntt=False, use_fp=True)
     gates, wire_set, inputs, outputs, dffs, _, _ = verilog_parser.read_verilog_text(aes128(), False)
     c = Circuit(gates, inputs, outputs, dffs)
@@ -501,7 +515,7 @@ def test_one_aes128_evaluation_every_wire_bit_exact():
     got = w.download()
     host = np.zeros_like(got)
     host[rows] = cts
-    n_check = len(off) - 1 if os.environ.get("HELM_TEST_FULL_AES") == "1" else 64
+    n_check = levels_checked or (64 if os.environ.get("HELM_TEST_SAMPLED_AES") == "1" else len(off) - 1)
     for l in range(n_check):
         s = slice(off[l], off[l + 1])
         orc.eval_level_fp(host, ops[s], i0[s], i1[s], i2[s], out[s])
