@@ -68,6 +68,10 @@ int helm_client_named_params(const char *name, helm_hip_params *p, double *lwe_s
         p->n = 16; p->k = 1; p->N = 1024; p->pbs_l = 3; p->pbs_logB = 7; p->ks_l = 8; p->ks_logB = 2;
         *lwe_std = 1e-7;
         *glwe_std = 1e-9;
+    } else if (s == "toy_1024_l2") { // N = 1024 with two decomposition levels: the L = 2 instantiations of every N = 1024 build
+        p->n = 16; p->k = 1; p->N = 1024; p->pbs_l = 2; p->pbs_logB = 7; p->ks_l = 8; p->ks_logB = 2;
+        *lwe_std = 1e-7;
+        *glwe_std = 1e-9;
     } else
         return fail(HELM_ERR_INVALID, "unknown parameter set '" + s + "'");
     return 0;

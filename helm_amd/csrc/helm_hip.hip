@@ -1388,6 +1388,310 @@ __global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_trio(const PbsJob *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------
+// k_pbs_tri10 (round 6): THREE bootstraps per workgroup at N = 1024 (k = 1: reference src/bin/helm.rs:141-146's set) - for the
+// remainders of a launch that hold between two and three bootstraps per CU, which until now cost a lockstep round with one
+// SIMD in four empty (0.93 - 0.97 of a full round).  Two-wave bootstraps cannot fill four SIMDs three at a time, and four
+// waves of the duo form (248 registers' worth of 16-value transforms) do not fit three times; so every wave here is
+// (polynomial r, TRANSFORM HALF h) with EIGHT values per lane: after its first stage (stride 512) a 1,024-point negacyclic
+// transform is two independent 512-point transforms on the position halves, whose butterflies and twiddles are the full
+// transform's stages 8 .. 0 restricted to positions with top bit h -
+//   twiddle of the butterfly on stride bit sb for half position q:  table[(1024 >> (sb+1)) + (((h << 9) | q) >> (sb+1))]
+// - so the bootstrapping key needs no second layout (spectrum position (h << 9) | q).  Wave (r, h), per step:
+//   - rotates / subtracts / decomposes polynomial r (all 16 values of a lane: both waves of a polynomial do) level by level,
+//     least significant first; per level the split stage and the half's first stage on the digits are the plain radix-4
+//     butterfly of the b^4 + 1 fields restricted to its two outputs (fwd_top2_digits: 5 operations per two values), then the
+//     512-point transform continues (ntt_forward<F, 9, ..., DIGITS = 3>) and the k + 1 = 2 products with its half of row r
+//     follow: column r stays in registers, the other column's sum is handed to wave (1 - r, h) through LDS;
+//   - barrier 1; adds the sum it receives, inverse-transforms its half of column r, publishes it;
+//   - barrier 2; does its half of the joining stage (h = 0: z0 + z1 -> coefficients j; h = 1: (z0 - z1) psi^-(N/2) ->
+//     coefficients j + N/2), lifts, updates its half of the accumulator copy both waves of the polynomial read next;
+//   - barrier 3.
+// Twelve identical waves, three per SIMD (wave w = 4 b + 2 r + h sits on SIMD w % 4: the four waves of a bootstrap on four
+// SIMDs).  LDS: one lane-twiddle table per transform half for the workgroup (the inverse of half h reads the FORWARD table of
+// half 1 - h mirrored: psi^-i = -psi^(2N - i) lands in the other half's index range), per wave the transform scratch and a
+// hand-over slot, per polynomial ONE copy of the accumulator (N words: the negacyclic sign of a rotated read is arithmetic -
+// the [acc | -acc] form of the other builds does not fit three times), 149.6 KB in all.
+// Same exact integers as every other build: identical ciphertexts.
+// ------------------------------------------------------------------------------------
+template <typename F_, int L_, int NB_ = 3>
+struct Tri10Cfg {
+    using F = F_;
+    static constexpr int LOGN = 10, K = 1, K1 = 2, L = L_, NB = NB_, NWB = 4, NW = NWB * NB_; // NB = 2: the same waves, two per SIMD
+    using G = Geo<10>;
+    using GH = Geo<9>; // the half transforms: 512 points, eight values per lane
+    static constexpr int MAX_SMALL_N = 1024;
+    static constexpr int TWH_ROWS = GH::TWB + GH::TWC;                               // rows of one half's lane table
+    static constexpr size_t TW_SHARED = sizeof(double) * 2 * TWH_ROWS * 64;          // at the workgroup's base: double [2][TWH_ROWS][64]
+    static constexpr int HO_OFF = GH::XPAD;                                          // the hand-over slot behind the transform scratch
+    static constexpr int WAVE_DOUBLES = GH::XPAD + GH::N;
+    // per bootstrap
+    static constexpr size_t X_OFF = 0;                                               // double [NWB][WAVE_DOUBLES]
+    static constexpr size_t ACC_OFF = X_OFF + sizeof(double) * NWB * WAVE_DOUBLES;   // u32 [K1][N]
+    static constexpr size_t MS_OFF = ACC_OFF + sizeof(uint32_t) * K1 * G::N;         // u16 [n+1]
+    static constexpr size_t BOOT_BYTES = (MS_OFF + sizeof(uint16_t) * (MAX_SMALL_N + 1) + 15) / 16 * 16;
+    static constexpr size_t BYTES = TW_SHARED + BOOT_BYTES * NB;
+    static_assert(BYTES <= 160 * 1024, "three bootstraps per workgroup must fit the CU's LDS");
+};
+
+// index into the 1,024-point forward table of lane-table row s (0 .. TWB + TWC - 1 of Geo<9>) of transform half hh
+__device__ inline int tw_lane_index_half10(int s, int lane, int hh)
+{
+    using G = Geo<9>;
+    int slot = 0;
+    for (int sb = G::BC + G::BB - 1; sb >= G::BC; sb--) {
+        const int eb = sb - G::BC, cnt = G::E >> (eb + 1);
+        if (s < slot + cnt) {
+            const int jh = (hh << 9) | G::jB(lane, 0) | ((s - slot) << (eb + 1 + G::BC));
+            return (1024 >> (sb + 1)) + (jh >> (sb + 1));
+        }
+        slot += cnt;
+    }
+    for (int sb = G::BC - 1; sb >= 0; sb--) {
+        const int cnt = G::E >> (sb + 1);
+        if (s < slot + cnt) {
+            const int jh = (hh << 9) | G::jC(lane, 0) | ((s - slot) << (sb + 1));
+            return (1024 >> (sb + 1)) + (jh >> (sb + 1));
+        }
+        slot += cnt;
+    }
+    return 0;
+}
+
+template <typename C, bool PRIO>
+__global__ __launch_bounds__(64 * C::NW, 1) void k_pbs_tri10(const PbsJob *__restrict__ jobs, const uint32_t *__restrict__ wires,
+                                                             const uint32_t *__restrict__ raw_in, const uint32_t *__restrict__ tvs,
+                                                             const double *__restrict__ bsk, const double *__restrict__ tw_fwd,
+                                                             const double *__restrict__ tw_inv, uint32_t *__restrict__ out_big, int n,
+                                                             int logB, int count)
+{
+    constexpr int L = C::L, K = 1, K1 = 2, NB = C::NB, NWB = C::NWB, N = 1024, EH = 8;
+    using F = typename C::F;
+    extern __shared__ __align__(16) unsigned char smem_wg[];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = w >> 2, wb = w & 3;  // bootstrap of the workgroup, wave of the bootstrap
+    const int r = wb >> 1, h = wb & 1; // polynomial, transform half
+    const int jix = (int)blockIdx.x * NB + b;
+    if (jix >= count) return; // the hardware barrier counts the surviving waves only
+    unsigned char *smem = smem_wg + C::TW_SHARED + (size_t)b * C::BOOT_BYTES;
+    double *X = reinterpret_cast<double *>(smem + C::X_OFF);
+    double *TWS = reinterpret_cast<double *>(smem_wg);
+    uint32_t *ACC = reinterpret_cast<uint32_t *>(smem + C::ACC_OFF);
+    uint16_t *MS = reinterpret_cast<uint16_t *>(smem + C::MS_OFF);
+    const int tid = wb * 64 + lane;
+    const PbsJob job = jobs[jix];
+    const size_t row = (size_t)n + 1;
+    {
+        const uint32_t *a0 = nullptr, *a1 = nullptr, *a2 = nullptr;
+        if (job.op < 0) a0 = raw_in + row * (size_t)job.in0;
+        else {
+            if (job.in0 >= 0) a0 = wires + row * (size_t)job.in0;
+            if (job.in1 >= 0) a1 = wires + row * (size_t)job.in1;
+            if (job.in2 >= 0) a2 = wires + row * (size_t)job.in2;
+        }
+        for (int i = tid; i <= n; i += 64 * NWB) {
+            uint32_t v;
+            if (job.op < 0) v = a0[i];
+            else v = gate_lincomb(job.op, job.which, a0 ? a0[i] : 0u, a1 ? a1[i] : 0u, a2 ? a2[i] : 0u, i == n);
+            MS[i] = (uint16_t)modswitch(v, 11);
+        }
+    }
+    // one table for the workgroup; each bootstrap's waves fill ALL of it (the same values: another bootstrap's waves may have
+    // left already, and nobody reads before the barrier below)
+    for (int q = wb; q < 2 * C::TWH_ROWS; q += NWB) {
+        const int hh = q / C::TWH_ROWS, s = q - hh * C::TWH_ROWS;
+        TWS[q * 64 + lane] = tw_fwd[tw_lane_index_half10(s, lane, hh)];
+    }
+    TwLane<9, false> twf0;
+    TwLane<9, true> twi;
+    twf0.base = TWS + h * C::TWH_ROWS * 64 + lane;
+    twi.base = TWS + (1 - h) * C::TWH_ROWS * 64 + (63 - lane);
+    {
+        // block A's lane-uniform twiddles (stride bits 8, 7, 6 of the half): forward those of half h, inverse those of half
+        // 1 - h (read mirrored by TwLane<., true>)
+        int slot = 0;
+#pragma unroll
+        for (int sb = 8; sb >= 6; sb--) {
+#pragma unroll
+            for (int hi = 0; hi < (EH >> (sb - 6 + 1)); hi++) {
+                twf0.ua[slot] = tw_fwd[(1024 >> (sb + 1)) + h * (512 >> (sb + 1)) + hi];
+                twi.ua[slot] = tw_fwd[(1024 >> (sb + 1)) + (1 - h) * (512 >> (sb + 1)) + hi];
+                slot++;
+            }
+        }
+    }
+    const double w9i = tw_inv[1]; // the joining stage (stride bit 9): psi^-(N/2)
+    // the split stage and the half's first stage on digits: x(q) = (d0 +- b^2 d4) + (c1 d2 + c2 d6), x(q + 256) = ... - ...
+    const double cA = h ? -F::B2 : F::B2, c1 = h ? F::B3 : F::B1, c2 = h ? F::B1 : F::B3;
+    __syncthreads();
+    TwLaneReg<9, false> twf;
+    twf.load(twf0);
+
+    // accumulator (0, X^{-b~} tv): wave (r, h) owns the coefficients j = 512 h + 64 e + lane of polynomial r
+    uint32_t *acc_r = ACC + (size_t)r * N;
+    uint32_t accr[EH];
+    auto acc_store = [&]() {
+        uint32_t *aw = acc_r + 512 * h + lane;
+#pragma unroll
+        for (int e = 0; e < EH; e++) aw[64 * e] = accr[e];
+    };
+    {
+        const int bt = (int)MS[n];
+        const uint32_t *tv = tvs + (size_t)job.tv * N;
+#pragma unroll
+        for (int e = 0; e < EH; e++) {
+            uint32_t v = 0;
+            if (r == K) {
+                const int idx = (512 * h + 64 * e + lane + bt) & (2 * N - 1);
+                v = tv[idx & (N - 1)];
+                if (idx >= N) v = 0u - v;
+            }
+            accr[e] = v;
+        }
+        acc_store();
+    }
+    __syncthreads();
+
+    double *xb = X + (size_t)wb * C::WAVE_DOUBLES;
+    const unsigned poly_bytes = (unsigned)(N / 2) * 16u;
+    const unsigned step_bytes = (unsigned)(K1 * K1 * L) * poly_bytes;
+    const unsigned row_off = (unsigned)(r * K1 * L) * poly_bytes; // + (c * L + lev) * poly_bytes
+    KeyBuf kb;
+    kb.init(bsk, (size_t)n * step_bytes, lane);
+    // this wave's eight spectrum positions (h << 9) | (lane << 3 | e) sit in the full-transform layout [e_f / 2][lane_f][2] at
+    // lane_f = 32 h + (lane >> 1), e_f = 8 (lane & 1) + e: double2 number 4 (lane & 1) + e / 2 of that lane
+    kb.lane16 = (lane & 1) * 4096 + (h * 32 + (lane >> 1)) * 16;
+    const uint32_t half_m1 = (1u << (logB - 1)) - 1u;
+    const int neg_B = -(1 << logB);
+    const int rep = logB * L;
+    const uint32_t rnd = 1u << (31 - rep);
+
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(3);
+    STAMP_DECL
+    for (int i = 0; i < n; i++) {
+        STAMP_BEGIN
+        // a zero rotation is not skipped: the bootstraps of a workgroup meet at the same barriers (its product is exactly zero)
+        const int a = __builtin_amdgcn_readfirstlane((int)MS[i]);
+        const unsigned so_i = (unsigned)i * step_bytes + row_off;
+        // ---- rotation and difference: st[e] = round((X^a acc - acc)[64 e + lane]) >> (32 - rep) -------------------------------
+        uint32_t st[16];
+        {
+            // rotated index (64 e + lane - a) mod 2N: bits 0-9 address the one copy, bit 10 is the negacyclic sign
+            const int base = (lane - a) & (2 * N - 1);
+            const uint32_t *own = acc_r + lane;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int t = base + 64 * e;
+                const uint32_t raw = acc_r[t & (N - 1)];
+                const uint32_t m = 0u - ((uint32_t)(t >> 10) & 1u);
+                // (all sixteen unrotated values from the copy too: picking the own half out of registers by h costs a select each)
+                st[e] = (((raw ^ m) - m) - own[64 * e] + rnd) >> (32 - rep);
+            }
+        }
+        double mine[EH], keep[EH];
+#pragma unroll
+        for (int lev = L - 1; lev >= 0; lev--) {
+            // this level's key words of both columns (0: column r, this wave's own; 1: the other one): issued before the
+            // transform that hides their latency
+            double2 kw[K1][EH / 2];
+#pragma unroll
+            for (int c = 0; c < K1; c++)
+#pragma unroll
+                for (int e2 = 0; e2 < EH / 2; e2++)
+                    kw[c][e2] = kb.load(so_i + (unsigned)((c ? 1 - r : r) * L + lev) * poly_bytes, e2 * 1024);
+            double x[1][EH];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const double d0 = (double)decompose_step(st[e], logB, half_m1, neg_B, lev == 0);
+                const double d2 = (double)decompose_step(st[e + 4], logB, half_m1, neg_B, lev == 0);
+                const double d4 = (double)decompose_step(st[e + 8], logB, half_m1, neg_B, lev == 0);
+                const double d6 = (double)decompose_step(st[e + 12], logB, half_m1, neg_B, lev == 0);
+                const double s0 = __builtin_fma(d4, cA, d0);
+                const double u = __builtin_fma(d6, c2, d2 * c1);
+                x[0][e] = s0 + u;
+                x[0][e + 4] = s0 - u;
+                HELM_BOUND(__builtin_fabs(x[0][e]) < F::P * 0.5 && __builtin_fabs(x[0][e + 4]) < F::P * 0.5, 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ntt_forward<F, 9, 1, decltype(twf), 0, NoHook, 3>(x, xb, twf, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PRIO)
+                if (lev == 0) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int e2 = 0; e2 < EH / 2; e2++) {
+                const double2 wr = kw[0][e2], wo = kw[1][e2];
+                const double t0 = mulmod<F>(x[0][2 * e2], wr.x), t1 = mulmod<F>(x[0][2 * e2 + 1], wr.y);
+                const double u0 = mulmod<F>(x[0][2 * e2], wo.x), u1 = mulmod<F>(x[0][2 * e2 + 1], wo.y);
+                mine[2 * e2] = lev == L - 1 ? t0 : mine[2 * e2] + t0;
+                mine[2 * e2 + 1] = lev == L - 1 ? t1 : mine[2 * e2 + 1] + t1;
+                keep[2 * e2] = lev == L - 1 ? u0 : keep[2 * e2] + u0;
+                keep[2 * e2 + 1] = lev == L - 1 ? u1 : keep[2 * e2 + 1] + u1;
+            }
+            if constexpr (PRIO) {
+                if (lev == L - 1) __builtin_amdgcn_s_setprio(2);
+                else if (lev == 1) __builtin_amdgcn_s_setprio(1);
+            }
+        }
+        {
+            double *dst = xb + C::HO_OFF + lane;
+#pragma unroll
+            for (int e = 0; e < EH; e++) dst[64 * e] = keep[e];
+        }
+        STAMP(0) // rotation, digits, forward half transforms, products, hand-over written
+        lds_block_sync();
+        STAMP(1) // barrier 1
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(3);
+        {
+            const double *src = X + (size_t)(2 * (1 - r) + h) * C::WAVE_DOUBLES + C::HO_OFF + lane;
+            if constexpr (!F::LAZY) {
+#pragma unroll
+                for (int e = 0; e < EH; e++) mine[e] = reduce<F>(mine[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < EH; e++) mine[e] = reduce<F>(mine[e] + reduce_unless_lazy<F>(src[64 * e]));
+        }
+        ntt_inverse<F, 9>(mine, xb, twi, lane);
+        {
+            double *zx = xb + lane;
+#pragma unroll
+            for (int e = 0; e < EH; e++) zx[64 * e] = mine[e];
+        }
+        STAMP(2) // hand-over summed, inverse half transform, published
+        lds_block_sync();
+        STAMP(3) // barrier 2
+        {
+            const double *zp = X + (size_t)(2 * r + (1 - h)) * C::WAVE_DOUBLES + lane;
+#pragma unroll
+            for (int e = 0; e < EH; e++) {
+                const double o = zp[64 * e];
+                // h = 0: z0 + z1 -> coefficient j;  h = 1: (z0 - z1) psi^-(N/2) -> coefficient j + N / 2 (own = z1, other = z0)
+                const double v = h ? mulmod<F>(o - mine[e], w9i) : mine[e] + o;
+                accr[e] += to_torus32(reduce<F>(v));
+            }
+        }
+        acc_store();
+        STAMP(4) // joining stage, lift, accumulator update
+        lds_block_sync();
+        STAMP(5) // barrier 3
+    }
+    STAMP_END(w)
+
+    // ---- sample extract (coefficient 0): every wave writes its half of its polynomial -------------------------------
+    uint32_t *ob = out_big + (size_t)jix * ((size_t)K * N + 1);
+    if (r < K) {
+#pragma unroll
+        for (int e = 0; e < EH; e++) {
+            const int j = 512 * h + 64 * e + lane;
+            if (j == 0) ob[r * N] = accr[e];
+            else ob[r * N + (N - j)] = 0u - accr[e];
+        }
+    } else if (h == 0 && lane == 0) {
+        ob[K * N] = accr[0];
+    }
+}
+
 #if HELM_HIP_TU == 0 // the keyswitch, linear and table kernels: main translation unit only (see launch_pbs_wide)
 // ------------------------------------------------------------------------------------
 // k_keyswitch: grid (ceil(jobs / 4), column chunks); 256 threads; one output column per
@@ -1808,9 +2112,10 @@ struct helm_hip_ctx {
     int pbs_variant = 0;     // 0 = by launch size, 4 wide, 5 lockstep, 6 duo (the two bootstraps of a workgroup in step), 7 duo
                              // staggered, 9 trio (HELM_HIP_PBS_VARIANT; 1, 2, 3, 8 named builds retired in round 6: refused)
     int duo_build = 2;       // the two-per-CU build the size dispatch uses at N = 512: 1 k_pbs_duo in step, 2 staggered, 0 none (HELM_HIP_DUO)
-    int duo1024 = 1;         // N = 1024: more than one and at most two bootstraps per CU on k_pbs_duo's compact layout (1 in step, 2
-                             // staggered, 0: a lockstep round; HELM_HIP_DUO1024).  Round 5, same process, alternating, helm_cuda,
-                             // 512 bootstraps: the two-wave build of rounds 1-4 6.04 ms, in step 5.50 - 5.55 (stepping priorities), staggered 5.75
+    int duo1024 = 3;         // N = 1024: more than one and at most two bootstraps per CU (HELM_HIP_DUO1024): 3 k_pbs_tri10's waves, two
+                             // bootstraps per workgroup (round 6: 512 bootstraps of helm_cuda 5.11 -> 4.41 ms, profiles/r06/ab_tri10.jsonl);
+                             // 1 / 2 k_pbs_duo's compact layout in step / staggered (round 5: 5.50 - 5.55 / 5.75 ms in the 51-bit field, the
+                             // two-wave build of rounds 1-4 6.04); 0: a lockstep round
     int duo1024_flags = 1;   // its issue priorities (HELM_HIP_DUO1024_FLAGS; bits as duo_flags): on, stepping down - flat (5) and off (0) measured 5 % slower
     int trio = 1;            // remainders of two to three bootstraps per CU on k_pbs_trio (HELM_HIP_TRIO=0: a partial lockstep round, round 3's choice)
     int trio_flags = 1;      // bit 0: issue-priority staging (HELM_HIP_TRIO_FLAGS)
@@ -2116,6 +2421,32 @@ static hipError_t launch_pbs_trio(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t
     return hipGetLastError();
 }
 
+template <typename C>
+static hipError_t launch_pbs_tri10(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
+                                   const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
+{
+    static std::atomic<bool> attr_done[64]; // (rank threads of one process launch concurrently)
+    auto kern = (ctx->trio_flags & 1) ? k_pbs_tri10<C, true> : k_pbs_tri10<C, false>; // priority staging on / off (A/B)
+    if (!attr_done[ctx->device & 63]) {
+        for (auto kk : {k_pbs_tri10<C, true>, k_pbs_tri10<C, false>}) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)C::BYTES);
+            if (e != hipSuccess) return e;
+        }
+        attr_done[ctx->device & 63] = true;
+        if (getenv("HELM_HIP_VERBOSE")) {
+            hipFuncAttributes fa{};
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
+            fprintf(stderr, "[helm_hip] k_pbs_tri10: %d waves, LDS %zu B, regs %d, scratch %zu B\n", C::NW, (size_t)C::BYTES,
+                    fa.numRegs, (size_t)fa.localSizeBytes);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((count + C::NB - 1) / C::NB)), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, wires,
+                       raw, tvs, ctx->bsk, ctx->tw_fwd, ctx->tw_inv, out_big, ctx->P.n, ctx->P.pbs_logB, (int)count);
+    print_stamps(ctx, C::NW, "tri10: forward work | bar 1 | sum + inverse half | bar 2 | join + lift | bar 3");
+    return hipGetLastError();
+}
+
 // Two translation units from this one source (Makefile): the whole file is compiled under the compiler's max-ILP scheduling
 // strategy (-mllvm -amdgpu-sched-strategy=max-ilp: +1.9 % on the lockstep k_pbs, same box, alternating, identical
 // ciphertexts), except k_pbs_wide, which that strategy slows down by 0.9 % and which is therefore compiled a second time
@@ -2174,11 +2505,14 @@ static hipError_t wide_launch(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t cou
 // Build choice by launch size (measured: profiles/r04/microbench.jsonl, profiles/r05/microbench*.jsonl; relative costs in
 // helm_hip_launch_costs).  A launch runs its full rounds of 4 bootstraps per CU on the lockstep k_pbs and the remainder by size:
 //   <= 1 per CU   k_pbs_wide   (k+1) L waves per bootstrap: the latency of ONE chain (a single netlist's levels)
-//   <= 2 per CU   k_pbs_duo    two bootstraps per workgroup, staggered by half a step (N = 1024: the compact LDS layout, in step)
-//   <= 3 per CU   k_pbs_trio   three bootstraps per workgroup, four waves each (k = 2, N = 512); other sets: a lockstep round
+//   <= 2 per CU   k_pbs_duo    two bootstraps per workgroup, staggered by half a step (N = 1024: k_pbs_tri10's waves, two
+//                              bootstraps per workgroup - 14 % faster there than k_pbs_duo's compact layout)
+//   <= 3 per CU   k_pbs_trio   three bootstraps per workgroup, four waves each (k = 2, N = 512); k_pbs_tri10 (N = 1024: twelve
+//                              (polynomial, transform half) waves); other sets: a lockstep round
 //   more          another lockstep round
-// HELM_HIP_PBS_VARIANT=4|5|6|7|9 forces wide | lockstep | duo in step | duo staggered | trio for the whole launch (parity tests
-// and same-box A/B runs); every other value is refused by helm_hip_ctx_create.
+// HELM_HIP_PBS_VARIANT=4|5|6|7|9 forces wide | lockstep | duo in step | duo staggered | trio for the whole launch, 8 (N = 1024)
+// k_pbs_tri10 with two bootstraps per workgroup (parity tests and same-box A/B runs); every other value is refused by
+// helm_hip_ctx_create.
 template <typename F, int LOGN, int K, int L>
 static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t count, const uint32_t *wires,
                                const uint32_t *raw, const uint32_t *tvs, uint32_t *out_big)
@@ -2191,7 +2525,7 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
 #define HELM_LOCK_TW TW_LANE_FREG
 #endif
     using Lock = PbsCfg<F, LOGN, K, L, LOGN == 9 ? HELM_LOCK_TW : TW_LANE>;
-    constexpr bool HAS_TRIO = LOGN == 9 && K == 2;
+    constexpr bool HAS_TRIO = (LOGN == 9 && K == 2) || (LOGN == 10 && K == 1); // k_pbs_trio | k_pbs_tri10
     const int64_t cus = ctx->n_cus;
     int v = ctx->pbs_variant;
     if (v == 0) {
@@ -2219,7 +2553,11 @@ static hipError_t launch_pbs_f(helm_hip_ctx *ctx, const PbsJob *jobs, int64_t co
     if (v == 4) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big);
     if (v == 6 || v == 7) return wide_launch<F, LOGN, K, L>(ctx, jobs, count, wires, raw, tvs, out_big, v - 5);
     if (v == 9) {
-        if constexpr (HAS_TRIO) return launch_pbs_trio<TrioCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
+        if constexpr (LOGN == 9 && K == 2) return launch_pbs_trio<TrioCfg<F, LOGN, K, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
+        else if constexpr (LOGN == 10 && K == 1) return launch_pbs_tri10<Tri10Cfg<F, L>>(ctx, jobs, count, wires, raw, tvs, out_big);
+    }
+    if (v == 8) { // (N = 1024: HELM_HIP_DUO1024=3) k_pbs_tri10's waves, two bootstraps per workgroup
+        if constexpr (LOGN == 10 && K == 1) return launch_pbs_tri10<Tri10Cfg<F, L, 2>>(ctx, jobs, count, wires, raw, tvs, out_big);
     }
     return launch_pbs_v<Lock>(ctx, jobs, count, wires, raw, tvs, out_big);
 }
@@ -2433,12 +2771,12 @@ int helm_hip_ctx_create(int device_id, const helm_hip_params *params, helm_hip_c
         if (const char *v = getenv("HELM_HIP_PBS_VARIANT")) {
             ctx->pbs_variant = atoi(v);
             const int pv = ctx->pbs_variant;
-            if (!(pv == 0 || pv == 4 || pv == 5 || pv == 6 || pv == 7 || pv == 9))
+            if (!(pv == 0 || pv == 4 || pv == 5 || pv == 6 || pv == 7 || pv == 9 || (pv == 8 && P.N == 1024)))
                 return fail(HELM_ERR_INVALID, std::string("HELM_HIP_PBS_VARIANT=") + v + ": builds are 4 wide, 5 lockstep, 6 / 7 duo in step / "
                                               "staggered, 9 trio (1 latency, 2 balanced, 3 throughput, 8 sym were retired in round 6)");
         }
         if (const char *v = getenv("HELM_HIP_DUO")) ctx->duo_build = atoi(v) >= 0 && atoi(v) <= 2 ? atoi(v) : 2;
-        if (const char *v = getenv("HELM_HIP_DUO1024")) ctx->duo1024 = atoi(v) == 1 || atoi(v) == 2 ? atoi(v) : 0;
+        if (const char *v = getenv("HELM_HIP_DUO1024")) ctx->duo1024 = atoi(v) >= 1 && atoi(v) <= 3 ? atoi(v) : 0;
         if (const char *v = getenv("HELM_HIP_DUO1024_FLAGS")) ctx->duo1024_flags = atoi(v);
         if (const char *v = getenv("HELM_HIP_DUO_FLAGS")) ctx->duo_flags = atoi(v);
         if (const char *v = getenv("HELM_HIP_TRIO")) ctx->trio = atoi(v) != 0;
@@ -2616,8 +2954,10 @@ int helm_hip_launch_costs(const helm_hip_ctx *ctx, double cost[4])
              // in the lazy field FpI: 3.41 / 5.11 / 7.55 / 7.76 ms, profiles/r05/ab_field1024.jsonl)
         const bool lazy = ctx->field == 50;
         cost[0] = lazy ? 0.44 : 0.45;
-        cost[1] = ctx->duo1024 ? (lazy ? 0.66 : 0.64) : 1.0;
-        cost[2] = lazy ? 0.97 : 0.93;
+        // round 6 (profiles/r06/ab_tri10.jsonl, same process, alternating): k_pbs_tri10 with two / three bootstraps per workgroup -
+        // FpI 4.41 / 6.19 of 7.80 ms, FpH 4.65 / 6.49 of 8.32 ms (k_pbs_duo: 5.11 of 7.80; a partial lockstep round: 7.49 / 7.94)
+        cost[1] = ctx->duo1024 == 3 ? 0.57 : ctx->duo1024 ? (lazy ? 0.66 : 0.64) : 1.0;
+        cost[2] = ctx->trio ? (lazy ? 0.80 : 0.78) : (lazy ? 0.97 : 0.93);
     }
     cost[3] = 1.0;
     return 0;

@@ -84,11 +84,16 @@ struct FpI {
     static constexpr bool LAZY = true;
     static constexpr double B1 = 5440.0, B2 = 29593600.0, B3 = 160989184000.0;
 };
+// ntt_inverse's LEAN form (half of the recentrings at its two transposes) rests on slot-class bounds derived with
+// 2^53 / p >= 13.6 (tests/test_lazy_bounds.py): the 49.2-bit fields only.  FpI (2^53 / p = 10.28) recentres every slot.
+template <typename F> struct lean_inverse_ok : std::false_type {};
 template <typename F> struct has_short_roots : std::false_type {};
 template <> struct has_short_roots<FpI> : std::true_type {};
 template <> struct has_short_roots<FpG> : std::true_type {};
 template <> struct has_short_roots<FpG2> : std::true_type {};
 template <> struct has_short_roots<FpH> : std::true_type {};
+template <> struct lean_inverse_ok<FpG> : std::true_type {};
+template <> struct lean_inverse_ok<FpG2> : std::true_type {};
 
 // -DHELM_CHECK_BOUNDS: the contracts the lazy arithmetic rests on, checked at run time (a debug build, one translation unit:
 // `make libhelm_hip_check.so`, tests/test_gpu_bounds_check.py).  Every value is an exact integer held in a double, which is
@@ -503,6 +508,11 @@ __device__ __forceinline__ void fwd_top2_digits(double (&x)[M][E])
 // DIGITS (fields b^4 + 1 only): the inputs are decomposition digits -
 //   2  |x| <= 2^12 and the table normalised to psi^(N/4) = b (the boolean engine): the first two stages as fwd_top2_digits;
 //   1  |x| <= 2^23 (the 64-bit-torus engine): the first stage's products as plain multiplications by the table's psi^(N/2).
+//   3  a HALF transform of a 2N-point transform on digits (k_pbs_tri10): the caller has done the 2N-point transform's first two
+//      stages - the split into halves and this half's first stage (stride bit LOGN-1) - as plain products of digits with the
+//      short roots, exactly the values fwd_top2_digits produces; the transform continues at stride bit LOGN-2.  The twiddle
+//      source must hold the 2N-point table's entries of this half.  Bounds as DIGITS == 2 of the 2N-point transform (the same
+//      butterflies): block A ends below 1.2 p, so SKIP_T1 applies.
 template <typename F, int LOGN, int M, typename TW, int PRIO = 0, typename HOOK = NoHook, int DIGITS = 0>
 __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double *xbuf, const TW &tw, int lane,
                                             const HOOK &before_last = HOOK())
@@ -514,13 +524,16 @@ __device__ __forceinline__ void ntt_forward(double (&x)[M][Geo<LOGN>::E], double
         static_assert(G::BA >= 3, "stages 1 and 2 pair slots e, e + E/2 and e, e + E/4 of block A");
         fwd_top2_digits<F, M, G::E>(x);
         fwd_block<F, LOGN, M, 6, LOGN - 3, LOGN - G::BA, 3>(x, tw, G::jA(lane, 0)); // the rest of block A
+    } else if constexpr (DIGITS == 3 && has_short_roots<F>::value) {
+        static_assert(G::BA >= 2, "the caller has done stride bit LOGN-1 of block A");
+        fwd_block<F, LOGN, M, 6, LOGN - 2, LOGN - G::BA, 1>(x, tw, G::jA(lane, 0)); // the rest of block A
     } else
         fwd_block<F, LOGN, M, 6, LOGN - 1, LOGN - G::BA, 0>(x, tw, G::jA(lane, 0));
     if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);
     double *pA = xbuf + G::baseA(lane), *pB = xbuf + G::baseB(lane), *pC = xbuf + G::baseC(lane);
     // the recentring fields: after fwd_top2_digits block A ends below 1.2 p (its first two stages add almost nothing), so
     // block B (three stages) stays below 4.5 p of 2^53 = 5.26 p without a recentring here (tests/test_lazy_bounds.py)
-    constexpr bool SKIP_T1 = DIGITS == 2 && has_short_roots<F>::value && G::BB == 3;
+    constexpr bool SKIP_T1 = (DIGITS == 2 || DIGITS == 3) && has_short_roots<F>::value && G::BB == 3;
     static_assert(!SKIP_T1 || (G::BA >= 3 && G::BB == 3), "SKIP_T1: block A ends below 1.2 p only behind fwd_top2_digits, and block B must be three stages");
 #pragma unroll
     for (int m = 0; m < M; m++)
@@ -579,7 +592,7 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *x
 #ifndef HELM_LEAN_INVERSE
 #define HELM_LEAN_INVERSE 1
 #endif
-    constexpr bool LEAN = HELM_LEAN_INVERSE != 0 && F::LAZY && CENTRE && LOGN == 9 && G::BA == 3 && G::BB == 3 && G::BC == 3;
+    constexpr bool LEAN = HELM_LEAN_INVERSE != 0 && F::LAZY && lean_inverse_ok<F>::value && CENTRE && LOGN == 9 && G::BA == 3 && G::BB == 3 && G::BC == 3;
     // what the slot classes above assume of the layout: eight values per lane, three blocks of three stages, so that a
     // transpose hands a lane eight values of ONE slot of the block before (tests/test_lazy_bounds.py recomputes the bounds)
     static_assert(!LEAN || (G::E == 8 && G::BA + G::BB + G::BC == LOGN), "LEAN inverse: slot-class bounds are derived for Geo<9>");

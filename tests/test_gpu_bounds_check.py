@@ -21,9 +21,10 @@ import numpy as np
 sys.path.insert(0, %r)
 import helm_amd, oracle
 res = {}
-# helm_cuda (round 5: the lazy field FpI, bounds closer to 2^53 than FpG's): 40 -> the wide build, 1400 -> a lockstep round +
-# k_pbs_duo's compact layout, 1700 -> two lockstep rounds, the last workgroups partial
-for name, B in (("toy_k2", 40), ("boolean_default", 300), ("helm_cuda", 40), ("helm_cuda", 1400), ("helm_cuda", 1700)):
+# helm_cuda (round 5: the lazy field FpI, bounds closer to 2^53 than FpG's): 40 gates -> the wide build, 1250 (1,428 bootstraps
+# on 256 CUs) -> a lockstep round + k_pbs_duo's compact layout, 1400 (1,600) -> a lockstep round + k_pbs_tri10 (round 6), 1700
+# (1,943) -> two lockstep rounds, the last workgroups partial
+for name, B in (("toy_k2", 40), ("boolean_default", 300), ("helm_cuda", 40), ("helm_cuda", 1250), ("helm_cuda", 1400), ("helm_cuda", 1700)):
     ck = helm_amd.ClientKey.generate(name, seed=3)
     sk = helm_amd.ServerKey(ck, device=0)
     if name == "toy_k2":
@@ -64,7 +65,7 @@ def test_no_contract_of_the_lazy_arithmetic_is_broken_and_the_check_can_fire():
     assert p.returncode == 0, p.stderr[-3000:]
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert res["selftest"][0] == 1 and sum(res["selftest"][1:]) == 0, res["selftest"]   # the one contract broken on purpose
-    for name in ("toy_k2:40", "boolean_default:300", "helm_cuda:40", "helm_cuda:1400", "helm_cuda:1700"):
+    for name in ("toy_k2:40", "boolean_default:300", "helm_cuda:40", "helm_cuda:1250", "helm_cuda:1400", "helm_cuda:1700"):
         r = res[name]
         assert r["decrypt_ok"] and r["bit_exact_sample"], (name, r)
         assert r["violations"] == [0] * 8, (name, r["violations"])

@@ -204,7 +204,9 @@ def test_upload_rejects_duplicate_rows():
                                           (4, "toy"), (5, "toy"),                          # k = 1, l = 2
                                           (6, "toy"), (7, "toy"),
                                           (4, "toy_1024"), (5, "toy_1024"),                # N = 1024: wide, lockstep
-                                          (6, "toy_1024"), (7, "toy_1024")])               # ... and k_pbs_duo's compact layout
+                                          (6, "toy_1024"), (7, "toy_1024"),                # ... and k_pbs_duo's compact layout
+                                          (9, "toy_1024"), (8, "toy_1024"),                # k_pbs_tri10: three / two per workgroup, (polynomial, transform half) waves
+                                          (4, "toy_1024_l2"), (5, "toy_1024_l2"), (6, "toy_1024_l2"), (9, "toy_1024_l2"), (8, "toy_1024_l2")])   # N = 1024, l = 2
 def test_every_build_of_k_pbs_bit_exact(variant, name, monkeypatch):
     """HELM_HIP_PBS_VARIANT forces one build of the blind-rotate kernel for a whole launch (wide, lockstep,
     duo in step / staggered, trio - every build the size dispatch can select); each must reproduce the oracle bit for bit.  Nine
@@ -298,11 +300,11 @@ def test_retired_builds_are_refused_by_name(variant, monkeypatch):
         helm_amd.ServerKey(ck)
 
 
-@pytest.mark.parametrize("variant", [4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8, 9])
 def test_n1024_builds_bit_exact_in_the_51_bit_field_too(variant, monkeypatch):
     """Round 5: N = 1024 sets run in the lazy field FpI (p = 5440^4 + 1) when the loaded key's own bound allows it - the toy and
     the cited set do, so test_every_build_of_k_pbs_bit_exact[*-toy_1024] now covers FpI's kernels.  The 51-bit field stays
-    the fallback for keys that do not fit: its four N = 1024 builds (wide, lockstep, duo in step / staggered)
+    the fallback for keys that do not fit: its six N = 1024 builds (wide, lockstep, duo in step / staggered, tri10 with two / three bootstraps per workgroup)
     against the oracle under HELM_HIP_FIELD=51.  Parameters: reference src/bin/helm.rs:141-146."""
     monkeypatch.setenv("HELM_HIP_FIELD", "51")
     monkeypatch.setenv("HELM_HIP_PBS_VARIANT", str(variant))
@@ -439,8 +441,9 @@ def test_vector_alu_keyswitch_fallback_bit_exact(name, monkeypatch):
 @pytest.mark.parametrize("name", ["boolean_default", "helm_cuda"])
 def test_whole_launch_every_row_bit_exact(name):
     """EVERY output row of one launch that takes the size dispatch through a full lockstep round AND a two-per-CU remainder
-    (4 CU + CU + 5 gates: lockstep k_pbs + k_pbs_duo - staggered at N = 512, the compact layout at N = 1024) and of one that
-    ends in a one-per-CU remainder (4 CU + 7: k_pbs_wide), all gate types incl. MUX, NOT and constants, against the oracle's
+    (4 CU + CU + 5 gates: lockstep k_pbs + k_pbs_duo staggered at N = 512, + k_pbs_tri10 with two per workgroup at N = 1024), of one that
+    ends in a one-per-CU remainder (4 CU + 7: k_pbs_wide) and of one of three per CU (3 CU + 5 bootstraps' worth of gates:
+    k_pbs_trio at N = 512, k_pbs_tri10 at N = 1024, the last workgroup partial), all gate types incl. MUX, NOT and constants, against the oracle's
     SIMD route (oracle/fp_route.inc: exact fp64 NTT over a different prime than the GPU's, the route bench.py's cpu_baseline
     times) - not a sample: the matrix-core keyswitch's tiles, every workgroup position and both kernels of the launch."""
     import torch
@@ -454,8 +457,18 @@ def test_whole_launch_every_row_bit_exact(name):
     bits = rng.integers(0, 2, n_in)
     ct = ck.encrypt(bits.astype(bool))
     kinds = [oracle.AND, oracle.OR, oracle.NAND, oracle.NOR, oracle.XOR, oracle.XNOR, oracle.MUX, oracle.NOT]
-    for count in (5 * cu + 5, 4 * cu + 7):
-        ops = rng.choice(kinds, size=count, p=[.16, .12, .16, .12, .16, .12, .1, .06]).astype(np.int32)
+    for count in (5 * cu + 5, 4 * cu + 7, -(3 * cu + 5)):
+        if count < 0:
+            # a launch of exactly 3 CU + 5 BOOTSTRAPS (a MUX is two, a NOT none): gates drawn until the count is met
+            ops = []
+            while sum(2 if o == oracle.MUX else 0 if o == oracle.NOT else 1 for o in ops) < -count - 1:
+                ops.append(int(rng.choice(kinds, p=[.16, .12, .16, .12, .16, .12, .1, .06])))
+            ops.append(oracle.AND)
+            ops = np.array(ops, dtype=np.int32)
+            count = len(ops)
+            assert sum(2 if o == oracle.MUX else 0 if o == oracle.NOT else 1 for o in ops) in (3 * cu + 5, 3 * cu + 6)
+        else:
+            ops = rng.choice(kinds, size=count, p=[.16, .12, .16, .12, .16, .12, .1, .06]).astype(np.int32)
         i0 = rng.integers(0, n_in, count).astype(np.int32)
         i1 = np.where(ops == oracle.NOT, -1, rng.integers(0, n_in, count)).astype(np.int32)
         i2 = np.where(ops == oracle.MUX, rng.integers(0, n_in, count), -1).astype(np.int32)
