@@ -237,6 +237,73 @@ class WrongResult(RuntimeError):
     pass
 
 
+class PowerSampler:
+    """Socket power, shader clock and temperature of ONE GPU read from its hwmon files (amdgpu: power1_input / power1_average in
+    microwatts, power1_cap, freq1_input = sclk in Hz, temp*_input in millidegrees) every `period` seconds on a host thread
+    while the timed steps run - no subprocess, no HIP call, nothing on the GPU.  The device is found by its PCI address.
+    Answers VERDICT r05 item 5: is the clock the kernels hold (2.1 - 2.4 of 2.4 GHz nominal) a power cap or not."""
+
+    def __init__(self, pci, period=0.25):
+        import glob
+        import threading
+        self.period, self.samples, self.dir, self.cap_w = period, [], None, None
+        for dev in glob.glob("/sys/class/drm/card*/device"):
+            try:
+                if os.path.basename(os.path.realpath(dev)).lower().startswith(pci.lower()):
+                    mons = glob.glob(os.path.join(dev, "hwmon", "hwmon*"))
+                    if mons:
+                        self.dir = mons[0]
+                        break
+            except OSError:
+                continue
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _loop(self):
+        while not self._stop.is_set():
+            pw = self._read("power1_input")
+            if pw is None:
+                pw = self._read("power1_average")
+            self.samples.append((time.perf_counter(), pw, self._read("freq1_input"), self._read("temp2_input") or self._read("temp1_input")))
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.dir:
+            self.cap_w = (self._read("power1_cap") or 0) / 1e6 or None
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self.dir:
+            self._thread.join(timeout=2)
+        return False
+
+    def summary(self):
+        if not self.dir or len(self.samples) < 2:
+            return {"available": False, "why": "no readable hwmon directory for the device" if not self.dir else "run too short for two samples"}
+        pw = [x[1] / 1e6 for x in self.samples if x[1]]
+        fr = [x[2] / 1e6 for x in self.samples if x[2]]
+        tp = [x[3] / 1e3 for x in self.samples if x[3]]
+        res = {"available": True, "samples": len(self.samples), "period_s": self.period, "source": os.path.join(self.dir, "{power1_input,freq1_input,temp*_input}"),
+               "socket_power_w": {"mean": round(sum(pw) / len(pw), 1), "max": round(max(pw), 1), "min": round(min(pw), 1)} if pw else None,
+               "power_cap_w": self.cap_w,
+               "sclk_mhz_hwmon": {"mean": round(sum(fr) / len(fr), 1), "max": round(max(fr), 1), "min": round(min(fr), 1)} if fr else None,
+               "temperature_c": {"mean": round(sum(tp) / len(tp), 1), "max": round(max(tp), 1)} if tp else None}
+        if pw and self.cap_w:
+            frac = sum(pw) / len(pw) / self.cap_w
+            res["mean_power_over_cap"] = round(frac, 3)
+            res["power_capped"] = bool(frac >= 0.95 or max(pw) >= 0.99 * self.cap_w)
+        return res
+
+
 def check_outputs(ck, wires, index, nw, keys_pt, what):
     import numpy as np
     from helm_amd.netlists import aes128_reference_encrypt
@@ -482,11 +549,13 @@ class Bench:
         runner.collective_ms(reset=True)
         self.sk.timing_enable(True)
         self.sk.timing(reset=True)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            runner.run()
-        sync()
-        elapsed = time.perf_counter() - t0
+        pr = torch.cuda.get_device_properties(self.local_rank)
+        with PowerSampler(f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}") as power:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                runner.run()
+            sync()
+            elapsed = time.perf_counter() - t0
         tm = self.sk.timing(reset=True)
         self.sk.timing_enable(False)
         clock_ghz = self.sk.kernel_clock_ghz()
@@ -511,7 +580,7 @@ class Bench:
                                         if sharded else 0.0),
              "collectives_per_step": (int(tm.exchange_count) // steps if (sharded and self.comm is not None)
                                       else len(runner.sharded_levels) if sharded else 0),
-             "overlapped": overlapped, "setup_s": t_setup,
+             "overlapped": overlapped, "setup_s": t_setup, "power": power.summary(),
              "tm": tm, "clock_ghz": clock_ghz}
         if keep:
             r.update(prog=prog, wires=wires, keys_pt=keys_pt)
@@ -862,6 +931,9 @@ def fill_result(bench, result):
             "frac": round(achieved_tops / peak_tops, 4),
             "peak_assumes": f"{n_cus} CUs x 64 lanes x {PEAK_CLOCK_GHZ} GHz, one fp64 operation per lane and cycle",
             "held_clock_ghz": round(clock_ghz, 3) if clock_ghz else None,
+            # socket power and the driver's own clock reading over the timed steps (rank 0's GPU); a held clock
+            # below nominal with the power far under its cap is the part's own frequency management, not a power limit
+            "power_and_clock_over_the_timed_steps": head["power"],
             "frac_at_held_clock": round(achieved_tops / (peak_tops * clock_ghz / PEAK_CLOCK_GHZ), 4) if clock_ghz else None,
             "algorithmic_lane_ops_per_bootstrap": int(algo_ops),
             "frac_survey_priced": round(survey_tops / peak_tops, 4),
@@ -1217,8 +1289,10 @@ def _lut_m1c1_leg(device):
                        "the reference binary installs for LUT mode (helm.rs:301) [dimensions recalled; GLWE noise interpolated: approximate set]",
            "params": {"n": p.n, "k": p.k, "N": p.N, "pbs_l": p.pbs_l, "pbs_logB": p.pbs_logB, "ks_l": p.ks_l, "ks_logB": p.ks_logB},
            "luts_per_s": round(B / dt, 1), "decrypt_ok": ok,
+           # round 6: the CRT pair follows the loaded key (helm_si_field_bits): 46 = 2736^4 + 1, 2872^4 + 1 for a generated key
+           "crt_pair_bits": sk.field_bits(),
            "kernel_ms": {"k_pbs64k": round(tm.pbs_ms, 3), "keyswitch": round(tm.ks_ms, 3), "linear": round(tm.linear_ms, 3)},
-           "roofline": si_roofline("k_pbs64k<Pbs64kCfg<9, 3>>", si_algo_ops(p.n, p.k, p.N, p.pbs_l), tm.pbs_count, tm.pbs_ms,
+           "roofline": si_roofline("k_pbs64k<Pbs64kCfg<9, 3>, " + ("FpJ, FpJ2>" if sk.field_bits() == 46 else "FpG, FpG2>"), si_algo_ops(p.n, p.k, p.N, p.pbs_l), tm.pbs_count, tm.pbs_ms,
                                    tm.pbs_launches, n_cus, p.n * p.pbs_l * K1 * K1 * p.N * 8 * 2,
                                    (p.n + 1) * 8 + (p.k * p.N + 1) * 8 + p.N * 8)}
     sk.close()

@@ -222,6 +222,7 @@ SI_API = {
     "helm_si_ctx_destroy": (C.c_int, [vp]),
     "helm_si_ctx_fork": (C.c_int, [vp, C.POINTER(vp)]),
     "helm_si_get_params": (C.c_int, [vp, C.POINTER(SiParams)]),
+    "helm_si_field_bits": (C.c_int, [vp]),
     "helm_si_set_stream": (C.c_int, [vp, vp]),
     "helm_si_sync": (C.c_int, [vp]),
     "helm_si_load_bootstrap_key": (C.c_int, [vp, u64p, C.c_size_t]),

@@ -58,6 +58,10 @@ namespace {
 // exact and inside (-p/2, p/2), instead of a modular one (HELM_SI_PLAIN_STAGE1; p0 p1 / 2 = 2^97.5 covers more than before).
 using F0 = FpG;
 using F1 = FpG2;
+// Round 6: the 46-bit pair (ntt_fp64.h FpJ, FpJ2) for k_pbs64k contexts whose LOADED key keeps the exact products below
+// p p' / 2 = 2^90.62 (helm_si_load_bootstrap_key; helm_si_field_bits() says which pair a context computes in)
+using J0 = FpJ;
+using J1 = FpJ2;
 #ifndef HELM_SI_PLAIN_STAGE1
 #define HELM_SI_PLAIN_STAGE1 1
 #endif
@@ -419,11 +423,16 @@ struct Pbs64kCfg {
     static_assert(2 * BYTES <= 160 * 1024, "two ciphertexts per CU");
 };
 
-template <typename C, typename F>
+// F: this wave's field; FA, FB: the CRT pair (F is one of them)
+template <typename C, typename F, typename FA, typename FB>
 __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *__restrict__ bsk, int n, int logB,
                                             double p0inv_mod_p1, int p, int f, int lane)
 {
     constexpr int LOGN = C::LOGN, K1 = C::K1;
+    // 46-bit pair: both leading forward stages plain on the digits (|d| <= 2^17), no recentring of the column sums - the
+    // inverse transform takes them unreduced (ntt_inverse, WIDE)
+    constexpr bool WIDE = wide_headroom<F>::value;
+    constexpr int DIG = WIDE ? 2 : HELM_SI_PLAIN_STAGE1;
     using G = Geo<LOGN>;
     constexpr int N = G::N, E = G::E, H = E / 2;
     double *X = reinterpret_cast<double *>(smem + C::X_OFF);
@@ -494,7 +503,7 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
 #pragma unroll
             for (int e = 0; e < E; e++) x[0][e] = digit(e);
 #endif
-            ntt_forward<F, LOGN, 1, decltype(twf), 0, NoHook, HELM_SI_PLAIN_STAGE1>(x, xb, twf, lane); // (digits: stage 1 plain)
+            ntt_forward<F, LOGN, 1, decltype(twf), 0, NoHook, DIG>(x, xb, twf, lane); // (digits: stage 1 - 46-bit pair: stages 1 and 2 - plain)
 #pragma unroll
             for (int e = 0; e < E; e++) xb[e * 64 + lane] = x[0][e];
         }
@@ -509,8 +518,8 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
                 s0 = r == 0 ? t0 : s0 + t0;
                 s1 = r == 0 ? t1 : s1 + t1;
             }
-            mine[2 * u] = reduce<F>(s0);
-            mine[2 * u + 1] = reduce<F>(s1);
+            mine[2 * u] = WIDE ? s0 : reduce<F>(s0);   // (WIDE: |s| <= 4.5 p, what ntt_inverse's WIDE form takes)
+            mine[2 * u + 1] = WIDE ? s1 : reduce<F>(s1);
         };
 #pragma unroll
         for (int u = 0; u < H; u++) {
@@ -549,7 +558,7 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
             const uint32_t st = (uint32_t)((v + (1ull << (63 - logB))) >> (64 - logB));
             x[0][e] = (double)((int)((st + half_m1) & bmask) - (int)half_m1); // st <= B/2 stays, above it st - B
         }
-        ntt_forward<F, LOGN, 1, decltype(twf), 0, NoHook, HELM_SI_PLAIN_STAGE1>(x, xb, twf, lane); // (digits: stage 1 plain)
+        ntt_forward<F, LOGN, 1, decltype(twf), 0, NoHook, DIG>(x, xb, twf, lane); // (digits: stage 1 - 46-bit pair: stages 1 and 2 - plain)
         // the scratch becomes this wave's column sum: clear it, and wait until every wave is through its transform
 #pragma unroll
         for (int e = 0; e < E; e++) xb[e * 64 + lane] = 0.0;
@@ -583,7 +592,9 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
 #pragma unroll
         for (int e = 0; e < E; e++) mine[e] = reduce<F>(mine[e] + xb[e * 64 + lane]);
 #endif
-        ntt_inverse<F, LOGN>(mine, xb, twi, lane);
+        // WIDE: the outputs stay unreduced (<= 21 p): the CRT below reduces the DIFFERENCE of the two residues once instead of
+        // both residues (X = r0 + p0 t equals the exact integer for any representative r0 with |r0| + |V| + p0 |t| < p0 p1)
+        ntt_inverse<F, LOGN, decltype(twi), 0, !WIDE>(mine, xb, twi, lane);
         // ---- CRT: field-f wave lifts slots [f*H, f*H+H) of its polynomial ---------------------
 #pragma unroll
         for (int e = 0; e < H; e++) xb[e * 64 + lane] = mine[(1 - f) * H + e];
@@ -592,8 +603,8 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
         for (int e = 0; e < H; e++) {
             const double own = mine[f * H + e], oth = x_field[e * 64 + lane];
             const double r0 = f == 0 ? own : oth, r1 = f == 0 ? oth : own;
-            const double t = mulmod<F1>(r1 - r0, p0inv_mod_p1);
-            const uint64_t xv = (uint64_t)to_int64(r0) + F0::P_U64 * (uint64_t)to_int64(t);
+            const double t = mulmod<FB>(WIDE ? reduce<FB>(r1 - r0) : r1 - r0, p0inv_mod_p1);
+            const uint64_t xv = (uint64_t)to_int64(r0) + FA::P_U64 * (uint64_t)to_int64(t);
             const int j = G::jA(lane, f * H + e);
             const uint64_t nv = acc_p[j] + xv;
             acc_p[j] = nv;
@@ -603,7 +614,7 @@ __device__ __forceinline__ void pbs64k_body(unsigned char *smem, const double *_
     }
 }
 
-template <typename C>
+template <typename C, typename FA, typename FB>
 __global__ __launch_bounds__(64 * C::NW, C::NW / 2) void k_pbs64k(const Pbs64Job *__restrict__ jobs,
                                                           const uint64_t *__restrict__ small, // rows of n+1
                                                           const uint64_t *__restrict__ luts,  // rows of N
@@ -651,8 +662,8 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 2) void k_pbs64k(const Pbs64Job
         }
     }
     __syncthreads();
-    if (f == 0) pbs64k_body<C, F0>(smem, bsk, n, logB, p0inv_mod_p1, p, 0, lane);
-    else pbs64k_body<C, F1>(smem, bsk, n, logB, p0inv_mod_p1, p, 1, lane);
+    if (f == 0) pbs64k_body<C, FA, FA, FB>(smem, bsk, n, logB, p0inv_mod_p1, p, 0, lane);
+    else pbs64k_body<C, FB, FA, FB>(smem, bsk, n, logB, p0inv_mod_p1, p, 1, lane);
     // ---- sample extract (coefficient 0); wave (p, f) writes its half of the slots ------
     const uint64_t *acc_p = ACC + (size_t)p * C::ACC_LEN;
     uint64_t *ob = out + (size_t)job.out_row * ((size_t)K * N + 1);
@@ -1776,6 +1787,8 @@ struct helm_si_ctx {
     double *tw[2] = {nullptr, nullptr};
     double n_inv[2] = {0, 0}, two32[2] = {0, 0};
     double p0inv_mod_p1 = 0;
+    int pair = 0;                // CRT pair of the tables above: 0 = FpG / FpG2 (49 bits), 1 = FpJ / FpJ2 (46 bits: k_pbs64k contexts
+                                 // whose loaded key fits, helm_si_load_bootstrap_key)
     double *bsk = nullptr;
     double *bsk_split = nullptr; // layout of k_pbs64s (N >= 1024, pbs_l = 1)
     double *tw_sub = nullptr;    // derived half-transform tables [2 fields][2 halves][N/2]
@@ -1884,11 +1897,13 @@ hipError_t launch_pbs64k_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count
                            const uint64_t *luts, uint64_t *out, int *per_cu = nullptr)
 {
     static std::atomic<bool> attr_done[64]; // (rank threads of one process launch concurrently)
-    auto kern = k_pbs64k<C>;
+    auto kern = ctx->pair ? k_pbs64k<C, J0, J1> : k_pbs64k<C, F0, F1>; // the CRT pair follows the loaded key
     if (!attr_done[ctx->device & 63]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES);
-        if (e != hipSuccess) return e;
+        for (auto kk : {k_pbs64k<C, F0, F1>, k_pbs64k<C, J0, J1>}) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)C::BYTES);
+            if (e != hipSuccess) return e;
+        }
         attr_done[ctx->device & 63] = true;
     }
     if (per_cu) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, 64 * C::NW, C::BYTES);
@@ -2340,6 +2355,43 @@ int apply_luts_sharded(helm_si_ctx *ctx, helm_si_wires *w, const int32_t *in_idx
     return 0;
 }
 
+// The forward twiddle tables (bit-reversed powers of a primitive 2N-th root psi), 1/N, 2^32 and the CRT constant of one pair
+// of fields.  pair 1 (the 46-bit fields): psi is chosen with psi^(N/4) = b, so that the first three table entries are b^2, b,
+// b^3 - what the plain radix-4 top of a forward transform on digits multiplies by (fwd_top2_digits).
+int setup_pair_tables(helm_si_ctx *ctx, int pair)
+{
+    const uint64_t pm[2] = {pair ? J0::P_U64 : F0::P_U64, pair ? J1::P_U64 : F1::P_U64};
+    const uint64_t gen[2] = {pair ? J0::GEN : F0::GEN, pair ? J1::GEN : F1::GEN};
+    const double b1[2] = {J0::B1, J1::B1}, b2[2] = {J0::B2, J1::B2}, b3[2] = {J0::B3, J1::B3};
+    const int N = ctx->P.N, logN = ctx->logN;
+    for (int f = 0; f < 2; f++) {
+        uint64_t psi = powmod_u64(gen[f], (pm[f] - 1) / (2 * (uint64_t)N), pm[f]);
+        if (pair) { // psi^(N/4) is one of the primitive eighth roots b, b^3, -b, -b^3: an odd power of psi puts it on b
+            uint64_t pick = 0;
+            for (uint64_t t = 1; t < 8 && !pick; t += 2)
+                if (powmod_u64(powmod_u64(psi, t, pm[f]), (uint64_t)N / 4, pm[f]) == (uint64_t)b1[f]) pick = t;
+            if (!pick) return fail(HELM_ERR_STATE, "internal: no 2N-th root of unity with psi^(N/4) = b");
+            psi = powmod_u64(psi, pick, pm[f]);
+        }
+        std::vector<double> tf(N);
+        uint64_t a = 1;
+        for (int i = 0; i < N; i++) {
+            tf[bitrev(i, logN)] = centred(a, pm[f]);
+            a = mulmod_u64(a, psi, pm[f]);
+        }
+        if (pair && (tf[1] != b2[f] || tf[2] != b1[f] || tf[3] != b3[f]))
+            return fail(HELM_ERR_STATE, "internal: the first twiddles are not the constants the kernels assume");
+        ctx->n_inv[f] = centred(powmod_u64((uint64_t)N, pm[f] - 2, pm[f]), pm[f]);
+        ctx->two32[f] = centred((1ull << 32) % pm[f], pm[f]);
+        if (!ctx->tw[f]) HIP_TRY(hipMalloc(&ctx->tw[f], sizeof(double) * N));
+        HIP_TRY(hipMemcpy(ctx->tw[f], tf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    }
+    ctx->p0inv_mod_p1 = centred(powmod_u64(pm[0] % pm[1], pm[1] - 2, pm[1]), pm[1]);
+    ctx->pair = pair;
+    return 0;
+}
+
+
 } // namespace
 
 extern "C" {
@@ -2393,21 +2445,11 @@ int helm_si_ctx_create(int device_id, const helm_si_params *params, helm_si_ctx 
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     const uint64_t pm[2] = {F0::P_U64, F1::P_U64}, gen[2] = {F0::GEN, F1::GEN};
-    const int N = P.N, logN = ctx->logN;
-    for (int f = 0; f < 2; f++) {
-        const uint64_t psi = powmod_u64(gen[f], (pm[f] - 1) / (2 * (uint64_t)N), pm[f]);
-        std::vector<double> tf(N);
-        uint64_t a = 1;
-        for (int i = 0; i < N; i++) {
-            tf[bitrev(i, logN)] = centred(a, pm[f]);
-            a = mulmod_u64(a, psi, pm[f]);
-        }
-        ctx->n_inv[f] = centred(powmod_u64((uint64_t)N, pm[f] - 2, pm[f]), pm[f]);
-        ctx->two32[f] = centred((1ull << 32) % pm[f], pm[f]);
-        HIP_TRY(hipMalloc(&ctx->tw[f], sizeof(double) * N));
-        HIP_TRY(hipMemcpy(ctx->tw[f], tf.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    const int N = P.N;
+    if (int rc = setup_pair_tables(ctx, 0)) {
+        (void)helm_si_ctx_destroy(ctx);
+        return rc;
     }
-    ctx->p0inv_mod_p1 = centred(powmod_u64(pm[0] % pm[1], pm[1] - 2, pm[1]), pm[1]);
     ctx->group = group;
     if (group > 1) { // the 2N powers of psi per field: monomial products in the transform domain
         std::vector<double> pw((size_t)4 * N);
@@ -2462,6 +2504,7 @@ int helm_si_ctx_fork(helm_si_ctx *primary, helm_si_ctx **out)
         ctx->two32[f] = primary->two32[f];
     }
     ctx->p0inv_mod_p1 = primary->p0inv_mod_p1;
+    ctx->pair = primary->pair;
     ctx->bsk = primary->bsk;
     ctx->bsk_split = primary->bsk_split;
     ctx->tw_sub = primary->tw_sub;
@@ -2545,6 +2588,12 @@ int helm_si_get_params(const helm_si_ctx *ctx, helm_si_params *out)
     return 0;
 }
 
+int helm_si_field_bits(const helm_si_ctx *ctx)
+{
+    if (!ctx) return fail(HELM_ERR_INVALID, "null argument");
+    return ctx->pair ? 46 : 49;
+}
+
 int helm_si_set_stream(helm_si_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return fail(HELM_ERR_INVALID, "null ctx");
@@ -2599,9 +2648,54 @@ int helm_si_load_bootstrap_key(helm_si_ctx *ctx, const uint64_t *bsk_std, size_t
     HIP_TRY(hipMalloc(&t_std.p, n_words * sizeof(uint64_t)));
     uint64_t *d_std = static_cast<uint64_t *>(t_std.p);
     if (!ctx->bsk && ctx->group == 1) HIP_TRY(hipMalloc(&ctx->bsk, n_words * 2 * sizeof(double)));
+    if (P.k >= 2 && P.N == 512 && P.pbs_l == 1 && ctx->group == 1 && !ctx->lane_of) {
+        // k_pbs64k contexts: the CRT pair follows the key at hand.  An exact product of a blind-rotation step is at most
+        // B/2 x the largest l1-norm over the key polynomials that meet in one output column (or, transposed, in one row) - an
+        // exact guarantee for this key and every input.  Below p p' / 2 of the 46-bit pair (and with digits of at most 17 bits,
+        // whose products with b^3 stay exact doubles): FpJ / FpJ2, whose headroom drops stage 2's modular multiplications and
+        // most recentrings (ntt_fp64.h); otherwise the 49-bit pair.  HELM_SI_FIELD=49 keeps the 49-bit pair.
+        long double worst = 0;
+        const size_t per_step = (size_t)P.pbs_l * K1 * K1; // src is [i][lev][r][c][N]
+        std::vector<long double> l1(per_step);
+        for (size_t i = 0; i < (size_t)P.n; i++) {
+            for (size_t q = 0; q < per_step; q++) {
+                const uint64_t *poly = bsk_std + (i * per_step + q) * P.N;
+                long double sum = 0;
+                for (int j = 0; j < P.N; j++) {
+                    const int64_t v = (int64_t)poly[j];
+                    sum += v < 0 ? -(long double)v : (long double)v;
+                }
+                l1[q] = sum;
+            }
+            for (size_t c = 0; c < K1; c++) {
+                long double by_col = 0, by_row = 0;
+                for (size_t q = 0; q < per_step; q++) {
+                    if (q % K1 == c) by_col += l1[q];
+                    if ((q / K1) % K1 == c) by_row += l1[q];
+                }
+                worst = std::max(worst, std::max(by_col, by_row));
+            }
+        }
+        const long double key_bound = worst * (long double)(1ull << (P.pbs_logB - 1));
+        // (margin 5 %: the CRT's quotient t = (r1 - r0) / p0 mod p1 comes out of mulmod within 0.512 p1, so the lifted value is
+        // the exact integer as long as that stays below 0.488 p0 p1)
+        int want = (key_bound * 1.05L < (long double)J0::P * (long double)J1::P / 2 && P.pbs_logB <= 18) ? 1 : 0;
+        if (const char *v = getenv("HELM_SI_FIELD")) if (atoi(v) == 49) want = 0;
+        if (want != ctx->pair) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream)); // nothing in flight may still read the other pair's tables
+            ctx->have_bsk = false;
+            if (int rc = setup_pair_tables(ctx, want)) return rc;
+        }
+    }
     HIP_TRY(hipMemcpyAsync(d_std, bsk_std, n_words * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->pair) { // (N = 512 only)
+        hipLaunchKernelGGL((k_bsk_convert64<J0, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk,
+                           ctx->tw[0], ctx->n_inv[0], ctx->two32[0], (int)K1, P.pbs_l, 0);
+        hipLaunchKernelGGL((k_bsk_convert64<J1, 9>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk,
+                           ctx->tw[1], ctx->n_inv[1], ctx->two32[1], (int)K1, P.pbs_l, 1);
+    }
 #define CONV(LN)                                                                                                     \
-    if (ctx->logN == LN && ctx->group == 1) {                                                                                           \
+    if (ctx->logN == LN && ctx->group == 1 && !ctx->pair) {                                                                                           \
         hipLaunchKernelGGL((k_bsk_convert64<F0, LN>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk, \
                            ctx->tw[0], ctx->n_inv[0], ctx->two32[0], (int)K1, P.pbs_l, 0);                           \
         hipLaunchKernelGGL((k_bsk_convert64<F1, LN>), dim3((unsigned)polys), dim3(64), 0, ctx->stream, d_std, ctx->bsk, \

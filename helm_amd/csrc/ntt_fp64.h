@@ -84,6 +84,37 @@ struct FpI {
     static constexpr bool LAZY = true;
     static constexpr double B1 = 5440.0, B2 = 29593600.0, B3 = 160989184000.0;
 };
+// Round 6: a 46-bit CRT pair for 64-bit-torus sets with short exact products - the set the reference binary installs for LUT
+// mode, PARAM_MESSAGE_1_CARRY_1_KS_PBS (src/bin/helm.rs:301: k = 3, N = 512, one level of 18 bits): its exact products are
+// below B/2 x the largest l1-norm of a column of the LOADED key, about 2^90.0 for a generated key (worst case of the set:
+// 2^91), and p p' / 2 = 2^90.62 covers that - helm_si_load_bootstrap_key computes the bound for the key at hand, a key that
+// does not fit keeps the 49-bit pair (exact either way: identical ciphertexts).  What the smaller primes buy is HEADROOM:
+// 2^53 / p = 160 and 132 instead of 13.6.  b^3 is 34.3 / 34.5 bits, so on 17-bit digits BOTH leading stages of a forward
+// transform are the plain radix-4 butterfly (fwd_top2_digits: every term digit x root <= 2^51.5, an exact double; the 49-bit
+// pair can only do stage 1), nothing in a forward transform, the products or their sums needs a recentring, and the inverse
+// transform recentres ONE slot at each of its two transposes instead of eight (ntt_inverse, WIDE).
+//   FpJ   2736^4 + 1 = 2^45.67 (generator 5; 2^16 | p - 1)      FpJ2  2872^4 + 1 = 2^45.95 (generator 3; 2^12 | p - 1)
+struct FpJ {
+    static constexpr double P = 56035644604417.0;
+    static constexpr uint64_t P_U64 = 56035644604417ull;
+    static constexpr uint64_t GEN = 5;
+    static constexpr bool LAZY = true;
+    static constexpr double B1 = 2736.0, B2 = 7485696.0, B3 = 20480864256.0;
+};
+struct FpJ2 {
+    static constexpr double P = 68035838611457.0;
+    static constexpr uint64_t P_U64 = 68035838611457ull;
+    static constexpr uint64_t GEN = 3;
+    static constexpr bool LAZY = true;
+    static constexpr double B1 = 2872.0, B2 = 8248384.0, B3 = 23689358848.0;
+};
+static_assert(2736ull * 2736 * 2736 * 2736 + 1 == FpJ::P_U64 && 2872ull * 2872 * 2872 * 2872 + 1 == FpJ2::P_U64, "p = b^4 + 1");
+static_assert(2736ull * 2736 == 7485696ull && 7485696ull * 2736 == 20480864256ull && 2872ull * 2872 == 8248384ull &&
+                  8248384ull * 2872 == 23689358848ull, "b^2, b^3");
+// fields with 2^53 / p >= 128: values may stay unreduced through whole transforms (see FpJ)
+template <typename F> struct wide_headroom : std::false_type {};
+template <> struct wide_headroom<FpJ> : std::true_type {};
+template <> struct wide_headroom<FpJ2> : std::true_type {};
 // ntt_inverse's LEAN form (half of the recentrings at its two transposes) rests on slot-class bounds derived with
 // 2^53 / p >= 13.6 (tests/test_lazy_bounds.py): the 49.2-bit fields only.  FpI (2^53 / p = 10.28) recentres every slot.
 template <typename F> struct lean_inverse_ok : std::false_type {};
@@ -92,6 +123,8 @@ template <> struct has_short_roots<FpI> : std::true_type {};
 template <> struct has_short_roots<FpG> : std::true_type {};
 template <> struct has_short_roots<FpG2> : std::true_type {};
 template <> struct has_short_roots<FpH> : std::true_type {};
+template <> struct has_short_roots<FpJ> : std::true_type {};
+template <> struct has_short_roots<FpJ2> : std::true_type {};
 template <> struct lean_inverse_ok<FpG> : std::true_type {};
 template <> struct lean_inverse_ok<FpG2> : std::true_type {};
 
@@ -500,8 +533,10 @@ __device__ __forceinline__ void fwd_top2_digits(double (&x)[M][E])
             x[m][e + 2 * Q] = a4 + v;
             x[m][e + 3 * Q] = a4 - v;
             // every term is digit x (at most 38 bits): exact and far inside (-p/2, p/2) - the premise of the plain stages
-            HELM_BOUND(__builtin_fabs(x[m][e]) < F::P * 0.5 && __builtin_fabs(x[m][e + Q]) < F::P * 0.5 &&
-                           __builtin_fabs(x[m][e + 2 * Q]) < F::P * 0.5 && __builtin_fabs(x[m][e + 3 * Q]) < F::P * 0.5, 2);
+            // (the 46-bit fields on 17-bit digits: exact below 2^51.5, 48 p of the 128 p a double holds - wide_headroom)
+            [[maybe_unused]] constexpr double LIM = wide_headroom<F>::value ? 0x1p52 : F::P * 0.5;
+            HELM_BOUND(__builtin_fabs(x[m][e]) < LIM && __builtin_fabs(x[m][e + Q]) < LIM &&
+                           __builtin_fabs(x[m][e + 2 * Q]) < LIM && __builtin_fabs(x[m][e + 3 * Q]) < LIM, 2);
         }
 }
 
@@ -596,16 +631,26 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *x
     // what the slot classes above assume of the layout: eight values per lane, three blocks of three stages, so that a
     // transpose hands a lane eight values of ONE slot of the block before (tests/test_lazy_bounds.py recomputes the bounds)
     static_assert(!LEAN || (G::E == 8 && G::BA + G::BB + G::BC == LOGN), "LEAN inverse: slot-class bounds are derived for Geo<9>");
+    // WIDE (fields with 2^53 / p >= 128, three blocks of three stages, centred output; tests/test_lazy_bounds.py): inputs up to
+    // 4.5 p UNREDUCED (a sum of four products of at most 1.1 p each).  After a three-stage block on inputs <= m the pure-sum slot holds 8 m, every other
+    // slot passed a multiplication on the way (<= 2.3 p from m = 4 p); recentring slot 0 alone at each transpose keeps the next
+    // block's inputs <= 2.6 p and every sum <= 8 x 4.5 p = 36 p, a quarter of what a double holds exactly.
+    // (CENTRE = false: the outputs stay as the last block leaves them, <= 8 x 2.6 p = 21 p - for a caller that reduces downstream)
+    constexpr bool WIDE = wide_headroom<F>::value && LOGN == 9 && G::BA == 3 && G::BB == 3 && G::BC == 3;
     if constexpr (LEAN) {
 #pragma unroll
         for (int e = 0; e < G::E; e++) HELM_BOUND(__builtin_fabs(x[e]) <= F::P * 0.5000001, 3);
+    }
+    if constexpr (WIDE) {
+#pragma unroll
+        for (int e = 0; e < G::E; e++) HELM_BOUND(__builtin_fabs(x[e]) <= F::P * 4.5, 3);
     }
     inv_block<F, LOGN, 0, 0, G::BC - 1, 0>(x, tw, G::jC(lane, 0));
     before_write();
     if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO - 1);
     double *pA = xbuf + G::baseA(lane), *pB = xbuf + G::baseB(lane), *pC = xbuf + G::baseC(lane);
 #pragma unroll
-    for (int e = 0; e < G::E; e++) pC[e] = (LEAN && e >= 3) ? x[e] : reduce<F>(x[e]);
+    for (int e = 0; e < G::E; e++) pC[e] = ((LEAN && e >= 3) || (WIDE && e >= 1)) ? x[e] : reduce<F>(x[e]);
     lds_wave_sync();
 #pragma unroll
     for (int e = 0; e < G::E; e++) x[e] = pB[G::offB2(e)];
@@ -613,7 +658,7 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *x
     inv_block<F, LOGN, G::BC, G::BC, G::BC + G::BB - 1, G::TWC>(x, tw, G::jB(lane, 0));
     if constexpr (PRIO > 1) __builtin_amdgcn_s_setprio(PRIO - 2);
 #pragma unroll
-    for (int e = 0; e < G::E; e++) pB[G::offB1(e)] = (LEAN && e >= 5) ? x[e] : reduce<F>(x[e]);
+    for (int e = 0; e < G::E; e++) pB[G::offB1(e)] = ((LEAN && e >= 5) || (WIDE && e >= 1)) ? x[e] : reduce<F>(x[e]);
     lds_wave_sync();
 #pragma unroll
     for (int e = 0; e < G::E; e++) x[e] = pA[G::offA1(e)];
@@ -622,6 +667,8 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[Geo<LOGN>::E], double *x
     if constexpr (CENTRE) {
 #pragma unroll
         for (int e = 0; e < G::E; e++) x[e] = reduce<F>(x[e]);
+    } else if constexpr (WIDE) {
+        // nothing: see WIDE above
     } else if constexpr (G::BA == 4) {
         // four doublings from 0.5 p: the pure-sum slot reaches 8 p, every other slot passed a multiplication on the way
         // (<= 4.8 p); recentring slot 0 keeps sums and differences of two such values below 2^53 = 14.2 p

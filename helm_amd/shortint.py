@@ -157,6 +157,11 @@ class SiServerKey:
             hip_check(v)
         return v
 
+    def field_bits(self):
+        """49 or 46: the CRT pair of prime fields this context's bootstrap kernels compute in (helm_si_field_bits: it follows
+        the loaded key for k > 1 contexts)."""
+        return int(hip.helm_si_field_bits(self._h))
+
     def set_stream(self, stream_ptr):
         nv.require_one_hip_runtime(type(self).__name__ + ".set_stream")  # the handle is another framework's
         hip_check(hip.helm_si_set_stream(self._h, nv.vp(stream_ptr)))

@@ -82,6 +82,16 @@ int helm_si_ctx_destroy(helm_si_ctx *ctx);
  * Rows written through one lane must not be touched through another until both have been synchronised. */
 int helm_si_ctx_fork(helm_si_ctx *primary, helm_si_ctx **lane_out);
 int helm_si_get_params(const helm_si_ctx *ctx, helm_si_params *out);
+/* The CRT pair of prime fields the bootstrap kernels of this context compute in, as its size class: 49 = 5072^4 + 1 and
+ * 5096^4 + 1 (every parameter set), 46 = 2736^4 + 1 and 2872^4 + 1 - k > 1 contexts (k_pbs64k: the set reference
+ * src/bin/helm.rs:301 installs for LUT mode) whose LOADED key keeps the exact products of a blind-rotation step below
+ * p p' / 2 = 2^90.6: helm_si_load_bootstrap_key computes B/2 x the largest l1-norm of a key column for the key at hand (an
+ * exact guarantee for that key and every input; a generated key fits, the worst case of the set does not and keeps 49), so
+ * the value may change when a key is loaded (HELM_SI_FIELD=49 in the environment keeps the 49-bit pair).  Results do not
+ * depend on it (exact integer arithmetic either way); reported because the operation count of the kernel does: the smaller
+ * primes leave 2^53 / p >= 128 of headroom, so both leading stages of a forward transform on 17-bit digits are plain
+ * multiplications and most recentrings go.  Negative on error. */
+int helm_si_field_bits(const helm_si_ctx *ctx);
 int helm_si_set_stream(helm_si_ctx *ctx, void *hip_stream);
 int helm_si_sync(helm_si_ctx *ctx);
 /* Dispatch priority of the context's OWN stream (no effect after helm_si_set_stream): high != 0 = the device's highest

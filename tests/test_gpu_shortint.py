@@ -151,6 +151,7 @@ def test_full_parameter_set_m1c1():
     ck = helm_amd.SiClientKey.generate("shortint_m1c1", seed=1)
     assert (ck.params.n, ck.params.k, ck.params.N, ck.t) == (684, 3, 512, 4)
     sk = helm_amd.SiServerKey(ck)
+    assert sk.field_bits() == 46   # round 6: the generated key's exact products fit the 46-bit CRT pair
     orc = oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk)
     vals = np.arange(ck.t, dtype=np.uint64)
     cts = ck.encrypt(vals)
@@ -180,6 +181,49 @@ def test_full_parameter_set_m1c1():
         assert np.array_equal(g, host[out]), hex(tb)
         assert list(ck.decrypt(g)) == [fn(int(a), int(b)) for a, b in bits.tolist()]
     sk.close()
+
+
+def _pbs_rows_bit_exact(ck, sk, orc, seed, small):
+    luts = np.stack([orc.make_lut(lambda x: (5 * x + 3) % ck.t), orc.make_lut(lambda x: x & 1)])
+    idx = ((np.arange(ck.t) + seed) % 2).astype(np.int32)
+    got = sk.pbs_batch(small, luts, idx)
+    for g in range(ck.t):
+        assert np.array_equal(got[g], orc.bootstrap(small[g], luts[idx[g]])), f"ciphertext {g}"
+    return got
+
+
+def test_k_pbs64k_crt_pair_follows_the_loaded_key(monkeypatch):
+    """Round 6: k > 1 contexts (k_pbs64k, the kernel of reference src/bin/helm.rs:301's set) compute in the 46-bit CRT pair
+    2736^4 + 1, 2872^4 + 1 when B/2 x the largest l1-norm of a column of the LOADED key stays below p p' / 2 (an exact
+    guarantee for that key and every input), in the 49-bit pair otherwise: a generated key fits, a key with every coefficient
+    at the largest magnitude does not, HELM_SI_FIELD=49 keeps the 49-bit pair.  Bit-exact against the oracle under each; the
+    same ciphertexts from either pair; loading another key into the same context moves the pair back and forth; a set with
+    20-bit digits (si_toy_512_k2) never takes the 46-bit pair (digit x b^3 must stay an exact double)."""
+    from helm_amd._native import hip, hip_check, as_u64p
+    ck = helm_amd.SiClientKey.generate("si_toy_512_k3", seed=5)
+    sk = helm_amd.SiServerKey(ck)
+    assert sk.field_bits() == 46
+    small = sk.keyswitch_batch(ck.encrypt(np.arange(ck.t, dtype=np.uint64)))   # the same inputs for every key and pair
+    got46 = _pbs_rows_bit_exact(ck, sk, oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk), 1, small)
+    worst = np.full_like(ck.bsk, 0x7FFFFFFFFFFFFFFF)
+    hip_check(hip.helm_si_load_bootstrap_key(sk._h, as_u64p(worst), worst.size))   # the same context: the tables follow the key
+    assert sk.field_bits() == 49
+    _pbs_rows_bit_exact(ck, sk, oracle.Oracle64(ck.params.as_tuple(), worst, ck.ksk), 2, small)
+    own = np.ascontiguousarray(ck.bsk, dtype=np.uint64).reshape(-1)
+    hip_check(hip.helm_si_load_bootstrap_key(sk._h, as_u64p(own), own.size))
+    assert sk.field_bits() == 46
+    assert np.array_equal(_pbs_rows_bit_exact(ck, sk, oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk), 1, small), got46)
+    sk.close()
+    monkeypatch.setenv("HELM_SI_FIELD", "49")
+    sk49 = helm_amd.SiServerKey(ck)
+    assert sk49.field_bits() == 49
+    assert np.array_equal(_pbs_rows_bit_exact(ck, sk49, oracle.Oracle64(ck.params.as_tuple(), ck.bsk, ck.ksk), 1, small), got46)
+    sk49.close()
+    monkeypatch.delenv("HELM_SI_FIELD")
+    ck2 = helm_amd.SiClientKey.generate("si_toy_512_k2", seed=5)
+    sk2 = helm_amd.SiServerKey(ck2)
+    assert sk2.field_bits() == 49 and ck2.params.pbs_logB == 20
+    sk2.close()
 
 
 def test_full_parameter_set_multibit3():

@@ -169,3 +169,55 @@ def test_lean_inverse_transform_bounds():
         m3, pk3 = block([max(half if e < 5 else m2[e] for e in range(8))] * 8)
         assert max(pk1, pk2, pk3) < 0.78 * LIMIT          # 0.75 (FpG), 0.76 (FpG2)
         assert max(m3) < 7 * p                             # the final recentring sees at most 6.7 p
+
+
+def test_46_bit_pair_of_the_binarys_lut_set_stays_exact_without_recentring():
+    """Round 6: k_pbs64k under PARAM_MESSAGE_1_CARRY_1_KS_PBS's dimensions (reference src/bin/helm.rs:301: k = 3, N = 512, one level
+    of 18 bits) in the 46-bit pair FpJ = 2736^4 + 1, FpJ2 = 2872^4 + 1 (2^53 / p = 160, 132), chosen when the LOADED key's
+    exact products fit p p' / 2.  Recomputed here: the plain radix-4 top on 17-bit digits is exact; the whole forward
+    transform, the products and the column sums of k + 1 = 4 products stay exact with NO recentring; the inverse transform
+    (ntt_inverse, WIDE) takes the column sums unreduced (<= 4.5 p) and recentres slot 0 alone at each of its two transposes."""
+    import math
+    for b in (2736, 2872):
+        p = b ** 4 + 1
+        assert (p - 1) % 1024 == 0 and pow(b, 4, p) == p - 1          # 2N = 1,024 divides p - 1; b a primitive eighth root
+        assert LIMIT / p > 128
+        d = 2.0 ** 17                                                 # |digit| <= B / 2, pbs_logB = 18
+        m = d * (1 + b * b) + d * (b + b ** 3)                        # fwd_top2_digits: exact terms
+        assert d * b ** 3 < LIMIT and m < 2.0 ** 52                   # what HELM_CHECK_BOUNDS counts against
+        for stage in range(3, 10):                                    # seven Cooley-Tukey stages, nothing recentred
+            m = m + mulmod_bound(m, p)
+            assert m < LIMIT
+        assert m / p < 60
+        prod = mulmod_bound(m, p)
+        assert prod / p < 1.11                                        # (1.01 p in FpJ, 1.10 p in FpJ2)
+        col = 4 * prod                                                # k + 1 = 4 rows meet in a column (gather form)
+        assert col / p < 4.5                                          # the bound ntt_inverse's WIDE form is entered with
+
+        def block(vals):
+            vals, peak = list(vals), 0.0
+            for eb in range(3):
+                new = vals[:]
+                for e0 in range(8):
+                    if (e0 >> eb) & 1:
+                        continue
+                    e1 = e0 | (1 << eb)
+                    s = vals[e0] + vals[e1]
+                    assert s < LIMIT
+                    peak = max(peak, s)
+                    new[e0], new[e1] = s, mulmod_bound(s, p)
+                vals = new
+            return vals, peak
+
+        half = p / 2 + 1
+        m1, pk1 = block([4.5 * p] * 8)                                # inputs: the unreduced column sums
+        assert m1[0] / p < 36.1 and max(m1[1:]) / p < 2.6
+        m2, pk2 = block([max(half if e < 1 else m1[e] for e in range(8))] * 8)   # slot 0 recentred at the first transpose
+        m3, pk3 = block([max(half if e < 1 else m2[e] for e in range(8))] * 8)   # ... and at the second
+        assert max(pk1, pk2, pk3) / p < 36.1 and max(pk1, pk2, pk3) < 0.28 * LIMIT
+        assert max(m3) / p < 20                                       # the final recentring (CENTRE) sees at most that
+    # the pair covers a generated key of the set (about 2^90.0) and not its worst case (2^91): the key decides
+    pp_half = (2736 ** 4 + 1) * (2872 ** 4 + 1) / 2
+    typical = 4 * 1 * 512 * 2.0 ** 62 * 2.0 ** 17
+    worst = 4 * 1 * 512 * 2.0 ** 63 * 2.0 ** 17
+    assert typical * 1.3 < pp_half < worst and abs(math.log2(pp_half) - 90.62) < 0.01
