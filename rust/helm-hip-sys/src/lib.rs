@@ -95,6 +95,7 @@ extern "C" {
     // ---- include/helm_hip.h ---------------------------------------------------------------
     pub fn helm_hip_last_error() -> *const c_char;
     pub fn helm_hip_device_count() -> c_int;
+    pub fn helm_hip_runtime_copies(paths: *mut c_char, cap: usize) -> c_int;
     pub fn helm_hip_ctx_create(device_id: c_int, params: *const helm_hip_params, out: *mut *mut helm_hip_ctx) -> c_int;
     pub fn helm_hip_ctx_destroy(ctx: *mut helm_hip_ctx) -> c_int;
     pub fn helm_hip_set_stream(ctx: *mut helm_hip_ctx, hip_stream: *mut c_void) -> c_int;

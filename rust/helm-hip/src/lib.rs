@@ -52,6 +52,18 @@ pub(crate) fn check(rc: i32) {
     }
 }
 
+/// One HIP runtime per process: a host that links its own HIP next to this library must not end up with two
+/// copies of libamdhip64 mapped - a stream or device pointer of one is not valid in the other.  Called by every constructor
+/// of this crate before the first handle could cross; panics (HELM's own error style) with the paths of the copies.
+pub fn assert_one_hip_runtime() {
+    let mut buf = vec![0u8; 4096];
+    let n = unsafe { sys::helm_hip_runtime_copies(buf.as_mut_ptr() as *mut std::os::raw::c_char, buf.len()) };
+    if n > 1 {
+        let paths = String::from_utf8_lossy(&buf[..buf.iter().position(|&b| b == 0).unwrap_or(0)]).replace('\n', ", ");
+        panic!("helm-hip: {} HIP runtimes are mapped into this process ({}): load libhelm_hip.so after the host's own libamdhip64", n, paths);
+    }
+}
+
 pub(crate) fn check_host(rc: i32) {
     if rc != 0 {
         let m = unsafe { CStr::from_ptr(sys::helm_host_last_error()) };
@@ -85,6 +97,7 @@ impl<'a> HipGateCircuit<'a> {
     /// `GateCircuit::new(client_key, server_key, circuit)` (circuit.rs:383-391) with the server key
     /// replaced by an engine context holding the same key material.
     pub fn new(client_key: ClientKey, std_keys: &keys::StandardKeys, circuit: Circuit<'a>, device_id: i32) -> Self {
+        assert_one_hip_runtime();
         let mut ctx = std::ptr::null_mut();
         check(unsafe { sys::helm_hip_ctx_create(device_id, &std_keys.params, &mut ctx) });
         check(unsafe { sys::helm_hip_load_bootstrap_key(ctx, std_keys.bsk.as_ptr(), std_keys.bsk.len()) });
