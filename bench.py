@@ -343,13 +343,21 @@ def check_rank_devices(devices, world, n_gpus, rehearsal=False, host_fallback=Fa
         if not d["rccl_version"] and not (rehearsal or host_fallback):
             problems.append(f"rank {d['rank']}: the communicator is not RCCL's")
     if not rehearsal:
-        seen = {}
+        # two ranks on one device index is always wrong; the PCI address / uuid torch reports must differ as well - unless the
+        # platform reports the SAME identity for every device (then it says nothing, and the distinct indices stand)
+        by_index = {}
         for d in devices:
-            key = (d["pci"], d["uuid"])
-            if key in seen:
-                problems.append(f"ranks {seen[key]} and {d['rank']} share one device ({d['pci']}): one process per GPU needs "
-                                f"{world} different devices")
-            seen.setdefault(key, d["rank"])
+            if d["local_rank"] in by_index:
+                problems.append(f"ranks {by_index[d['local_rank']]} and {d['rank']} both use device index {d['local_rank']}")
+            by_index.setdefault(d["local_rank"], d["rank"])
+        keys = [(d["pci"], d["uuid"]) for d in devices]
+        if not (world > 1 and len(set(keys)) == 1 and len(by_index) == world):
+            seen = {}
+            for d, key in zip(devices, keys):
+                if key in seen:
+                    problems.append(f"ranks {seen[key]} and {d['rank']} share one device ({d['pci']}): one process per GPU needs "
+                                    f"{world} different devices")
+                seen.setdefault(key, d["rank"])
     return problems
 
 

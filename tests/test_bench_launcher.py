@@ -108,8 +108,13 @@ def test_rank_layout_is_checked_not_assumed():
                 "comm_rank": rank if comm_rank is None else comm_rank, "rccl_version": rccl}
     good = [rec(0, "0000:05:00"), rec(1, "0000:15:00")]
     assert bench.check_rank_devices(good, 2, 2) == []
-    assert any("share one device" in p for p in bench.check_rank_devices([rec(0, "0000:05:00"), rec(1, "0000:05:00")], 2, 2))
-    assert bench.check_rank_devices([rec(0, "0000:05:00"), rec(1, "0000:05:00")], 2, 2, rehearsal=True) == []
+    three = [rec(0, "0000:05:00"), rec(1, "0000:15:00"), rec(2, "0000:05:00")]
+    assert any("ranks 0 and 2 share one device" in p for p in bench.check_rank_devices(three, 3, 3))
+    same_index = [rec(0, "0000:05:00"), dict(rec(1, "0000:15:00"), local_rank=0)]
+    assert any("both use device index 0" in p for p in bench.check_rank_devices(same_index, 2, 2))
+    # a platform that reports ONE identity for every device says nothing: distinct device indices stand, no false alarm
+    assert bench.check_rank_devices([rec(0, "0000:00:00"), rec(1, "0000:00:00")], 2, 2) == []
+    assert bench.check_rank_devices([rec(0, "0000:05:00"), dict(rec(1, "0000:05:00"), local_rank=0)], 2, 2, rehearsal=True) == []
     assert any("world size 2 != --gpus 8" in p for p in bench.check_rank_devices(good, 2, 8))
     assert any("reports world size 1" in p for p in bench.check_rank_devices([rec(0, "a", world=1), rec(1, "b")], 2, 2))
     assert any("reports rank 0" in p for p in bench.check_rank_devices([rec(0, "a"), rec(1, "b", comm_rank=0)], 2, 2))
