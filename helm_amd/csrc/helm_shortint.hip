@@ -1897,7 +1897,10 @@ hipError_t launch_pbs64k_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count
                            const uint64_t *luts, uint64_t *out, int *per_cu = nullptr)
 {
     static std::atomic<bool> attr_done[64]; // (rank threads of one process launch concurrently)
-    auto kern = ctx->pair ? k_pbs64k<C, J0, J1> : k_pbs64k<C, F0, F1>; // the CRT pair follows the loaded key
+    // the CRT pair follows the key loaded into the PRIMARY context (a lane shares its key and tables: helm_si_ctx_fork; a key
+    // loaded after the fork may have moved the pair)
+    const helm_si_ctx *root = ctx->lane_of ? ctx->lane_of : ctx;
+    auto kern = root->pair ? k_pbs64k<C, J0, J1> : k_pbs64k<C, F0, F1>;
     if (!attr_done[ctx->device & 63]) {
         for (auto kk : {k_pbs64k<C, F0, F1>, k_pbs64k<C, J0, J1>}) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1907,8 +1910,8 @@ hipError_t launch_pbs64k_c(helm_si_ctx *ctx, const Pbs64Job *jobs, int64_t count
         attr_done[ctx->device & 63] = true;
     }
     if (per_cu) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, 64 * C::NW, C::BYTES);
-    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, small, luts, ctx->bsk,
-                       ctx->tw[0], ctx->tw[1], out, ctx->P.n, ctx->P.pbs_logB, ctx->p0inv_mod_p1);
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(64 * C::NW), C::BYTES, ctx->stream, jobs, small, luts, root->bsk,
+                       root->tw[0], root->tw[1], out, ctx->P.n, ctx->P.pbs_logB, root->p0inv_mod_p1);
     return hipGetLastError();
 }
 
@@ -2591,7 +2594,7 @@ int helm_si_get_params(const helm_si_ctx *ctx, helm_si_params *out)
 int helm_si_field_bits(const helm_si_ctx *ctx)
 {
     if (!ctx) return fail(HELM_ERR_INVALID, "null argument");
-    return ctx->pair ? 46 : 49;
+    return (ctx->lane_of ? ctx->lane_of : ctx)->pair ? 46 : 49;
 }
 
 int helm_si_set_stream(helm_si_ctx *ctx, void *hip_stream)
